@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by running the REFERENCE's own Python in the build container.
+
+Run here only (needs /root/reference, which does not exist on the GPU box):
+    python tests/golden/make_golden.py
+
+The reference's hot path imports three third-party packages that are not installed and
+not vendored (torch_scatter, torch_geometric, rdkit, lmdb).  This script
+seeds ``sys.modules`` with minimal stand-ins for them -- the documented semantics of
+``scatter_add`` / ``scatter_softmax`` / ``add_self_loops`` written with stock torch ops,
+import-only mocks for the rest -- then imports
+    fragnet.model.gat.gat2            (FragNetFineTune, FragNetLayerA)
+    fragnet.model.gat.pretrain_heads  (FragNetPreTrain)
+    fragnet.dataset.data              (collate_fn, collate_fn_pt)
+from /root/reference and records inputs -> outputs.  Nothing from the reference is
+written into the fixtures except numbers it computed.
+
+Fixture layout (one .npz per case):
+    cfg                  json: constructor kwargs, seed, loss kind
+    batch/<key>          the batch dict produced by the reference's collate_fn
+    pkeys, psums         state-dict key names and float64 (sum, abs-sum) per tensor
+    out/<name>           model outputs, loss, per-layer encoder outputs
+    gfull/<param>        gradient, whole tensor (numel <= 8192)
+    gsamp/<param>        gradient, 1024 evenly spaced elements + gsum/<param> (sum, abs-sum)
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+
+# ----------------------------------------------------------------------------- stand-ins
+def _stub_scatter_add(src, index, dim=-1, out=None, dim_size=None):
+    assert dim == 0 and out is None
+    rows = dim_size if dim_size is not None else (int(index.max()) + 1 if index.numel() else 0)
+    res = torch.zeros((rows,) + tuple(src.shape[1:]), dtype=src.dtype)
+    idx = index.reshape((-1,) + (1,) * (src.dim() - 1)).expand_as(src)
+    return res.scatter_add_(0, idx, src)
+
+
+def _stub_scatter_softmax(src, index, dim=-1, dim_size=None):
+    assert dim == 0
+    rows = dim_size if dim_size is not None else int(index.max()) + 1
+    idx = index.reshape((-1,) + (1,) * (src.dim() - 1)).expand_as(src)
+    mx = torch.full((rows,) + tuple(src.shape[1:]), float("-inf"), dtype=src.dtype)
+    mx = mx.scatter_reduce(0, idx, src, reduce="amax", include_self=True)
+    ex = (src - mx.gather(0, idx)).exp()
+    den = torch.zeros_like(mx).scatter_add_(0, idx, ex)
+    return ex / den.gather(0, idx)
+
+
+def _stub_add_self_loops(edge_index, *a, **k):
+    n = int(edge_index.max()) + 1
+    loop = torch.arange(n, dtype=edge_index.dtype)
+    return torch.cat([edge_index, loop.unsqueeze(0).repeat(2, 1)], dim=1), None
+
+
+def install_stubs():
+    ts = types.ModuleType("torch_scatter")
+    ts.scatter_add = _stub_scatter_add
+    ts.scatter_softmax = _stub_scatter_softmax
+    sys.modules["torch_scatter"] = ts
+    for name in ("torch_geometric", "torch_geometric.utils", "torch_geometric.nn", "torch_geometric.nn.norm",
+                 "torch_geometric.data", "torch_geometric.datasets", "rdkit", "rdkit.Chem", "rdkit.Chem.BRICS",
+                 "rdkit.Chem.rdmolfiles", "rdkit.Chem.AllChem", "rdkit.Chem.rdDistGeom", "rdkit.Chem.rdMolAlign",
+                 "rdkit.Chem.Scaffolds", "rdkit.Chem.Scaffolds.MurckoScaffold", "rdkit.Geometry", "lmdb",
+                 "rdkit.Chem.rdMolTransforms", "rdkit.Chem.rdchem"):
+        sys.modules[name] = mock.MagicMock(name=name)
+    sys.modules["torch_geometric.utils"].add_self_loops = _stub_add_self_loops
+    sys.modules["torch_geometric"].utils = sys.modules["torch_geometric.utils"]
+    sys.path.insert(0, REF)
+
+
+# ----------------------------------------------------------------------------- helpers
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def param_checksums(model):
+    keys, sums = [], []
+    for k, v in model.state_dict().items():
+        keys.append(k)
+        v = v.double()
+        sums.append([float(v.sum()), float(v.abs().sum())])
+    return keys, np.asarray(sums, dtype=np.float64)
+
+
+def zero_dead_bias(model):
+    """The reference's per-layer ``bias`` is uninitialised memory and dead; make it 0 so checksums are finite."""
+    with torch.no_grad():
+        for layer in model.pretrain.layers:
+            layer.bias.zero_()
+
+
+def pack_grads(model, store):
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.detach().double().reshape(-1)
+        store[f"gsum/{name}"] = np.asarray([float(g.sum()), float(g.abs().sum())])
+        if g.numel() <= 8192:
+            store[f"gfull/{name}"] = p.grad.detach().numpy().copy()
+        else:
+            pick = torch.linspace(0, g.numel() - 1, 1024).long()
+            store[f"gsamp/{name}"] = p.grad.detach().reshape(-1)[pick].numpy().copy()
+
+
+def run_layer_trace(model, batch):
+    """Per-layer raw outputs (before dropout/ReLU) of the reference encoder, via forward hooks."""
+    trace = []
+    hooks = [l.register_forward_hook(lambda m, i, o: trace.append([t.detach().numpy().copy() for t in o[:4]]))
+             for l in model.pretrain.layers]
+    return trace, hooks
+
+
+def save_case(name, cfg, batch, model, outputs, loss, trace):
+    store = {"cfg": np.asarray(json.dumps(cfg))}
+    for k, v in batch.items():
+        store[f"batch/{k}"] = v.numpy()
+    keys, sums = param_checksums(model)
+    store["pkeys"] = np.asarray(json.dumps(keys))
+    store["psums"] = sums
+    for k, v in outputs.items():
+        store[f"out/{k}"] = v.detach().numpy()
+    store["out/loss"] = np.asarray(float(loss), dtype=np.float64)
+    for li, outs in enumerate(trace):
+        for nm, arr in zip(("x_atoms", "x_frags", "bond", "fbond"), outs):
+            store[f"out/layer{li}/{nm}"] = arr
+    pack_grads(model, store)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, loss={float(loss):.6f}")
+
+
+# ----------------------------------------------------------------------------- cases
+def edge_case_molecules():
+    """single fragment (self connection), two fragments (2-node fragment-bond graph), lone counter-ion,
+    two-atom component (one-bond fragment), two heavy atoms only, and the notebook molecule."""
+    from fragnet_amd import synth
+    mols = []
+    rng = np.random.default_rng(11)
+    mols.append(synth.make_molecule(rng, mu=6, p_cut=0.0))                       # 1 fragment
+    while True:                                                                   # exactly 2 fragments
+        m = synth.make_molecule(rng, mu=7, p_cut=0.25)
+        if int(m.n_frags) == 2:
+            mols.append(m)
+            break
+    for want_ion in (True, False):                                                # both salt flavours
+        while True:
+            m = synth.make_molecule(rng, mu=6, p_cut=0.3, p_salt=1.0)
+            deg = torch.bincount(m.edge_index[0], minlength=m.x_atoms.size(0))
+            if bool((deg == 0).any()) == want_ion:
+                mols.append(m)
+                break
+    mols.append(synth.make_molecule(rng, mu=0.1, p_cut=0.0))                      # n_heavy = 2
+    mols.append(synth.notebook_molecule())
+    return mols
+
+
+def main():
+    install_stubs()
+    with quiet():
+        from fragnet.model.gat import gat2 as ref_gat2
+        from fragnet.model.gat import pretrain_heads as ref_pt
+        from fragnet.dataset import data as ref_data
+    from fragnet_amd import synth
+
+    torch.set_num_threads(1)
+    torch.use_deterministic_algorithms(True)
+
+    # ---- collate fixture: per-molecule tensors -> reference collate_fn / collate_fn_pt
+    mols = edge_case_molecules() + synth.synth_molecules(3, seed=5, profile="tox21", pretrain_targets=False)
+    for m in mols:      # pretrain targets for the _pt variant
+        e, n = m.edge_index.shape[1], m.x_atoms.shape[0]
+        g = torch.Generator().manual_seed(e * 1000 + n)
+        m.bnd_lngth, m.bnd_angl, m.dh_angl = torch.rand(e, 1, generator=g), torch.rand(n, 1, generator=g), torch.rand(e, 1, generator=g)
+    mols_reg = [m for m in mols if m.y.dim() == 1]
+    store = {}
+    fields = ["x_atoms", "edge_index", "edge_attr", "frag_index", "cnx_attr", "x_frags", "atom_id_frag_id", "n_frags",
+              "node_features_bonds", "edge_index_bonds", "edge_attr_bonds", "node_feautures_fbondg",
+              "edge_index_fbondg", "edge_attr_fbondg", "y", "bnd_lngth", "bnd_angl", "dh_angl"]
+    store["n_mols"] = np.asarray(len(mols_reg))
+    for i, m in enumerate(mols_reg):
+        for f in fields:
+            store[f"mol{i}/{f}"] = getattr(m, f).numpy()
+    ref_ft = ref_data.collate_fn(mols_reg)
+    ref_ptb = ref_data.collate_fn_pt(mols_reg)
+    for k, v in ref_ft.items():
+        store[f"ft/{k}"] = v.numpy()
+    for k, v in ref_ptb.items():
+        store[f"pt/{k}"] = v.numpy()
+    ref_one = ref_data.collate_fn(mols_reg[:1])          # the len(data_list)==1 branch of get_incr_*
+    for k, v in ref_one.items():
+        store[f"one/{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "collate_edge6.npz"), **store)
+    print("collate_edge6 written,", len(mols_reg), "molecules")
+
+    # ---- model cases
+    def ft_case(name, mols, cfg, loss_kind, seed=0):
+        batch = ref_data.collate_fn(mols)
+        torch.manual_seed(seed)
+        with quiet():
+            model = ref_gat2.FragNetFineTune(**cfg)
+        zero_dead_bias(model)
+        model.train()
+        trace, hooks = run_layer_trace(model, batch)
+        with quiet():
+            out = model(batch)
+        for h in hooks:
+            h.remove()
+        if loss_kind == "mse":
+            loss = torch.nn.functional.mse_loss(out.view(-1), batch["y"])
+        else:
+            from fragnet.train.utils import compute_bce_loss
+            loss = compute_bce_loss(out, batch["y"].view(out.shape))
+        loss.backward()
+        save_case(name, {"kind": "finetune", "ctor": cfg, "seed": seed, "loss": loss_kind}, batch, model,
+                  {"logits": out}, loss, trace)
+
+    esol_cfg = dict(n_classes=1, atom_features=167, frag_features=167, edge_features=17, num_layer=4, num_heads=4,
+                    drop_ratio=0.0, h1=128, h2=1024, h3=1024, h4=512, act="relu", emb_dim=128, fthead="FTHead3")
+    ft_case("ft_esol_b8", synth.synth_molecules(8, seed=1000, profile="esol"), esol_cfg, "mse")
+    tox_cfg = dict(n_classes=12, atom_features=167, frag_features=167, edge_features=17, num_layer=3, num_heads=4,
+                   drop_ratio=0.0, h1=64, act="gelu", emb_dim=128, fthead="FTHead4")
+    ft_case("ft_tox21_b4", synth.synth_molecules(4, seed=2000, profile="tox21"), tox_cfg, "bce", seed=3)
+    edge_cfg = dict(n_classes=1, atom_features=167, frag_features=167, edge_features=17, num_layer=2, num_heads=4,
+                    drop_ratio=0.0, h1=32, h2=64, h3=64, h4=32, act="silu", emb_dim=128, fthead="FTHead3")
+    ft_case("ft_edge_b6", edge_case_molecules(), edge_cfg, "mse", seed=5)
+
+    # ---- pretrain case
+    pt_mols = synth.synth_molecules(4, seed=3000, profile="esol", pretrain_targets=True)
+    batch = ref_data.collate_fn_pt(pt_mols)
+    cfg = dict(num_layer=4, drop_ratio=0.0, num_heads=4, emb_dim=128, atom_features=167, frag_features=167,
+               edge_features=17, fedge_in=6, fbond_edge_in=6)
+    torch.manual_seed(1)
+    with quiet():
+        model = ref_pt.FragNetPreTrain(**cfg)
+    zero_dead_bias(model)
+    model.train()
+    trace, hooks = run_layer_trace(model, batch)
+    with quiet():
+        bl, ba, da, gr = model(batch)
+    for h in hooks:
+        h.remove()
+    mse = torch.nn.MSELoss()
+    # the reference's pretrain step, pretrain_utils.py:21-26 (bond-length loss is overwritten)
+    loss_lngth = mse(bl, batch["bnd_lngth"])
+    loss_angle = mse(ba, batch["bnd_angl"])
+    loss_lngth = mse(da, batch["dh_angl"])
+    loss_E = mse(gr.view(-1), batch["y"])
+    loss = loss_lngth + loss_angle + loss_lngth + loss_E
+    loss.backward()
+    save_case("pt_esol_b4", {"kind": "pretrain", "ctor": cfg, "seed": 1, "loss": "pretrain"}, batch, model,
+              {"bond_length": bl, "bond_angle": ba, "dihedral": da, "graph_rep": gr}, loss, trace)
+
+    # ---- one layer with return_attentions + masks (interpretability outputs)
+    b = ref_data.collate_fn(synth.synth_molecules(3, seed=4000, profile="esol"))
+    torch.manual_seed(2)
+    with quiet():
+        layer = ref_gat2.FragNetLayerA(atom_in=167, atom_out=128, frag_in=167, frag_out=128, edge_in=17, edge_out=128,
+                                       fedge_in=6, num_heads=4, fbond_edge_in=6, return_attentions=True,
+                                       bond_mask=4, frag_bond_mask=1, atom_mask_individual=3)
+    with torch.no_grad():
+        layer.bias.zero_()
+    with quiet():
+        outs = layer(b["x_atoms"], b["edge_index"], b["edge_attr"], b["frag_index"], b["x_frags"],
+                     b["atom_to_frag_ids"], b["node_features_bonds"], b["edge_index_bonds_graph"],
+                     b["edge_attr_bonds"], b["node_features_fbonds"], b["edge_index_fbonds"], b["edge_attr_fbonds"])
+    store = {"cfg": np.asarray(json.dumps({"seed": 2, "bond_mask": 4, "frag_bond_mask": 1, "atom_mask_individual": 3}))}
+    for k, v in b.items():
+        store[f"batch/{k}"] = v.numpy()
+    names = ("x_atoms", "x_frags", "bond", "fbond", "attn_atoms", "attn_frags", "attn_bonds", "attn_fbonds")
+    for nm, t in zip(names, outs):
+        store[f"out/{nm}"] = t.detach().numpy()
+    keys, sums = [], []
+    for k, v in layer.state_dict().items():
+        keys.append(k)
+        sums.append([float(v.double().sum()), float(v.double().abs().sum())])
+    store["pkeys"] = np.asarray(json.dumps(keys))
+    store["psums"] = np.asarray(sums)
+    np.savez_compressed(os.path.join(HERE, "layer_attn_masks_b3.npz"), **store)
+    print("layer_attn_masks_b3 written")
+
+
+if __name__ == "__main__":
+    main()
