@@ -1,0 +1,98 @@
+"""ctypes binding of libfragnet_hip.so (C-ABI in include/fragnet_hip.h).
+
+There is no fallback: if the library is missing or a call fails, this raises.  The shared object is
+built in-tree by ``__graft_entry__.build()`` / ``python -m fragnet_amd.build`` into fragnet_amd/lib/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfragnet_hip.so")
+
+FN_D = 128
+FN_MAX_TASKS = 16
+FN_MAX_EDGE_K = 8
+FN_MAX_PART = 1024
+ROLE_PLAIN, ROLE_DST, ROLE_SRC = 0, 1, 2
+
+i32, i64, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
+ip = C.POINTER(C.c_int)
+
+
+class CsrTask(C.Structure):
+    _fields_ = [("key", vp), ("other_key", vp), ("n_real", i64), ("n_loops", i64), ("n_seg", i64),
+                ("item_base", i64), ("seg_base", i64), ("role", i32), ("partner", i32)]
+
+
+class EdgeTerm(C.Structure):
+    _fields_ = [("mode", i32), ("K", i32), ("d_e", i32), ("mid_off", i32),
+                ("s_edge", vp), ("x", vp), ("embW", vp), ("embb", vp)]
+
+
+class GatPlan(C.Structure):
+    _fields_ = [("rowptr_d", vp), ("eid_d", vp), ("src_d", vp), ("rowptr_s", vp), ("dst_s", vp), ("dpos_s", vp),
+                ("pos_base_d", i32), ("pos_base_s", i32), ("n", i64), ("m", i64), ("m_real", i64)]
+
+
+# name -> argtypes; every function returns int (0 ok / <0 argument error / >0 hipError_t) unless noted.
+SIGNATURES = {
+    "fn_abi_version": [],
+    "fn_last_error": [],
+    "fn_plan_layout": [C.POINTER(CsrTask), C.c_int, C.POINTER(i64), C.POINTER(i64)],
+    "fn_plan_build": [C.POINTER(CsrTask), C.c_int, vp, vp, vp, vp, vp, vp],
+    "fn_node_scalars_f32": [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, i64, C.c_int, vp],
+    "fn_gat_fwd_f32": [vp, vp, vp, vp, C.c_int, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp, C.c_int, vp],
+    "fn_gat_bwd_dst_f32": [vp, vp, vp, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp, vp, ip, C.c_int, vp],
+    "fn_gat_bwd_src_f32": [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(GatPlan), vp, vp, ip, C.c_int, vp],
+    "fn_gat_bwd_finalize_f32": [vp, C.c_int, vp, C.c_int, C.POINTER(EdgeTerm), vp, C.c_int, C.c_int, C.c_int, vp, vp, vp,
+                                C.c_int, vp],
+    "fn_attn_by_src_f32": [vp, C.POINTER(GatPlan), vp, C.c_int, vp],
+    "fn_row_dots_f32": [vp, vp, C.c_int, C.c_int, C.c_int, vp, i64, vp],
+    "fn_row_dots_bwd_f32": [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, ip, i64, vp],
+    "fn_colsum_f32": [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp],
+    "fn_segment_sum_f32": [vp, i64, vp, vp, i32, vp, i64, i64, vp],
+    "fn_gather_rows_f32": [vp, vp, vp, i64, i64, vp],
+    "fn_segment_softmax_f32": [vp, vp, vp, i32, vp, i64, i64, vp],
+    "fn_segment_softmax_bwd_f32": [vp, vp, vp, vp, i32, vp, i64, i64, vp],
+    "fn_dropout_act_f32": [vp, vp, i64, f32, u64, u64, C.c_int, vp],
+    "fn_dropout_act_bwd_f32": [vp, vp, vp, i64, f32, u64, u64, C.c_int, vp],
+    "fn_edge_concat_f32": [vp, vp, vp, vp, i64, vp],
+}
+
+_lib = None
+
+
+class FragnetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library once; raises FragnetHipError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FragnetHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). fragnet_amd has no CPU/PyTorch fallback for its kernels.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == "fn_last_error" else C.c_int
+    if lib.fn_abi_version() != 1:
+        raise FragnetHipError(f"ABI version mismatch: library {lib.fn_abi_version()}, binding 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().fn_last_error()
+        raise FragnetHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def call(name: str, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,1018 @@
+// libfragnet_hip.so -- gfx950 (MI355X / CDNA4) kernels for FragNet's four-level message passing.
+// C-ABI declared in include/fragnet_hip.h (which cites the reference call sites replaced).
+//
+// Layout conventions used by every row kernel below:
+//   * node tables are [rows, 128] fp32; one 32-lane half-wavefront owns one row, each lane one
+//     float4 (16 B) => a wave64 moves two 512-B rows per load instruction, fully coalesced;
+//   * with H heads, head h owns the 32/H consecutive lanes [h*LPH, (h+1)*LPH) of the half-wave, so
+//     every per-head reduction is an xor-butterfly over LPH lanes and never leaves the half-wave;
+//   * a block is 256 threads = 8 rows; grids are capped and grid-strided so that the number of
+//     per-block partial-sum rows any backward kernel writes is bounded by FN_MAX_PART.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "fragnet_hip.h"
+
+namespace {
+
+thread_local char tl_err[256] = "";
+
+int fail(int code, const char* what) {
+    snprintf(tl_err, sizeof(tl_err), "%s", what);
+    return code;
+}
+
+int launch_status(const char* where) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(tl_err, sizeof(tl_err), "%s: %s", where, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+inline hipStream_t S(fn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kBlock = 256;
+constexpr int kRows = 8;          // rows (half-waves) per block
+constexpr int kGridCap = 2048;    // memory-bound kernels: ~8 blocks per CU, grid-stride the rest
+
+inline int row_grid(int64_t rows, int cap) {
+    int64_t g = (rows + kRows - 1) / kRows;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+inline int flat_grid(int64_t work, int cap) {
+    int64_t g = (work + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ void fma4(float4& acc, float s, float4 v) {
+    acc.x = fmaf(s, v.x, acc.x); acc.y = fmaf(s, v.y, acc.y);
+    acc.z = fmaf(s, v.z, acc.z); acc.w = fmaf(s, v.w, acc.w);
+}
+
+template <int W> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = W / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+template <int W> __device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int off = W / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// =====================================================================================
+// Graph plan
+// =====================================================================================
+struct PlanTasks {
+    int n;
+    int64_t total_items;
+    int64_t total_segs;
+    fn_csr_task t[FN_MAX_TASKS];
+};
+
+__device__ __forceinline__ int find_task(const PlanTasks& P, int64_t g) {
+    int ti = 0;
+    while (ti + 1 < P.n && g >= P.t[ti + 1].item_base) ++ti;
+    return ti;
+}
+
+__device__ __forceinline__ int64_t item_key(const fn_csr_task& T, int64_t local) {
+    return local < T.n_real ? T.key[local] : local - T.n_real;
+}
+__device__ __forceinline__ int64_t item_other(const fn_csr_task& T, int64_t local) {
+    return local < T.n_real ? T.other_key[local] : local - T.n_real;
+}
+
+__global__ void k_plan_hist(PlanTasks P, int32_t* __restrict__ rowptr_all, int32_t* __restrict__ status) {
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < P.total_items;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const fn_csr_task& T = P.t[find_task(P, g)];
+        int64_t k = item_key(T, g - T.item_base);
+        if (k < 0 || k >= T.n_seg) { atomicOr(status, 1); continue; }
+        atomicAdd(&rowptr_all[T.seg_base + k + 1], 1);
+    }
+}
+
+// inclusive scan of a[0..len) in place; one 1024-thread block, 8 consecutive items per thread per chunk
+__global__ __launch_bounds__(1024) void k_plan_scan(int32_t* __restrict__ a, int64_t len) {
+    __shared__ int32_t wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int32_t carry = 0;
+    for (int64_t base = 0; base < len; base += 1024 * 8) {
+        const int64_t i0 = base + (int64_t)tid * 8;
+        int32_t v[8];
+        int32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            sum += (i0 + k < len) ? a[i0 + k] : 0;
+            v[k] = sum;
+        }
+        int32_t x = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int32_t y = __shfl_up(x, off);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wave_tot[wid] = x;
+        __syncthreads();
+        int32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            int32_t wt = wave_tot[w];
+            before += (w < wid) ? wt : 0;
+            total += wt;
+        }
+        const int32_t excl = carry + before + (x - sum);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i0 + k < len) a[i0 + k] = v[k] + excl;
+        carry += total;
+        __syncthreads();
+    }
+}
+
+__global__ void k_plan_fill(PlanTasks P, const int32_t* __restrict__ rowptr_all, int32_t* __restrict__ cursor,
+                            int32_t* __restrict__ perm_all) {
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < P.total_items;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const fn_csr_task& T = P.t[find_task(P, g)];
+        const int64_t local = g - T.item_base;
+        int64_t k = item_key(T, local);
+        if (k < 0 || k >= T.n_seg) continue;
+        const int64_t seg = T.seg_base + k;
+        const int32_t pos = rowptr_all[seg] + atomicAdd(&cursor[seg], 1);
+        perm_all[pos] = (int32_t)local;
+    }
+}
+
+// ascending item id inside every segment => summation order of the reference's sequential scatter_add
+__global__ void k_plan_segsort(const int32_t* __restrict__ rowptr_all, int32_t* __restrict__ perm_all, int64_t total_segs) {
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total_segs;
+         s += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t b = rowptr_all[s], e = rowptr_all[s + 1];
+        for (int32_t i = b + 1; i < e; ++i) {
+            const int32_t v = perm_all[i];
+            int32_t q = i - 1;
+            while (q >= b && perm_all[q] > v) { perm_all[q + 1] = perm_all[q]; --q; }
+            perm_all[q + 1] = v;
+        }
+    }
+}
+
+template <int ROLE>
+__global__ void k_plan_aux(PlanTasks P, const int32_t* __restrict__ perm_all, int32_t* __restrict__ aux_a,
+                           int32_t* __restrict__ aux_b, int32_t* __restrict__ inv) {
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < P.total_items;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const fn_csr_task& T = P.t[find_task(P, g)];
+        if (T.role != ROLE) continue;
+        const int64_t item = perm_all[g];
+        aux_a[g] = (int32_t)item_other(T, item);
+        if (ROLE == FN_ROLE_DST) inv[T.item_base + item] = (int32_t)(g - T.item_base);
+        else aux_b[g] = inv[P.t[T.partner].item_base + item];
+    }
+}
+
+// =====================================================================================
+// Attention level
+// =====================================================================================
+constexpr int kWfLd = FN_MAX_EDGE_K + 1;
+
+// folded edge-embedding weights: Wf[h][k] = sum_c att[h, mid+c] * embW[c,k],  Wf[h][K] = sum_c att[h, mid+c] * embb[c]
+__device__ __forceinline__ void fold_edge_embed(const fn_edge_term& et, const float* att, int att_w, int H,
+                                                float (*sWf)[kWfLd]) {
+    if (et.mode == 2) {
+        const int ne = H * (et.K + 1);
+        for (int i = threadIdx.x; i < ne; i += blockDim.x) {
+            const int hh = i / (et.K + 1), k = i % (et.K + 1);
+            float acc = 0.f;
+            for (int c = 0; c < et.d_e; ++c) {
+                const float a = att[hh * att_w + et.mid_off + c];
+                acc = fmaf(a, (k < et.K) ? et.embW[c * et.K + k] : et.embb[c], acc);
+            }
+            sWf[hh][k] = acc;
+        }
+    }
+    __syncthreads();
+}
+
+template <int H>
+__device__ __forceinline__ float edge_logit(int pos, int head, float sd, const float* __restrict__ s_src,
+                                            const fn_gat_plan& pl, const fn_edge_term& et,
+                                            const float (*sWf)[kWfLd], float slope, int& src_out) {
+    const int src = pl.src_d[pos];
+    const int eid = pl.eid_d[pos];
+    float e = 0.f;
+    if (eid < pl.m_real) {
+        if (et.mode == 0) {
+            e = et.s_edge[(size_t)eid * H + head];
+        } else {
+            e = sWf[head][et.K];
+            for (int k = 0; k < et.K; ++k) e = fmaf(et.x[(size_t)eid * et.K + k], sWf[head][k], e);
+        }
+    }
+    const float z = sd + s_src[(size_t)src * H + head] + e;
+    src_out = src;
+    return z > 0.f ? z : slope * z;
+}
+
+template <int H>
+__global__ __launch_bounds__(kBlock) void k_node_scalars(const float* __restrict__ h, const float* __restrict__ att,
+                                                         int att_w, int dst_off, int src_off,
+                                                         float* __restrict__ s_dst, float* __restrict__ s_src, int64_t n) {
+    constexpr int LPH = 32 / H;
+    const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH;
+    const float4 ad = ld4(att + head * att_w + dst_off + j * 4);
+    const float4 as = ld4(att + head * att_w + src_off + j * 4);
+    for (int64_t r = (int64_t)blockIdx.x * kRows + (threadIdx.x >> 5); r < n; r += (int64_t)gridDim.x * kRows) {
+        const float4 x = ld4(h + r * FN_D + lane * 4);
+        const float pd = group_sum<LPH>(dot4(x, ad));
+        const float ps = group_sum<LPH>(dot4(x, as));
+        if (j == 0) { s_dst[r * H + head] = pd; s_src[r * H + head] = ps; }
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h, const float* __restrict__ s_dst,
+                                                    const float* __restrict__ s_src, const float* __restrict__ att,
+                                                    int att_w, fn_edge_term et, fn_gat_plan pl, float slope,
+                                                    float* __restrict__ out, float* __restrict__ p_sorted,
+                                                    float* __restrict__ probs_orig) {
+    constexpr int LPH = 32 / H;
+    __shared__ float sWf[8][kWfLd];
+    fold_edge_embed(et, att, att_w, H, sWf);
+    const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH;
+    for (int64_t t = (int64_t)blockIdx.x * kRows + (threadIdx.x >> 5); t < pl.n; t += (int64_t)gridDim.x * kRows) {
+        const int beg = pl.rowptr_d[t] - pl.pos_base_d;
+        const int deg = pl.rowptr_d[t + 1] - pl.rowptr_d[t];
+        const float sd = s_dst[t * H + head];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (deg <= 2 * LPH) {
+            // lane j of each head group owns in-edges j and LPH + j: all scalar gathers of a node are
+            // issued in one round, then probabilities are broadcast edge by edge for the row gathers
+            int srcA = 0, srcB = 0;
+            float lA = -INFINITY, lB = -INFINITY;
+            const bool hasA = j < deg, hasB = j + LPH < deg;
+            if (hasA) lA = edge_logit<H>(beg + j, head, sd, s_src, pl, et, sWf, slope, srcA);
+            if (hasB) lB = edge_logit<H>(beg + LPH + j, head, sd, s_src, pl, et, sWf, slope, srcB);
+            const float mx = group_max<LPH>(fmaxf(lA, lB));
+            const float eA = hasA ? expf(lA - mx) : 0.f;
+            const float eB = hasB ? expf(lB - mx) : 0.f;
+            const float den = group_sum<LPH>(eA + eB);
+            const float pA = hasA ? eA / den : 0.f;
+            const float pB = hasB ? eB / den : 0.f;
+            if (hasA) {
+                p_sorted[(size_t)(beg + j) * H + head] = lA > 0.f ? pA : -pA;
+                if (probs_orig) probs_orig[(size_t)pl.eid_d[beg + j] * H + head] = pA;
+            }
+            if (hasB) {
+                p_sorted[(size_t)(beg + LPH + j) * H + head] = lB > 0.f ? pB : -pB;
+                if (probs_orig) probs_orig[(size_t)pl.eid_d[beg + LPH + j] * H + head] = pB;
+            }
+            const int cntA = deg < LPH ? deg : LPH;
+
+            for (int k = 0; k < cntA; ++k) {
+                const float pk = __shfl(pA, k, LPH);
+                const int sk = __shfl(srcA, k, LPH);
+                fma4(acc, pk, ld4(h + (size_t)sk * FN_D + lane * 4));
+            }
+
+            for (int k = 0; k < deg - LPH; ++k) {
+                const float pk = __shfl(pB, k, LPH);
+                const int sk = __shfl(srcB, k, LPH);
+                fma4(acc, pk, ld4(h + (size_t)sk * FN_D + lane * 4));
+            }
+        } else {
+            // rare high in-degree node: every lane walks the edge list (three passes)
+            int sk = 0;
+            float mx = -INFINITY;
+            for (int i = 0; i < deg; ++i) mx = fmaxf(mx, edge_logit<H>(beg + i, head, sd, s_src, pl, et, sWf, slope, sk));
+            float den = 0.f;
+            for (int i = 0; i < deg; ++i) den += expf(edge_logit<H>(beg + i, head, sd, s_src, pl, et, sWf, slope, sk) - mx);
+            for (int i = 0; i < deg; ++i) {
+                const float l = edge_logit<H>(beg + i, head, sd, s_src, pl, et, sWf, slope, sk);
+                const float p = expf(l - mx) / den;
+                if (j == 0) {
+                    p_sorted[(size_t)(beg + i) * H + head] = l > 0.f ? p : -p;
+                    if (probs_orig) probs_orig[(size_t)pl.eid_d[beg + i] * H + head] = p;
+                }
+                fma4(acc, p, ld4(h + (size_t)sk * FN_D + lane * 4));
+            }
+        }
+        st4(out + t * FN_D + lane * 4, acc);
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(kBlock) void k_gat_bwd_dst(const float* __restrict__ g_out, const float* __restrict__ h,
+                                                        const float* __restrict__ p_sorted, fn_edge_term et,
+                                                        fn_gat_plan pl, float slope, float* __restrict__ dz_sorted,
+                                                        float* __restrict__ g_s_dst, float* __restrict__ g_s_edge,
+                                                        float* __restrict__ part_e) {
+    constexpr int LPH = 32 / H;
+    __shared__ float sP[kRows][8][kWfLd];
+    const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH, hw = threadIdx.x >> 5;
+    float pw[kWfLd];
+#pragma unroll
+    for (int k = 0; k < kWfLd; ++k) pw[k] = 0.f;
+
+    auto emit = [&](int pos, float dz) {
+        dz_sorted[(size_t)pos * H + head] = dz;
+        const int eid = pl.eid_d[pos];
+        if (eid < pl.m_real) {
+            if (et.mode == 0) {
+                g_s_edge[(size_t)eid * H + head] = dz;
+            } else {
+                pw[FN_MAX_EDGE_K] += dz;
+#pragma unroll
+                for (int k = 0; k < FN_MAX_EDGE_K; ++k)
+                    if (k < et.K) pw[k] = fmaf(dz, et.x[(size_t)eid * et.K + k], pw[k]);
+            }
+        }
+    };
+
+    for (int64_t t = (int64_t)blockIdx.x * kRows + hw; t < pl.n; t += (int64_t)gridDim.x * kRows) {
+        const int beg = pl.rowptr_d[t] - pl.pos_base_d;
+        const int deg = pl.rowptr_d[t + 1] - pl.rowptr_d[t];
+        const float4 g = ld4(g_out + t * FN_D + lane * 4);
+        if (deg <= 2 * LPH) {
+            float dpA = 0.f, dpB = 0.f;
+
+            for (int k = 0; k < deg; ++k) {
+                const int sk = pl.src_d[beg + k];
+                const float d = group_sum<LPH>(dot4(g, ld4(h + (size_t)sk * FN_D + lane * 4)));
+                if (k == j) dpA = d;
+                if (k == j + LPH) dpB = d;
+            }
+            const bool hasA = j < deg, hasB = j + LPH < deg;
+            const float psA = hasA ? p_sorted[(size_t)(beg + j) * H + head] : 0.f;
+            const float psB = hasB ? p_sorted[(size_t)(beg + LPH + j) * H + head] : 0.f;
+            const float pA = fabsf(psA), pB = fabsf(psB);
+            const float c = group_sum<LPH>(pA * dpA + pB * dpB);
+            const float dzA = pA * (dpA - c) * ((__float_as_uint(psA) >> 31) ? slope : 1.f);
+            const float dzB = pB * (dpB - c) * ((__float_as_uint(psB) >> 31) ? slope : 1.f);
+            if (hasA) emit(beg + j, dzA);
+            if (hasB) emit(beg + LPH + j, dzB);
+            const float gs = group_sum<LPH>(dzA + dzB);
+            if (j == 0) g_s_dst[t * H + head] = gs;
+        } else {
+            float c = 0.f;
+            for (int k = 0; k < deg; ++k) {
+                const int sk = pl.src_d[beg + k];
+                const float d = group_sum<LPH>(dot4(g, ld4(h + (size_t)sk * FN_D + lane * 4)));
+                c = fmaf(fabsf(p_sorted[(size_t)(beg + k) * H + head]), d, c);
+            }
+            float gs = 0.f;
+            for (int k = 0; k < deg; ++k) {
+                const int sk = pl.src_d[beg + k];
+                const float d = group_sum<LPH>(dot4(g, ld4(h + (size_t)sk * FN_D + lane * 4)));
+                const float ps = p_sorted[(size_t)(beg + k) * H + head];
+                const float dz = fabsf(ps) * (d - c) * ((__float_as_uint(ps) >> 31) ? slope : 1.f);
+                if (j == 0) emit(beg + k, dz);
+                gs += dz;
+            }
+            if (j == 0) g_s_dst[t * H + head] = gs;
+        }
+    }
+
+    if (et.mode == 2) {
+        // deterministic block partial of sum_e dz[e,h] * (x[e,0..K), 1)
+#pragma unroll
+        for (int k = 0; k < kWfLd; ++k) {
+            const float v = group_sum<LPH>(pw[k]);
+            if (j == 0) sP[hw][head][k] = v;
+        }
+        __syncthreads();
+        const int ne = H * (et.K + 1);
+        for (int i = threadIdx.x; i < ne; i += blockDim.x) {
+            const int hh = i / (et.K + 1), k = i % (et.K + 1);
+            const int kk = (k == et.K) ? FN_MAX_EDGE_K : k;
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < kRows; ++w) a += sP[w][hh][kk];
+            part_e[(size_t)blockIdx.x * ne + i] = a;
+        }
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(kBlock) void k_gat_bwd_src(const float* __restrict__ g_out, const float* __restrict__ h,
+                                                        const float* __restrict__ p_sorted,
+                                                        const float* __restrict__ dz_sorted,
+                                                        const float* __restrict__ g_s_dst, const float* __restrict__ att,
+                                                        int att_w, int dst_off, int src_off, fn_gat_plan pl,
+                                                        float* __restrict__ g_h, float* __restrict__ part_a) {
+    constexpr int LPH = 32 / H;
+    __shared__ float sA[kRows][2 * FN_D];
+    const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH, hw = threadIdx.x >> 5;
+    const float4 ad = ld4(att + head * att_w + dst_off + j * 4);
+    const float4 as = ld4(att + head * att_w + src_off + j * 4);
+    float4 qd = make_float4(0.f, 0.f, 0.f, 0.f), qs = qd;
+    for (int64_t s = (int64_t)blockIdx.x * kRows + hw; s < pl.n; s += (int64_t)gridDim.x * kRows) {
+        const int beg = pl.rowptr_s[s] - pl.pos_base_s;
+        const int deg = pl.rowptr_s[s + 1] - pl.rowptr_s[s];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float gss = 0.f;
+
+        for (int i = 0; i < deg; ++i) {
+            const int t = pl.dst_s[beg + i];
+            const size_t pos = (size_t)pl.dpos_s[beg + i] * H + head;
+            fma4(acc, fabsf(p_sorted[pos]), ld4(g_out + (size_t)t * FN_D + lane * 4));
+            gss += dz_sorted[pos];
+        }
+        const float gsd = g_s_dst[s * H + head];
+        const float4 hr = ld4(h + s * FN_D + lane * 4);
+        fma4(acc, gsd, ad);
+        fma4(acc, gss, as);
+        st4(g_h + s * FN_D + lane * 4, acc);
+        fma4(qd, gsd, hr);
+        fma4(qs, gss, hr);
+    }
+    st4(&sA[hw][lane * 4], qd);
+    st4(&sA[hw][FN_D + lane * 4], qs);
+    __syncthreads();
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < kRows; ++w) a += sA[w][threadIdx.x];
+    part_a[(size_t)blockIdx.x * (2 * FN_D) + threadIdx.x] = a;
+}
+
+__global__ __launch_bounds__(1024) void k_gat_finalize(const float* __restrict__ part_a, int n_a,
+                                                       const float* __restrict__ part_e, int n_e, fn_edge_term et,
+                                                       const float* __restrict__ att, int att_w, int dst_off,
+                                                       int src_off, float* __restrict__ g_att,
+                                                       float* __restrict__ g_embW, float* __restrict__ g_embb, int H) {
+    __shared__ float red[4][2 * FN_D];
+    __shared__ float redE[8][128];
+    __shared__ float sE[128];
+    const int tid = threadIdx.x;
+    {
+        const int col = tid & 255, grp = tid >> 8;
+        float acc = 0.f;
+        for (int r = grp; r < n_a; r += 4) acc += part_a[(size_t)r * (2 * FN_D) + col];
+        red[grp][col] = acc;
+    }
+    const int ne = (et.mode == 2) ? H * (et.K + 1) : 0;     // <= 72
+    if (ne) {
+        const int col = tid & 127, grp = tid >> 7;
+        float acc = 0.f;
+        if (col < ne)
+            for (int r = grp; r < n_e; r += 8) acc += part_e[(size_t)r * ne + col];
+        redE[grp][col] = acc;
+    }
+    __syncthreads();
+    const int DH = FN_D / H;
+    if (tid < 2 * FN_D) {
+        const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        const int part = tid >> 7, cc = tid & 127;
+        g_att[(cc / DH) * att_w + (part ? src_off : dst_off) + (cc % DH)] = v;
+    }
+    if (ne) {
+        if (tid < 128) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) v += redE[g][tid];
+            sE[tid] = v;
+        }
+        __syncthreads();
+        const int K = et.K, d_e = et.d_e;
+        if (tid < H * d_e) {
+            const int hh = tid / d_e, c = tid % d_e;
+            float a = sE[hh * (K + 1) + K] * et.embb[c];
+            for (int k = 0; k < K; ++k) a = fmaf(sE[hh * (K + 1) + k], et.embW[c * K + k], a);
+            g_att[hh * att_w + et.mid_off + c] = a;
+        }
+        if (tid < d_e * K) {
+            const int c = tid / K, k = tid % K;
+            float a = 0.f;
+            for (int hh = 0; hh < H; ++hh) a = fmaf(sE[hh * (K + 1) + k], att[hh * att_w + et.mid_off + c], a);
+            g_embW[tid] = a;
+        }
+        if (tid < d_e) {
+            float a = 0.f;
+            for (int hh = 0; hh < H; ++hh) a = fmaf(sE[hh * (K + 1) + K], att[hh * att_w + et.mid_off + tid], a);
+            g_embb[tid] = a;
+        }
+    }
+}
+
+template <int H>
+__global__ void k_attn_by_src(const float* __restrict__ p_sorted, fn_gat_plan pl, float* __restrict__ attn) {
+    const int64_t total = pl.n * H;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / H;
+        const int head = (int)(i % H);
+        const int beg = pl.rowptr_s[s] - pl.pos_base_s, deg = pl.rowptr_s[s + 1] - pl.rowptr_s[s];
+        float a = 0.f;
+        for (int k = 0; k < deg; ++k) a += fabsf(p_sorted[(size_t)pl.dpos_s[beg + k] * H + head]);
+        attn[i] = a;
+    }
+}
+
+// =====================================================================================
+// Row dots (full-width edge term) and its backward
+// =====================================================================================
+__global__ __launch_bounds__(kBlock) void k_row_dots(const float* __restrict__ x, const float* __restrict__ A, int lda,
+                                                     int off, int J, float* __restrict__ s, int64_t rows) {
+    const int lane = threadIdx.x & 31;
+    float4 a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = (q < J) ? ld4(A + q * lda + off + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t r = (int64_t)blockIdx.x * kRows + (threadIdx.x >> 5); r < rows; r += (int64_t)gridDim.x * kRows) {
+        const float4 v = ld4(x + r * FN_D + lane * 4);
+        float mine = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q < J) {
+                const float d = group_sum<32>(dot4(v, a[q]));
+                if (lane == q) mine = d;
+            }
+        }
+        if (lane < J) s[r * J + lane] = mine;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_row_dots_bwd(const float* __restrict__ g_s, const float* __restrict__ x,
+                                                         const float* __restrict__ A, int lda, int off, int J,
+                                                         float* __restrict__ g_x, float* __restrict__ part, int64_t rows) {
+    __shared__ float sR[kRows][FN_D];
+    const int lane = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    float4 a[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a[i] = (i < J) ? ld4(A + i * lda + off + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t r = (int64_t)blockIdx.x * kRows + hw; r < rows; r += (int64_t)gridDim.x * kRows) {
+        const float4 v = ld4(x + r * FN_D + lane * 4);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < J) {
+                const float gs = g_s[r * J + i];
+                fma4(acc, gs, a[i]);
+                fma4(q[i], gs, v);
+            }
+        }
+        st4(g_x + r * FN_D + lane * 4, acc);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i < J) {                                    // J is a kernel argument: uniform branch
+            st4(&sR[hw][lane * 4], q[i]);
+            __syncthreads();
+            if (threadIdx.x < FN_D) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < kRows; ++w) v += sR[w][threadIdx.x];
+                part[(size_t)blockIdx.x * (J * FN_D) + i * FN_D + threadIdx.x] = v;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void k_colsum(const float* __restrict__ part, int n_rows, int cols, float* __restrict__ out, int ld, int off) {
+    // one wave per 64 columns x all rows would be enough; rows <= FN_MAX_PART so a 4-way split + LDS combine
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < cols)
+        for (int r = grp; r < n_rows; r += 4) acc += part[(size_t)r * cols + c];
+    red[grp][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (grp == 0 && c < cols)
+        out[(c / FN_D) * ld + off + (c % FN_D)] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// =====================================================================================
+// Segment sum / gather / segment softmax (the torch-scatter operator surface)
+// =====================================================================================
+__global__ __launch_bounds__(kBlock) void k_segment_sum128(const float* __restrict__ src, int64_t src_ld,
+                                                           const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ perm, int32_t pos_base,
+                                                           float* __restrict__ out, int64_t n_seg) {
+    const int lane = threadIdx.x & 31;
+    for (int64_t s = (int64_t)blockIdx.x * kRows + (threadIdx.x >> 5); s < n_seg; s += (int64_t)gridDim.x * kRows) {
+        const int beg = rowptr[s] - pos_base, deg = rowptr[s + 1] - rowptr[s];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+
+        for (int i = 0; i < deg; ++i) {
+            const float4 v = ld4(src + (size_t)perm[beg + i] * src_ld + lane * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        st4(out + s * FN_D + lane * 4, acc);
+    }
+}
+
+__global__ void k_segment_sum_any(const float* __restrict__ src, int64_t src_ld, const int32_t* __restrict__ rowptr,
+                                  const int32_t* __restrict__ perm, int32_t pos_base, float* __restrict__ out,
+                                  int64_t n_seg, int64_t width) {
+    const int64_t total = n_seg * width;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / width, c = i % width;
+        const int beg = rowptr[s] - pos_base, deg = rowptr[s + 1] - rowptr[s];
+        float acc = 0.f;
+        for (int k = 0; k < deg; ++k) acc += src[(size_t)perm[beg + k] * src_ld + c];
+        out[i] = acc;
+    }
+}
+
+__global__ void k_gather_rows4(const float* __restrict__ table, const int64_t* __restrict__ index,
+                               float* __restrict__ out, int64_t rows, int64_t w4) {
+    const int64_t total = rows * w4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / w4, c = i % w4;
+        st4(out + i * 4, ld4(table + ((size_t)index[r] * w4 + c) * 4));
+    }
+}
+
+__global__ void k_gather_rows1(const float* __restrict__ table, const int64_t* __restrict__ index,
+                               float* __restrict__ out, int64_t rows, int64_t width) {
+    const int64_t total = rows * width;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = table[(size_t)index[i / width] * width + (i % width)];
+}
+
+__global__ void k_segment_softmax(const float* __restrict__ logits, const int32_t* __restrict__ rowptr,
+                                  const int32_t* __restrict__ perm, int32_t pos_base, float* __restrict__ probs,
+                                  int64_t n_seg, int64_t width) {
+    const int64_t total = n_seg * width;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / width, c = i % width;
+        const int beg = rowptr[s] - pos_base, deg = rowptr[s + 1] - rowptr[s];
+        float mx = -INFINITY;
+        for (int k = 0; k < deg; ++k) mx = fmaxf(mx, logits[(size_t)perm[beg + k] * width + c]);
+        float den = 0.f;
+        for (int k = 0; k < deg; ++k) den += expf(logits[(size_t)perm[beg + k] * width + c] - mx);
+        for (int k = 0; k < deg; ++k) {
+            const size_t o = (size_t)perm[beg + k] * width + c;
+            probs[o] = expf(logits[o] - mx) / den;
+        }
+    }
+}
+
+__global__ void k_segment_softmax_bwd(const float* __restrict__ probs, const float* __restrict__ g_probs,
+                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm,
+                                      int32_t pos_base, float* __restrict__ g_logits, int64_t n_seg, int64_t width) {
+    const int64_t total = n_seg * width;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / width, c = i % width;
+        const int beg = rowptr[s] - pos_base, deg = rowptr[s + 1] - rowptr[s];
+        float dot = 0.f;
+        for (int k = 0; k < deg; ++k) {
+            const size_t o = (size_t)perm[beg + k] * width + c;
+            dot = fmaf(probs[o], g_probs[o], dot);
+        }
+        for (int k = 0; k < deg; ++k) {
+            const size_t o = (size_t)perm[beg + k] * width + c;
+            g_logits[o] = probs[o] * (g_probs[o] - dot);
+        }
+    }
+}
+
+// =====================================================================================
+// dropout + ReLU epilogue (Philox-4x32-10)
+// =====================================================================================
+__device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t seed) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+__device__ __forceinline__ float keep_scale(uint32_t bits, float p, float inv_keep) {
+    const float u = (float)(bits >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? inv_keep : 0.f;
+}
+
+template <bool BWD>
+__global__ void k_dropout_act(const float* __restrict__ a, const float* __restrict__ y_saved, float* __restrict__ o,
+                              int64_t numel, float p, uint64_t seed, uint64_t offset, int relu) {
+    const int64_t n4 = (numel + 3) / 4;
+    const float inv_keep = p < 1.f ? 1.f / (1.f - p) : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float m[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p > 0.f) {
+            const uint4 r = philox4x32_10(offset + (uint64_t)i, seed);
+            m[0] = keep_scale(r.x, p, inv_keep); m[1] = keep_scale(r.y, p, inv_keep);
+            m[2] = keep_scale(r.z, p, inv_keep); m[3] = keep_scale(r.w, p, inv_keep);
+        }
+        const int64_t e0 = i * 4;
+        if (e0 + 3 < numel) {
+            const float4 v = ld4(a + e0);
+            float4 res;
+            if (!BWD) {
+                res = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
+                if (relu) { res.x = fmaxf(res.x, 0.f); res.y = fmaxf(res.y, 0.f); res.z = fmaxf(res.z, 0.f); res.w = fmaxf(res.w, 0.f); }
+            } else {
+                const float4 ys = relu ? ld4(y_saved + e0) : make_float4(1.f, 1.f, 1.f, 1.f);
+                res = make_float4(ys.x > 0.f || !relu ? v.x * m[0] : 0.f, ys.y > 0.f || !relu ? v.y * m[1] : 0.f,
+                                  ys.z > 0.f || !relu ? v.z * m[2] : 0.f, ys.w > 0.f || !relu ? v.w * m[3] : 0.f);
+            }
+            st4(o + e0, res);
+        } else {
+            for (int q = 0; q < 4 && e0 + q < numel; ++q) {
+                float v = a[e0 + q] * m[q];
+                if (!BWD) { if (relu) v = fmaxf(v, 0.f); }
+                else if (relu && !(y_saved[e0 + q] > 0.f)) v = 0.f;
+                o[e0 + q] = v;
+            }
+        }
+    }
+}
+
+__global__ void k_edge_concat(const float* __restrict__ x, const float* __restrict__ e_attr,
+                              const int64_t* __restrict__ edge_index, float* __restrict__ out, int64_t E) {
+    const int64_t total = E * 96;     // float4 slots per row: 3 x 32
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i / 96;
+        const int q = (int)(i % 96);
+        float4 v;
+        if (q < 32) v = ld4(x + (size_t)edge_index[e] * FN_D + q * 4);
+        else if (q < 64) v = ld4(x + (size_t)edge_index[E + e] * FN_D + (q - 32) * 4);
+        else v = ld4(e_attr + (size_t)e * FN_D + (q - 64) * 4);
+        st4(out + i * 4, v);
+    }
+}
+
+#define FN_DISPATCH_H(heads, CALL)                         \
+    switch (heads) {                                       \
+        case 1: { constexpr int HH = 1; CALL; } break;     \
+        case 2: { constexpr int HH = 2; CALL; } break;     \
+        case 4: { constexpr int HH = 4; CALL; } break;     \
+        case 8: { constexpr int HH = 8; CALL; } break;     \
+        default: return fail(FN_EUNSUPPORTED, "heads must be 1, 2, 4 or 8 (128 = heads * head_dim)"); \
+    }
+
+bool bad_edge_term(const fn_edge_term* et) {
+    if (!et) return true;
+    if (et->mode == 0) return false;
+    if (et->mode != 2) return true;
+    return et->K < 1 || et->K > FN_MAX_EDGE_K || et->d_e < 1 || et->d_e > 128 || !et->x || !et->embW || !et->embb;
+}
+
+}  // namespace
+
+// =====================================================================================
+// C-ABI
+// =====================================================================================
+extern "C" {
+
+int fn_abi_version(void) { return FN_ABI_VERSION; }
+const char* fn_last_error(void) { return tl_err; }
+
+int fn_plan_layout(fn_csr_task* tasks, int n_tasks, int64_t* total_items, int64_t* total_segs) {
+    if (!tasks || n_tasks < 0 || !total_items || !total_segs) return fail(FN_EINVAL, "fn_plan_layout: null argument");
+    if (n_tasks > FN_MAX_TASKS) return fail(FN_ETOOMANY, "fn_plan_layout: more than FN_MAX_TASKS tasks");
+    int64_t items = 0, segs = 0;
+    for (int i = 0; i < n_tasks; ++i) {
+        fn_csr_task& t = tasks[i];
+        if (t.n_real < 0 || t.n_loops < 0 || t.n_seg < 0) return fail(FN_EINVAL, "fn_plan_layout: negative size");
+        if (t.role != FN_ROLE_PLAIN && (t.partner < 0 || t.partner >= n_tasks)) return fail(FN_EINVAL, "fn_plan_layout: bad partner");
+        t.item_base = items;
+        t.seg_base = segs;
+        items += t.n_real + t.n_loops;
+        segs += t.n_seg;
+    }
+    if (items >= (1ll << 31) - 1 || segs >= (1ll << 31) - 1) return fail(FN_EINVAL, "fn_plan_layout: plan exceeds int32 positions");
+    *total_items = items;
+    *total_segs = segs;
+    return 0;
+}
+
+int fn_plan_build(const fn_csr_task* tasks, int n_tasks, int32_t* rowptr_all, int32_t* perm_all, int32_t* aux_a,
+                  int32_t* aux_b, int32_t* ws_i32, fn_stream_t stream) {
+    if (!tasks || n_tasks < 1 || !rowptr_all || !perm_all || !aux_a || !aux_b || !ws_i32)
+        return fail(FN_EINVAL, "fn_plan_build: null argument");
+    if (n_tasks > FN_MAX_TASKS) return fail(FN_ETOOMANY, "fn_plan_build: more than FN_MAX_TASKS tasks");
+    PlanTasks P;
+    P.n = n_tasks;
+    int64_t items = 0, segs = 0;
+    bool any_pair = false;
+    for (int i = 0; i < n_tasks; ++i) {
+        P.t[i] = tasks[i];
+        if (tasks[i].item_base != items || tasks[i].seg_base != segs) return fail(FN_EINVAL, "fn_plan_build: run fn_plan_layout first");
+        if (tasks[i].n_real > 0 && !tasks[i].key) return fail(FN_EINVAL, "fn_plan_build: null key");
+        if (tasks[i].role != FN_ROLE_PLAIN) {
+            any_pair = true;
+            if (tasks[i].n_real > 0 && !tasks[i].other_key) return fail(FN_EINVAL, "fn_plan_build: null other_key");
+        }
+        items += tasks[i].n_real + tasks[i].n_loops;
+        segs += tasks[i].n_seg;
+    }
+    P.total_items = items;
+    P.total_segs = segs;
+    hipStream_t st = S(stream);
+    int32_t* cursor = ws_i32;
+    int32_t* inv = ws_i32 + segs;
+    int32_t* status = ws_i32 + segs + items;
+    hipError_t e = hipMemsetAsync(rowptr_all, 0, (size_t)(segs + 1) * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(ws_i32, 0, (size_t)(segs + items + 4) * 4, st);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail((int)e, "fn_plan_build: memset failed"); }
+    if (items > 0) {
+        const int g = flat_grid(items, kGridCap);
+        hipLaunchKernelGGL(k_plan_hist, dim3(g), dim3(kBlock), 0, st, P, rowptr_all, status);
+        hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, rowptr_all + 1, segs);
+        hipLaunchKernelGGL(k_plan_fill, dim3(g), dim3(kBlock), 0, st, P, rowptr_all, cursor, perm_all);
+        hipLaunchKernelGGL(k_plan_segsort, dim3(flat_grid(segs, kGridCap)), dim3(kBlock), 0, st, rowptr_all, perm_all, segs);
+        if (any_pair) {
+            hipLaunchKernelGGL(k_plan_aux<FN_ROLE_DST>, dim3(g), dim3(kBlock), 0, st, P, perm_all, aux_a, aux_b, inv);
+            hipLaunchKernelGGL(k_plan_aux<FN_ROLE_SRC>, dim3(g), dim3(kBlock), 0, st, P, perm_all, aux_a, aux_b, inv);
+        }
+    }
+    return launch_status("fn_plan_build");
+}
+
+int fn_node_scalars_f32(const float* h, const float* att, int att_w, int dst_off, int src_off, float* s_dst,
+                        float* s_src, int64_t n, int heads, fn_stream_t stream) {
+    if (!h || !att || !s_dst || !s_src || n < 0) return fail(FN_EINVAL, "fn_node_scalars_f32: bad argument");
+    if ((att_w | dst_off | src_off) & 3) return fail(FN_EINVAL, "fn_node_scalars_f32: att blocks must be 16-byte aligned");
+    if (n == 0) return 0;
+    FN_DISPATCH_H(heads, hipLaunchKernelGGL(k_node_scalars<HH>, dim3(row_grid(n, kGridCap)), dim3(kBlock), 0, S(stream),
+                                            h, att, att_w, dst_off, src_off, s_dst, s_src, n));
+    return launch_status("fn_node_scalars_f32");
+}
+
+int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const float* att, int att_w,
+                   const fn_edge_term* et, const fn_gat_plan* plan, float neg_slope, float* out, float* p_sorted,
+                   float* probs_orig, int heads, fn_stream_t stream) {
+    if (!h || !s_dst || !s_src || !att || !plan || !out || bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_fwd_f32: bad argument");
+    if (plan->m > 0 && !p_sorted) return fail(FN_EINVAL, "fn_gat_fwd_f32: null p_sorted");
+    if (et->mode == 0 && plan->m_real > 0 && !et->s_edge) return fail(FN_EINVAL, "fn_gat_fwd_f32: null s_edge");
+    if (plan->n == 0) return 0;
+    FN_DISPATCH_H(heads, hipLaunchKernelGGL(k_gat_fwd<HH>, dim3(row_grid(plan->n, 8 * kGridCap)), dim3(kBlock), 0, S(stream),
+                                            h, s_dst, s_src, att, att_w, *et, *plan, neg_slope, out, p_sorted, probs_orig));
+    return launch_status("fn_gat_fwd_f32");
+}
+
+int fn_gat_bwd_dst_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et,
+                       const fn_gat_plan* plan, float neg_slope, float* dz_sorted, float* g_s_dst, float* g_s_edge,
+                       float* part_e, int* n_part_e, int heads, fn_stream_t stream) {
+    if (!g_out || !h || !plan || !g_s_dst || !n_part_e || bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: bad argument");
+    if (plan->m > 0 && (!p_sorted || !dz_sorted)) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: null edge buffer");
+    if (et->mode == 0 && plan->m_real > 0 && !g_s_edge) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: null g_s_edge");
+    if (et->mode == 2 && !part_e) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: null part_e");
+    *n_part_e = 0;
+    if (plan->n == 0) return 0;
+    const int g = row_grid(plan->n, FN_MAX_PART);
+    *n_part_e = (et->mode == 2) ? g : 0;
+    FN_DISPATCH_H(heads, hipLaunchKernelGGL(k_gat_bwd_dst<HH>, dim3(g), dim3(kBlock), 0, S(stream), g_out, h, p_sorted, *et,
+                                            *plan, neg_slope, dz_sorted, g_s_dst, g_s_edge, part_e));
+    return launch_status("fn_gat_bwd_dst_f32");
+}
+
+int fn_gat_bwd_src_f32(const float* g_out, const float* h, const float* p_sorted, const float* dz_sorted,
+                       const float* g_s_dst, const float* att, int att_w, int dst_off, int src_off,
+                       const fn_gat_plan* plan, float* g_h, float* part_a, int* n_part_a, int heads, fn_stream_t stream) {
+    if (!g_out || !h || !g_s_dst || !att || !plan || !g_h || !part_a || !n_part_a) return fail(FN_EINVAL, "fn_gat_bwd_src_f32: bad argument");
+    if (plan->m > 0 && (!p_sorted || !dz_sorted)) return fail(FN_EINVAL, "fn_gat_bwd_src_f32: null edge buffer");
+    if ((att_w | dst_off | src_off) & 3) return fail(FN_EINVAL, "fn_gat_bwd_src_f32: att blocks must be 16-byte aligned");
+    *n_part_a = 0;
+    if (plan->n == 0) return 0;
+    const int g = row_grid(plan->n, FN_MAX_PART);
+    *n_part_a = g;
+    FN_DISPATCH_H(heads, hipLaunchKernelGGL(k_gat_bwd_src<HH>, dim3(g), dim3(kBlock), 0, S(stream), g_out, h, p_sorted,
+                                            dz_sorted, g_s_dst, att, att_w, dst_off, src_off, *plan, g_h, part_a));
+    return launch_status("fn_gat_bwd_src_f32");
+}
+
+int fn_gat_bwd_finalize_f32(const float* part_a, int n_part_a, const float* part_e, int n_part_e, const fn_edge_term* et,
+                            const float* att, int att_w, int dst_off, int src_off, float* g_att, float* g_embW,
+                            float* g_embb, int heads, fn_stream_t stream) {
+    if (!part_a || n_part_a < 0 || n_part_e < 0 || !att || !g_att || bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_bwd_finalize_f32: bad argument");
+    if (et->mode == 2 && (!part_e || !g_embW || !g_embb)) return fail(FN_EINVAL, "fn_gat_bwd_finalize_f32: null mode-2 buffer");
+    if (heads != 1 && heads != 2 && heads != 4 && heads != 8) return fail(FN_EUNSUPPORTED, "heads must be 1, 2, 4 or 8");
+    hipLaunchKernelGGL(k_gat_finalize, dim3(1), dim3(1024), 0, S(stream), part_a, n_part_a, part_e, n_part_e, *et, att,
+                       att_w, dst_off, src_off, g_att, g_embW, g_embb, heads);
+    return launch_status("fn_gat_bwd_finalize_f32");
+}
+
+int fn_attn_by_src_f32(const float* p_sorted, const fn_gat_plan* plan, float* attn, int heads, fn_stream_t stream) {
+    if (!plan || !attn || (plan->m > 0 && !p_sorted)) return fail(FN_EINVAL, "fn_attn_by_src_f32: bad argument");
+    if (plan->n == 0) return 0;
+    FN_DISPATCH_H(heads, hipLaunchKernelGGL(k_attn_by_src<HH>, dim3(flat_grid(plan->n * heads, kGridCap)), dim3(kBlock), 0,
+                                            S(stream), p_sorted, *plan, attn));
+    return launch_status("fn_attn_by_src_f32");
+}
+
+int fn_row_dots_f32(const float* x, const float* A, int lda, int off, int J, float* s, int64_t rows, fn_stream_t stream) {
+    if (!x || !A || !s || rows < 0 || J < 1 || J > 8 || ((lda | off) & 3)) return fail(FN_EINVAL, "fn_row_dots_f32: bad argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(k_row_dots, dim3(row_grid(rows, kGridCap)), dim3(kBlock), 0, S(stream), x, A, lda, off, J, s, rows);
+    return launch_status("fn_row_dots_f32");
+}
+
+int fn_row_dots_bwd_f32(const float* g_s, const float* x, const float* A, int lda, int off, int J, float* g_x,
+                        float* part, int* n_part, int64_t rows, fn_stream_t stream) {
+    if (!g_s || !x || !A || !g_x || !part || !n_part || rows < 0 || J < 1 || J > 8 || ((lda | off) & 3))
+        return fail(FN_EINVAL, "fn_row_dots_bwd_f32: bad argument");
+    const int g = row_grid(rows, FN_MAX_PART);
+    *n_part = g;
+    hipLaunchKernelGGL(k_row_dots_bwd, dim3(g), dim3(kBlock), 0, S(stream), g_s, x, A, lda, off, J, g_x, part, rows);
+    return launch_status("fn_row_dots_bwd_f32");
+}
+
+int fn_colsum_f32(const float* part, int n_rows, int cols, float* out, int ld, int off, fn_stream_t stream) {
+    if (!part || !out || n_rows < 0 || cols < 1) return fail(FN_EINVAL, "fn_colsum_f32: bad argument");
+    hipLaunchKernelGGL(k_colsum, dim3((cols + 63) / 64), dim3(kBlock), 0, S(stream), part, n_rows, cols, out, ld, off);
+    return launch_status("fn_colsum_f32");
+}
+
+int fn_segment_sum_f32(const float* src, int64_t src_ld, const int32_t* rowptr, const int32_t* perm, int32_t pos_base,
+                       float* out, int64_t n_seg, int64_t width, fn_stream_t stream) {
+    if (!rowptr || !out || n_seg < 0 || width < 1 || src_ld < width) return fail(FN_EINVAL, "fn_segment_sum_f32: bad argument");
+    if (n_seg == 0) return 0;
+    if (!src || !perm) return fail(FN_EINVAL, "fn_segment_sum_f32: null src/perm");
+    if (width == FN_D && (src_ld & 3) == 0 && (((uintptr_t)src | (uintptr_t)out) & 15) == 0)
+        hipLaunchKernelGGL(k_segment_sum128, dim3(row_grid(n_seg, kGridCap)), dim3(kBlock), 0, S(stream), src, src_ld, rowptr,
+                           perm, pos_base, out, n_seg);
+    else
+        hipLaunchKernelGGL(k_segment_sum_any, dim3(flat_grid(n_seg * width, kGridCap)), dim3(kBlock), 0, S(stream), src, src_ld,
+                           rowptr, perm, pos_base, out, n_seg, width);
+    return launch_status("fn_segment_sum_f32");
+}
+
+int fn_gather_rows_f32(const float* table, const int64_t* index, float* out, int64_t rows, int64_t width, fn_stream_t stream) {
+    if (rows < 0 || width < 1 || !out) return fail(FN_EINVAL, "fn_gather_rows_f32: bad argument");
+    if (rows == 0) return 0;
+    if (!table || !index) return fail(FN_EINVAL, "fn_gather_rows_f32: null table/index");
+    if ((width & 3) == 0 && (((uintptr_t)table | (uintptr_t)out) & 15) == 0)
+        hipLaunchKernelGGL(k_gather_rows4, dim3(flat_grid(rows * (width / 4), kGridCap)), dim3(kBlock), 0, S(stream), table, index,
+                           out, rows, width / 4);
+    else
+        hipLaunchKernelGGL(k_gather_rows1, dim3(flat_grid(rows * width, kGridCap)), dim3(kBlock), 0, S(stream), table, index, out,
+                           rows, width);
+    return launch_status("fn_gather_rows_f32");
+}
+
+int fn_segment_softmax_f32(const float* logits, const int32_t* rowptr, const int32_t* perm, int32_t pos_base, float* probs,
+                           int64_t n_seg, int64_t width, fn_stream_t stream) {
+    if (!rowptr || n_seg < 0 || width < 1) return fail(FN_EINVAL, "fn_segment_softmax_f32: bad argument");
+    if (n_seg == 0) return 0;
+    if (!logits || !perm || !probs) return fail(FN_EINVAL, "fn_segment_softmax_f32: null buffer");
+    hipLaunchKernelGGL(k_segment_softmax, dim3(flat_grid(n_seg * width, kGridCap)), dim3(kBlock), 0, S(stream), logits, rowptr,
+                       perm, pos_base, probs, n_seg, width);
+    return launch_status("fn_segment_softmax_f32");
+}
+
+int fn_segment_softmax_bwd_f32(const float* probs, const float* g_probs, const int32_t* rowptr, const int32_t* perm,
+                               int32_t pos_base, float* g_logits, int64_t n_seg, int64_t width, fn_stream_t stream) {
+    if (!rowptr || n_seg < 0 || width < 1) return fail(FN_EINVAL, "fn_segment_softmax_bwd_f32: bad argument");
+    if (n_seg == 0) return 0;
+    if (!probs || !g_probs || !perm || !g_logits) return fail(FN_EINVAL, "fn_segment_softmax_bwd_f32: null buffer");
+    hipLaunchKernelGGL(k_segment_softmax_bwd, dim3(flat_grid(n_seg * width, kGridCap)), dim3(kBlock), 0, S(stream), probs,
+                       g_probs, rowptr, perm, pos_base, g_logits, n_seg, width);
+    return launch_status("fn_segment_softmax_bwd_f32");
+}
+
+int fn_dropout_act_f32(const float* x, float* y, int64_t numel, float p, uint64_t seed, uint64_t offset, int relu,
+                       fn_stream_t stream) {
+    if (numel < 0 || p < 0.f || p > 1.f) return fail(FN_EINVAL, "fn_dropout_act_f32: bad argument");
+    if (numel == 0) return 0;
+    if (!x || !y || (((uintptr_t)x | (uintptr_t)y) & 15)) return fail(FN_EINVAL, "fn_dropout_act_f32: null or misaligned buffer");
+    hipLaunchKernelGGL(k_dropout_act<false>, dim3(flat_grid((numel + 3) / 4, kGridCap)), dim3(kBlock), 0, S(stream), x,
+                       (const float*)nullptr, y, numel, p, seed, offset, relu);
+    return launch_status("fn_dropout_act_f32");
+}
+
+int fn_dropout_act_bwd_f32(const float* g_y, const float* y, float* g_x, int64_t numel, float p, uint64_t seed,
+                           uint64_t offset, int relu, fn_stream_t stream) {
+    if (numel < 0 || p < 0.f || p > 1.f) return fail(FN_EINVAL, "fn_dropout_act_bwd_f32: bad argument");
+    if (numel == 0) return 0;
+    if (!g_y || !g_x || (relu && !y) || (((uintptr_t)g_y | (uintptr_t)g_x | (uintptr_t)y) & 15))
+        return fail(FN_EINVAL, "fn_dropout_act_bwd_f32: null or misaligned buffer");
+    hipLaunchKernelGGL(k_dropout_act<true>, dim3(flat_grid((numel + 3) / 4, kGridCap)), dim3(kBlock), 0, S(stream), g_y, y, g_x,
+                       numel, p, seed, offset, relu);
+    return launch_status("fn_dropout_act_bwd_f32");
+}
+
+int fn_edge_concat_f32(const float* x, const float* e_attr, const int64_t* edge_index, float* out, int64_t E,
+                       fn_stream_t stream) {
+    if (E < 0) return fail(FN_EINVAL, "fn_edge_concat_f32: bad argument");
+    if (E == 0) return 0;
+    if (!x || !e_attr || !edge_index || !out) return fail(FN_EINVAL, "fn_edge_concat_f32: null buffer");
+    hipLaunchKernelGGL(k_edge_concat, dim3(flat_grid(E * 96, kGridCap)), dim3(kBlock), 0, S(stream), x, e_attr, edge_index, out, E);
+    return launch_status("fn_edge_concat_f32");
+}
+
+}  // extern "C"

@@ -1,0 +1,345 @@
+"""FragNet's four-level message-passing stack on the MI355X kernels.
+
+Module API, constructor signatures, parameter names and construction order (= RNG order = state-dict
+order) are the reference's, so the same seed gives the same weights and reference checkpoints load:
+  FragNetLayerA    fragnet/model/gat/gat2.py:40-330
+  FragNet          fragnet/model/gat/gat2.py:333-442
+  FTHead1..5       fragnet/model/gat/gat2.py:569-751
+  FragNetFineTune  fragnet/model/gat/gat2.py:758-826
+  PretrainTask     fragnet/model/gat/pretrain_heads.py:8-102
+  FragNetPreTrain  fragnet/model/gat/pretrain_heads.py:105-141 (twin: gat2_pretrain.py:7-27)
+
+``forward`` is not the reference's op list.  Each attention level is the decomposed form of SURVEY.md
+§3.3 -- two scalars per node and head, one scalar per edge and head, a destination-sorted segmented
+softmax-aggregate -- run by libfragnet_hip.so (fragnet_amd/ops.py); no [E, H, 3d] message tensor exists.
+Dense projections and MLP heads are library GEMMs (torch.nn.functional.linear -> rocBLAS/hipBLASLt).
+The parameters the reference constructs but never reads are constructed too and stay
+without gradient, exactly as there.  GPU tensors only: there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .plan import plan_for
+
+_ACTS = {
+    "relu": nn.ReLU, "silu": nn.SiLU, "gelu": nn.GELU, "celu": nn.CELU, "selu": nn.SELU,
+    "rrelu": nn.RReLU, "relu6": nn.ReLU6, "prelu": nn.PReLU, "leakyrelu": nn.LeakyReLU,
+}
+
+
+_LAYER_PLANS = {}      # tiny cache for direct layer calls: index-tensor identity -> GraphPlan
+
+
+def _plan_from_indices(N, E, F_, EF, edge_index, frag_index, a2f, eib, eifb):
+    from .plan import GraphPlan
+    key = tuple((t.data_ptr(), tuple(t.shape), t._version) for t in (edge_index, frag_index, a2f, eib, eifb))
+    plan = _LAYER_PLANS.get(key)
+    if plan is None:
+        if len(_LAYER_PLANS) >= 4:
+            _LAYER_PLANS.clear()
+        plan = GraphPlan([
+            dict(kind="gat", name="bond", dst=eib[0], src=eib[1], n=E, n_loops=0),
+            dict(kind="gat", name="atom", dst=edge_index[1], src=edge_index[0], n=N, n_loops=N),
+            dict(kind="gat", name="fbond", dst=eifb[0], src=eifb[1], n=EF, n_loops=0),
+            dict(kind="gat", name="frag", dst=frag_index[1], src=frag_index[0], n=F_, n_loops=0),
+            dict(kind="seg", name="a2f", key=a2f, n_seg=F_),
+        ], edge_index.device)
+        _LAYER_PLANS[key] = plan
+    return plan
+
+
+def _two_layer(width: int) -> nn.Sequential:
+    return nn.Sequential(nn.Linear(width, 2 * width), nn.ReLU(), nn.Linear(2 * width, width))
+
+
+class FragNetLayerA(nn.Module):
+    def __init__(self, atom_in=128, atom_out=128, frag_in=128, frag_out=128, edge_in=128, edge_out=128,
+                 fedge_in=128, num_heads=2, bond_edge_in=1, fbond_edge_in=8, return_attentions=False,
+                 add_frag_self_loops=False, bond_mask=None, frag_bond_mask=None, atom_mask_individual=None):
+        super().__init__()
+        if atom_out != 128 or edge_out != 128:
+            raise ValueError("the gfx950 kernels are specialised for emb_dim = 128 (every reference config)")
+        if num_heads not in (1, 2, 4, 8):
+            raise ValueError("num_heads must be 1, 2, 4 or 8")
+        self.add_frag_self_loops = add_frag_self_loops
+        self.return_attentions = return_attentions
+        self.edge_out = edge_out
+        self.num_heads = num_heads
+        # constructed-but-unused block (kept for RNG order and checkpoint compatibility)
+        self.atom_embed = nn.Linear(atom_in, atom_out)
+        self.frag_embed = nn.Linear(frag_in, frag_out)
+        self.edge_embed = nn.Linear(edge_in, edge_out)
+        self.bond_edge_embed = nn.Linear(edge_in, edge_out)
+        self.frag_message_mlp = nn.Linear(atom_out * 2, atom_out)
+        self.atom_mlp = _two_layer(atom_out)
+        self.frag_mlp = _two_layer(atom_out)
+        self.bias = nn.Parameter(torch.zeros(atom_out))      # reference: uninitialised, never read
+        self.leakyrelu = nn.LeakyReLU(0.2)
+        self.edge_attr_bond_embed2 = nn.Linear(edge_out, edge_out)
+        # live block
+        d = edge_out // num_heads
+        self.projection_b = nn.Linear(edge_in, d * num_heads)
+        self.projection_fb = nn.Linear(fedge_in, d * num_heads)
+        self.edge_attr_bond_embed = nn.Linear(bond_edge_in, d)
+        self.edge_attr_fbond_embed = nn.Linear(fbond_edge_in, d)
+        self.projection_a = nn.Linear(atom_in, (atom_out // num_heads) * num_heads)
+        self.a_b = nn.Parameter(torch.empty(num_heads, 3 * d))
+        self.a = nn.Parameter(torch.empty(num_heads, 2 * d + edge_out))
+        self.f = nn.Parameter(torch.empty(num_heads, 2 * d + edge_out))
+        self.f_a_b = nn.Parameter(torch.empty(num_heads, 3 * d))
+        for w in (self.projection_b.weight, self.a_b, self.a, self.f, self.f_a_b):
+            nn.init.xavier_uniform_(w.data, gain=1.414)
+        self.bond_mask = bond_mask
+        self.frag_bond_mask = frag_bond_mask
+        self.atom_mask_individual = atom_mask_individual
+
+    def forward(self, x_atoms, edge_index, edge_attr, frag_index, x_frags, atom_to_frag_ids,
+                node_feautures_bond_graph, edge_index_bonds_graph, edge_attr_bond_graph,
+                node_feautures_fbond_graph, edge_index_fbond_graph, edge_attr_fbond_graph):
+        """The reference's 12-argument layer signature (gat2.py:121-135).  ``edge_attr`` and ``x_frags`` are
+        accepted and ignored, as they are overwritten before use there (gat2.py:183, 234)."""
+        plan = _plan_from_indices(x_atoms.shape[0], node_feautures_bond_graph.shape[0], x_frags.shape[0],
+                                  node_feautures_fbond_graph.shape[0], edge_index, frag_index, atom_to_frag_ids,
+                                  edge_index_bonds_graph, edge_index_fbond_graph)
+        return self.run(x_atoms, node_feautures_bond_graph, node_feautures_fbond_graph, edge_attr_bond_graph,
+                        edge_attr_fbond_graph, plan)
+
+    def run(self, x_atoms, bond_nodes, fbond_nodes, bond_cos, fbond_attr, plan):
+        """x_atoms [N, atom_in]; bond_nodes [E, edge_in]; fbond_nodes [EF, fedge_in];
+        bond_cos [Eb, 1]; fbond_attr [EFB, fbond_edge_in]; plan: GraphPlan of the batch."""
+        H, d = self.num_heads, self.edge_out // self.num_heads
+        want = self.return_attentions
+        L = plan.levels
+
+        # L1 bond graph (gat2.py:137-169): affine-in-cos edge term folded in-kernel
+        r = ops.gat_level(F.linear(bond_nodes, self.projection_b.weight, self.projection_b.bias), self.a_b, L["bond"], H,
+                          x=bond_cos, embW=self.edge_attr_bond_embed.weight, embb=self.edge_attr_bond_embed.bias,
+                          want_probs=want)
+        new_bond, p_bond = (r[0], r[2]) if want else (r, None)
+        if self.bond_mask is not None:
+            with torch.no_grad():
+                new_bond[self.bond_mask:self.bond_mask + 2, :] = 0.0
+
+        # L2 atom graph with self loops (gat2.py:179-224): edge term = <new_bond[e], a[:, d:d+128]>, 0 on loops
+        s_edge = ops.row_dots(new_bond, self.a, d)
+        r = ops.gat_level(F.linear(x_atoms, self.projection_a.weight, self.projection_a.bias), self.a, L["atom"], H,
+                          s_edge=s_edge, want_probs=want)
+        atoms_new, p_atom = (r[0], r[2]) if want else (r, None)
+        if self.atom_mask_individual is not None:
+            with torch.no_grad():
+                atoms_new[self.atom_mask_individual, :] = 0.0
+
+        # L3 atom -> fragment sum (gat2.py:234)
+        frags = ops.segment_sum(atoms_new, plan.segs["a2f"], plan)
+
+        # L4a fragment-bond graph (gat2.py:239-272)
+        r = ops.gat_level(F.linear(fbond_nodes, self.projection_fb.weight, self.projection_fb.bias), self.f_a_b,
+                          L["fbond"], H, x=fbond_attr, embW=self.edge_attr_fbond_embed.weight,
+                          embb=self.edge_attr_fbond_embed.bias, want_probs=want)
+        new_fbond, p_fbond = (r[0], r[2]) if want else (r, None)
+        if self.frag_bond_mask is not None:
+            with torch.no_grad():
+                new_fbond[2 * self.frag_bond_mask, :] = 0.0
+                new_fbond[2 * self.frag_bond_mask + 1, :] = 0.0
+
+        # L4b fragment graph on the raw fragment sums (gat2.py:283-316)
+        s_edge_f = ops.row_dots(new_fbond, self.f, d)
+        r = ops.gat_level(frags, self.f, L["frag"], H, s_edge=s_edge_f, want_probs=want)
+        frags_new, p_frag = (r[0], r[2]) if want else (r, None)
+
+        if want:
+            return (atoms_new, frags_new, new_bond, new_fbond,
+                    ops.attn_by_src(p_atom, L["atom"], H), ops.attn_by_src(p_frag, L["frag"], H),
+                    ops.attn_by_src(p_bond, L["bond"], H), ops.attn_by_src(p_fbond, L["fbond"], H))
+        return atoms_new, frags_new, new_bond, new_fbond
+
+
+class FragNet(nn.Module):
+    def __init__(self, num_layer, drop_ratio=0.2, emb_dim=128, atom_features=167, frag_features=167,
+                 edge_features=17, fedge_in=6, fbond_edge_in=6, num_heads=4):
+        super().__init__()
+        self.num_layer = num_layer
+        self.dropout = nn.Dropout(p=drop_ratio)
+        self.act = nn.ReLU()
+        self.layers = nn.ModuleList()
+        self.layers.append(FragNetLayerA(atom_in=atom_features, atom_out=emb_dim, frag_in=frag_features,
+                                         frag_out=emb_dim, edge_in=edge_features, fedge_in=fedge_in,
+                                         fbond_edge_in=fbond_edge_in, edge_out=emb_dim, num_heads=num_heads))
+        for _ in range(num_layer - 1):
+            self.layers.append(FragNetLayerA(atom_in=emb_dim, atom_out=emb_dim, frag_in=emb_dim, frag_out=emb_dim,
+                                             edge_in=emb_dim, edge_out=emb_dim, fedge_in=emb_dim,
+                                             fbond_edge_in=fbond_edge_in, num_heads=num_heads))
+        self.rng = ops.PhiloxStream()
+
+    def forward(self, batch):
+        plan = plan_for(batch)
+        p, train = self.dropout.p, self.training
+        x_atoms = ops.dropout_act(batch["x_atoms"], p, train, False, self.rng)
+        # batch["x_frags"] is dead in the reference too: every layer overwrites it with the atom->fragment
+        # sum before first use (gat2.py:234); its dropout mask is drawn and discarded there (gat2.py:397).
+        bond_nodes, fbond_nodes = batch["node_features_bonds"], batch["node_features_fbonds"]
+        x_frags = None
+        for layer in self.layers:
+            x_atoms, x_frags, bond_nodes, fbond_nodes = layer.run(
+                x_atoms, bond_nodes, fbond_nodes, batch["edge_attr_bonds"], batch["edge_attr_fbonds"], plan)[:4]
+            x_atoms = ops.dropout_act(x_atoms, p, train, True, self.rng)
+            x_frags = ops.dropout_act(x_frags, p, train, True, self.rng)
+            bond_nodes = ops.dropout_act(bond_nodes, p, train, True, self.rng)
+            fbond_nodes = ops.dropout_act(fbond_nodes, p, train, True, self.rng)
+        return x_atoms, x_frags, bond_nodes, fbond_nodes
+
+
+# ------------------------------------------------------------------------------------ heads
+class FTHead1(nn.Sequential):
+    def __init__(self, emb_dim=128, h1=128, drop_ratio=0.2, n_classes=1):
+        super().__init__()
+        self.lin1 = nn.Linear(emb_dim * 2, h1)
+        self.out = nn.Linear(h1, n_classes)
+        self.dropout = nn.Dropout(p=drop_ratio)
+        self.activation = nn.ReLU()
+
+    def forward(self, enc):
+        return self.out(self.dropout(self.activation(self.lin1(self.dropout(enc)))))
+
+
+class _PredictorStack(nn.Sequential):
+    """act(dropout(linear(x))) between layers, plain last layer -- gat2.py:631-637, 719-725, 745-751."""
+
+    def _run(self, enc):
+        for lin in self.predictor[:-1]:
+            enc = self.activation(self.dropout(lin(enc)))
+        return self.predictor[-1](enc)
+
+
+class FTHead5(_PredictorStack):
+    def __init__(self, input_dim=128, h1=128, h2=1024, h4=512, drop_ratio=0.2, n_classes=1, act="relu"):
+        super().__init__()
+        self.dropout = nn.Dropout(p=drop_ratio)
+        self.activation = _ACTS[act]()
+        self.hidden_dims = [h1, h2]
+        dims = [input_dim * 2] + self.hidden_dims + [n_classes]
+        self.predictor = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+
+    def forward(self, enc):
+        return self._run(enc)
+
+
+class FTHead4(nn.Module):
+    def __init__(self, input_dim=128, h1=128, act="relu", n_classes=1, drop_ratio=0.2):
+        super().__init__()
+        self.activation = _ACTS[act]()
+        self.dense = nn.Linear(input_dim * 2, h1)
+        self.dropout = nn.Dropout(p=drop_ratio)
+        self.out_proj = nn.Linear(h1, n_classes)
+
+    def forward(self, x):
+        return self.out_proj(self.dropout(self.activation(self.dense(self.dropout(x)))))
+
+
+class FTHead3(_PredictorStack):
+    def __init__(self, input_dim=128, h1=128, h2=1024, h3=1024, h4=512, drop_ratio=0.2, n_classes=1, act="relu"):
+        super().__init__()
+        self.dropout = nn.Dropout(p=drop_ratio)
+        self.activation = _ACTS[act]()
+        self.hidden_dims = [h1, h2, h3, h4]
+        dims = [input_dim * 2] + self.hidden_dims + [n_classes]
+        self.predictor = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+
+    def forward(self, enc):
+        return self._run(enc)
+
+
+class FTHead2(_PredictorStack):
+    def __init__(self, input_dim=128, h1=128, drop_ratio=0.2, n_classes=1):
+        super().__init__()
+        self.lin1 = nn.Linear(input_dim * 2, h1)
+        self.out = nn.Linear(h1, n_classes)
+        self.dropout = nn.Dropout(p=drop_ratio)
+        self.activation = nn.ReLU()
+        self.hidden_dims = [1024, 1024, 512]
+        dims = [input_dim * 2] + self.hidden_dims + [n_classes]
+        self.predictor = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+        self.dropout = nn.Dropout(p=0.1)
+
+    def forward(self, enc):
+        return self._run(enc)
+
+
+def pooled(x_atoms, x_frags, batch):
+    """cat(sum of atoms per molecule, sum of fragments per molecule) -- gat2.py:820-823."""
+    plan = plan_for(batch)
+    atoms = ops.segment_sum(x_atoms, plan.segs["mol_atoms"], plan)
+    frags = ops.segment_sum(x_frags, plan.segs["mol_frags"], plan)
+    return torch.cat((atoms, frags), 1)
+
+
+class FragNetFineTune(nn.Module):
+    def __init__(self, n_classes=1, atom_features=167, frag_features=167, edge_features=17, num_layer=4,
+                 num_heads=4, drop_ratio=0.15, h1=256, h2=256, h3=256, h4=256, act="celu", emb_dim=128,
+                 fthead="FTHead3"):
+        super().__init__()
+        self.pretrain = FragNet(num_layer=num_layer, drop_ratio=drop_ratio, num_heads=num_heads, emb_dim=emb_dim,
+                                atom_features=atom_features, frag_features=frag_features, edge_features=edge_features)
+        if fthead == "FTHead1":
+            self.fthead = FTHead1(n_classes=n_classes)
+        elif fthead == "FTHead2":
+            self.fthead = FTHead2(n_classes=n_classes)
+        elif fthead == "FTHead3":
+            self.fthead = FTHead3(n_classes=n_classes, input_dim=emb_dim, h1=h1, h2=h2, h3=h3, h4=h4,
+                                  drop_ratio=drop_ratio, act=act)
+        elif fthead == "FTHead4":
+            self.fthead = FTHead4(n_classes=n_classes, h1=h1, drop_ratio=drop_ratio, act=act)
+
+    def forward(self, batch):
+        x_atoms, x_frags, _, _ = self.pretrain(batch)
+        return self.fthead(pooled(x_atoms, x_frags, batch))
+
+
+class PretrainTask(nn.Module):
+    def __init__(self, dim_in=128, dim_out=1, L=2):
+        super().__init__()
+
+        def tower(width):
+            return nn.ModuleList([nn.Linear(width // 2 ** l, width // 2 ** (l + 1)) for l in range(L)]
+                                 + [nn.Linear(width // 2 ** L, dim_out)])
+        self.bl_reduce_layer = nn.Linear(dim_in * 3, dim_in)
+        self.bl_layers = tower(dim_in)
+        self.ba_layers = tower(dim_in)
+        self.da_layers = tower(dim_in)
+        self.FC_layers = tower(dim_in * 2)
+        self.L = L
+        self.activation = nn.ReLU()
+
+    def _tower(self, layers, x):
+        for lin in layers[:-1]:
+            x = self.activation(lin(x))
+        return layers[-1](x)
+
+    def forward(self, x_atoms, x_frags, edge_attr, batch):
+        plan = plan_for(batch, edge_ends=True)
+        bl = self.bl_reduce_layer(ops.edge_concat(x_atoms, edge_attr, batch["edge_index"], plan))
+        for lin in self.bl_layers:
+            bl = lin(self.activation(bl))
+        ba = self._tower(self.ba_layers, x_atoms)
+        da = self._tower(self.da_layers, edge_attr)
+        graph_rep = self._tower(self.FC_layers, pooled(x_atoms, x_frags, batch))
+        return bl, ba, da, graph_rep
+
+
+class FragNetPreTrain(nn.Module):
+    def __init__(self, num_layer=4, drop_ratio=0.15, num_heads=4, emb_dim=128, atom_features=167,
+                 frag_features=167, edge_features=16, fedge_in=6, fbond_edge_in=6):
+        super().__init__()
+        self.pretrain = FragNet(num_layer=num_layer, drop_ratio=drop_ratio, num_heads=num_heads, emb_dim=emb_dim,
+                                atom_features=atom_features, frag_features=frag_features,
+                                edge_features=edge_features, fedge_in=fedge_in, fbond_edge_in=fbond_edge_in)
+        self.head = PretrainTask(128, 1)
+
+    def forward(self, batch):
+        plan_for(batch, edge_ends=True)          # build the plan once, with the bond-length head's CSRs
+        x_atoms, x_frags, e_edge, _ = self.pretrain(batch)
+        return self.head(x_atoms, x_frags, e_edge, batch)

@@ -1,0 +1,390 @@
+"""torch.autograd wrappers around the C-ABI kernels (include/fragnet_hip.h).
+
+PyTorch is plumbing here: it owns the device memory, the current HIP stream and the autograd tape.
+Every numeric step of the message-passing path runs in libfragnet_hip.so; CPU tensors are rejected.
+
+Operator surface mirrored from torch-scatter (the reference's fragnet/model/gat/gat2.py:5):
+    scatter_add(src, index, dim=0, out=None, dim_size=None)
+    scatter_softmax(src, index, dim=0, dim_size=None)
+plus the fused per-level op the model uses (gat_level) and the small epilogues around it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import EdgeTerm, FN_D, FN_MAX_PART
+from .plan import GraphPlan, Level, Segments, _stream_ptr
+
+NEG_SLOPE = 0.2   # nn.LeakyReLU(0.2), reference gat2.py:83
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.FragnetHipError(f"{name}: fragnet_amd kernels need GPU tensors (got {t.device}); there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _part_rows(n: int) -> int:
+    return max(1, min((n + 7) // 8, FN_MAX_PART))
+
+
+# ======================================================================================
+# one attention level
+# ======================================================================================
+class _GatLevel(torch.autograd.Function):
+    """out[n,128] = sum_e softmax_dst(LeakyReLU(s_dst + s_src + s_edge))_e * h[src_e].
+
+    Inputs (differentiable): h [n,128]; att [H, att_w]; then either s_edge [m_real,H] (mode 0) or the raw
+    edge attribute x [m_real,K] (not differentiated) with embW [d,K], embb [d] (mode 2)."""
+
+    @staticmethod
+    def forward(ctx, h, att, s_edge, x, embW, embb, level: Level, heads: int, dst_off: int, mid_off: int,
+                src_off: int, want_probs: bool):
+        h = _f32c(h, "h")
+        att = _f32c(att, "att")
+        dev = h.device
+        n, m, m_real = level.n, level.m, level.m_real
+        if h.shape != (n, FN_D):
+            raise ValueError(f"h must be [{n}, {FN_D}], got {tuple(h.shape)}")
+        att_w = att.shape[1]
+        mode = 0 if x is None else 2
+        if mode == 0:
+            s_edge = _f32c(s_edge, "s_edge")
+            if s_edge.shape != (m_real, heads):
+                raise ValueError(f"s_edge must be [{m_real}, {heads}], got {tuple(s_edge.shape)}")
+            et = EdgeTerm(0, 0, 0, 0, s_edge.data_ptr(), None, None, None)
+        else:
+            x, embW, embb = _f32c(x, "x"), _f32c(embW, "embW"), _f32c(embb, "embb")
+            K = x.shape[1] if x.dim() == 2 else 1
+            if x.numel() != m_real * K or embW.shape != (FN_D // heads, K):
+                raise ValueError("edge attribute / embedding shapes do not match the plan")
+            et = EdgeTerm(2, K, FN_D // heads, mid_off, None, x.data_ptr(), embW.data_ptr(), embb.data_ptr())
+        st = _stream_ptr(dev)
+        s_dst = torch.empty((n, heads), dtype=torch.float32, device=dev)
+        s_src = torch.empty((n, heads), dtype=torch.float32, device=dev)
+        _lib.call("fn_node_scalars_f32", h.data_ptr(), att.data_ptr(), att_w, dst_off, src_off, s_dst.data_ptr(),
+                  s_src.data_ptr(), n, heads, st)
+        out = torch.empty((n, FN_D), dtype=torch.float32, device=dev)
+        p_sorted = torch.empty((m, heads), dtype=torch.float32, device=dev)
+        probs = torch.empty((m, heads), dtype=torch.float32, device=dev) if want_probs else None
+        _lib.call("fn_gat_fwd_f32", h.data_ptr(), s_dst.data_ptr(), s_src.data_ptr(), att.data_ptr(), att_w,
+                  C.byref(et), C.byref(level.c), NEG_SLOPE, out.data_ptr(), p_sorted.data_ptr(), _ptr(probs), heads, st)
+        ctx.level, ctx.heads, ctx.mode = level, heads, mode
+        ctx.offs = (dst_off, mid_off, src_off)
+        ctx.save_for_backward(h, att, p_sorted, x, embW, embb)
+        ctx.set_materialize_grads(False)
+        if want_probs:
+            ctx.mark_non_differentiable(probs, p_sorted)
+            return out, probs, p_sorted
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out, *unused):
+        h, att, p_sorted, x, embW, embb = ctx.saved_tensors
+        level, heads, mode = ctx.level, ctx.heads, ctx.mode
+        dst_off, mid_off, src_off = ctx.offs
+        if g_out is None:
+            return (None,) * 12
+        g_out = _f32c(g_out, "g_out")
+        dev = h.device
+        n, m, m_real = level.n, level.m, level.m_real
+        att_w = att.shape[1]
+        st = _stream_ptr(dev)
+        if mode == 0:
+            et = EdgeTerm(0, 0, 0, 0, None, None, None, None)
+            g_s_edge = torch.empty((m_real, heads), dtype=torch.float32, device=dev)
+            part_e = None
+            K = 0
+        else:
+            K = x.shape[1] if x.dim() == 2 else 1
+            et = EdgeTerm(2, K, FN_D // heads, mid_off, None, x.data_ptr(), embW.data_ptr(), embb.data_ptr())
+            g_s_edge = None
+            part_e = torch.empty((_part_rows(n), heads * (K + 1)), dtype=torch.float32, device=dev)
+        dz = torch.empty((m, heads), dtype=torch.float32, device=dev)
+        g_s_dst = torch.empty((n, heads), dtype=torch.float32, device=dev)
+        n_e, n_a = C.c_int(0), C.c_int(0)
+        _lib.call("fn_gat_bwd_dst_f32", g_out.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), C.byref(et),
+                  C.byref(level.c), NEG_SLOPE, dz.data_ptr(), g_s_dst.data_ptr(), _ptr(g_s_edge), _ptr(part_e),
+                  C.byref(n_e), heads, st)
+        g_h = torch.empty((n, FN_D), dtype=torch.float32, device=dev)
+        part_a = torch.empty((_part_rows(n), 2 * FN_D), dtype=torch.float32, device=dev)
+        _lib.call("fn_gat_bwd_src_f32", g_out.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), dz.data_ptr(),
+                  g_s_dst.data_ptr(), att.data_ptr(), att_w, dst_off, src_off, C.byref(level.c), g_h.data_ptr(),
+                  part_a.data_ptr(), C.byref(n_a), heads, st)
+        g_att = torch.zeros_like(att)
+        g_embW = torch.empty_like(embW) if mode == 2 else None
+        g_embb = torch.empty_like(embb) if mode == 2 else None
+        _lib.call("fn_gat_bwd_finalize_f32", part_a.data_ptr(), n_a.value, _ptr(part_e), n_e.value, C.byref(et),
+                  att.data_ptr(), att_w, dst_off, src_off, g_att.data_ptr(), _ptr(g_embW), _ptr(g_embb), heads, st)
+        return g_h, g_att, g_s_edge, None, g_embW, g_embb, None, None, None, None, None, None
+
+
+def gat_level(h, att, level: Level, heads: int, *, s_edge=None, x=None, embW=None, embb=None, want_probs=False):
+    """``att`` = [dst(d) | edge | src(d)] per head, the reference's a_b / a / f / f_a_b layout."""
+    d = FN_D // heads
+    att_w = att.shape[1]
+    return _GatLevel.apply(h, att, s_edge, x, embW, embb, level, heads, 0, d, att_w - d, want_probs)
+
+
+def attn_by_src(p_sorted: torch.Tensor, level: Level, heads: int) -> torch.Tensor:
+    """scatter_add(attn_probs, source): attention mass per source node (gat2.py:165,219,268,312)."""
+    out = torch.empty((level.n, heads), dtype=torch.float32, device=p_sorted.device)
+    _lib.call("fn_attn_by_src_f32", p_sorted.data_ptr(), C.byref(level.c), out.data_ptr(), heads, _stream_ptr(out.device))
+    return out
+
+
+# ======================================================================================
+# full-width edge term: s[r, j] = <x[r, :], A[j, off:off+128]>
+# ======================================================================================
+class _RowDots(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, A, off: int):
+        x, A = _f32c(x, "x"), _f32c(A, "A")
+        rows, J = x.shape[0], A.shape[0]
+        if x.shape[1] != FN_D:
+            raise ValueError("row_dots needs 128-wide rows")
+        s = torch.empty((rows, J), dtype=torch.float32, device=x.device)
+        _lib.call("fn_row_dots_f32", x.data_ptr(), A.data_ptr(), A.shape[1], off, J, s.data_ptr(), rows, _stream_ptr(x.device))
+        ctx.off = off
+        ctx.save_for_backward(x, A)
+        return s
+
+    @staticmethod
+    def backward(ctx, g_s):
+        x, A = ctx.saved_tensors
+        g_s = _f32c(g_s, "g_s")
+        rows, J = x.shape[0], A.shape[0]
+        st = _stream_ptr(x.device)
+        g_x = torch.empty_like(x)
+        g_A = torch.zeros_like(A)
+        if rows:
+            part = torch.empty((_part_rows(rows), J * FN_D), dtype=torch.float32, device=x.device)
+            n_part = C.c_int(0)
+            _lib.call("fn_row_dots_bwd_f32", g_s.data_ptr(), x.data_ptr(), A.data_ptr(), A.shape[1], ctx.off, J,
+                      g_x.data_ptr(), part.data_ptr(), C.byref(n_part), rows, st)
+            _lib.call("fn_colsum_f32", part.data_ptr(), n_part.value, J * FN_D, g_A.data_ptr(), A.shape[1], ctx.off, st)
+        return g_x, g_A, None
+
+
+def row_dots(x, A, off: int):
+    return _RowDots.apply(x, A, off)
+
+
+# ======================================================================================
+# segment sum (scatter_add along dim 0) and its gather backward
+# ======================================================================================
+class _SegmentSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, seg: Segments, keep_plan):
+        src = _f32c(src, "src")
+        if src.shape[0] != seg.n_items:
+            raise ValueError(f"src has {src.shape[0]} rows, index has {seg.n_items}")
+        width = 1
+        for extent in src.shape[1:]:
+            width *= int(extent)
+        alloc = torch.zeros if seg.n_items == 0 else torch.empty
+        out = alloc((seg.n_seg,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+        if seg.n_seg and width and seg.n_items:
+            _lib.call("fn_segment_sum_f32", src.data_ptr(), width, seg.rowptr.data_ptr(), seg.perm.data_ptr(),
+                      seg.pos_base, out.data_ptr(), seg.n_seg, width, _stream_ptr(src.device))
+        ctx.seg, ctx.width, ctx.keep = seg, width, keep_plan
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        seg, width = ctx.seg, ctx.width
+        g_out = _f32c(g_out, "g_out")
+        g_src = torch.empty((seg.n_items,) + tuple(g_out.shape[1:]), dtype=torch.float32, device=g_out.device)
+        if seg.n_items and width:
+            _lib.call("fn_gather_rows_f32", g_out.data_ptr(), seg.index.data_ptr(), g_src.data_ptr(), seg.n_items, width,
+                      _stream_ptr(g_out.device))
+        return g_src, None, None
+
+
+def segment_sum(src, seg: Segments, plan=None):
+    return _SegmentSum.apply(src, seg, plan)
+
+
+class _GatherRows(torch.autograd.Function):
+    """index_select(table, 0, index) with a segment-sum backward (needs the CSR of ``index``)."""
+
+    @staticmethod
+    def forward(ctx, table, seg: Segments, keep_plan):
+        table = _f32c(table, "table")
+        width = table.shape[1]
+        out = torch.empty((seg.n_items, width), dtype=torch.float32, device=table.device)
+        if seg.n_items:
+            _lib.call("fn_gather_rows_f32", table.data_ptr(), seg.index.data_ptr(), out.data_ptr(), seg.n_items, width,
+                      _stream_ptr(table.device))
+        ctx.seg, ctx.keep, ctx.rows = seg, keep_plan, table.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        seg = ctx.seg
+        g = _f32c(g, "g")
+        width = g.shape[1]
+        out = torch.empty((ctx.rows, width), dtype=torch.float32, device=g.device)
+        _lib.call("fn_segment_sum_f32", g.data_ptr(), width, seg.rowptr.data_ptr(), seg.perm.data_ptr(), seg.pos_base,
+                  out.data_ptr(), seg.n_seg, width, _stream_ptr(g.device))
+        return out, None, None
+
+
+# ======================================================================================
+# torch-scatter operator surface
+# ======================================================================================
+def _dim0_only(dim, src):
+    if dim not in (0, -src.dim()):
+        raise NotImplementedError("fragnet_amd implements scatter along dim 0 (all the reference's call sites)")
+
+
+def _n_seg(index: torch.Tensor, dim_size) -> int:
+    if dim_size is not None:
+        return int(dim_size)
+    if index.numel() == 0:
+        return 0
+    return int(index.max()) + 1      # synchronises, exactly like torch-scatter does
+
+
+def scatter_add(src, index, dim: int = 0, out=None, dim_size=None):
+    """Drop-in for torch_scatter.scatter_add(src, index, dim=0): 1-D int64 ``index`` over the rows of ``src``."""
+    _dim0_only(dim, src)
+    if out is not None:
+        raise NotImplementedError("out= is not used on the reference path")
+    if index.dim() != 1 or index.numel() != src.shape[0]:
+        raise RuntimeError("index must be 1-D with one entry per row of src")
+    plan = GraphPlan.segments_only(index, _n_seg(index, dim_size))
+    return segment_sum(src, plan.segs["s"], plan)
+
+
+class _SegmentSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, seg: Segments, keep_plan):
+        src = _f32c(src, "src")
+        width = 1
+        for extent in src.shape[1:]:
+            width *= int(extent)
+        probs = torch.empty_like(src)
+        if src.numel():
+            _lib.call("fn_segment_softmax_f32", src.data_ptr(), seg.rowptr.data_ptr(), seg.perm.data_ptr(), seg.pos_base,
+                      probs.data_ptr(), seg.n_seg, width, _stream_ptr(src.device))
+        ctx.seg, ctx.width, ctx.keep = seg, width, keep_plan
+        ctx.save_for_backward(probs)
+        return probs
+
+    @staticmethod
+    def backward(ctx, g):
+        (probs,) = ctx.saved_tensors
+        seg = ctx.seg
+        g = _f32c(g, "g")
+        out = torch.empty_like(probs)
+        if probs.numel():
+            _lib.call("fn_segment_softmax_bwd_f32", probs.data_ptr(), g.data_ptr(), seg.rowptr.data_ptr(),
+                      seg.perm.data_ptr(), seg.pos_base, out.data_ptr(), seg.n_seg, ctx.width, _stream_ptr(g.device))
+        return out, None, None
+
+
+def scatter_softmax(src, index, dim: int = 0, dim_size=None):
+    """Drop-in for torch_scatter.scatter_softmax(src, index, dim=0)."""
+    _dim0_only(dim, src)
+    if index.dim() != 1 or index.numel() != src.shape[0]:
+        raise RuntimeError("index must be 1-D with one entry per row of src")
+    plan = GraphPlan.segments_only(index, _n_seg(index, dim_size))
+    return _SegmentSoftmax.apply(src, plan.segs["s"], plan)
+
+
+# ======================================================================================
+# act(dropout(x)) epilogue
+# ======================================================================================
+class PhiloxStream:
+    """Counter-based dropout stream: (seed, running offset). One Philox block = 4 floats."""
+
+    def __init__(self, seed: Optional[int] = None, rank: int = 0):
+        self.seed = None if seed is None else (int(seed) & 0xFFFFFFFFFFFFFFFF)
+        self.rank = rank
+        self.offset = 0
+
+    def take(self, numel: int):
+        if self.seed is None:
+            self.seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self.rank * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        off = self.offset
+        self.offset += (numel + 3) // 4
+        return self.seed, off
+
+
+class _DropoutAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p: float, relu: bool, seed: int, offset: int):
+        x = _f32c(x, "x")
+        y = torch.empty_like(x)
+        _lib.call("fn_dropout_act_f32", x.data_ptr(), y.data_ptr(), x.numel(), float(p), seed, offset, int(relu),
+                  _stream_ptr(x.device))
+        ctx.args = (float(p), bool(relu), seed, offset)
+        if relu:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        p, relu, seed, offset = ctx.args
+        y = ctx.saved_tensors[0] if relu else None
+        g = _f32c(g, "g")
+        gx = torch.empty_like(g)
+        _lib.call("fn_dropout_act_bwd_f32", g.data_ptr(), _ptr(y), gx.data_ptr(), g.numel(), p, seed, offset, int(relu),
+                  _stream_ptr(g.device))
+        return gx, None, None, None, None
+
+
+def dropout_act(x, p: float, training: bool, relu: bool, rng: PhiloxStream):
+    """relu(dropout(x)) (gat2.py:414-418) or plain dropout (gat2.py:396-397) as one elementwise kernel."""
+    p_eff = float(p) if training else 0.0
+    if p_eff == 0.0 and not relu:
+        return x
+    seed, off = rng.take(x.numel()) if p_eff > 0.0 else (0, 0)
+    return _DropoutAct.apply(x, p_eff, relu, seed, off)
+
+
+# ======================================================================================
+# pretrain bond-length head input: cat(x[src], x[dst], e_attr)
+# ======================================================================================
+class _EdgeConcat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, e_attr, edge_index, plan: GraphPlan):
+        x, e_attr = _f32c(x, "x"), _f32c(e_attr, "e_attr")
+        E = edge_index.shape[1]
+        edge_index = edge_index.contiguous()
+        out = torch.empty((E, 3 * FN_D), dtype=torch.float32, device=x.device)
+        _lib.call("fn_edge_concat_f32", x.data_ptr(), e_attr.data_ptr(), edge_index.data_ptr(), out.data_ptr(), E,
+                  _stream_ptr(x.device))
+        ctx.plan, ctx.n = plan, x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, n = ctx.plan, ctx.n
+        g = _f32c(g, "g")
+        st = _stream_ptr(g.device)
+        gx = torch.empty((n, FN_D), dtype=torch.float32, device=g.device)
+        tmp = torch.empty_like(gx)
+        s, d = plan.segs["edge_src"], plan.segs["edge_dst"]
+        ld = 3 * FN_D
+        _lib.call("fn_segment_sum_f32", g.data_ptr(), ld, s.rowptr.data_ptr(), s.perm.data_ptr(), s.pos_base,
+                  gx.data_ptr(), n, FN_D, st)
+        _lib.call("fn_segment_sum_f32", g.data_ptr() + 4 * FN_D, ld, d.rowptr.data_ptr(), d.perm.data_ptr(), d.pos_base,
+                  tmp.data_ptr(), n, FN_D, st)
+        gx += tmp
+        return gx, g[:, 2 * FN_D:].contiguous(), None, None
+
+
+def edge_concat(x, e_attr, edge_index, plan: GraphPlan):
+    return _EdgeConcat.apply(x, e_attr, edge_index, plan)

@@ -1,0 +1,173 @@
+"""Per-batch graph plan: every destination-sorted CSR the four levels, the atom->fragment sum and
+the pooling need, built by ONE fn_plan_build call (6 small kernels) and reused by all layers,
+forward and backward.
+
+Which row of each index tensor is the destination follows the reference's unpacking:
+``target, source = edge_index_bonds_graph`` / ``edge_index_fbond_graph`` (gat2.py:138,239) but
+``source, target = edge_index`` / ``frag_index`` (gat2.py:187,283).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import CsrTask, GatPlan, ROLE_DST, ROLE_PLAIN, ROLE_SRC
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_cuda_i64(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise _lib.FragnetHipError(f"{name} must live on the GPU: fragnet_amd has no CPU path (got {t.device})")
+    if t.dtype != torch.int64:
+        raise TypeError(f"{name} must be int64, got {t.dtype}")
+
+
+@dataclass
+class Segments:
+    """A plain CSR (segment sum / pooling)."""
+    rowptr: torch.Tensor      # int32 view [n_seg+1] (global positions)
+    perm: torch.Tensor        # int32 view [items]
+    pos_base: int
+    n_seg: int
+    n_items: int
+    index: torch.Tensor       # the int64 key (for the gather backward)
+
+
+@dataclass
+class Level:
+    """One attention level: destination CSR + source CSR."""
+    c: GatPlan                # ctypes struct handed to the kernels
+    n: int
+    m: int
+    m_real: int
+    keep: tuple               # tensors the raw pointers in ``c`` point into
+
+
+class GraphPlan:
+    def __init__(self, specs: List[dict], device):
+        """specs: list of dicts(kind='gat'|'seg', name, ...) -- use GraphPlan.from_batch / .segments_only."""
+        lib = _lib.load()
+        self.device = device
+        tasks = (CsrTask * _lib.FN_MAX_TASKS)()
+        nt = 0
+        layout = []
+        keep = []
+        for sp in specs:
+            if sp["kind"] == "gat":
+                dst, src = sp["dst"], sp["src"]
+                _require_cuda_i64(dst, sp["name"])
+                if not (dst.is_contiguous() and src.is_contiguous()):
+                    dst, src = dst.contiguous(), src.contiguous()
+                keep += [dst, src]
+                m_real = int(dst.numel())
+                for role, key, other, partner in ((ROLE_DST, dst, src, nt + 1), (ROLE_SRC, src, dst, nt)):
+                    tasks[nt] = CsrTask(key.data_ptr(), other.data_ptr(), m_real, int(sp["n_loops"]), int(sp["n"]),
+                                        0, 0, role, partner)
+                    nt += 1
+                layout.append(("gat", sp["name"], nt - 2, sp))
+            else:
+                key = sp["key"]
+                _require_cuda_i64(key, sp["name"])
+                key = key.contiguous()
+                keep.append(key)
+                tasks[nt] = CsrTask(key.data_ptr(), None, int(key.numel()), 0, int(sp["n_seg"]), 0, 0, ROLE_PLAIN, -1)
+                nt += 1
+                layout.append(("seg", sp["name"], nt - 1, sp, key))
+            if nt > _lib.FN_MAX_TASKS:
+                raise ValueError("too many CSR tasks for one plan")
+        tot_items, tot_segs = C.c_int64(), C.c_int64()
+        _lib.check(lib.fn_plan_layout(tasks, nt, C.byref(tot_items), C.byref(tot_segs)), "fn_plan_layout")
+        ti, ts = tot_items.value, tot_segs.value
+        # one int32 arena: rowptr | perm | aux_a | aux_b | workspace(cursor, inv, status)
+        arena = torch.empty(ts + 1 + 3 * ti + (ts + ti + 4), dtype=torch.int32, device=device)
+        self._arena = arena
+        self.rowptr = arena[: ts + 1]
+        self.perm = arena[ts + 1: ts + 1 + ti]
+        self.aux_a = arena[ts + 1 + ti: ts + 1 + 2 * ti]
+        self.aux_b = arena[ts + 1 + 2 * ti: ts + 1 + 3 * ti]
+        ws = arena[ts + 1 + 3 * ti:]
+        self._status = ws[ts + ti: ts + ti + 1]
+        _lib.check(lib.fn_plan_build(tasks, nt, self.rowptr.data_ptr(), self.perm.data_ptr(), self.aux_a.data_ptr(),
+                                     self.aux_b.data_ptr(), ws.data_ptr(), _stream_ptr(device)), "fn_plan_build")
+        self._keep = keep
+        self.levels: Dict[str, Level] = {}
+        self.segs: Dict[str, Segments] = {}
+        for ent in layout:
+            if ent[0] == "gat":
+                _, name, t0, sp = ent
+                d, s = tasks[t0], tasks[t0 + 1]
+                m = int(d.n_real + d.n_loops)
+                c = GatPlan(self.rowptr.data_ptr() + 4 * d.seg_base, self.perm.data_ptr() + 4 * d.item_base,
+                            self.aux_a.data_ptr() + 4 * d.item_base, self.rowptr.data_ptr() + 4 * s.seg_base,
+                            self.aux_a.data_ptr() + 4 * s.item_base, self.aux_b.data_ptr() + 4 * s.item_base,
+                            int(d.item_base), int(s.item_base), int(d.n_seg), m, int(d.n_real))
+                self.levels[name] = Level(c, int(d.n_seg), m, int(d.n_real), (self,))
+            else:
+                _, name, t0, sp, key = ent
+                t = tasks[t0]
+                self.segs[name] = Segments(self.rowptr[t.seg_base: t.seg_base + t.n_seg + 1],
+                                           self.perm[t.item_base: t.item_base + t.n_real], int(t.item_base),
+                                           int(t.n_seg), int(t.n_real), key)
+
+    def check(self):
+        """Synchronising validation: raises if any index was outside its segment range."""
+        if int(self._status.item()) != 0:
+            raise IndexError("graph plan: an index tensor holds values outside [0, num_nodes)")
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_batch(cls, batch: Dict[str, torch.Tensor], n_mols: Optional[int] = None, edge_ends: bool = False):
+        """Plan for the reference's batch dict.  ``edge_ends`` adds the two CSRs the
+        pretrain bond-length head's gather backward needs."""
+        dev = batch["x_atoms"].device
+        N = batch["x_atoms"].shape[0]
+        E = batch["node_features_bonds"].shape[0]
+        F = batch["x_frags"].shape[0]
+        EF = batch["node_features_fbonds"].shape[0]
+        if n_mols is None:
+            n_mols = batch["y"].shape[0] if "y" in batch else int(batch["batch"].max()) + 1
+        ei, fi = batch["edge_index"], batch["frag_index"]
+        eib, eifb = batch["edge_index_bonds_graph"], batch["edge_index_fbonds"]
+        if ei.shape[1] != E:
+            raise ValueError("edge_index and node_features_bonds disagree on the number of directed bonds")
+        if fi.shape[1] != EF:
+            raise ValueError("frag_index and node_features_fbonds disagree on the number of fragment edges")
+        specs = [
+            dict(kind="gat", name="bond", dst=eib[0], src=eib[1], n=E, n_loops=0),
+            dict(kind="gat", name="atom", dst=ei[1], src=ei[0], n=N, n_loops=N),
+            dict(kind="gat", name="fbond", dst=eifb[0], src=eifb[1], n=EF, n_loops=0),
+            dict(kind="gat", name="frag", dst=fi[1], src=fi[0], n=F, n_loops=0),
+            dict(kind="seg", name="a2f", key=batch["atom_to_frag_ids"], n_seg=F),
+            dict(kind="seg", name="mol_atoms", key=batch["batch"], n_seg=n_mols),
+            dict(kind="seg", name="mol_frags", key=batch["frag_batch"], n_seg=n_mols),
+        ]
+        if edge_ends:
+            specs += [dict(kind="seg", name="edge_src", key=ei[0], n_seg=N),
+                      dict(kind="seg", name="edge_dst", key=ei[1], n_seg=N)]
+        plan = cls(specs, dev)
+        plan.n_mols = n_mols
+        return plan
+
+    @classmethod
+    def segments_only(cls, index: torch.Tensor, n_seg: int):
+        plan = cls([dict(kind="seg", name="s", key=index, n_seg=n_seg)], index.device)
+        return plan
+
+
+PLAN_KEY = "_fragnet_plan"
+
+
+def plan_for(batch: Dict[str, torch.Tensor], edge_ends: bool = False) -> GraphPlan:
+    """The plan is cached on the batch dict, so one batch builds it once even if several modules ask."""
+    plan = batch.get(PLAN_KEY)
+    if plan is None or (edge_ends and "edge_src" not in plan.segs):
+        plan = GraphPlan.from_batch(batch, edge_ends=edge_ends)
+        batch[PLAN_KEY] = plan
+    return plan

@@ -1,0 +1,210 @@
+/*
+ * libfragnet_hip.so -- C-ABI of the MI355X (gfx950) kernels behind FragNet's message-passing hot path.
+ *
+ * This is the drop-in boundary of SURVEY.md §8(b): everything the reference obtains from the
+ * un-vendored torch-scatter / torch_geometric wheels on this path, plus the fused per-level
+ * kernels that replace the reference's index_select/cat/mul/sum/scatter chains.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes; no torch types.
+ *   - every pointer is a DEVICE pointer into caller-owned memory; the library never allocates,
+ *     frees or retains pointers; workspaces are caller-provided.
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no
+ *     internal synchronisation, no default-stream use; stateless and re-entrant.
+ *   - return 0 on success, a negative FN_E* code for an argument error, or a positive
+ *     hipError_t taken right after the launch.  fn_last_error() describes the last failure
+ *     on the calling thread.
+ *   - float data is fp32, row-major, feature width D = 128 (= heads * head_dim) where stated;
+ *     index data is int32 in plans (int64 only where the batch dict hands it over).
+ *
+ * Reference call sites each entry point replaces are cited as file:line under
+ * /root/reference/fragnet/.
+ */
+#ifndef FRAGNET_HIP_H
+#define FRAGNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FN_ABI_VERSION 1
+#define FN_D 128              /* feature width of every node table on the path (emb_dim) */
+#define FN_MAX_TASKS 16       /* CSR builds fused into one fn_plan_build call */
+#define FN_MAX_EDGE_K 8       /* widest raw edge attribute folded in-kernel (6 for fragment bonds) */
+
+#define FN_EINVAL (-1)        /* null pointer / negative size / misaligned */
+#define FN_EUNSUPPORTED (-2)  /* heads or width not in {1,2,4,8} x 128 */
+#define FN_ETOOMANY (-3)      /* more than FN_MAX_TASKS tasks */
+
+typedef void* fn_stream_t;    /* hipStream_t */
+
+int fn_abi_version(void);
+const char* fn_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Graph plan: destination-sorted CSRs, built once per batch and reused by all layers, fwd+bwd.
+ * Replaces the implicit index handling inside torch_scatter.scatter_add / scatter_softmax
+ * (model/gat/gat2.py:153,162,210,216,234,257,265,303,309,820,821) and
+ * torch_geometric.utils.add_self_loops (gat2.py:179: `n_loops` identity items i -> segment i
+ * appended after the real ones).
+ *
+ * One call builds up to FN_MAX_TASKS CSRs over a concatenated segment space:
+ *   rowptr_all[seg_base + s]            global position of segment s's first item
+ *   perm_all  [item_base + p]           task-local item id at sorted position p, ascending inside
+ *                                       a segment (=> deterministic, reference summation order)
+ * For a GAT level, two tasks are paired (role DST keyed by destination, role SRC keyed by source):
+ *   DST task: aux_a[pos] = source node of the edge at pos
+ *   SRC task: aux_a[pos] = destination node; aux_b[pos] = that edge's position (task-local) in the
+ *             paired DST task
+ * ------------------------------------------------------------------------------------------ */
+#define FN_ROLE_PLAIN 0
+#define FN_ROLE_DST 1
+#define FN_ROLE_SRC 2
+
+typedef struct fn_csr_task {
+    const int64_t* key;        /* [n_real] segment id per item (device)                        */
+    const int64_t* other_key;  /* [n_real] the opposite endpoint (roles DST/SRC), else NULL     */
+    int64_t n_real;            /* items with an explicit key                                    */
+    int64_t n_loops;           /* identity items appended: item n_real+i belongs to segment i   */
+    int64_t n_seg;             /* number of segments                                            */
+    int64_t item_base;         /* filled by fn_plan_layout                                      */
+    int64_t seg_base;          /* filled by fn_plan_layout                                      */
+    int32_t role;              /* FN_ROLE_*                                                     */
+    int32_t partner;           /* index of the paired task (roles DST/SRC), else -1             */
+} fn_csr_task;
+
+/* Host-side helper: fills item_base/seg_base, returns totals. */
+int fn_plan_layout(fn_csr_task* tasks, int n_tasks, int64_t* total_items, int64_t* total_segs);
+
+/* ws_i32 must hold total_segs + total_items + 4 int32.  ws_i32[total_segs + total_items] is a
+ * status word: non-zero after the call completes if any key was outside [0, n_seg). */
+int fn_plan_build(const fn_csr_task* tasks, int n_tasks,
+                  int32_t* rowptr_all /*[total_segs+1]*/, int32_t* perm_all /*[total_items]*/,
+                  int32_t* aux_a /*[total_items]*/, int32_t* aux_b /*[total_items]*/,
+                  int32_t* ws_i32, fn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One attention level (bond graph, atom graph, fragment-bond graph, fragment graph):
+ *   z_e = s_dst[dst] + s_src[src] + s_edge[e];  l_e = LeakyReLU(z_e);  p = softmax over in-edges
+ *   out[dst] = sum_e p_e * h[src]
+ * Replaces, per level, index_select x3 + cat + mul + sum + LeakyReLU + scatter_softmax + mul +
+ * scatter_add at gat2.py:146-164, 196-218, 250-267, 286-311.
+ *
+ * `att` is the reference's attention parameter [heads, att_w] = [dst | edge | src] blocks
+ * (a_b / f_a_b: att_w = 3d; a / f: att_w = 2d + 128).
+ * ------------------------------------------------------------------------------------------ */
+
+/* s_dst[n,H] = <h[n,head,:], att[head, dst_off:+d]>, s_src likewise (gat2.py:150,208,254,300). */
+int fn_node_scalars_f32(const float* h /*[n,128]*/, const float* att, int att_w, int dst_off, int src_off,
+                        float* s_dst /*[n,H]*/, float* s_src /*[n,H]*/, int64_t n, int heads, fn_stream_t stream);
+
+/* Edge term of the logit. mode 0: s_edge given per ORIGINAL edge id ([m_real,H]; loop items get 0).
+ * mode 2: s_edge[e,h] = <embW x[e] + embb, att[h, mid_off:+d_e]> folded in-kernel (the reference's
+ * edge_attr_bond_embed / edge_attr_fbond_embed Linear(K -> d_e), gat2.py:139,242). */
+typedef struct fn_edge_term {
+    int32_t mode;
+    int32_t K;                /* mode 2: raw attribute width (1 or 6) */
+    int32_t d_e;              /* mode 2: embed width (= head_dim)     */
+    int32_t mid_off;          /* mode 2: offset of the edge block in att */
+    const float* s_edge;      /* mode 0: [m_real, H] */
+    const float* x;           /* mode 2: [m_real, K] */
+    const float* embW;        /* mode 2: [d_e, K]    */
+    const float* embb;        /* mode 2: [d_e]       */
+} fn_edge_term;
+
+typedef struct fn_gat_plan {          /* slices of the fn_plan_build outputs for one level */
+    const int32_t* rowptr_d;  /* [n+1] global positions (DST task)  */
+    const int32_t* eid_d;     /* [m]   original edge id at sorted pos */
+    const int32_t* src_d;     /* [m]   source node at sorted pos      */
+    const int32_t* rowptr_s;  /* [n+1] (SRC task)                     */
+    const int32_t* dst_s;     /* [m]   destination node               */
+    const int32_t* dpos_s;    /* [m]   position in the DST order      */
+    int32_t pos_base_d;       /* item_base of the DST task            */
+    int32_t pos_base_s;       /* item_base of the SRC task            */
+    int64_t n;                /* nodes                                */
+    int64_t m;                /* edges incl. loop items               */
+    int64_t m_real;           /* edges with an explicit attribute     */
+} fn_gat_plan;
+
+/* p_sorted [m,H]: probabilities in destination-sorted order; the sign bit carries "z_e <= 0"
+ * (the LeakyReLU branch) for the backward pass.  probs_orig (nullable) [m,H] in original edge
+ * order, unsigned -- the reference's attn_probs. */
+int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const float* att, int att_w,
+                   const fn_edge_term* et, const fn_gat_plan* plan, float neg_slope,
+                   float* out /*[n,128]*/, float* p_sorted /*[m,H]*/, float* probs_orig /*nullable*/,
+                   int heads, fn_stream_t stream);
+
+/* Backward, destination pass: dz_sorted [m,H], g_s_dst [n,H]; mode 0 also g_s_edge [m_real,H]
+ * (original order); mode 2 writes per-block partial sums part_e [grid, H*(K+1)].
+ * Returns the grid size used through *n_part_e. */
+int fn_gat_bwd_dst_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et,
+                       const fn_gat_plan* plan, float neg_slope,
+                       float* dz_sorted, float* g_s_dst, float* g_s_edge /*mode0, nullable*/,
+                       float* part_e /*mode2: [FN_MAX_PART, H*(K+1)]*/, int* n_part_e,
+                       int heads, fn_stream_t stream);
+
+/* Backward, source pass: g_h [n,128] = sum_{e: src=n} p_e g_out[dst] + g_s_dst*a_dst + g_s_src*a_src,
+ * and per-block partial sums of dL/da_dst, dL/da_src: part_a [grid, 256]. */
+int fn_gat_bwd_src_f32(const float* g_out, const float* h, const float* p_sorted, const float* dz_sorted,
+                       const float* g_s_dst, const float* att, int att_w, int dst_off, int src_off,
+                       const fn_gat_plan* plan, float* g_h, float* part_a, int* n_part_a,
+                       int heads, fn_stream_t stream);
+
+/* Reduces the partials into g_att [H, att_w] (dst/src blocks, and the edge block in mode 2) and,
+ * in mode 2, g_embW [d_e,K], g_embb [d_e].  g_att must be zero-initialised by the caller. */
+int fn_gat_bwd_finalize_f32(const float* part_a, int n_part_a, const float* part_e, int n_part_e,
+                            const fn_edge_term* et, const float* att, int att_w, int dst_off, int src_off,
+                            float* g_att, float* g_embW, float* g_embb, int heads, fn_stream_t stream);
+
+#define FN_MAX_PART 1024      /* upper bound on partial rows any kernel writes */
+
+/* attention mass per SOURCE node: scatter_add(attn_probs, source) at gat2.py:165,219,268,312 */
+int fn_attn_by_src_f32(const float* p_sorted, const fn_gat_plan* plan, float* attn /*[n,H]*/, int heads,
+                       fn_stream_t stream);
+
+/* s[r, j] = <x[r, 0:128], A[j*lda + off : +128]>, j < J <= 8: the full-width edge term of the atom and
+ * fragment graphs (edge block of `a` / `f`, gat2.py:203-208, 293-300). */
+int fn_row_dots_f32(const float* x, const float* A, int lda, int off, int J, float* s, int64_t rows, fn_stream_t stream);
+/* g_x[r,:] = sum_j g_s[r,j] A[j]; part [grid, J*128] partial sums of g_A[j,:] = sum_r g_s[r,j] x[r,:] */
+int fn_row_dots_bwd_f32(const float* g_s, const float* x, const float* A, int lda, int off, int J,
+                        float* g_x, float* part, int* n_part, int64_t rows, fn_stream_t stream);
+/* out[(c / 128) * ld + off + c % 128] = sum_r part[r, c], c < cols */
+int fn_colsum_f32(const float* part, int n_rows, int cols, float* out, int ld, int off, fn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * torch_scatter.scatter_add / scatter_softmax along dim 0 on a CSR built by fn_plan_build
+ * (gat2.py:234 atom->fragment sum; gat2.py:820-821 and pretrain_heads.py:93-94 pooling).
+ * ------------------------------------------------------------------------------------------ */
+int fn_segment_sum_f32(const float* src /*[items, src_ld >= width]*/, int64_t src_ld, const int32_t* rowptr,
+                       const int32_t* perm, int32_t pos_base, float* out /*[n_seg,width]*/, int64_t n_seg,
+                       int64_t width, fn_stream_t stream);
+/* backward of the above and of index_select: out[i,:] = table[index[i],:] */
+int fn_gather_rows_f32(const float* table, const int64_t* index, float* out, int64_t rows, int64_t width,
+                       fn_stream_t stream);
+/* probs[item,:] = softmax of logits over the items of each segment, per column (original item order) */
+int fn_segment_softmax_f32(const float* logits, const int32_t* rowptr, const int32_t* perm, int32_t pos_base,
+                           float* probs, int64_t n_seg, int64_t width, fn_stream_t stream);
+/* g_logits = p * (g_p - sum_seg p*g_p) */
+int fn_segment_softmax_bwd_f32(const float* probs, const float* g_probs, const int32_t* rowptr, const int32_t* perm,
+                               int32_t pos_base, float* g_logits, int64_t n_seg, int64_t width, fn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * act(dropout(x)) between layers (gat2.py:396-397, 414-418, 436-440): Philox-4x32-10 mask keyed by
+ * (seed, offset + element/4), y = relu(keep ? x/(1-p) : 0); relu = 0 gives plain dropout.
+ * Backward recomputes the mask from the same (seed, offset).
+ * ------------------------------------------------------------------------------------------ */
+int fn_dropout_act_f32(const float* x, float* y, int64_t numel, float p, uint64_t seed, uint64_t offset,
+                       int relu, fn_stream_t stream);
+int fn_dropout_act_bwd_f32(const float* g_y, const float* y, float* g_x, int64_t numel, float p, uint64_t seed,
+                           uint64_t offset, int relu, fn_stream_t stream);
+
+/* cat(x[src_e], x[dst_e], e_attr[e]) -> [E, 384] for the bond-length head (pretrain_heads.py:67-70) */
+int fn_edge_concat_f32(const float* x /*[N,128]*/, const float* e_attr /*[E,128]*/, const int64_t* edge_index /*[2,E]*/,
+                       float* out /*[E,384]*/, int64_t E, fn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRAGNET_HIP_H */

@@ -1,0 +1,409 @@
+"""GPU parity: the HIP path (through the C-ABI) against the oracle and the golden vectors.
+
+Tolerance: the north star asks logits/loss within 1e-4 fp32 of the reference CPU path; integer index
+maps bit-exact.  Kernel-level comparisons use 2e-5 absolute on O(1) values (summation order differs
+from the reference's one-reduction ``torch.sum`` only in fp32 round-off).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import check_grads, load_case
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+ATOL = 1e-4
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from fragnet_amd import _lib
+    from fragnet_amd.build import build_lib
+    build_lib()
+    _lib.load()
+
+
+def _to_dev(batch):
+    from fragnet_amd.data import batch_to
+    return batch_to(batch, DEV)
+
+
+# ------------------------------------------------------------------------------- plan (integers: bit-exact)
+def _check_csr(keys: torch.Tensor, n_seg: int, rowptr: torch.Tensor, perm: torch.Tensor, base: int):
+    keys = keys.cpu().numpy()
+    rowptr = rowptr.cpu().numpy().astype(np.int64) - base
+    perm = perm.cpu().numpy()
+    order = np.argsort(keys, kind="stable")
+    counts = np.bincount(keys, minlength=n_seg)
+    want_ptr = np.concatenate([[0], np.cumsum(counts)])
+    assert np.array_equal(rowptr, want_ptr)
+    assert np.array_equal(perm, order)          # ascending item id inside each segment
+
+
+def test_plan_matches_stable_argsort():
+    from fragnet_amd import data, synth
+    from fragnet_amd.plan import GraphPlan
+    batch = _to_dev(data.collate_fn(synth.synth_molecules(37, seed=9, profile="tox21", p_salt=0.3)))
+    plan = GraphPlan.from_batch(batch, edge_ends=True)
+    torch.cuda.synchronize()
+    plan.check()
+    for name, key in (("a2f", "atom_to_frag_ids"), ("mol_atoms", "batch"), ("mol_frags", "frag_batch")):
+        s = plan.segs[name]
+        _check_csr(batch[key], s.n_seg, s.rowptr, s.perm, s.pos_base)
+    _check_csr(batch["edge_index"][0], batch["x_atoms"].shape[0], plan.segs["edge_src"].rowptr,
+               plan.segs["edge_src"].perm, plan.segs["edge_src"].pos_base)
+    # attention levels: check through the raw arena
+    N = batch["x_atoms"].shape[0]
+    lv = plan.levels["atom"]
+    ei = batch["edge_index"].cpu()
+    loops = torch.arange(N)
+    dst = torch.cat([ei[1], loops]).numpy()
+    src = torch.cat([ei[0], loops]).numpy()
+    c = lv.c
+    arena = plan._arena.cpu().numpy()
+    base_ptr = plan._arena.data_ptr()
+    off = lambda p: (p - base_ptr) // 4
+    rp = arena[off(c.rowptr_d): off(c.rowptr_d) + N + 1].astype(np.int64) - c.pos_base_d
+    eid = arena[off(c.eid_d): off(c.eid_d) + lv.m]
+    srcd = arena[off(c.src_d): off(c.src_d) + lv.m]
+    order = np.argsort(dst, kind="stable")
+    assert np.array_equal(eid, order)
+    assert np.array_equal(srcd, src[order])
+    assert np.array_equal(rp, np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=N))]))
+    rps = arena[off(c.rowptr_s): off(c.rowptr_s) + N + 1].astype(np.int64) - c.pos_base_s
+    dsts = arena[off(c.dst_s): off(c.dst_s) + lv.m]
+    dpos = arena[off(c.dpos_s): off(c.dpos_s) + lv.m]
+    order_s = np.argsort(src, kind="stable")
+    assert np.array_equal(dsts, dst[order_s])
+    inv = np.empty(lv.m, dtype=np.int64)
+    inv[order] = np.arange(lv.m)
+    assert np.array_equal(dpos, inv[order_s])
+    assert np.array_equal(rps, np.concatenate([[0], np.cumsum(np.bincount(src, minlength=N))]))
+
+
+def test_plan_flags_out_of_range_index():
+    from fragnet_amd.plan import GraphPlan
+    idx = torch.tensor([0, 1, 5, 2], device=DEV)
+    plan = GraphPlan.segments_only(idx, 3)
+    with pytest.raises(IndexError):
+        plan.check()
+
+
+# ------------------------------------------------------------------------------- torch-scatter operator surface
+@pytest.mark.parametrize("shape", [(1000, 128), (513, 4), (77,), (300, 4, 32), (0, 128)])
+def test_scatter_add_matches_oracle(shape):
+    from fragnet_amd import ops
+    from oracle.scatter_ref import scatter_add as ref_add
+    g = torch.Generator().manual_seed(1)
+    src = torch.randn(*shape, generator=g)
+    index = torch.randint(0, 50, (shape[0],), generator=g)
+    want = ref_add(src, index, dim_size=50)
+    s = src.to(DEV).requires_grad_(True)
+    got = ops.scatter_add(s, index.to(DEV), dim=0, dim_size=50)
+    torch.testing.assert_close(got.cpu(), want, atol=2e-5, rtol=1e-5)
+    w = torch.randn(*want.shape, generator=g)
+    got.backward(w.to(DEV))
+    torch.testing.assert_close(s.grad.cpu(), w[index] if shape[0] else w[:0].reshape(shape), atol=0, rtol=0)
+
+
+def test_scatter_add_infers_size_like_torch_scatter():
+    from fragnet_amd import ops
+    src = torch.arange(12, dtype=torch.float32, device=DEV).view(6, 2)
+    idx = torch.tensor([3, 0, 3, 1, 0, 3], device=DEV)
+    out = ops.scatter_add(src, idx)
+    assert out.shape == (4, 2)
+    assert out.cpu().tolist() == [[10.0, 12.0], [6.0, 7.0], [0.0, 0.0], [14.0, 17.0]]
+
+
+def test_scatter_softmax_matches_oracle():
+    from fragnet_amd import ops
+    from oracle.scatter_ref import scatter_softmax as ref_sm
+    g = torch.Generator().manual_seed(2)
+    src = torch.randn(2000, 4, generator=g) * 3
+    index = torch.randint(0, 300, (2000,), generator=g)
+    a = src.clone().requires_grad_(True)
+    want = ref_sm(a, index, dim=0)
+    w = torch.randn(2000, 4, generator=g)
+    want.backward(w)
+    s = src.to(DEV).requires_grad_(True)
+    got = ops.scatter_softmax(s, index.to(DEV), dim=0)
+    torch.testing.assert_close(got.cpu(), want.detach(), atol=2e-6, rtol=1e-5)
+    got.backward(w.to(DEV))
+    torch.testing.assert_close(s.grad.cpu(), a.grad, atol=2e-6, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------- one attention level
+def _level_case(n, m, heads, loops, seed, hub=False):
+    g = torch.Generator().manual_seed(seed)
+    dst = torch.randint(0, n, (m,), generator=g)
+    src = torch.randint(0, n, (m,), generator=g)
+    if hub:                      # a node with in-degree far above 2*LPH exercises the serial path
+        dst[: m // 3] = 1
+    dst[-1] = n - 1
+    return dst, src, g
+
+
+@pytest.mark.parametrize("heads,mode,loops,hub", [(4, 2, False, False), (4, 0, True, False), (4, 0, False, True),
+                                                  (8, 2, False, True), (2, 0, True, False), (1, 2, False, False)])
+def test_gat_level_matches_materialised_reference(heads, mode, loops, hub):
+    from fragnet_amd import ops
+    from fragnet_amd.plan import GraphPlan
+    from oracle.fragnet_ref import gat_level_materialised
+    n, m, d = 257, 1500, 128 // heads
+    dst, src, g = _level_case(n, m, heads, loops, seed=heads * 10 + mode, hub=hub)
+    h = torch.randn(n, 128, generator=g)
+    K = 6
+    if mode == 2:
+        att = torch.randn(heads, 3 * d, generator=g) * 0.3
+        x = torch.randn(m, K, generator=g)
+        embW = torch.randn(d, K, generator=g) * 0.5
+        embb = torch.randn(d, generator=g) * 0.5
+    else:
+        att = torch.randn(heads, 2 * d + 128, generator=g) * 0.3
+        feat = torch.randn(m, 128, generator=g)
+    w_out = torch.randn(n, 128, generator=g)
+
+    # ---- oracle (materialised messages)
+    leaves = [t.clone().requires_grad_(True) for t in ((h, att, embW, embb) if mode == 2 else (h, att, feat))]
+    if mode == 2:
+        rh, ratt, rW, rb = leaves
+        edge_vec = torch.nn.functional.linear(x, rW, rb)
+    else:
+        rh, ratt, rfeat = leaves
+        edge_vec = rfeat
+    rdst, rsrc = dst, src
+    if loops:
+        rdst = torch.cat([dst, torch.arange(n)])
+        rsrc = torch.cat([src, torch.arange(n)])
+        edge_vec = torch.cat([edge_vec, torch.zeros(n, edge_vec.shape[1])])
+    want, want_p, want_attn = gat_level_materialised(rh.view(n, heads, d), edge_vec, ratt, rdst, rsrc, heads)
+    want = want.view(n, 128)
+    (want * w_out).sum().backward()
+
+    # ---- HIP
+    plan = GraphPlan([dict(kind="gat", name="l", dst=dst.to(DEV), src=src.to(DEV), n=n, n_loops=n if loops else 0)], DEV)
+    lv = plan.levels["l"]
+    dl = [t.detach().clone().to(DEV).requires_grad_(True) for t in ((h, att, embW, embb) if mode == 2 else (h, att, feat))]
+    if mode == 2:
+        out, probs, p_sorted = ops.gat_level(dl[0], dl[1], lv, heads, x=x.to(DEV), embW=dl[2], embb=dl[3], want_probs=True)
+    else:
+        s_edge = ops.row_dots(dl[2], dl[1], d)
+        out, probs, p_sorted = ops.gat_level(dl[0], dl[1], lv, heads, s_edge=s_edge, want_probs=True)
+    (out * w_out.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    plan.check()
+    torch.testing.assert_close(out.detach().cpu(), want.detach(), atol=2e-5, rtol=1e-4)
+    torch.testing.assert_close(probs.cpu(), want_p.detach(), atol=2e-6, rtol=1e-4)
+    torch.testing.assert_close(ops.attn_by_src(p_sorted, lv, heads).cpu(), want_attn.detach(), atol=2e-5, rtol=1e-4)
+    for got, ref, nm in zip(dl, leaves, ("h", "att", "embW/feat", "embb")):
+        scale = max(1.0, float(ref.grad.abs().max()))
+        torch.testing.assert_close(got.grad.cpu(), ref.grad, atol=5e-5 * scale, rtol=1e-4, msg=lambda s: f"grad {nm}: {s}")
+
+
+def test_gat_level_isolated_nodes_and_empty_graph():
+    from fragnet_amd import ops
+    from fragnet_amd.plan import GraphPlan
+    n = 10
+    dst = torch.tensor([0, 0, 9], device=DEV)
+    src = torch.tensor([1, 2, 3], device=DEV)
+    plan = GraphPlan([dict(kind="gat", name="l", dst=dst, src=src, n=n, n_loops=0)], DEV)
+    h = torch.randn(n, 128, device=DEV)
+    att = torch.randn(4, 192, device=DEV)
+    out = ops.gat_level(h, att, plan.levels["l"], 4, s_edge=torch.zeros(3, 4, device=DEV))
+    assert torch.equal(out[1:9], torch.zeros(8, 128, device=DEV))        # no in-edges => zero row, like scatter_add
+    torch.testing.assert_close(out[9], h[3])                             # single in-edge => probability 1
+    assert torch.isfinite(out).all()
+
+
+def test_dropout_act_statistics_and_backward_mask():
+    from fragnet_amd import ops
+    rng = ops.PhiloxStream(seed=1234)
+    x = (torch.randn(1 << 20, device=DEV).abs() + 0.1).requires_grad_(True)
+    y = ops.dropout_act(x, 0.25, True, True, rng)
+    kept = (y > 0).float().mean().item()
+    assert abs(kept - 0.75) < 0.005
+    torch.testing.assert_close(y[y > 0], (x.detach() / 0.75)[y > 0])
+    y.sum().backward()
+    assert torch.equal(x.grad > 0, y > 0)
+    torch.testing.assert_close(x.grad[y > 0], torch.full_like(x.grad[y > 0], 1 / 0.75))
+    y2 = ops.dropout_act(x.detach(), 0.25, True, True, rng)               # next offset => different mask
+    assert not torch.equal(y2 > 0, y > 0)
+    z = ops.dropout_act(torch.randn(1001, device=DEV), 0.5, False, True, rng)   # eval: plain ReLU, odd length
+    assert (z >= 0).all()
+
+
+# ------------------------------------------------------------------------------- whole model vs the reference's outputs
+def _run_ft(case):
+    from fragnet_amd.model import FragNetFineTune, pooled
+    cfg, batch, out, grads, pkeys, psums = load_case(case)
+    torch.manual_seed(cfg["seed"])
+    model = FragNetFineTune(**cfg["ctor"]).to(DEV)
+    model.train()
+    b = _to_dev(batch)
+    traces = []
+    hooks = []
+    enc = model.pretrain
+    orig_runs = [l.run for l in enc.layers]
+    for l, run in zip(enc.layers, orig_runs):
+        def wrapped(*a, _run=run, **k):
+            r = _run(*a, **k)
+            traces.append([t.detach().cpu() for t in r[:4]])
+            return r
+        l.run = wrapped
+    logits = model(b)
+    for l, run in zip(enc.layers, orig_runs):
+        l.run = run
+    return cfg, b, out, grads, model, logits, traces
+
+
+@pytest.mark.parametrize("case", ["ft_esol_b8", "ft_tox21_b4", "ft_edge_b6"])
+def test_finetune_matches_reference_golden(case):
+    from oracle import fragnet_ref as ref
+    cfg, b, out, grads, model, logits, traces = _run_ft(case)
+    for li, outs in enumerate(traces):
+        for nm, t in zip(("x_atoms", "x_frags", "bond", "fbond"), outs):
+            torch.testing.assert_close(t, torch.from_numpy(out[f"layer{li}/{nm}"]), atol=ATOL, rtol=1e-4,
+                                       msg=lambda s: f"layer {li} {nm}: {s}")
+    torch.testing.assert_close(logits.detach().cpu(), torch.from_numpy(out["logits"]), atol=ATOL, rtol=1e-4)
+    if cfg["loss"] == "mse":
+        loss = torch.nn.functional.mse_loss(logits.view(-1), b["y"])
+    else:
+        loss = ref.finetune_bce_loss(logits, b["y"])          # plain torch ops on GPU tensors
+    assert abs(loss.item() - float(out["loss"])) < ATOL
+    loss.backward()
+    torch.cuda.synchronize()
+    b["_fragnet_plan"].check()
+    check_grads(model, grads, atol=ATOL, rtol=2e-3)
+
+
+def test_pretrain_matches_reference_golden():
+    from fragnet_amd.model import FragNetPreTrain
+    from oracle import fragnet_ref as ref
+    cfg, batch, out, grads, pkeys, psums = load_case("pt_esol_b4")
+    torch.manual_seed(cfg["seed"])
+    model = FragNetPreTrain(**cfg["ctor"]).to(DEV)
+    model.train()
+    b = _to_dev(batch)
+    outs = model(b)
+    for nm, t in zip(("bond_length", "bond_angle", "dihedral", "graph_rep"), outs):
+        torch.testing.assert_close(t.detach().cpu(), torch.from_numpy(out[nm]), atol=ATOL, rtol=1e-4)
+    loss = ref.pretrain_loss(outs, b)
+    assert abs(loss.item() - float(out["loss"])) < ATOL
+    loss.backward()
+    check_grads(model, grads, atol=ATOL, rtol=2e-3)
+    # bond-length head is differentiable too (the reference trainer just never uses it)
+    model.zero_grad()
+    outs = model(_to_dev(batch))
+    outs[0].sum().backward()
+    assert model.head.bl_reduce_layer.weight.grad.abs().sum() > 0
+
+
+def test_bond_length_head_gradient_matches_oracle():
+    from fragnet_amd.model import FragNetPreTrain
+    from oracle import fragnet_ref as ref
+    cfg, batch, out, grads, pkeys, psums = load_case("pt_esol_b4")
+    torch.manual_seed(cfg["seed"])
+    gold = ref.FragNetPreTrain(**cfg["ctor"])
+    torch.manual_seed(cfg["seed"])
+    model = FragNetPreTrain(**cfg["ctor"]).to(DEV)
+    gold(batch)[0].pow(2).mean().backward()
+    model(_to_dev(batch))[0].pow(2).mean().backward()
+    for (n1, p1), (n2, p2) in zip(gold.named_parameters(), model.named_parameters()):
+        if p1.grad is None:
+            continue
+        scale = max(1.0, float(p1.grad.abs().max()))
+        torch.testing.assert_close(p2.grad.cpu(), p1.grad, atol=ATOL * scale, rtol=2e-3, msg=lambda s: f"{n1}: {s}")
+
+
+def test_layer_attentions_and_masks_match_reference_golden():
+    import json, os
+    from fragnet_amd.model import FragNetLayerA
+    from tests.helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "layer_attn_masks_b3.npz"))
+    cfg = json.loads(str(z["cfg"]))
+    b = {k[len("batch/"):]: torch.from_numpy(z[k]).to(DEV) for k in z.files if k.startswith("batch/")}
+    torch.manual_seed(cfg["seed"])
+    layer = FragNetLayerA(atom_in=167, atom_out=128, frag_in=167, frag_out=128, edge_in=17, edge_out=128, fedge_in=6,
+                          num_heads=4, fbond_edge_in=6, return_attentions=True, bond_mask=cfg["bond_mask"],
+                          frag_bond_mask=cfg["frag_bond_mask"], atom_mask_individual=cfg["atom_mask_individual"]).to(DEV)
+    outs = layer(b["x_atoms"], b["edge_index"], b["edge_attr"], b["frag_index"], b["x_frags"], b["atom_to_frag_ids"],
+                 b["node_features_bonds"], b["edge_index_bonds_graph"], b["edge_attr_bonds"],
+                 b["node_features_fbonds"], b["edge_index_fbonds"], b["edge_attr_fbonds"])
+    names = ("x_atoms", "x_frags", "bond", "fbond", "attn_atoms", "attn_frags", "attn_bonds", "attn_fbonds")
+    for nm, t in zip(names, outs):
+        torch.testing.assert_close(t.detach().cpu(), torch.from_numpy(z[f"out/{nm}"]), atol=ATOL, rtol=1e-4,
+                                   msg=lambda s: f"{nm}: {s}")
+
+
+# ------------------------------------------------------------------------------- full size (BASELINE config 2): B = 512
+@pytest.fixture(scope="module")
+def esol512():
+    from fragnet_amd import data, synth
+    return data.collate_fn(synth.synth_molecules(512, seed=1000, profile="esol"))
+
+
+def _esol_model(drop=0.0):
+    from fragnet_amd.model import FragNetFineTune
+    torch.manual_seed(0)
+    return FragNetFineTune(n_classes=1, num_layer=4, drop_ratio=drop, h1=128, h2=1024, h3=1024, h4=512, act="relu",
+                           fthead="FTHead3").to(DEV)
+
+
+def test_b512_matches_oracle_on_a_64_molecule_slice_and_is_permutation_equivariant(esol512):
+    """Molecules never exchange messages, so (a) the first 64 molecules of the B=512 batch give the same logits
+    as the oracle run on those 64 alone, (b) re-ordering the molecules re-orders the logits."""
+    from fragnet_amd import data, synth
+    from oracle import fragnet_ref as ref
+    mols = synth.synth_molecules(512, seed=1000, profile="esol")
+    model = _esol_model().eval()
+    with torch.no_grad():
+        full = model(_to_dev(esol512)).cpu()
+        perm = torch.randperm(512, generator=torch.Generator().manual_seed(3)).tolist()
+        shuffled = model(_to_dev(data.collate_fn([mols[i] for i in perm]))).cpu()
+    torch.testing.assert_close(shuffled, full[perm], atol=2e-5, rtol=1e-4)
+    torch.manual_seed(0)
+    gold = ref.FragNetFineTune(n_classes=1, num_layer=4, drop_ratio=0.0, h1=128, h2=1024, h3=1024, h4=512, act="relu",
+                               fthead="FTHead3").eval()
+    with torch.no_grad():
+        want = gold(data.collate_fn(mols[:64]))
+    torch.testing.assert_close(full[:64], want, atol=ATOL, rtol=1e-4)
+
+
+def test_b512_training_step_is_bitwise_reproducible(esol512):
+    """No float atomics anywhere on the path: two runs of fwd+bwd give identical bits."""
+    outs = []
+    for _ in range(2):
+        model = _esol_model()
+        model.train()
+        b = _to_dev(esol512)
+        loss = torch.nn.functional.mse_loss(model(b).view(-1), b["y"])
+        loss.backward()
+        outs.append((loss.item(), model.pretrain.layers[0].a_b.grad.clone(), model.pretrain.layers[3].projection_a.weight.grad.clone()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+def test_b512_gradients_match_oracle_b64():
+    from fragnet_amd import data, synth
+    from oracle import fragnet_ref as ref
+    mols = synth.synth_molecules(64, seed=1000, profile="esol")
+    batch = data.collate_fn(mols)
+    torch.manual_seed(0)
+    gold = ref.FragNetFineTune(n_classes=1, num_layer=4, drop_ratio=0.0, h1=128, h2=1024, h3=1024, h4=512, act="relu",
+                               fthead="FTHead3")
+    gold.train()
+    ref.finetune_regr_loss(gold(batch), batch["y"]).backward()
+    model = _esol_model()
+    model.train()
+    b = _to_dev(batch)
+    torch.nn.functional.mse_loss(model(b).view(-1), b["y"]).backward()
+    for (n1, p1), (n2, p2) in zip(gold.named_parameters(), model.named_parameters()):
+        assert n1 == n2
+        if p1.grad is None:
+            assert p2.grad is None, n2
+            continue
+        scale = max(1.0, float(p1.grad.abs().max()))
+        torch.testing.assert_close(p2.grad.cpu(), p1.grad, atol=ATOL * scale, rtol=2e-3, msg=lambda s: f"{n1}: {s}")
