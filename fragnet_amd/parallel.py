@@ -1,0 +1,114 @@
+"""Data parallelism for the FragNet hot path: one process per GPU, molecules sharded by rank, ONE
+all-reduce per step over a single flat fp32 buffer that the live parameters' ``.grad`` tensors alias.
+
+Why this shape: molecules never exchange messages, so there is no activation
+traffic; the only exchange is the gradient sum.  The live gradients are 1.9 M floats (7.7 MB, finetune)
+-- latency-bound on xGMI -- so they travel as one contiguous bucket in one RCCL call instead of the
+reference's per-parameter DDP buckets (Lightning Fabric DDP, fragnet/train/finetune/finetune_gat2_pl.py:230-248).
+Parameters the model never reads get no gradient and are not in the bucket, which is
+also why stock DDP would need ``find_unused_parameters`` here.
+
+Backend: "nccl" (= RCCL on ROCm) on GPUs; "gloo" works for the CPU tests of the bucket logic.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: Optional[str] = None) -> tuple:
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract). Returns (rank, local_rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_indices(n_items: int, rank: int, world: int, weights: Optional[Sequence[float]] = None) -> List[int]:
+    """Molecule indices owned by ``rank``.  Without weights: round robin (r::world).  With per-molecule
+    weights (e.g. bond-graph edge counts, the dominant cost): greedy longest-processing-time balance."""
+    if weights is None:
+        return list(range(rank, n_items, world))
+    order = sorted(range(n_items), key=lambda i: -weights[i])
+    loads = [0.0] * world
+    owner = [0] * n_items
+    for i in order:
+        r = min(range(world), key=lambda q: (loads[q], q))
+        owner[i] = r
+        loads[r] += weights[i]
+    return [i for i in range(n_items) if owner[i] == rank]
+
+
+class FlatGradBucket:
+    """Aliases the gradients of ``params`` into one contiguous buffer.
+
+    Call ``zero()`` instead of ``optimizer.zero_grad()`` (setting grads to None would drop the aliases),
+    run backward, then ``all_reduce()`` averages the whole bucket across ranks in one collective."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("FlatGradBucket needs at least one parameter")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=dt, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off: off + n].view_as(p)
+            off += n
+
+    @classmethod
+    def for_live_parameters(cls, model: torch.nn.Module, probe_backward) -> "FlatGradBucket":
+        """``probe_backward()`` runs one forward+backward; parameters that received a gradient are live."""
+        for p in model.parameters():
+            p.grad = None
+        probe_backward()
+        live = [p for p in model.parameters() if p.grad is not None]
+        return cls(live)
+
+    @property
+    def nbytes(self) -> int:
+        return self.flat.numel() * self.flat.element_size()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def intact(self) -> bool:
+        base = self.flat.untyped_storage().data_ptr()
+        return all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in self.params)
+
+    def all_reduce(self, group=None, async_op: bool = False):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return None
+        world = dist.get_world_size(group)
+        if self.flat.is_cuda:
+            return dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=False)
+        self.flat.div_(world)
+        return work
+
+
+def weighted_loss_scale(local_count: int, device, group=None) -> float:
+    """local_count / (global_count / world): multiply a per-rank MEAN loss by this so that averaging the
+    gradients across ranks equals the gradient of the global mean, when ranks hold different numbers of
+    atoms / bonds (pretrain angle and dihedral terms)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 1.0
+    t = torch.tensor([float(local_count)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    world = dist.get_world_size(group)
+    return float(local_count) * world / float(t.item())

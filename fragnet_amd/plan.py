@@ -86,13 +86,14 @@ class GraphPlan:
         _lib.check(lib.fn_plan_layout(tasks, nt, C.byref(tot_items), C.byref(tot_segs)), "fn_plan_layout")
         ti, ts = tot_items.value, tot_segs.value
         # one int32 arena: rowptr | perm | aux_a | aux_b | workspace(cursor, inv, status)
-        arena = torch.empty(ts + 1 + 3 * ti + (ts + ti + 4), dtype=torch.int32, device=device)
+        ta = max(ti, 1)                 # keep every region non-empty so its pointer is never null
+        arena = torch.empty(ts + 1 + 3 * ta + (ts + ti + 4), dtype=torch.int32, device=device)
         self._arena = arena
         self.rowptr = arena[: ts + 1]
-        self.perm = arena[ts + 1: ts + 1 + ti]
-        self.aux_a = arena[ts + 1 + ti: ts + 1 + 2 * ti]
-        self.aux_b = arena[ts + 1 + 2 * ti: ts + 1 + 3 * ti]
-        ws = arena[ts + 1 + 3 * ti:]
+        self.perm = arena[ts + 1: ts + 1 + ta]
+        self.aux_a = arena[ts + 1 + ta: ts + 1 + 2 * ta]
+        self.aux_b = arena[ts + 1 + 2 * ta: ts + 1 + 3 * ta]
+        ws = arena[ts + 1 + 3 * ta:]
         self._status = ws[ts + ti: ts + ti + 1]
         _lib.check(lib.fn_plan_build(tasks, nt, self.rowptr.data_ptr(), self.perm.data_ptr(), self.aux_a.data_ptr(),
                                      self.aux_b.data_ptr(), ws.data_ptr(), _stream_ptr(device)), "fn_plan_build")
