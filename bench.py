@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Headline benchmark: molecules/s of one full training step of FragNetFineTune on ESOL-shape batches
+of 512 molecules per GPU (BASELINE.json configs[1]; `e1pt4.yaml` model: 4 layers, 4 heads, emb 128,
+FTHead3 128/1024/1024/512, drop 0.1, fp32), synthetic data already resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A step = graph plan build + zero grads + forward + MSE loss + backward + (N>1: one flat-bucket
+gradient all-reduce over RCCL) + Adam step, on a batch the model has not seen in the previous step
+(a pool of pre-collated batches, seeds 1000+i).  Weak scaling: every rank owns 512 molecules per step.
+
+Besides the contract fields the JSON line carries
+  roofline      for the dominant scatter kernel (bond-graph level, the largest of the four): algorithmic
+                bytes (SURVEY.md §8d closed form on this batch's n, m) / launch time, measured here with
+                HIP events on the launch stream over back-to-back launches on a resident batch
+  cpu_baseline  the oracle (reference-faithful pure-torch restatement) timed on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MODEL_CFG = dict(n_classes=1, atom_features=167, frag_features=167, edge_features=17, num_layer=4, num_heads=4,
+                 drop_ratio=0.1, h1=128, h2=1024, h3=1024, h4=512, act="relu", emb_dim=128, fthead="FTHead3")
+PER_GPU_BATCH = 512
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s HBM3E spec peak
+
+
+def level_bytes(n, m, H=4, D=128):
+    """SURVEY.md §8d compulsory-traffic model for one attention level, fp32 + int32 indices."""
+    fwd = 4 * ((n + 1) + m + m * H + 2 * n * H + n * D + n * D + m * H)
+    bwd = 4 * (2 * n * D + 2 * m * H + 2 * m + n * D + m * H + 2 * n * H)
+    return fwd, bwd
+
+
+def step_bytes(batch):
+    """Whole-step algorithmic bytes (4 layers x 4 levels fwd+bwd + L3 + pooling + projections), §8d."""
+    N = batch["x_atoms"].shape[0]
+    E = batch["node_features_bonds"].shape[0]
+    Eb = batch["edge_index_bonds_graph"].shape[1]
+    F = batch["x_frags"].shape[0]
+    EF = batch["node_features_fbonds"].shape[0]
+    EFB = batch["edge_index_fbonds"].shape[1]
+    B = batch["y"].shape[0]
+    D, H = 128, 4
+    total = 0
+    for layer in range(4):
+        k_b, k_a, k_fb = (17, 167, 6) if layer == 0 else (128, 128, 128)
+        for n, m, K in ((E, Eb, k_b), (N, E + N, k_a), (EF, EFB, k_fb), (F, EF, None)):
+            f, b = level_bytes(n, m)
+            total += f + b
+            if K is not None:
+                total += 4 * (n * K + n * D) + 4 * (n * D + 2 * n * K)      # projection fwd + bwd
+            total += 2 * 4 * 2 * n * H                                       # node-scalar epilogue fwd+bwd
+        total += 2 * 4 * (E * D + (E + N) * H) + 2 * 4 * (EF * D + EF * H)  # full-width edge terms (L2, L4b)
+        total += 2 * 4 * (N * D + N + F * D)                                  # L3 each way
+    total += 2 * 4 * (N * D + N + B * D) + 2 * 4 * (F * D + F + B * D)       # pooling each way
+    return total
+
+
+def make_pool(n_batches, rank, device):
+    from fragnet_amd import data, synth
+    pool = []
+    for i in range(n_batches):
+        mols = synth.synth_molecules(PER_GPU_BATCH, seed=1000 + 97 * rank + i, profile="esol")
+        pool.append(data.batch_to(data.collate_fn(mols), device))
+    return pool
+
+
+def cpu_baseline(budget_s=25.0):
+    """Oracle (reference-faithful CPU path), same model, same step, bounded sample."""
+    from fragnet_amd import data, synth
+    from oracle import fragnet_ref as ref
+    torch.manual_seed(0)
+    model = ref.FragNetFineTune(**MODEL_CFG)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+
+    def step(batch):
+        opt.zero_grad()
+        loss = ref.finetune_regr_loss(model(batch), batch["y"])
+        loss.backward()
+        opt.step()
+
+    step(data.collate_fn(synth.synth_molecules(32, seed=999, profile="esol")))      # warm-up, untimed
+    batch = data.collate_fn(synth.synth_molecules(PER_GPU_BATCH, seed=1000, profile="esol"))
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 3 and (time.perf_counter() - t_all) < budget_s:
+        t0 = time.perf_counter()
+        step(batch)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": round(PER_GPU_BATCH / best, 2), "unit": "molecules/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{len(times)} training step(s) of one ESOL-shape batch of {PER_GPU_BATCH} (best of {len(times)}, "
+                      f"{best:.2f} s/step) after a 32-molecule warm-up; oracle/fragnet_ref.py, torch {torch.__version__} CPU",
+            "host_cpus": os.cpu_count()}
+
+
+def kernel_roofline(batch, model, iters=50):
+    """Dominant scatter kernels at the bond-graph level, timed back to back with HIP events on the launch stream."""
+    import ctypes as C
+    from fragnet_amd import _lib
+    from fragnet_amd.plan import GraphPlan, _stream_ptr
+    dev = batch["x_atoms"].device
+    plan = GraphPlan.from_batch(batch)
+    lv = plan.levels["bond"]
+    layer = model.pretrain.layers[1]
+    n, m, H = lv.n, lv.m, 4
+    g = torch.Generator(device="cpu").manual_seed(0)
+    h = torch.randn(n, 128, generator=g).to(dev)
+    gout = torch.randn(n, 128, generator=g).to(dev)
+    att = layer.a_b.detach().contiguous()
+    embW, embb = layer.edge_attr_bond_embed.weight.detach().contiguous(), layer.edge_attr_bond_embed.bias.detach().contiguous()
+    x = batch["edge_attr_bonds"].contiguous()
+    et = _lib.EdgeTerm(2, 1, 32, 32, None, x.data_ptr(), embW.data_ptr(), embb.data_ptr())
+    f32 = dict(dtype=torch.float32, device=dev)
+    s_dst, s_src = torch.empty(n, H, **f32), torch.empty(n, H, **f32)
+    out, p_sorted, dz = torch.empty(n, 128, **f32), torch.empty(m, H, **f32), torch.empty(m, H, **f32)
+    g_s_dst, g_h = torch.empty(n, H, **f32), torch.empty(n, 128, **f32)
+    part_e, part_a = torch.empty(1024, H * 2, **f32), torch.empty(1024, 256, **f32)
+    n_e, n_a = C.c_int(0), C.c_int(0)
+    st = _stream_ptr(dev)
+    _lib.call("fn_node_scalars_f32", h.data_ptr(), att.data_ptr(), 96, 0, 64, s_dst.data_ptr(), s_src.data_ptr(), n, H, st)
+
+    def fwd():
+        _lib.call("fn_gat_fwd_f32", h.data_ptr(), s_dst.data_ptr(), s_src.data_ptr(), att.data_ptr(), 96, C.byref(et),
+                  C.byref(lv.c), 0.2, out.data_ptr(), p_sorted.data_ptr(), None, H, st)
+
+    def bwd_dst():
+        _lib.call("fn_gat_bwd_dst_f32", gout.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), C.byref(et), C.byref(lv.c), 0.2,
+                  dz.data_ptr(), g_s_dst.data_ptr(), None, part_e.data_ptr(), C.byref(n_e), H, st)
+
+    def bwd_src():
+        _lib.call("fn_gat_bwd_src_f32", gout.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), dz.data_ptr(), g_s_dst.data_ptr(),
+                  att.data_ptr(), 96, 0, 64, C.byref(lv.c), g_h.data_ptr(), part_a.data_ptr(), C.byref(n_a), H, st)
+
+    D = 128
+    fwd_b = 4 * ((n + 1) + m + m * H + 2 * n * H + n * D + n * D + m * H)
+    # backward split of B_agg' (§8d) over the two passes: each operand read once, each result written once
+    bwd_dst_b = 4 * (2 * n * D + m * H + m + m * H + n * H)            # g_out, h, probs, idx -> dz, g_s_dst
+    bwd_src_b = 4 * (2 * n * D + 2 * m * H + m + n * H + n * D)        # g_out, h, probs, dz, idx, g_s_dst -> g_h
+    res = {}
+    for name, fn, nbytes in (("k_gat_fwd", fwd, fwd_b), ("k_gat_bwd_dst", bwd_dst, bwd_dst_b), ("k_gat_bwd_src", bwd_src, bwd_src_b)):
+        for _ in range(5):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) * 1000.0 / iters
+        res[name] = {"us_per_launch": round(us, 2), "algorithmic_bytes": nbytes, "GBps": round(nbytes / us / 1e3, 1),
+                     "n": n, "m": m}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pool", type=int, default=4, help="distinct pre-collated batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from fragnet_amd import parallel
+    from fragnet_amd.model import FragNetFineTune
+    from fragnet_amd.plan import PLAN_KEY
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    rank, local_rank, world = parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    pool = make_pool(args.pool, rank, dev)
+    torch.manual_seed(0)
+    model = FragNetFineTune(**MODEL_CFG).to(dev)
+    model.train()
+    model.pretrain.rng.rank = rank
+
+    def fwd_bwd(batch):
+        batch.pop(PLAN_KEY, None)                      # every step pays for its own graph plan
+        loss = torch.nn.functional.mse_loss(model(batch).view(-1), batch["y"])
+        loss.backward()
+        return loss
+
+    opt = parallel.FlatAdam.for_live_parameters(model, lambda: fwd_bwd(pool[0]), lr=1e-4)
+    bucket = opt
+
+    def step(i):
+        opt.zero_grad()
+        loss = fwd_bwd(pool[i % len(pool)])
+        opt.step()                                   # one cat + (N>1: one all-reduce) + one fused Adam
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = PER_GPU_BATCH * world * args.steps / elapsed
+        sb = step_bytes(pool[0])
+        line = {
+            "metric": "molecules/sec fwd+bwd (full training step), ESOL-shape batch=512 per GPU",
+            "value": round(value, 1), "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "ESOL finetune batch=512 fp32 (BASELINE configs[1]): FragNetFineTune 4 layers x 4 heads, "
+                                   "emb 128, FTHead3 128/1024/1024/512, drop 0.1; synthetic ESOL-shape molecules (synth.py)",
+                       "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world, "parallelism": f"dp{world}",
+                       "step": "plan+zero_grad+fwd+mse+bwd" + ("+allreduce(flat %.1f MB)" % (bucket.nbytes / 1e6) if world > 1 else "") + "+adam",
+                       "atoms": int(pool[0]["x_atoms"].shape[0]), "bond_graph_edges": int(pool[0]["edge_index_bonds_graph"].shape[1])},
+            "final_loss": round(final_loss, 6),
+            "step_algorithmic_GB": round(sb / 1e9, 4),
+            "step_achieved_GBps": round(sb / (ms * 1e-3) / 1e9, 1),
+            "step_frac_of_hbm_peak": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        }
+        if not args.no_roofline:
+            kr = kernel_roofline(pool[0], model)
+            dom = max(kr, key=lambda k: kr[k]["us_per_launch"])
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_per_launch.json")
+            if os.path.exists(pmc):
+                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+            line["roofline"] = {"bound": "hbm", "kernel": dom + "<4> @ bond-graph level", "achieved": kr[dom]["GBps"],
+                                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(kr[dom]["GBps"] / HBM_PEAK_GBPS, 4),
+                                "traffic": traffic, "us_per_launch": kr[dom]["us_per_launch"],
+                                "algorithmic_bytes_per_launch": kr[dom]["algorithmic_bytes"],
+                                "method": "50 back-to-back launches, HIP events on the launch stream", "all": kr}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+            line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

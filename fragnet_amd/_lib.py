@@ -77,6 +77,9 @@ def load():
         raise FragnetHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). fragnet_amd has no CPU/PyTorch fallback for its kernels.")
+    # torch ships its own libamdhip64; it must be the HIP runtime this library binds to (same streams,
+    # same allocations), so torch is imported before the dlopen.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch

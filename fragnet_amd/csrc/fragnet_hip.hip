@@ -143,6 +143,50 @@ __global__ __launch_bounds__(1024) void k_plan_scan(int32_t* __restrict__ a, int
     }
 }
 
+constexpr int kScanChunk = 2048;   // items per block in the multi-block scan (256 threads x 8)
+
+__global__ __launch_bounds__(256) void k_scan_reduce(const int32_t* __restrict__ a, int64_t len, int32_t* __restrict__ block_sums) {
+    __shared__ int32_t ws[4];
+    const int64_t i0 = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 8;
+    int32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += (i0 + k < len) ? a[i0 + k] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// inclusive scan of one 2048-item chunk per block, offset by the inclusive scan of the preceding block sums
+__global__ __launch_bounds__(256) void k_scan_apply(int32_t* __restrict__ a, int64_t len, const int32_t* __restrict__ block_incl) {
+    __shared__ int32_t wave_tot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t i0 = (int64_t)blockIdx.x * kScanChunk + (int64_t)tid * 8;
+    int32_t v[8];
+    int32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sum += (i0 + k < len) ? a[i0 + k] : 0;
+        v[k] = sum;
+    }
+    int32_t x = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int32_t y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_tot[wid] = x;
+    __syncthreads();
+    int32_t before = blockIdx.x ? block_incl[blockIdx.x - 1] : 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) before += (w < wid) ? wave_tot[w] : 0;
+    const int32_t excl = before + (x - sum);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (i0 + k < len) a[i0 + k] = v[k] + excl;
+}
+
 __global__ void k_plan_fill(PlanTasks P, const int32_t* __restrict__ rowptr_all, int32_t* __restrict__ cursor,
                             int32_t* __restrict__ perm_all) {
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < P.total_items;
@@ -157,16 +201,37 @@ __global__ void k_plan_fill(PlanTasks P, const int32_t* __restrict__ rowptr_all,
     }
 }
 
-// ascending item id inside every segment => summation order of the reference's sequential scatter_add
+// ascending item id inside every segment => summation order of the reference's sequential scatter_add.
+// Segments of <= 16 items (every molecular graph level) are sorted in registers by an odd-even network.
 __global__ void k_plan_segsort(const int32_t* __restrict__ rowptr_all, int32_t* __restrict__ perm_all, int64_t total_segs) {
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total_segs;
          s += (int64_t)gridDim.x * blockDim.x) {
         const int32_t b = rowptr_all[s], e = rowptr_all[s + 1];
-        for (int32_t i = b + 1; i < e; ++i) {
-            const int32_t v = perm_all[i];
-            int32_t q = i - 1;
-            while (q >= b && perm_all[q] > v) { perm_all[q + 1] = perm_all[q]; --q; }
-            perm_all[q + 1] = v;
+        const int32_t len = e - b;
+        if (len <= 1) continue;
+        if (len <= 16) {
+            int32_t v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = (k < len) ? perm_all[b + k] : 0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                for (int k = (r & 1); k + 1 < 16; k += 2) {
+                    const int32_t lo = min(v[k], v[k + 1]), hi = max(v[k], v[k + 1]);
+                    v[k] = lo;
+                    v[k + 1] = hi;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < len) perm_all[b + k] = v[k];
+        } else {
+            for (int32_t i = b + 1; i < e; ++i) {
+                const int32_t v = perm_all[i];
+                int32_t q = i - 1;
+                while (q >= b && perm_all[q] > v) { perm_all[q + 1] = perm_all[q]; --q; }
+                perm_all[q + 1] = v;
+            }
         }
     }
 }
@@ -449,23 +514,37 @@ __global__ __launch_bounds__(kBlock) void k_gat_bwd_src(const float* __restrict_
     part_a[(size_t)blockIdx.x * (2 * FN_D) + threadIdx.x] = a;
 }
 
+// blocks 0..7: column tiles (32 columns each) of the [n_a, 256] a_dst/a_src partials; block 8 (mode 2 only):
+// the [n_e, H*(K+1)] edge-embedding partials and the chain rule through the folded weights.
 __global__ __launch_bounds__(1024) void k_gat_finalize(const float* __restrict__ part_a, int n_a,
                                                        const float* __restrict__ part_e, int n_e, fn_edge_term et,
                                                        const float* __restrict__ att, int att_w, int dst_off,
                                                        int src_off, float* __restrict__ g_att,
                                                        float* __restrict__ g_embW, float* __restrict__ g_embb, int H) {
-    __shared__ float red[4][2 * FN_D];
+    __shared__ float red[32][33];
     __shared__ float redE[8][128];
     __shared__ float sE[128];
     const int tid = threadIdx.x;
-    {
-        const int col = tid & 255, grp = tid >> 8;
+    if (blockIdx.x < 8) {
+        const int c = tid & 31, rg = tid >> 5;
+        const int col = blockIdx.x * 32 + c;
         float acc = 0.f;
-        for (int r = grp; r < n_a; r += 4) acc += part_a[(size_t)r * (2 * FN_D) + col];
-        red[grp][col] = acc;
+        for (int r = rg; r < n_a; r += 32) acc += part_a[(size_t)r * (2 * FN_D) + col];
+        red[rg][c] = acc;
+        __syncthreads();
+        if (tid < 32) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 32; ++g) v += red[g][tid];
+            const int DH = FN_D / H;
+            const int cc = col & 127, part = col >> 7;
+            g_att[(cc / DH) * att_w + (part ? src_off : dst_off) + (cc % DH)] = v;
+        }
+        return;
     }
-    const int ne = (et.mode == 2) ? H * (et.K + 1) : 0;     // <= 72
-    if (ne) {
+    const int K = et.K, d_e = et.d_e;
+    const int ne = H * (K + 1);     // <= 72
+    {
         const int col = tid & 127, grp = tid >> 7;
         float acc = 0.f;
         if (col < ne)
@@ -473,38 +552,29 @@ __global__ __launch_bounds__(1024) void k_gat_finalize(const float* __restrict__
         redE[grp][col] = acc;
     }
     __syncthreads();
-    const int DH = FN_D / H;
-    if (tid < 2 * FN_D) {
-        const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-        const int part = tid >> 7, cc = tid & 127;
-        g_att[(cc / DH) * att_w + (part ? src_off : dst_off) + (cc % DH)] = v;
-    }
-    if (ne) {
-        if (tid < 128) {
-            float v = 0.f;
+    if (tid < 128) {
+        float v = 0.f;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) v += redE[g][tid];
-            sE[tid] = v;
-        }
-        __syncthreads();
-        const int K = et.K, d_e = et.d_e;
-        if (tid < H * d_e) {
-            const int hh = tid / d_e, c = tid % d_e;
-            float a = sE[hh * (K + 1) + K] * et.embb[c];
-            for (int k = 0; k < K; ++k) a = fmaf(sE[hh * (K + 1) + k], et.embW[c * K + k], a);
-            g_att[hh * att_w + et.mid_off + c] = a;
-        }
-        if (tid < d_e * K) {
-            const int c = tid / K, k = tid % K;
-            float a = 0.f;
-            for (int hh = 0; hh < H; ++hh) a = fmaf(sE[hh * (K + 1) + k], att[hh * att_w + et.mid_off + c], a);
-            g_embW[tid] = a;
-        }
-        if (tid < d_e) {
-            float a = 0.f;
-            for (int hh = 0; hh < H; ++hh) a = fmaf(sE[hh * (K + 1) + K], att[hh * att_w + et.mid_off + tid], a);
-            g_embb[tid] = a;
-        }
+        for (int g = 0; g < 8; ++g) v += redE[g][tid];
+        sE[tid] = v;
+    }
+    __syncthreads();
+    if (tid < H * d_e) {
+        const int hh = tid / d_e, c = tid % d_e;
+        float a = sE[hh * (K + 1) + K] * et.embb[c];
+        for (int k = 0; k < K; ++k) a = fmaf(sE[hh * (K + 1) + k], et.embW[c * K + k], a);
+        g_att[hh * att_w + et.mid_off + c] = a;
+    }
+    if (tid < d_e * K) {
+        const int c = tid / K, k = tid % K;
+        float a = 0.f;
+        for (int hh = 0; hh < H; ++hh) a = fmaf(sE[hh * (K + 1) + k], att[hh * att_w + et.mid_off + c], a);
+        g_embW[tid] = a;
+    }
+    if (tid < d_e) {
+        float a = 0.f;
+        for (int hh = 0; hh < H; ++hh) a = fmaf(sE[hh * (K + 1) + K], att[hh * att_w + et.mid_off + tid], a);
+        g_embb[tid] = a;
     }
 }
 
@@ -584,17 +654,23 @@ __global__ __launch_bounds__(kBlock) void k_row_dots_bwd(const float* __restrict
     }
 }
 
-__global__ void k_colsum(const float* __restrict__ part, int n_rows, int cols, float* __restrict__ out, int ld, int off) {
-    // one wave per 64 columns x all rows would be enough; rows <= FN_MAX_PART so a 4-way split + LDS combine
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+// 1024 threads = 32 columns x 32 row groups; grid = ceil(cols / 32)
+__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ part, int n_rows, int cols,
+                                                  float* __restrict__ out, int ld, int off) {
+    __shared__ float red[32][33];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + c;
     float acc = 0.f;
-    if (c < cols)
-        for (int r = grp; r < n_rows; r += 4) acc += part[(size_t)r * cols + c];
-    red[grp][threadIdx.x & 63] = acc;
+    if (col < cols)
+        for (int r = rg; r < n_rows; r += 32) acc += part[(size_t)r * cols + col];
+    red[rg][c] = acc;
     __syncthreads();
-    if (grp == 0 && c < cols)
-        out[(c / FN_D) * ld + off + (c % FN_D)] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x < 32 && col < cols) {
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) v += red[g][threadIdx.x];
+        out[(col / FN_D) * ld + off + (col % FN_D)] = v;
+    }
 }
 
 // =====================================================================================
@@ -832,7 +908,14 @@ int fn_plan_build(const fn_csr_task* tasks, int n_tasks, int32_t* rowptr_all, in
     if (items > 0) {
         const int g = flat_grid(items, kGridCap);
         hipLaunchKernelGGL(k_plan_hist, dim3(g), dim3(kBlock), 0, st, P, rowptr_all, status);
-        hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, rowptr_all + 1, segs);
+        {
+            // multi-block inclusive scan of the histogram: block sums -> scan of block sums -> per-chunk scan
+            const int nb = (int)((segs + kScanChunk - 1) / kScanChunk);
+            int32_t* block_sums = ws_i32 + segs + items + 4;
+            hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, rowptr_all + 1, segs, block_sums);
+            hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, block_sums, (int64_t)nb);
+            hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, rowptr_all + 1, segs, block_sums);
+        }
         hipLaunchKernelGGL(k_plan_fill, dim3(g), dim3(kBlock), 0, st, P, rowptr_all, cursor, perm_all);
         hipLaunchKernelGGL(k_plan_segsort, dim3(flat_grid(segs, kGridCap)), dim3(kBlock), 0, st, rowptr_all, perm_all, segs);
         if (any_pair) {
@@ -902,7 +985,7 @@ int fn_gat_bwd_finalize_f32(const float* part_a, int n_part_a, const float* part
     if (!part_a || n_part_a < 0 || n_part_e < 0 || !att || !g_att || bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_bwd_finalize_f32: bad argument");
     if (et->mode == 2 && (!part_e || !g_embW || !g_embb)) return fail(FN_EINVAL, "fn_gat_bwd_finalize_f32: null mode-2 buffer");
     if (heads != 1 && heads != 2 && heads != 4 && heads != 8) return fail(FN_EUNSUPPORTED, "heads must be 1, 2, 4 or 8");
-    hipLaunchKernelGGL(k_gat_finalize, dim3(1), dim3(1024), 0, S(stream), part_a, n_part_a, part_e, n_part_e, *et, att,
+    hipLaunchKernelGGL(k_gat_finalize, dim3(et->mode == 2 ? 9 : 8), dim3(1024), 0, S(stream), part_a, n_part_a, part_e, n_part_e, *et, att,
                        att_w, dst_off, src_off, g_att, g_embW, g_embb, heads);
     return launch_status("fn_gat_bwd_finalize_f32");
 }
@@ -934,7 +1017,7 @@ int fn_row_dots_bwd_f32(const float* g_s, const float* x, const float* A, int ld
 
 int fn_colsum_f32(const float* part, int n_rows, int cols, float* out, int ld, int off, fn_stream_t stream) {
     if (!part || !out || n_rows < 0 || cols < 1) return fail(FN_EINVAL, "fn_colsum_f32: bad argument");
-    hipLaunchKernelGGL(k_colsum, dim3((cols + 63) / 64), dim3(kBlock), 0, S(stream), part, n_rows, cols, out, ld, off);
+    hipLaunchKernelGGL(k_colsum, dim3((cols + 31) / 32), dim3(1024), 0, S(stream), part, n_rows, cols, out, ld, off);
     return launch_status("fn_colsum_f32");
 }
 

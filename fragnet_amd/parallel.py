@@ -112,3 +112,75 @@ def weighted_loss_scale(local_count: int, device, group=None) -> float:
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     world = dist.get_world_size(group)
     return float(local_count) * world / float(t.item())
+
+
+class FlatAdam:
+    """Adam over the live parameters as ONE flat tensor.
+
+    The live parameters' storage is re-pointed into a single contiguous fp32 buffer; after backward the
+    gradients are gathered into a matching flat buffer by one ``torch.cat`` (one kernel instead of one
+    accumulate per parameter), averaged across ranks by one all-reduce, and applied by one fused Adam
+    kernel.  Element-wise identical to ``torch.optim.Adam(model.parameters(), lr)`` -- the reference's
+    optimiser (finetune_gat2.py:257, pretrain_gat2.py:165) -- because Adam is element-wise and parameters
+    without gradient are skipped there too.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("FlatAdam needs at least one parameter")
+        with torch.no_grad():
+            flat = torch.cat([p.data.reshape(-1) for p in self.params])
+            off = 0
+            for p in self.params:
+                n = p.numel()
+                p.data = flat[off: off + n].view_as(p)
+                off += n
+        self.flat = torch.nn.Parameter(flat)
+        self.grad = torch.zeros_like(flat)
+        kw = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        try:
+            self.opt = torch.optim.Adam([self.flat], fused=flat.is_cuda, **kw)
+        except (RuntimeError, TypeError):
+            self.opt = torch.optim.Adam([self.flat], **kw)
+
+    @classmethod
+    def for_live_parameters(cls, model: torch.nn.Module, probe_backward, **kw) -> "FlatAdam":
+        for p in model.parameters():
+            p.grad = None
+        probe_backward()
+        live = [p for p in model.parameters() if p.grad is not None]
+        for p in live:
+            p.grad = None
+        return cls(live, **kw)
+
+    @property
+    def nbytes(self) -> int:
+        return self.grad.numel() * self.grad.element_size()
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self):
+        missing = [i for i, p in enumerate(self.params) if p.grad is None]
+        if missing:
+            raise RuntimeError(f"{len(missing)} live parameter(s) received no gradient this step")
+        torch.cat([p.grad.reshape(-1) for p in self.params], out=self.grad)
+
+    def all_reduce(self, group=None):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        if self.grad.is_cuda:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.AVG, group=group)
+        else:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+            self.grad.div_(dist.get_world_size(group))
+
+    def step(self, group=None):
+        """gather -> all-reduce (if distributed) -> Adam."""
+        self.gather_grads()
+        self.all_reduce(group)
+        self.flat.grad = self.grad
+        self.opt.step()
