@@ -66,11 +66,11 @@ def step_bytes(batch):
     return total
 
 
-def make_pool(n_batches, rank, device):
+def make_pool(n_batches, rank, device, batch=PER_GPU_BATCH):
     from fragnet_amd import data, synth
     pool = []
     for i in range(n_batches):
-        mols = synth.synth_molecules(PER_GPU_BATCH, seed=1000 + 97 * rank + i, profile="esol")
+        mols = synth.synth_molecules(batch, seed=1000 + 97 * rank + i, profile="esol")
         pool.append(data.batch_to(data.collate_fn(mols), device))
     return pool
 
@@ -121,7 +121,7 @@ def kernel_roofline(batch, model, iters=50):
     gout = torch.randn(n, 128, generator=g).to(dev)
     att = layer.a_b.detach().contiguous()
     embW, embb = layer.edge_attr_bond_embed.weight.detach().contiguous(), layer.edge_attr_bond_embed.bias.detach().contiguous()
-    x = batch["edge_attr_bonds"].contiguous()
+    x = plan.sorted_attr("bond", batch["edge_attr_bonds"])
     et = _lib.EdgeTerm(2, 1, 32, 32, None, x.data_ptr(), embW.data_ptr(), embb.data_ptr())
     f32 = dict(dtype=torch.float32, device=dev)
     s_dst, s_src = torch.empty(n, H, **f32), torch.empty(n, H, **f32)
@@ -138,7 +138,7 @@ def kernel_roofline(batch, model, iters=50):
 
     def bwd_dst():
         _lib.call("fn_gat_bwd_dst_f32", gout.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), C.byref(et), C.byref(lv.c), 0.2,
-                  dz.data_ptr(), g_s_dst.data_ptr(), None, part_e.data_ptr(), C.byref(n_e), H, st)
+                  dz.data_ptr(), g_s_dst.data_ptr(), part_e.data_ptr(), C.byref(n_e), H, st)
 
     def bwd_src():
         _lib.call("fn_gat_bwd_src_f32", gout.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), dz.data_ptr(), g_s_dst.data_ptr(),
@@ -150,6 +150,7 @@ def kernel_roofline(batch, model, iters=50):
     bwd_dst_b = 4 * (2 * n * D + m * H + m + m * H + n * H)            # g_out, h, probs, idx -> dz, g_s_dst
     bwd_src_b = 4 * (2 * n * D + 2 * m * H + m + n * H + n * D)        # g_out, h, probs, dz, idx, g_s_dst -> g_h
     res = {}
+    fwd()
     for name, fn, nbytes in (("k_gat_fwd", fwd, fwd_b), ("k_gat_bwd_dst", bwd_dst, bwd_dst_b), ("k_gat_bwd_src", bwd_src, bwd_src_b)):
         for _ in range(5):
             fn()
@@ -174,6 +175,8 @@ def main():
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-collated batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--kernels-only", action="store_true", help="only time the bond-level scatter kernels (dev loop)")
+    ap.add_argument("--kbatch", type=int, default=PER_GPU_BATCH, help="molecules per batch for --kernels-only")
     args = ap.parse_args()
 
     from fragnet_amd import parallel
@@ -188,9 +191,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    pool = make_pool(args.pool, rank, dev)
+    pool = make_pool(1, rank, dev, args.kbatch) if args.kernels_only else make_pool(args.pool, rank, dev)
     torch.manual_seed(0)
     model = FragNetFineTune(**MODEL_CFG).to(dev)
+    if args.kernels_only:
+        print(json.dumps(kernel_roofline(pool[0], model)))
+        return
     model.train()
     model.pretrain.rng.rank = rank
 
@@ -248,6 +254,7 @@ def main():
         }
         if not args.no_roofline:
             kr = kernel_roofline(pool[0], model)
+            kr = {k: v for k, v in kr.items() if not k.startswith("_")}
             dom = max(kr, key=lambda k: kr[k]["us_per_launch"])
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_per_launch.json")

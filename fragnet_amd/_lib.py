@@ -28,12 +28,12 @@ class CsrTask(C.Structure):
 
 class EdgeTerm(C.Structure):
     _fields_ = [("mode", i32), ("K", i32), ("d_e", i32), ("mid_off", i32),
-                ("s_edge", vp), ("x", vp), ("embW", vp), ("embb", vp)]
+                ("s_sorted", vp), ("x_sorted", vp), ("embW", vp), ("embb", vp)]
 
 
 class GatPlan(C.Structure):
     _fields_ = [("rowptr_d", vp), ("eid_d", vp), ("src_d", vp), ("rowptr_s", vp), ("dst_s", vp), ("dpos_s", vp),
-                ("pos_base_d", i32), ("pos_base_s", i32), ("n", i64), ("m", i64), ("m_real", i64)]
+                ("inv_d", vp), ("pos_base_d", i32), ("pos_base_s", i32), ("n", i64), ("m", i64), ("m_real", i64)]
 
 
 # name -> argtypes; every function returns int (0 ok / <0 argument error / >0 hipError_t) unless noted.
@@ -44,13 +44,14 @@ SIGNATURES = {
     "fn_plan_build": [C.POINTER(CsrTask), C.c_int, vp, vp, vp, vp, vp, vp],
     "fn_node_scalars_f32": [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, i64, C.c_int, vp],
     "fn_gat_fwd_f32": [vp, vp, vp, vp, C.c_int, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp, C.c_int, vp],
-    "fn_gat_bwd_dst_f32": [vp, vp, vp, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp, vp, ip, C.c_int, vp],
+    "fn_gat_bwd_dst_f32": [vp, vp, vp, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp, ip, C.c_int, vp],
     "fn_gat_bwd_src_f32": [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(GatPlan), vp, vp, ip, C.c_int, vp],
     "fn_gat_bwd_finalize_f32": [vp, C.c_int, vp, C.c_int, C.POINTER(EdgeTerm), vp, C.c_int, C.c_int, C.c_int, vp, vp, vp,
                                 C.c_int, vp],
     "fn_attn_by_src_f32": [vp, C.POINTER(GatPlan), vp, C.c_int, vp],
-    "fn_row_dots_f32": [vp, vp, C.c_int, C.c_int, C.c_int, vp, i64, vp],
-    "fn_row_dots_bwd_f32": [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, ip, i64, vp],
+    "fn_row_dots_sorted_f32": [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(GatPlan), vp, vp],
+    "fn_row_dots_sorted_bwd_f32": [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(GatPlan), vp, vp, ip, vp],
+    "fn_sort_edge_attr_f32": [vp, C.c_int, C.POINTER(GatPlan), vp, vp],
     "fn_colsum_f32": [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp],
     "fn_segment_sum_f32": [vp, i64, vp, vp, i32, vp, i64, i64, vp],
     "fn_gather_rows_f32": [vp, vp, vp, i64, i64, vp],

@@ -38,6 +38,14 @@ inline hipStream_t S(fn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 constexpr int kBlock = 256;
 constexpr int kRows = 8;          // rows (half-waves) per block
 constexpr int kGridCap = 2048;    // memory-bound kernels: ~8 blocks per CU, grid-stride the rest
+constexpr int kBwdRows = 16;      // rows (half-waves) per block in the attention backward kernels
+
+inline int bwd_grid(int64_t rows) {
+    int64_t g = (rows + kBwdRows - 1) / kBwdRows;
+    if (g < 1) g = 1;
+    if (g > FN_MAX_PART) g = FN_MAX_PART;
+    return (int)g;
+}
 
 inline int row_grid(int64_t rows, int cap) {
     int64_t g = (rows + kRows - 1) / kRows;
@@ -59,6 +67,22 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a
 __device__ __forceinline__ void fma4(float4& acc, float s, float4 v) {
     acc.x = fmaf(s, v.x, acc.x); acc.y = fmaf(s, v.y, acc.y);
     acc.z = fmaf(s, v.z, acc.z); acc.w = fmaf(s, v.w, acc.w);
+}
+
+// XCD-aware work split.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has
+// its own 4 MiB L2), so logical block ids are remapped to give every XCD one CONTIGUOUS range of rows: the
+// source rows a destination gathers belong to the same molecule, i.e. to neighbouring rows, and then stay
+// in that XCD's L2 instead of being fetched by all eight.  Bijective for any grid size; speed only.
+__device__ __forceinline__ int xcd_block(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+// [begin, end) of the row groups (RB rows each) owned by this block: contiguous chunks, XCD-swizzled
+__device__ __forceinline__ void block_groups(int64_t n_rows, int rb, int64_t& begin, int64_t& end) {
+    const int64_t groups = (n_rows + rb - 1) / rb;
+    const int64_t per = (groups + gridDim.x - 1) / gridDim.x;
+    begin = (int64_t)xcd_block(blockIdx.x, gridDim.x) * per;
+    end = begin + per < groups ? begin + per : groups;
 }
 
 template <int W> __device__ __forceinline__ float group_sum(float v) {
@@ -187,8 +211,9 @@ __global__ __launch_bounds__(256) void k_scan_apply(int32_t* __restrict__ a, int
         if (i0 + k < len) a[i0 + k] = v[k] + excl;
 }
 
+// unordered fill (integer atomics): tmp[pos] = task-local item id, seg_of[pos] = global segment id
 __global__ void k_plan_fill(PlanTasks P, const int32_t* __restrict__ rowptr_all, int32_t* __restrict__ cursor,
-                            int32_t* __restrict__ perm_all) {
+                            int32_t* __restrict__ tmp, int32_t* __restrict__ seg_of) {
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < P.total_items;
          g += (int64_t)gridDim.x * blockDim.x) {
         const fn_csr_task& T = P.t[find_task(P, g)];
@@ -197,56 +222,41 @@ __global__ void k_plan_fill(PlanTasks P, const int32_t* __restrict__ rowptr_all,
         if (k < 0 || k >= T.n_seg) continue;
         const int64_t seg = T.seg_base + k;
         const int32_t pos = rowptr_all[seg] + atomicAdd(&cursor[seg], 1);
-        perm_all[pos] = (int32_t)local;
+        tmp[pos] = (int32_t)local;
+        seg_of[pos] = (int32_t)seg;
     }
 }
 
-// ascending item id inside every segment => summation order of the reference's sequential scatter_add.
-// Segments of <= 16 items (every molecular graph level) are sorted in registers by an odd-even network.
-__global__ void k_plan_segsort(const int32_t* __restrict__ rowptr_all, int32_t* __restrict__ perm_all, int64_t total_segs) {
-    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total_segs;
-         s += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t b = rowptr_all[s], e = rowptr_all[s + 1];
-        const int32_t len = e - b;
-        if (len <= 1) continue;
-        if (len <= 16) {
-            int32_t v[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = (k < len) ? perm_all[b + k] : 0x7fffffff;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-#pragma unroll
-                for (int k = (r & 1); k + 1 < 16; k += 2) {
-                    const int32_t lo = min(v[k], v[k + 1]), hi = max(v[k], v[k + 1]);
-                    v[k] = lo;
-                    v[k + 1] = hi;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (k < len) perm_all[b + k] = v[k];
-        } else {
-            for (int32_t i = b + 1; i < e; ++i) {
-                const int32_t v = perm_all[i];
-                int32_t q = i - 1;
-                while (q >= b && perm_all[q] > v) { perm_all[q + 1] = perm_all[q]; --q; }
-                perm_all[q + 1] = v;
-            }
-        }
+// rank sort inside each segment: one thread per filled slot counts the smaller ids of its segment and
+// writes its id to that rank => ascending item id = summation order of the reference's sequential scatter_add.
+// Work is sum(len^2) independent cached loads (len <= ~30 for every molecular index space).
+__global__ void k_plan_ranksort(const int32_t* __restrict__ rowptr_all, const int32_t* __restrict__ tmp,
+                                const int32_t* __restrict__ seg_of, int32_t* __restrict__ perm_all,
+                                int64_t total_items, int64_t total_segs) {
+    const int32_t filled = rowptr_all[total_segs];          // < total_items only if some keys were out of range
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < filled;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t seg = seg_of[g];
+        const int32_t b = rowptr_all[seg], e = rowptr_all[seg + 1];
+        const int32_t v = tmp[g];
+        int32_t rank = 0;
+        for (int32_t q = b; q < e; ++q) rank += (tmp[q] < v) ? 1 : 0;
+        perm_all[b + rank] = v;
     }
 }
 
 template <int ROLE>
 __global__ void k_plan_aux(PlanTasks P, const int32_t* __restrict__ perm_all, int32_t* __restrict__ aux_a,
-                           int32_t* __restrict__ aux_b, int32_t* __restrict__ inv) {
+                           int32_t* __restrict__ aux_b) {
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < P.total_items;
          g += (int64_t)gridDim.x * blockDim.x) {
         const fn_csr_task& T = P.t[find_task(P, g)];
         if (T.role != ROLE) continue;
         const int64_t item = perm_all[g];
+        if (item < 0 || item >= T.n_real + T.n_loops) continue;      // unfilled slot (some key was out of range)
         aux_a[g] = (int32_t)item_other(T, item);
-        if (ROLE == FN_ROLE_DST) inv[T.item_base + item] = (int32_t)(g - T.item_base);
-        else aux_b[g] = inv[P.t[T.partner].item_base + item];
+        if (ROLE == FN_ROLE_DST) aux_b[T.item_base + item] = (int32_t)(g - T.item_base);   // inverse permutation
+        else aux_b[g] = aux_b[P.t[T.partner].item_base + item];
     }
 }
 
@@ -254,6 +264,34 @@ __global__ void k_plan_aux(PlanTasks P, const int32_t* __restrict__ perm_all, in
 // Attention level
 // =====================================================================================
 constexpr int kWfLd = FN_MAX_EDGE_K + 1;
+
+// ---- reductions over the LPH lanes of one head group.  DPP row operations (one VALU op each) instead of
+// ds_bpermute: row_half_mirror pairs lane i with 7-i inside each 8 lanes, quad_perm covers xor 1 / xor 2.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141; // lane i <- lane 7-i  (within 8)
+constexpr int kDppMirror = 0x140;     // lane i <- lane 15-i (within 16)
+
+template <int W> __device__ __forceinline__ float head_sum(float v) {
+    static_assert(W == 4 || W == 8 || W == 16 || W == 32, "head group width");
+    if (W == 32) v += __shfl_xor(v, 16);
+    if (W >= 16) v += dpp_mov<kDppMirror>(v);
+    if (W >= 8) v += dpp_mov<kDppHalfMirror>(v);
+    v += dpp_mov<kDppXor2>(v);
+    v += dpp_mov<kDppXor1>(v);
+    return v;
+}
+template <int W> __device__ __forceinline__ float head_max(float v) {
+    if (W == 32) v = fmaxf(v, __shfl_xor(v, 16));
+    if (W >= 16) v = fmaxf(v, dpp_mov<kDppMirror>(v));
+    if (W >= 8) v = fmaxf(v, dpp_mov<kDppHalfMirror>(v));
+    v = fmaxf(v, dpp_mov<kDppXor2>(v));
+    v = fmaxf(v, dpp_mov<kDppXor1>(v));
+    return v;
+}
 
 // folded edge-embedding weights: Wf[h][k] = sum_c att[h, mid+c] * embW[c,k],  Wf[h][K] = sum_c att[h, mid+c] * embb[c]
 __device__ __forceinline__ void fold_edge_embed(const fn_edge_term& et, const float* att, int att_w, int H,
@@ -273,24 +311,13 @@ __device__ __forceinline__ void fold_edge_embed(const fn_edge_term& et, const fl
     __syncthreads();
 }
 
+// edge term of the logit for the edge at destination-sorted position pos (both forms are coalesced reads)
 template <int H>
-__device__ __forceinline__ float edge_logit(int pos, int head, float sd, const float* __restrict__ s_src,
-                                            const fn_gat_plan& pl, const fn_edge_term& et,
-                                            const float (*sWf)[kWfLd], float slope, int& src_out) {
-    const int src = pl.src_d[pos];
-    const int eid = pl.eid_d[pos];
-    float e = 0.f;
-    if (eid < pl.m_real) {
-        if (et.mode == 0) {
-            e = et.s_edge[(size_t)eid * H + head];
-        } else {
-            e = sWf[head][et.K];
-            for (int k = 0; k < et.K; ++k) e = fmaf(et.x[(size_t)eid * et.K + k], sWf[head][k], e);
-        }
-    }
-    const float z = sd + s_src[(size_t)src * H + head] + e;
-    src_out = src;
-    return z > 0.f ? z : slope * z;
+__device__ __forceinline__ float edge_term_at(int pos, int head, const fn_edge_term& et, const float (*sWf)[kWfLd]) {
+    if (et.mode == 0) return et.s_sorted[(size_t)pos * H + head];
+    float e = sWf[head][et.K];
+    for (int k = 0; k < et.K; ++k) e = fmaf(et.x_sorted[(size_t)pos * et.K + k], sWf[head][k], e);
+    return e;
 }
 
 template <int H>
@@ -301,11 +328,37 @@ __global__ __launch_bounds__(kBlock) void k_node_scalars(const float* __restrict
     const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH;
     const float4 ad = ld4(att + head * att_w + dst_off + j * 4);
     const float4 as = ld4(att + head * att_w + src_off + j * 4);
-    for (int64_t r = (int64_t)blockIdx.x * kRows + (threadIdx.x >> 5); r < n; r += (int64_t)gridDim.x * kRows) {
+    int64_t g0, g1;
+    block_groups(n, kRows, g0, g1);
+    for (int64_t gi = g0; gi < g1; ++gi) {
+        const int64_t r = gi * kRows + (threadIdx.x >> 5);
+        if (r >= n) continue;
         const float4 x = ld4(h + r * FN_D + lane * 4);
-        const float pd = group_sum<LPH>(dot4(x, ad));
-        const float ps = group_sum<LPH>(dot4(x, as));
+        const float pd = head_sum<LPH>(dot4(x, ad));
+        const float ps = head_sum<LPH>(dot4(x, as));
         if (j == 0) { s_dst[r * H + head] = pd; s_src[r * H + head] = ps; }
+    }
+}
+
+// acc += sum_{k < cnt} p_k * h[src_k], p/src held by lane k of each head group; four row gathers in flight
+template <int H>
+__device__ __forceinline__ void gather_accumulate(float4& acc, const float* __restrict__ h, float pv, int srcv,
+                                                  int cnt, int lane) {
+    constexpr int LPH = 32 / H;
+    for (int k0 = 0; k0 < cnt; k0 += 4) {
+        float4 r[4];
+        float pk[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + i;
+            const int kk = k < cnt ? k : cnt - 1;
+            const int sk = __shfl(srcv, kk, LPH);
+            const float p = __shfl(pv, kk, LPH);
+            pk[i] = k < cnt ? p : 0.f;
+            r[i] = ld4(h + (size_t)sk * FN_D + lane * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fma4(acc, pk[i], r[i]);
     }
 }
 
@@ -319,55 +372,58 @@ __global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h,
     __shared__ float sWf[8][kWfLd];
     fold_edge_embed(et, att, att_w, H, sWf);
     const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH;
-    for (int64_t t = (int64_t)blockIdx.x * kRows + (threadIdx.x >> 5); t < pl.n; t += (int64_t)gridDim.x * kRows) {
+    int64_t g0, g1;
+    block_groups(pl.n, kRows, g0, g1);
+    for (int64_t gi = g0; gi < g1; ++gi) {
+        const int64_t t = gi * kRows + (threadIdx.x >> 5);
+        if (t >= pl.n) continue;
         const int beg = pl.rowptr_d[t] - pl.pos_base_d;
         const int deg = pl.rowptr_d[t + 1] - pl.rowptr_d[t];
         const float sd = s_dst[t * H + head];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (deg <= 2 * LPH) {
-            // lane j of each head group owns in-edges j and LPH + j: all scalar gathers of a node are
-            // issued in one round, then probabilities are broadcast edge by edge for the row gathers
-            int srcA = 0, srcB = 0;
-            float lA = -INFINITY, lB = -INFINITY;
+            // lane j of each head group owns in-edges j and LPH + j: the scalar gathers of a node go out in one
+            // round; probabilities and source ids are then broadcast edge by edge for the row gathers
             const bool hasA = j < deg, hasB = j + LPH < deg;
-            if (hasA) lA = edge_logit<H>(beg + j, head, sd, s_src, pl, et, sWf, slope, srcA);
-            if (hasB) lB = edge_logit<H>(beg + LPH + j, head, sd, s_src, pl, et, sWf, slope, srcB);
-            const float mx = group_max<LPH>(fmaxf(lA, lB));
+            const int posA = beg + j, posB = beg + LPH + j;
+            int srcA = 0, srcB = 0;
+            float zA = 0.f, zB = 0.f;
+            if (hasA) { srcA = pl.src_d[posA]; zA = edge_term_at<H>(posA, head, et, sWf); }
+            if (hasB) { srcB = pl.src_d[posB]; zB = edge_term_at<H>(posB, head, et, sWf); }
+            if (hasA) zA += sd + s_src[(size_t)srcA * H + head];
+            if (hasB) zB += sd + s_src[(size_t)srcB * H + head];
+            const float lA = hasA ? (zA > 0.f ? zA : slope * zA) : -INFINITY;
+            const float lB = hasB ? (zB > 0.f ? zB : slope * zB) : -INFINITY;
+            const float mx = head_max<LPH>(fmaxf(lA, lB));
             const float eA = hasA ? expf(lA - mx) : 0.f;
             const float eB = hasB ? expf(lB - mx) : 0.f;
-            const float den = group_sum<LPH>(eA + eB);
+            const float den = head_sum<LPH>(eA + eB);
             const float pA = hasA ? eA / den : 0.f;
             const float pB = hasB ? eB / den : 0.f;
             if (hasA) {
-                p_sorted[(size_t)(beg + j) * H + head] = lA > 0.f ? pA : -pA;
-                if (probs_orig) probs_orig[(size_t)pl.eid_d[beg + j] * H + head] = pA;
+                p_sorted[(size_t)posA * H + head] = lA > 0.f ? pA : -pA;
+                if (probs_orig) probs_orig[(size_t)pl.eid_d[posA] * H + head] = pA;
             }
             if (hasB) {
-                p_sorted[(size_t)(beg + LPH + j) * H + head] = lB > 0.f ? pB : -pB;
-                if (probs_orig) probs_orig[(size_t)pl.eid_d[beg + LPH + j] * H + head] = pB;
+                p_sorted[(size_t)posB * H + head] = lB > 0.f ? pB : -pB;
+                if (probs_orig) probs_orig[(size_t)pl.eid_d[posB] * H + head] = pB;
             }
-            const int cntA = deg < LPH ? deg : LPH;
-
-            for (int k = 0; k < cntA; ++k) {
-                const float pk = __shfl(pA, k, LPH);
-                const int sk = __shfl(srcA, k, LPH);
-                fma4(acc, pk, ld4(h + (size_t)sk * FN_D + lane * 4));
-            }
-
-            for (int k = 0; k < deg - LPH; ++k) {
-                const float pk = __shfl(pB, k, LPH);
-                const int sk = __shfl(srcB, k, LPH);
-                fma4(acc, pk, ld4(h + (size_t)sk * FN_D + lane * 4));
-            }
+            gather_accumulate<H>(acc, h, pA, srcA, deg < LPH ? deg : LPH, lane);
+            if (deg > LPH) gather_accumulate<H>(acc, h, pB, srcB, deg - LPH, lane);
         } else {
             // rare high in-degree node: every lane walks the edge list (three passes)
+            auto logit = [&](int pos, int& sk) {
+                sk = pl.src_d[pos];
+                const float z = sd + s_src[(size_t)sk * H + head] + edge_term_at<H>(pos, head, et, sWf);
+                return z > 0.f ? z : slope * z;
+            };
             int sk = 0;
             float mx = -INFINITY;
-            for (int i = 0; i < deg; ++i) mx = fmaxf(mx, edge_logit<H>(beg + i, head, sd, s_src, pl, et, sWf, slope, sk));
+            for (int i = 0; i < deg; ++i) mx = fmaxf(mx, logit(beg + i, sk));
             float den = 0.f;
-            for (int i = 0; i < deg; ++i) den += expf(edge_logit<H>(beg + i, head, sd, s_src, pl, et, sWf, slope, sk) - mx);
+            for (int i = 0; i < deg; ++i) den += expf(logit(beg + i, sk) - mx);
             for (int i = 0; i < deg; ++i) {
-                const float l = edge_logit<H>(beg + i, head, sd, s_src, pl, et, sWf, slope, sk);
+                const float l = logit(beg + i, sk);
                 const float p = expf(l - mx) / den;
                 if (j == 0) {
                     p_sorted[(size_t)(beg + i) * H + head] = l > 0.f ? p : -p;
@@ -380,14 +436,14 @@ __global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h,
     }
 }
 
-template <int H>
-__global__ __launch_bounds__(kBlock) void k_gat_bwd_dst(const float* __restrict__ g_out, const float* __restrict__ h,
-                                                        const float* __restrict__ p_sorted, fn_edge_term et,
-                                                        fn_gat_plan pl, float slope, float* __restrict__ dz_sorted,
-                                                        float* __restrict__ g_s_dst, float* __restrict__ g_s_edge,
-                                                        float* __restrict__ part_e) {
+// Backward kernels use RB rows (half-waves) per block so that the per-block partial rows stay few.
+template <int H, int RB>
+__global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(const float* __restrict__ g_out, const float* __restrict__ h,
+                                                         const float* __restrict__ p_sorted, fn_edge_term et,
+                                                         fn_gat_plan pl, float slope, float* __restrict__ dz_sorted,
+                                                         float* __restrict__ g_s_dst, float* __restrict__ part_e) {
     constexpr int LPH = 32 / H;
-    __shared__ float sP[kRows][8][kWfLd];
+    __shared__ float sP[RB][8][kWfLd];
     const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH, hw = threadIdx.x >> 5;
     float pw[kWfLd];
 #pragma unroll
@@ -395,54 +451,57 @@ __global__ __launch_bounds__(kBlock) void k_gat_bwd_dst(const float* __restrict_
 
     auto emit = [&](int pos, float dz) {
         dz_sorted[(size_t)pos * H + head] = dz;
-        const int eid = pl.eid_d[pos];
-        if (eid < pl.m_real) {
-            if (et.mode == 0) {
-                g_s_edge[(size_t)eid * H + head] = dz;
-            } else {
-                pw[FN_MAX_EDGE_K] += dz;
+        if (et.mode == 2) {
+            pw[FN_MAX_EDGE_K] += dz;
 #pragma unroll
-                for (int k = 0; k < FN_MAX_EDGE_K; ++k)
-                    if (k < et.K) pw[k] = fmaf(dz, et.x[(size_t)eid * et.K + k], pw[k]);
-            }
+            for (int k = 0; k < FN_MAX_EDGE_K; ++k)
+                if (k < et.K) pw[k] = fmaf(dz, et.x_sorted[(size_t)pos * et.K + k], pw[k]);
         }
     };
 
-    for (int64_t t = (int64_t)blockIdx.x * kRows + hw; t < pl.n; t += (int64_t)gridDim.x * kRows) {
+    for (int64_t t = (int64_t)blockIdx.x * RB + hw; t < pl.n; t += (int64_t)gridDim.x * RB) {
         const int beg = pl.rowptr_d[t] - pl.pos_base_d;
         const int deg = pl.rowptr_d[t + 1] - pl.rowptr_d[t];
         const float4 g = ld4(g_out + t * FN_D + lane * 4);
         if (deg <= 2 * LPH) {
-            float dpA = 0.f, dpB = 0.f;
-
-            for (int k = 0; k < deg; ++k) {
-                const int sk = pl.src_d[beg + k];
-                const float d = group_sum<LPH>(dot4(g, ld4(h + (size_t)sk * FN_D + lane * 4)));
-                if (k == j) dpA = d;
-                if (k == j + LPH) dpB = d;
-            }
             const bool hasA = j < deg, hasB = j + LPH < deg;
             const float psA = hasA ? p_sorted[(size_t)(beg + j) * H + head] : 0.f;
             const float psB = hasB ? p_sorted[(size_t)(beg + LPH + j) * H + head] : 0.f;
+            float dpA = 0.f, dpB = 0.f;
+            for (int k0 = 0; k0 < deg; k0 += 4) {
+                float4 r[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int kk = (k0 + i < deg) ? k0 + i : deg - 1;
+                    r[i] = ld4(h + (size_t)pl.src_d[beg + kk] * FN_D + lane * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d = head_sum<LPH>(dot4(g, r[i]));
+                    const int k = k0 + i;                    // k >= deg never matches an owned slot that is used
+                    if (k == j) dpA = d;
+                    if (k == j + LPH) dpB = d;
+                }
+            }
             const float pA = fabsf(psA), pB = fabsf(psB);
-            const float c = group_sum<LPH>(pA * dpA + pB * dpB);
+            const float c = head_sum<LPH>(pA * dpA + pB * dpB);
             const float dzA = pA * (dpA - c) * ((__float_as_uint(psA) >> 31) ? slope : 1.f);
             const float dzB = pB * (dpB - c) * ((__float_as_uint(psB) >> 31) ? slope : 1.f);
             if (hasA) emit(beg + j, dzA);
             if (hasB) emit(beg + LPH + j, dzB);
-            const float gs = group_sum<LPH>(dzA + dzB);
+            const float gs = head_sum<LPH>(dzA + dzB);
             if (j == 0) g_s_dst[t * H + head] = gs;
         } else {
             float c = 0.f;
             for (int k = 0; k < deg; ++k) {
                 const int sk = pl.src_d[beg + k];
-                const float d = group_sum<LPH>(dot4(g, ld4(h + (size_t)sk * FN_D + lane * 4)));
+                const float d = head_sum<LPH>(dot4(g, ld4(h + (size_t)sk * FN_D + lane * 4)));
                 c = fmaf(fabsf(p_sorted[(size_t)(beg + k) * H + head]), d, c);
             }
             float gs = 0.f;
             for (int k = 0; k < deg; ++k) {
                 const int sk = pl.src_d[beg + k];
-                const float d = group_sum<LPH>(dot4(g, ld4(h + (size_t)sk * FN_D + lane * 4)));
+                const float d = head_sum<LPH>(dot4(g, ld4(h + (size_t)sk * FN_D + lane * 4)));
                 const float ps = p_sorted[(size_t)(beg + k) * H + head];
                 const float dz = fabsf(ps) * (d - c) * ((__float_as_uint(ps) >> 31) ? slope : 1.f);
                 if (j == 0) emit(beg + k, dz);
@@ -456,7 +515,7 @@ __global__ __launch_bounds__(kBlock) void k_gat_bwd_dst(const float* __restrict_
         // deterministic block partial of sum_e dz[e,h] * (x[e,0..K), 1)
 #pragma unroll
         for (int k = 0; k < kWfLd; ++k) {
-            const float v = group_sum<LPH>(pw[k]);
+            const float v = head_sum<LPH>(pw[k]);
             if (j == 0) sP[hw][head][k] = v;
         }
         __syncthreads();
@@ -466,39 +525,48 @@ __global__ __launch_bounds__(kBlock) void k_gat_bwd_dst(const float* __restrict_
             const int kk = (k == et.K) ? FN_MAX_EDGE_K : k;
             float a = 0.f;
 #pragma unroll
-            for (int w = 0; w < kRows; ++w) a += sP[w][hh][kk];
+            for (int w = 0; w < RB; ++w) a += sP[w][hh][kk];
             part_e[(size_t)blockIdx.x * ne + i] = a;
         }
     }
 }
 
-template <int H>
-__global__ __launch_bounds__(kBlock) void k_gat_bwd_src(const float* __restrict__ g_out, const float* __restrict__ h,
-                                                        const float* __restrict__ p_sorted,
-                                                        const float* __restrict__ dz_sorted,
-                                                        const float* __restrict__ g_s_dst, const float* __restrict__ att,
-                                                        int att_w, int dst_off, int src_off, fn_gat_plan pl,
-                                                        float* __restrict__ g_h, float* __restrict__ part_a) {
+template <int H, int RB>
+__global__ __launch_bounds__(RB * 32) void k_gat_bwd_src(const float* __restrict__ g_out, const float* __restrict__ h,
+                                                         const float* __restrict__ p_sorted,
+                                                         const float* __restrict__ dz_sorted,
+                                                         const float* __restrict__ g_s_dst, const float* __restrict__ att,
+                                                         int att_w, int dst_off, int src_off, fn_gat_plan pl,
+                                                         float* __restrict__ g_h, float* __restrict__ part_a) {
     constexpr int LPH = 32 / H;
-    __shared__ float sA[kRows][2 * FN_D];
+    __shared__ float sA[RB][2 * FN_D];
     const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH, hw = threadIdx.x >> 5;
     const float4 ad = ld4(att + head * att_w + dst_off + j * 4);
     const float4 as = ld4(att + head * att_w + src_off + j * 4);
     float4 qd = make_float4(0.f, 0.f, 0.f, 0.f), qs = qd;
-    for (int64_t s = (int64_t)blockIdx.x * kRows + hw; s < pl.n; s += (int64_t)gridDim.x * kRows) {
+    for (int64_t s = (int64_t)blockIdx.x * RB + hw; s < pl.n; s += (int64_t)gridDim.x * RB) {
         const int beg = pl.rowptr_s[s] - pl.pos_base_s;
         const int deg = pl.rowptr_s[s + 1] - pl.rowptr_s[s];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        float gss = 0.f;
-
-        for (int i = 0; i < deg; ++i) {
-            const int t = pl.dst_s[beg + i];
-            const size_t pos = (size_t)pl.dpos_s[beg + i] * H + head;
-            fma4(acc, fabsf(p_sorted[pos]), ld4(g_out + (size_t)t * FN_D + lane * 4));
-            gss += dz_sorted[pos];
-        }
         const float gsd = g_s_dst[s * H + head];
         const float4 hr = ld4(h + s * FN_D + lane * 4);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float gss = 0.f;
+        for (int i0 = 0; i0 < deg; i0 += 4) {
+            float4 r[4];
+            float pk[4], dk[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = i0 + i < deg;
+                const int ii = ok ? i0 + i : deg - 1;
+                const int t = pl.dst_s[beg + ii];
+                const size_t pos = (size_t)pl.dpos_s[beg + ii] * H + head;
+                pk[i] = ok ? fabsf(p_sorted[pos]) : 0.f;
+                dk[i] = ok ? dz_sorted[pos] : 0.f;
+                r[i] = ld4(g_out + (size_t)t * FN_D + lane * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { fma4(acc, pk[i], r[i]); gss += dk[i]; }
+        }
         fma4(acc, gsd, ad);
         fma4(acc, gss, as);
         st4(g_h + s * FN_D + lane * 4, acc);
@@ -508,10 +576,12 @@ __global__ __launch_bounds__(kBlock) void k_gat_bwd_src(const float* __restrict_
     st4(&sA[hw][lane * 4], qd);
     st4(&sA[hw][FN_D + lane * 4], qs);
     __syncthreads();
-    float a = 0.f;
+    for (int c = threadIdx.x; c < 2 * FN_D; c += blockDim.x) {
+        float a = 0.f;
 #pragma unroll
-    for (int w = 0; w < kRows; ++w) a += sA[w][threadIdx.x];
-    part_a[(size_t)blockIdx.x * (2 * FN_D) + threadIdx.x] = a;
+        for (int w = 0; w < RB; ++w) a += sA[w][c];
+        part_a[(size_t)blockIdx.x * (2 * FN_D) + c] = a;
+    }
 }
 
 // blocks 0..7: column tiles (32 columns each) of the [n_a, 256] a_dst/a_src partials; block 8 (mode 2 only):
@@ -592,31 +662,43 @@ __global__ void k_attn_by_src(const float* __restrict__ p_sorted, fn_gat_plan pl
 }
 
 // =====================================================================================
-// Row dots (full-width edge term) and its backward
+// Full-width edge term (atom graph / fragment graph), produced directly in destination-sorted order
 // =====================================================================================
-__global__ __launch_bounds__(kBlock) void k_row_dots(const float* __restrict__ x, const float* __restrict__ A, int lda,
-                                                     int off, int J, float* __restrict__ s, int64_t rows) {
+// s_sorted[pos, j] = <feat[eid(pos), :], A[j, off:off+128]>, 0 at loop positions (eid >= m_real)
+__global__ __launch_bounds__(kBlock) void k_row_dots_sorted(const float* __restrict__ feat, const float* __restrict__ A,
+                                                            int lda, int off, int J, fn_gat_plan pl,
+                                                            float* __restrict__ s_sorted) {
     const int lane = threadIdx.x & 31;
     float4 a[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) a[q] = (q < J) ? ld4(A + q * lda + off + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t r = (int64_t)blockIdx.x * kRows + (threadIdx.x >> 5); r < rows; r += (int64_t)gridDim.x * kRows) {
-        const float4 v = ld4(x + r * FN_D + lane * 4);
+    int64_t g0, g1;
+    block_groups(pl.m, kRows, g0, g1);
+    for (int64_t gi = g0; gi < g1; ++gi) {
+        const int64_t pos = gi * kRows + (threadIdx.x >> 5);
+        if (pos >= pl.m) continue;
+        const int eid = pl.eid_d[pos];
         float mine = 0.f;
+        if (eid < pl.m_real) {                       // uniform inside the half-wave
+            const float4 v = ld4(feat + (size_t)eid * FN_D + lane * 4);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (q < J) {
-                const float d = group_sum<32>(dot4(v, a[q]));
-                if (lane == q) mine = d;
+            for (int q = 0; q < 8; ++q) {
+                if (q < J) {
+                    const float d = head_sum<32>(dot4(v, a[q]));
+                    if (lane == q) mine = d;
+                }
             }
         }
-        if (lane < J) s[r * J + lane] = mine;
+        if (lane < J) s_sorted[pos * J + lane] = mine;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_row_dots_bwd(const float* __restrict__ g_s, const float* __restrict__ x,
-                                                         const float* __restrict__ A, int lda, int off, int J,
-                                                         float* __restrict__ g_x, float* __restrict__ part, int64_t rows) {
+// g_feat[e,:] = sum_j g_s_sorted[inv(e), j] A[j];  part [grid, J*128]: partial sums of g_A[j,:] = sum_e g_s[e,j] feat[e,:]
+__global__ __launch_bounds__(kBlock) void k_row_dots_sorted_bwd(const float* __restrict__ g_s_sorted,
+                                                                const float* __restrict__ feat,
+                                                                const float* __restrict__ A, int lda, int off, int J,
+                                                                fn_gat_plan pl, float* __restrict__ g_feat,
+                                                                float* __restrict__ part) {
     __shared__ float sR[kRows][FN_D];
     const int lane = threadIdx.x & 31, hw = threadIdx.x >> 5;
     float4 a[8], q[8];
@@ -625,18 +707,23 @@ __global__ __launch_bounds__(kBlock) void k_row_dots_bwd(const float* __restrict
         a[i] = (i < J) ? ld4(A + i * lda + off + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int64_t r = (int64_t)blockIdx.x * kRows + hw; r < rows; r += (int64_t)gridDim.x * kRows) {
-        const float4 v = ld4(x + r * FN_D + lane * 4);
+    int64_t g0, g1;
+    block_groups(pl.m_real, kRows, g0, g1);
+    for (int64_t gi = g0; gi < g1; ++gi) {
+        const int64_t e = gi * kRows + hw;
+        if (e >= pl.m_real) continue;
+        const size_t pos = (size_t)pl.inv_d[e];
+        const float4 v = ld4(feat + e * FN_D + lane * 4);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if (i < J) {
-                const float gs = g_s[r * J + i];
+                const float gs = g_s_sorted[pos * J + i];
                 fma4(acc, gs, a[i]);
                 fma4(q[i], gs, v);
             }
         }
-        st4(g_x + r * FN_D + lane * 4, acc);
+        st4(g_feat + e * FN_D + lane * 4, acc);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -651,6 +738,17 @@ __global__ __launch_bounds__(kBlock) void k_row_dots_bwd(const float* __restrict
             }
             __syncthreads();
         }
+    }
+}
+
+// x_sorted[pos, :] = x[eid(pos), :] (zeros at loop positions): raw edge attributes are permuted once per batch
+__global__ void k_sort_edge_attr(const float* __restrict__ x, int K, fn_gat_plan pl, float* __restrict__ x_sorted) {
+    const int64_t total = pl.m * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pos = i / K;
+        const int k = (int)(i % K);
+        const int eid = pl.eid_d[pos];
+        x_sorted[i] = eid < pl.m_real ? x[(size_t)eid * K + k] : 0.f;
     }
 }
 
@@ -681,7 +779,11 @@ __global__ __launch_bounds__(kBlock) void k_segment_sum128(const float* __restri
                                                            const int32_t* __restrict__ perm, int32_t pos_base,
                                                            float* __restrict__ out, int64_t n_seg) {
     const int lane = threadIdx.x & 31;
-    for (int64_t s = (int64_t)blockIdx.x * kRows + (threadIdx.x >> 5); s < n_seg; s += (int64_t)gridDim.x * kRows) {
+    int64_t g0, g1;
+    block_groups(n_seg, kRows, g0, g1);
+    for (int64_t gi = g0; gi < g1; ++gi) {
+        const int64_t s = gi * kRows + (threadIdx.x >> 5);
+        if (s >= n_seg) continue;
         const int beg = rowptr[s] - pos_base, deg = rowptr[s + 1] - rowptr[s];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -844,7 +946,7 @@ bool bad_edge_term(const fn_edge_term* et) {
     if (!et) return true;
     if (et->mode == 0) return false;
     if (et->mode != 2) return true;
-    return et->K < 1 || et->K > FN_MAX_EDGE_K || et->d_e < 1 || et->d_e > 128 || !et->x || !et->embW || !et->embb;
+    return et->K < 1 || et->K > FN_MAX_EDGE_K || et->d_e < 1 || et->d_e > 128 || !et->x_sorted || !et->embW || !et->embb;
 }
 
 }  // namespace
@@ -900,7 +1002,7 @@ int fn_plan_build(const fn_csr_task* tasks, int n_tasks, int32_t* rowptr_all, in
     P.total_segs = segs;
     hipStream_t st = S(stream);
     int32_t* cursor = ws_i32;
-    int32_t* inv = ws_i32 + segs;
+    int32_t* tmp = ws_i32 + segs;          // unordered fill target (total_items)
     int32_t* status = ws_i32 + segs + items;
     hipError_t e = hipMemsetAsync(rowptr_all, 0, (size_t)(segs + 1) * 4, st);
     if (e == hipSuccess) e = hipMemsetAsync(ws_i32, 0, (size_t)(segs + items + 4) * 4, st);
@@ -916,11 +1018,11 @@ int fn_plan_build(const fn_csr_task* tasks, int n_tasks, int32_t* rowptr_all, in
             hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, block_sums, (int64_t)nb);
             hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, rowptr_all + 1, segs, block_sums);
         }
-        hipLaunchKernelGGL(k_plan_fill, dim3(g), dim3(kBlock), 0, st, P, rowptr_all, cursor, perm_all);
-        hipLaunchKernelGGL(k_plan_segsort, dim3(flat_grid(segs, kGridCap)), dim3(kBlock), 0, st, rowptr_all, perm_all, segs);
+        hipLaunchKernelGGL(k_plan_fill, dim3(g), dim3(kBlock), 0, st, P, rowptr_all, cursor, tmp, aux_a);
+        hipLaunchKernelGGL(k_plan_ranksort, dim3(g), dim3(kBlock), 0, st, rowptr_all, tmp, aux_a, perm_all, items, segs);
         if (any_pair) {
-            hipLaunchKernelGGL(k_plan_aux<FN_ROLE_DST>, dim3(g), dim3(kBlock), 0, st, P, perm_all, aux_a, aux_b, inv);
-            hipLaunchKernelGGL(k_plan_aux<FN_ROLE_SRC>, dim3(g), dim3(kBlock), 0, st, P, perm_all, aux_a, aux_b, inv);
+            hipLaunchKernelGGL(k_plan_aux<FN_ROLE_DST>, dim3(g), dim3(kBlock), 0, st, P, perm_all, aux_a, aux_b);
+            hipLaunchKernelGGL(k_plan_aux<FN_ROLE_SRC>, dim3(g), dim3(kBlock), 0, st, P, perm_all, aux_a, aux_b);
         }
     }
     return launch_status("fn_plan_build");
@@ -941,7 +1043,7 @@ int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const
                    float* probs_orig, int heads, fn_stream_t stream) {
     if (!h || !s_dst || !s_src || !att || !plan || !out || bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_fwd_f32: bad argument");
     if (plan->m > 0 && !p_sorted) return fail(FN_EINVAL, "fn_gat_fwd_f32: null p_sorted");
-    if (et->mode == 0 && plan->m_real > 0 && !et->s_edge) return fail(FN_EINVAL, "fn_gat_fwd_f32: null s_edge");
+    if (et->mode == 0 && plan->m > 0 && !et->s_sorted) return fail(FN_EINVAL, "fn_gat_fwd_f32: null s_sorted");
     if (plan->n == 0) return 0;
     FN_DISPATCH_H(heads, hipLaunchKernelGGL(k_gat_fwd<HH>, dim3(row_grid(plan->n, 8 * kGridCap)), dim3(kBlock), 0, S(stream),
                                             h, s_dst, s_src, att, att_w, *et, *plan, neg_slope, out, p_sorted, probs_orig));
@@ -949,18 +1051,18 @@ int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const
 }
 
 int fn_gat_bwd_dst_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et,
-                       const fn_gat_plan* plan, float neg_slope, float* dz_sorted, float* g_s_dst, float* g_s_edge,
-                       float* part_e, int* n_part_e, int heads, fn_stream_t stream) {
-    if (!g_out || !h || !plan || !g_s_dst || !n_part_e || bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: bad argument");
+                       const fn_gat_plan* plan, float neg_slope, float* dz_sorted, float* g_s_dst, float* part_e,
+                       int* n_part_e, int heads, fn_stream_t stream) {
+    if (!g_out || !h || !plan || !g_s_dst || !n_part_e || !et) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: bad argument");
+    if (et->mode != 0 && bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: bad edge term");
     if (plan->m > 0 && (!p_sorted || !dz_sorted)) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: null edge buffer");
-    if (et->mode == 0 && plan->m_real > 0 && !g_s_edge) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: null g_s_edge");
     if (et->mode == 2 && !part_e) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: null part_e");
     *n_part_e = 0;
     if (plan->n == 0) return 0;
-    const int g = row_grid(plan->n, FN_MAX_PART);
+    const int g = bwd_grid(plan->n);
     *n_part_e = (et->mode == 2) ? g : 0;
-    FN_DISPATCH_H(heads, hipLaunchKernelGGL(k_gat_bwd_dst<HH>, dim3(g), dim3(kBlock), 0, S(stream), g_out, h, p_sorted, *et,
-                                            *plan, neg_slope, dz_sorted, g_s_dst, g_s_edge, part_e));
+    FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_dst<HH, kBwdRows>), dim3(g), dim3(kBwdRows * 32), 0, S(stream), g_out, h,
+                                            p_sorted, *et, *plan, neg_slope, dz_sorted, g_s_dst, part_e));
     return launch_status("fn_gat_bwd_dst_f32");
 }
 
@@ -972,9 +1074,9 @@ int fn_gat_bwd_src_f32(const float* g_out, const float* h, const float* p_sorted
     if ((att_w | dst_off | src_off) & 3) return fail(FN_EINVAL, "fn_gat_bwd_src_f32: att blocks must be 16-byte aligned");
     *n_part_a = 0;
     if (plan->n == 0) return 0;
-    const int g = row_grid(plan->n, FN_MAX_PART);
+    const int g = bwd_grid(plan->n);
     *n_part_a = g;
-    FN_DISPATCH_H(heads, hipLaunchKernelGGL(k_gat_bwd_src<HH>, dim3(g), dim3(kBlock), 0, S(stream), g_out, h, p_sorted,
+    FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src<HH, kBwdRows>), dim3(g), dim3(kBwdRows * 32), 0, S(stream), g_out, h, p_sorted,
                                             dz_sorted, g_s_dst, att, att_w, dst_off, src_off, *plan, g_h, part_a));
     return launch_status("fn_gat_bwd_src_f32");
 }
@@ -998,21 +1100,35 @@ int fn_attn_by_src_f32(const float* p_sorted, const fn_gat_plan* plan, float* at
     return launch_status("fn_attn_by_src_f32");
 }
 
-int fn_row_dots_f32(const float* x, const float* A, int lda, int off, int J, float* s, int64_t rows, fn_stream_t stream) {
-    if (!x || !A || !s || rows < 0 || J < 1 || J > 8 || ((lda | off) & 3)) return fail(FN_EINVAL, "fn_row_dots_f32: bad argument");
-    if (rows == 0) return 0;
-    hipLaunchKernelGGL(k_row_dots, dim3(row_grid(rows, kGridCap)), dim3(kBlock), 0, S(stream), x, A, lda, off, J, s, rows);
-    return launch_status("fn_row_dots_f32");
+int fn_row_dots_sorted_f32(const float* feat, const float* A, int lda, int off, int J, const fn_gat_plan* plan,
+                           float* s_sorted, fn_stream_t stream) {
+    if (!A || !plan || J < 1 || J > 8 || ((lda | off) & 3)) return fail(FN_EINVAL, "fn_row_dots_sorted_f32: bad argument");
+    if (plan->m == 0) return 0;
+    if (!s_sorted || (plan->m_real > 0 && !feat)) return fail(FN_EINVAL, "fn_row_dots_sorted_f32: null buffer");
+    hipLaunchKernelGGL(k_row_dots_sorted, dim3(row_grid(plan->m, kGridCap)), dim3(kBlock), 0, S(stream), feat, A, lda, off, J,
+                       *plan, s_sorted);
+    return launch_status("fn_row_dots_sorted_f32");
 }
 
-int fn_row_dots_bwd_f32(const float* g_s, const float* x, const float* A, int lda, int off, int J, float* g_x,
-                        float* part, int* n_part, int64_t rows, fn_stream_t stream) {
-    if (!g_s || !x || !A || !g_x || !part || !n_part || rows < 0 || J < 1 || J > 8 || ((lda | off) & 3))
-        return fail(FN_EINVAL, "fn_row_dots_bwd_f32: bad argument");
-    const int g = row_grid(rows, FN_MAX_PART);
+int fn_row_dots_sorted_bwd_f32(const float* g_s_sorted, const float* feat, const float* A, int lda, int off, int J,
+                               const fn_gat_plan* plan, float* g_feat, float* part, int* n_part, fn_stream_t stream) {
+    if (!A || !plan || !part || !n_part || J < 1 || J > 8 || ((lda | off) & 3))
+        return fail(FN_EINVAL, "fn_row_dots_sorted_bwd_f32: bad argument");
+    if (plan->m_real > 0 && (!g_s_sorted || !feat || !g_feat || !plan->inv_d))
+        return fail(FN_EINVAL, "fn_row_dots_sorted_bwd_f32: null buffer");
+    const int g = row_grid(plan->m_real, FN_MAX_PART);
     *n_part = g;
-    hipLaunchKernelGGL(k_row_dots_bwd, dim3(g), dim3(kBlock), 0, S(stream), g_s, x, A, lda, off, J, g_x, part, rows);
-    return launch_status("fn_row_dots_bwd_f32");
+    hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(g), dim3(kBlock), 0, S(stream), g_s_sorted, feat, A, lda, off, J, *plan,
+                       g_feat, part);
+    return launch_status("fn_row_dots_sorted_bwd_f32");
+}
+
+int fn_sort_edge_attr_f32(const float* x, int K, const fn_gat_plan* plan, float* x_sorted, fn_stream_t stream) {
+    if (!plan || K < 1) return fail(FN_EINVAL, "fn_sort_edge_attr_f32: bad argument");
+    if (plan->m == 0) return 0;
+    if (!x_sorted || (plan->m_real > 0 && !x)) return fail(FN_EINVAL, "fn_sort_edge_attr_f32: null buffer");
+    hipLaunchKernelGGL(k_sort_edge_attr, dim3(flat_grid(plan->m * K, kGridCap)), dim3(kBlock), 0, S(stream), x, K, *plan, x_sorted);
+    return launch_status("fn_sort_edge_attr_f32");
 }
 
 int fn_colsum_f32(const float* part, int n_rows, int cols, float* out, int ld, int off, fn_stream_t stream) {

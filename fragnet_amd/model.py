@@ -117,7 +117,8 @@ class FragNetLayerA(nn.Module):
 
         # L1 bond graph (gat2.py:137-169): affine-in-cos edge term folded in-kernel
         r = ops.gat_level(F.linear(bond_nodes, self.projection_b.weight, self.projection_b.bias), self.a_b, L["bond"], H,
-                          x=bond_cos, embW=self.edge_attr_bond_embed.weight, embb=self.edge_attr_bond_embed.bias,
+                          x_sorted=plan.sorted_attr("bond", bond_cos), embW=self.edge_attr_bond_embed.weight,
+                          embb=self.edge_attr_bond_embed.bias,
                           want_probs=want)
         new_bond, p_bond = (r[0], r[2]) if want else (r, None)
         if self.bond_mask is not None:
@@ -125,9 +126,9 @@ class FragNetLayerA(nn.Module):
                 new_bond[self.bond_mask:self.bond_mask + 2, :] = 0.0
 
         # L2 atom graph with self loops (gat2.py:179-224): edge term = <new_bond[e], a[:, d:d+128]>, 0 on loops
-        s_edge = ops.row_dots(new_bond, self.a, d)
+        s_edge = ops.row_dots_sorted(new_bond, self.a, d, L["atom"])
         r = ops.gat_level(F.linear(x_atoms, self.projection_a.weight, self.projection_a.bias), self.a, L["atom"], H,
-                          s_edge=s_edge, want_probs=want)
+                          s_sorted=s_edge, want_probs=want)
         atoms_new, p_atom = (r[0], r[2]) if want else (r, None)
         if self.atom_mask_individual is not None:
             with torch.no_grad():
@@ -138,7 +139,7 @@ class FragNetLayerA(nn.Module):
 
         # L4a fragment-bond graph (gat2.py:239-272)
         r = ops.gat_level(F.linear(fbond_nodes, self.projection_fb.weight, self.projection_fb.bias), self.f_a_b,
-                          L["fbond"], H, x=fbond_attr, embW=self.edge_attr_fbond_embed.weight,
+                          L["fbond"], H, x_sorted=plan.sorted_attr("fbond", fbond_attr), embW=self.edge_attr_fbond_embed.weight,
                           embb=self.edge_attr_fbond_embed.bias, want_probs=want)
         new_fbond, p_fbond = (r[0], r[2]) if want else (r, None)
         if self.frag_bond_mask is not None:
@@ -147,8 +148,8 @@ class FragNetLayerA(nn.Module):
                 new_fbond[2 * self.frag_bond_mask + 1, :] = 0.0
 
         # L4b fragment graph on the raw fragment sums (gat2.py:283-316)
-        s_edge_f = ops.row_dots(new_fbond, self.f, d)
-        r = ops.gat_level(frags, self.f, L["frag"], H, s_edge=s_edge_f, want_probs=want)
+        s_edge_f = ops.row_dots_sorted(new_fbond, self.f, d, L["frag"])
+        r = ops.gat_level(frags, self.f, L["frag"], H, s_sorted=s_edge_f, want_probs=want)
         frags_new, p_frag = (r[0], r[2]) if want else (r, None)
 
         if want:

@@ -44,31 +44,32 @@ def _part_rows(n: int) -> int:
 class _GatLevel(torch.autograd.Function):
     """out[n,128] = sum_e softmax_dst(LeakyReLU(s_dst + s_src + s_edge))_e * h[src_e].
 
-    Inputs (differentiable): h [n,128]; att [H, att_w]; then either s_edge [m_real,H] (mode 0) or the raw
-    edge attribute x [m_real,K] (not differentiated) with embW [d,K], embb [d] (mode 2)."""
+    Inputs (differentiable): h [n,128]; att [H, att_w]; then either s_sorted [m,H] (mode 0: the edge term in
+    destination-sorted order, from row_dots_sorted) or x_sorted [m,K] (mode 2: the raw edge attribute in
+    destination-sorted order, not differentiated) with embW [d,K], embb [d]."""
 
     @staticmethod
-    def forward(ctx, h, att, s_edge, x, embW, embb, level: Level, heads: int, dst_off: int, mid_off: int,
+    def forward(ctx, h, att, s_sorted, x_sorted, embW, embb, level: Level, heads: int, dst_off: int, mid_off: int,
                 src_off: int, want_probs: bool):
         h = _f32c(h, "h")
         att = _f32c(att, "att")
         dev = h.device
-        n, m, m_real = level.n, level.m, level.m_real
+        n, m = level.n, level.m
         if h.shape != (n, FN_D):
             raise ValueError(f"h must be [{n}, {FN_D}], got {tuple(h.shape)}")
         att_w = att.shape[1]
-        mode = 0 if x is None else 2
+        mode = 0 if x_sorted is None else 2
         if mode == 0:
-            s_edge = _f32c(s_edge, "s_edge")
-            if s_edge.shape != (m_real, heads):
-                raise ValueError(f"s_edge must be [{m_real}, {heads}], got {tuple(s_edge.shape)}")
-            et = EdgeTerm(0, 0, 0, 0, s_edge.data_ptr(), None, None, None)
+            s_sorted = _f32c(s_sorted, "s_sorted")
+            if s_sorted.shape != (m, heads):
+                raise ValueError(f"s_sorted must be [{m}, {heads}], got {tuple(s_sorted.shape)}")
+            et = EdgeTerm(0, 0, 0, 0, s_sorted.data_ptr(), None, None, None)
         else:
-            x, embW, embb = _f32c(x, "x"), _f32c(embW, "embW"), _f32c(embb, "embb")
-            K = x.shape[1] if x.dim() == 2 else 1
-            if x.numel() != m_real * K or embW.shape != (FN_D // heads, K):
+            x_sorted, embW, embb = _f32c(x_sorted, "x_sorted"), _f32c(embW, "embW"), _f32c(embb, "embb")
+            K = x_sorted.shape[1]
+            if x_sorted.shape[0] != m or embW.shape != (FN_D // heads, K):
                 raise ValueError("edge attribute / embedding shapes do not match the plan")
-            et = EdgeTerm(2, K, FN_D // heads, mid_off, None, x.data_ptr(), embW.data_ptr(), embb.data_ptr())
+            et = EdgeTerm(2, K, FN_D // heads, mid_off, None, x_sorted.data_ptr(), embW.data_ptr(), embb.data_ptr())
         st = _stream_ptr(dev)
         s_dst = torch.empty((n, heads), dtype=torch.float32, device=dev)
         s_src = torch.empty((n, heads), dtype=torch.float32, device=dev)
@@ -81,7 +82,7 @@ class _GatLevel(torch.autograd.Function):
                   C.byref(et), C.byref(level.c), NEG_SLOPE, out.data_ptr(), p_sorted.data_ptr(), _ptr(probs), heads, st)
         ctx.level, ctx.heads, ctx.mode = level, heads, mode
         ctx.offs = (dst_off, mid_off, src_off)
-        ctx.save_for_backward(h, att, p_sorted, x, embW, embb)
+        ctx.save_for_backward(h, att, p_sorted, x_sorted, embW, embb)
         ctx.set_materialize_grads(False)
         if want_probs:
             ctx.mark_non_differentiable(probs, p_sorted)
@@ -90,34 +91,30 @@ class _GatLevel(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out, *unused):
-        h, att, p_sorted, x, embW, embb = ctx.saved_tensors
+        h, att, p_sorted, x_sorted, embW, embb = ctx.saved_tensors
         level, heads, mode = ctx.level, ctx.heads, ctx.mode
         dst_off, mid_off, src_off = ctx.offs
         if g_out is None:
             return (None,) * 12
         g_out = _f32c(g_out, "g_out")
         dev = h.device
-        n, m, m_real = level.n, level.m, level.m_real
+        n, m = level.n, level.m
         att_w = att.shape[1]
         st = _stream_ptr(dev)
         if mode == 0:
             et = EdgeTerm(0, 0, 0, 0, None, None, None, None)
-            g_s_edge = torch.empty((m_real, heads), dtype=torch.float32, device=dev)
             part_e = None
-            K = 0
         else:
-            K = x.shape[1] if x.dim() == 2 else 1
-            et = EdgeTerm(2, K, FN_D // heads, mid_off, None, x.data_ptr(), embW.data_ptr(), embb.data_ptr())
-            g_s_edge = None
-            part_e = torch.empty((_part_rows(n), heads * (K + 1)), dtype=torch.float32, device=dev)
+            K = x_sorted.shape[1]
+            et = EdgeTerm(2, K, FN_D // heads, mid_off, None, x_sorted.data_ptr(), embW.data_ptr(), embb.data_ptr())
+            part_e = torch.empty((FN_MAX_PART, heads * (K + 1)), dtype=torch.float32, device=dev)
         dz = torch.empty((m, heads), dtype=torch.float32, device=dev)
         g_s_dst = torch.empty((n, heads), dtype=torch.float32, device=dev)
         n_e, n_a = C.c_int(0), C.c_int(0)
         _lib.call("fn_gat_bwd_dst_f32", g_out.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), C.byref(et),
-                  C.byref(level.c), NEG_SLOPE, dz.data_ptr(), g_s_dst.data_ptr(), _ptr(g_s_edge), _ptr(part_e),
-                  C.byref(n_e), heads, st)
+                  C.byref(level.c), NEG_SLOPE, dz.data_ptr(), g_s_dst.data_ptr(), _ptr(part_e), C.byref(n_e), heads, st)
         g_h = torch.empty((n, FN_D), dtype=torch.float32, device=dev)
-        part_a = torch.empty((_part_rows(n), 2 * FN_D), dtype=torch.float32, device=dev)
+        part_a = torch.empty((FN_MAX_PART, 2 * FN_D), dtype=torch.float32, device=dev)
         _lib.call("fn_gat_bwd_src_f32", g_out.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), dz.data_ptr(),
                   g_s_dst.data_ptr(), att.data_ptr(), att_w, dst_off, src_off, C.byref(level.c), g_h.data_ptr(),
                   part_a.data_ptr(), C.byref(n_a), heads, st)
@@ -126,14 +123,15 @@ class _GatLevel(torch.autograd.Function):
         g_embb = torch.empty_like(embb) if mode == 2 else None
         _lib.call("fn_gat_bwd_finalize_f32", part_a.data_ptr(), n_a.value, _ptr(part_e), n_e.value, C.byref(et),
                   att.data_ptr(), att_w, dst_off, src_off, g_att.data_ptr(), _ptr(g_embW), _ptr(g_embb), heads, st)
-        return g_h, g_att, g_s_edge, None, g_embW, g_embb, None, None, None, None, None, None
+        # dL/ds_sorted is dz itself (mode 0)
+        return g_h, g_att, (dz if mode == 0 else None), None, g_embW, g_embb, None, None, None, None, None, None
 
 
-def gat_level(h, att, level: Level, heads: int, *, s_edge=None, x=None, embW=None, embb=None, want_probs=False):
+def gat_level(h, att, level: Level, heads: int, *, s_sorted=None, x_sorted=None, embW=None, embb=None, want_probs=False):
     """``att`` = [dst(d) | edge | src(d)] per head, the reference's a_b / a / f / f_a_b layout."""
     d = FN_D // heads
     att_w = att.shape[1]
-    return _GatLevel.apply(h, att, s_edge, x, embW, embb, level, heads, 0, d, att_w - d, want_probs)
+    return _GatLevel.apply(h, att, s_sorted, x_sorted, embW, embb, level, heads, 0, d, att_w - d, want_probs)
 
 
 def attn_by_src(p_sorted: torch.Tensor, level: Level, heads: int) -> torch.Tensor:
@@ -144,40 +142,42 @@ def attn_by_src(p_sorted: torch.Tensor, level: Level, heads: int) -> torch.Tenso
 
 
 # ======================================================================================
-# full-width edge term: s[r, j] = <x[r, :], A[j, off:off+128]>
+# full-width edge term, destination-sorted: s_sorted[pos, j] = <feat[eid(pos), :], A[j, off:off+128]>
 # ======================================================================================
-class _RowDots(torch.autograd.Function):
+class _RowDotsSorted(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, A, off: int):
-        x, A = _f32c(x, "x"), _f32c(A, "A")
-        rows, J = x.shape[0], A.shape[0]
-        if x.shape[1] != FN_D:
-            raise ValueError("row_dots needs 128-wide rows")
-        s = torch.empty((rows, J), dtype=torch.float32, device=x.device)
-        _lib.call("fn_row_dots_f32", x.data_ptr(), A.data_ptr(), A.shape[1], off, J, s.data_ptr(), rows, _stream_ptr(x.device))
-        ctx.off = off
-        ctx.save_for_backward(x, A)
+    def forward(ctx, feat, A, off: int, level: Level):
+        feat, A = _f32c(feat, "feat"), _f32c(A, "A")
+        J = A.shape[0]
+        if feat.shape != (level.m_real, FN_D):
+            raise ValueError(f"feat must be [{level.m_real}, {FN_D}], got {tuple(feat.shape)}")
+        s = torch.empty((level.m, J), dtype=torch.float32, device=feat.device)
+        _lib.call("fn_row_dots_sorted_f32", feat.data_ptr(), A.data_ptr(), A.shape[1], off, J, C.byref(level.c), s.data_ptr(),
+                  _stream_ptr(feat.device))
+        ctx.off, ctx.level = off, level
+        ctx.save_for_backward(feat, A)
         return s
 
     @staticmethod
     def backward(ctx, g_s):
-        x, A = ctx.saved_tensors
+        feat, A = ctx.saved_tensors
+        level = ctx.level
         g_s = _f32c(g_s, "g_s")
-        rows, J = x.shape[0], A.shape[0]
-        st = _stream_ptr(x.device)
-        g_x = torch.empty_like(x)
+        J = A.shape[0]
+        st = _stream_ptr(feat.device)
+        g_feat = torch.empty_like(feat)
         g_A = torch.zeros_like(A)
-        if rows:
-            part = torch.empty((_part_rows(rows), J * FN_D), dtype=torch.float32, device=x.device)
+        if level.m_real:
+            part = torch.empty((FN_MAX_PART, J * FN_D), dtype=torch.float32, device=feat.device)
             n_part = C.c_int(0)
-            _lib.call("fn_row_dots_bwd_f32", g_s.data_ptr(), x.data_ptr(), A.data_ptr(), A.shape[1], ctx.off, J,
-                      g_x.data_ptr(), part.data_ptr(), C.byref(n_part), rows, st)
+            _lib.call("fn_row_dots_sorted_bwd_f32", g_s.data_ptr(), feat.data_ptr(), A.data_ptr(), A.shape[1], ctx.off, J,
+                      C.byref(level.c), g_feat.data_ptr(), part.data_ptr(), C.byref(n_part), st)
             _lib.call("fn_colsum_f32", part.data_ptr(), n_part.value, J * FN_D, g_A.data_ptr(), A.shape[1], ctx.off, st)
-        return g_x, g_A, None
+        return g_feat, g_A, None, None
 
 
-def row_dots(x, A, off: int):
-    return _RowDots.apply(x, A, off)
+def row_dots_sorted(feat, A, off: int, level: Level):
+    return _RowDotsSorted.apply(feat, A, off, level)
 
 
 # ======================================================================================

@@ -98,6 +98,7 @@ class GraphPlan:
         _lib.check(lib.fn_plan_build(tasks, nt, self.rowptr.data_ptr(), self.perm.data_ptr(), self.aux_a.data_ptr(),
                                      self.aux_b.data_ptr(), ws.data_ptr(), _stream_ptr(device)), "fn_plan_build")
         self._keep = keep
+        self._sorted = {}
         self.levels: Dict[str, Level] = {}
         self.segs: Dict[str, Segments] = {}
         for ent in layout:
@@ -108,7 +109,7 @@ class GraphPlan:
                 c = GatPlan(self.rowptr.data_ptr() + 4 * d.seg_base, self.perm.data_ptr() + 4 * d.item_base,
                             self.aux_a.data_ptr() + 4 * d.item_base, self.rowptr.data_ptr() + 4 * s.seg_base,
                             self.aux_a.data_ptr() + 4 * s.item_base, self.aux_b.data_ptr() + 4 * s.item_base,
-                            int(d.item_base), int(s.item_base), int(d.n_seg), m, int(d.n_real))
+                            self.aux_b.data_ptr() + 4 * d.item_base, int(d.item_base), int(s.item_base), int(d.n_seg), m, int(d.n_real))
                 self.levels[name] = Level(c, int(d.n_seg), m, int(d.n_real), (self,))
             else:
                 _, name, t0, sp, key = ent
@@ -116,6 +117,25 @@ class GraphPlan:
                 self.segs[name] = Segments(self.rowptr[t.seg_base: t.seg_base + t.n_seg + 1],
                                            self.perm[t.item_base: t.item_base + t.n_real], int(t.item_base),
                                            int(t.n_seg), int(t.n_real), key)
+
+    def sorted_attr(self, name: str, x: torch.Tensor) -> torch.Tensor:
+        """Raw edge attribute of level ``name`` permuted into destination-sorted order, once per batch
+        (the reference feeds the same edge_attr_bonds / edge_attr_fbonds to every layer, gat2.py:430,433)."""
+        key = (name, x.data_ptr(), x._version)
+        hit = self._sorted.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        lv = self.levels[name]
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise _lib.FragnetHipError("edge attributes must be float32 GPU tensors")
+        x = x.contiguous()
+        K = x.shape[1] if x.dim() == 2 else 1
+        if x.numel() != lv.m_real * K:
+            raise ValueError(f"edge attribute of level {name} has {x.shape[0]} rows, the plan has {lv.m_real} edges")
+        out = torch.empty((lv.m, K), dtype=torch.float32, device=x.device)
+        _lib.call("fn_sort_edge_attr_f32", x.data_ptr(), K, C.byref(lv.c), out.data_ptr(), _stream_ptr(x.device))
+        self._sorted[name] = (key, out)
+        return out
 
     def check(self):
         """Synchronising validation: raises if any index was outside its segment range."""

@@ -55,7 +55,7 @@ const char* fn_last_error(void);
  *   perm_all  [item_base + p]           task-local item id at sorted position p, ascending inside
  *                                       a segment (=> deterministic, reference summation order)
  * For a GAT level, two tasks are paired (role DST keyed by destination, role SRC keyed by source):
- *   DST task: aux_a[pos] = source node of the edge at pos
+ *   DST task: aux_a[pos] = source node of the edge at pos; aux_b[item] = position of edge `item` (inverse perm)
  *   SRC task: aux_a[pos] = destination node; aux_b[pos] = that edge's position (task-local) in the
  *             paired DST task
  * ------------------------------------------------------------------------------------------ */
@@ -101,16 +101,18 @@ int fn_plan_build(const fn_csr_task* tasks, int n_tasks,
 int fn_node_scalars_f32(const float* h /*[n,128]*/, const float* att, int att_w, int dst_off, int src_off,
                         float* s_dst /*[n,H]*/, float* s_src /*[n,H]*/, int64_t n, int heads, fn_stream_t stream);
 
-/* Edge term of the logit. mode 0: s_edge given per ORIGINAL edge id ([m_real,H]; loop items get 0).
- * mode 2: s_edge[e,h] = <embW x[e] + embb, att[h, mid_off:+d_e]> folded in-kernel (the reference's
- * edge_attr_bond_embed / edge_attr_fbond_embed Linear(K -> d_e), gat2.py:139,242). */
+/* Edge term of the logit, always addressed by DESTINATION-SORTED edge position (coalesced, no
+ * dependent gather).  mode 0: s_sorted [m,H] given (fn_row_dots_sorted_f32; 0 at loop positions).
+ * mode 2: s[pos,h] = <embW x_sorted[pos] + embb, att[h, mid_off:+d_e]> folded in-kernel (the reference's
+ * edge_attr_bond_embed / edge_attr_fbond_embed Linear(K -> d_e), gat2.py:139,242); x_sorted is the raw
+ * attribute permuted once per batch by fn_sort_edge_attr_f32 (it is the same in every layer). */
 typedef struct fn_edge_term {
     int32_t mode;
     int32_t K;                /* mode 2: raw attribute width (1 or 6) */
     int32_t d_e;              /* mode 2: embed width (= head_dim)     */
     int32_t mid_off;          /* mode 2: offset of the edge block in att */
-    const float* s_edge;      /* mode 0: [m_real, H] */
-    const float* x;           /* mode 2: [m_real, K] */
+    const float* s_sorted;    /* mode 0: [m, H] */
+    const float* x_sorted;    /* mode 2: [m, K] */
     const float* embW;        /* mode 2: [d_e, K]    */
     const float* embb;        /* mode 2: [d_e]       */
 } fn_edge_term;
@@ -122,6 +124,7 @@ typedef struct fn_gat_plan {          /* slices of the fn_plan_build outputs for
     const int32_t* rowptr_s;  /* [n+1] (SRC task)                     */
     const int32_t* dst_s;     /* [m]   destination node               */
     const int32_t* dpos_s;    /* [m]   position in the DST order      */
+    const int32_t* inv_d;     /* [m]   original edge id -> position in the DST order */
     int32_t pos_base_d;       /* item_base of the DST task            */
     int32_t pos_base_s;       /* item_base of the SRC task            */
     int64_t n;                /* nodes                                */
@@ -137,12 +140,12 @@ int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const
                    float* out /*[n,128]*/, float* p_sorted /*[m,H]*/, float* probs_orig /*nullable*/,
                    int heads, fn_stream_t stream);
 
-/* Backward, destination pass: dz_sorted [m,H], g_s_dst [n,H]; mode 0 also g_s_edge [m_real,H]
- * (original order); mode 2 writes per-block partial sums part_e [grid, H*(K+1)].
+/* Backward, destination pass: dz_sorted [m,H] (= dL/ds_sorted, the gradient of the mode-0 edge term),
+ * g_s_dst [n,H]; mode 2 writes per-block partial sums part_e [grid, H*(K+1)].
  * Returns the grid size used through *n_part_e. */
 int fn_gat_bwd_dst_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et,
                        const fn_gat_plan* plan, float neg_slope,
-                       float* dz_sorted, float* g_s_dst, float* g_s_edge /*mode0, nullable*/,
+                       float* dz_sorted, float* g_s_dst,
                        float* part_e /*mode2: [FN_MAX_PART, H*(K+1)]*/, int* n_part_e,
                        int heads, fn_stream_t stream);
 
@@ -165,12 +168,17 @@ int fn_gat_bwd_finalize_f32(const float* part_a, int n_part_a, const float* part
 int fn_attn_by_src_f32(const float* p_sorted, const fn_gat_plan* plan, float* attn /*[n,H]*/, int heads,
                        fn_stream_t stream);
 
-/* s[r, j] = <x[r, 0:128], A[j*lda + off : +128]>, j < J <= 8: the full-width edge term of the atom and
- * fragment graphs (edge block of `a` / `f`, gat2.py:203-208, 293-300). */
-int fn_row_dots_f32(const float* x, const float* A, int lda, int off, int J, float* s, int64_t rows, fn_stream_t stream);
-/* g_x[r,:] = sum_j g_s[r,j] A[j]; part [grid, J*128] partial sums of g_A[j,:] = sum_r g_s[r,j] x[r,:] */
-int fn_row_dots_bwd_f32(const float* g_s, const float* x, const float* A, int lda, int off, int J,
-                        float* g_x, float* part, int* n_part, int64_t rows, fn_stream_t stream);
+/* s_sorted[pos, j] = <feat[eid(pos), 0:128], A[j*lda + off : +128]>, j < J <= 8, 0 at loop positions: the
+ * full-width edge term of the atom and fragment graphs (edge block of `a` / `f`, gat2.py:203-208, 293-300),
+ * written directly in destination-sorted order. */
+int fn_row_dots_sorted_f32(const float* feat /*[m_real,128]*/, const float* A, int lda, int off, int J,
+                           const fn_gat_plan* plan, float* s_sorted /*[m,J]*/, fn_stream_t stream);
+/* g_feat[e,:] = sum_j g_s_sorted[inv_d[e], j] A[j]; part [grid, J*128] partial sums of g_A[j,:] */
+int fn_row_dots_sorted_bwd_f32(const float* g_s_sorted, const float* feat, const float* A, int lda, int off, int J,
+                               const fn_gat_plan* plan, float* g_feat, float* part, int* n_part, fn_stream_t stream);
+/* x_sorted[pos,:] = x[eid(pos),:] (0 at loop positions): once per batch for the raw edge attributes */
+int fn_sort_edge_attr_f32(const float* x /*[m_real,K]*/, int K, const fn_gat_plan* plan, float* x_sorted /*[m,K]*/,
+                          fn_stream_t stream);
 /* out[(c / 128) * ld + off + c % 128] = sum_r part[r, c], c < cols */
 int fn_colsum_f32(const float* part, int n_rows, int cols, float* out, int ld, int off, fn_stream_t stream);
 

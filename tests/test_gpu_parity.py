@@ -81,6 +81,13 @@ def test_plan_matches_stable_argsort():
     inv = np.empty(lv.m, dtype=np.int64)
     inv[order] = np.arange(lv.m)
     assert np.array_equal(dpos, inv[order_s])
+    inv_d = arena[off(c.inv_d): off(c.inv_d) + lv.m]
+    assert np.array_equal(inv_d, inv)
+    # raw edge attributes permuted into destination order, zeros on the loop positions
+    attr = torch.arange(ei.shape[1] * 3, dtype=torch.float32, device=DEV).view(-1, 3)
+    got = plan.sorted_attr("atom", attr).cpu().numpy()
+    want = np.concatenate([attr.cpu().numpy(), np.zeros((N, 3), np.float32)])[order]
+    assert np.array_equal(got, want)
     assert np.array_equal(rps, np.concatenate([[0], np.cumsum(np.bincount(src, minlength=N))]))
 
 
@@ -188,10 +195,11 @@ def test_gat_level_matches_materialised_reference(heads, mode, loops, hub):
     lv = plan.levels["l"]
     dl = [t.detach().clone().to(DEV).requires_grad_(True) for t in ((h, att, embW, embb) if mode == 2 else (h, att, feat))]
     if mode == 2:
-        out, probs, p_sorted = ops.gat_level(dl[0], dl[1], lv, heads, x=x.to(DEV), embW=dl[2], embb=dl[3], want_probs=True)
+        out, probs, p_sorted = ops.gat_level(dl[0], dl[1], lv, heads, x_sorted=plan.sorted_attr("l", x.to(DEV)), embW=dl[2],
+                                             embb=dl[3], want_probs=True)
     else:
-        s_edge = ops.row_dots(dl[2], dl[1], d)
-        out, probs, p_sorted = ops.gat_level(dl[0], dl[1], lv, heads, s_edge=s_edge, want_probs=True)
+        s_edge = ops.row_dots_sorted(dl[2], dl[1], d, lv)
+        out, probs, p_sorted = ops.gat_level(dl[0], dl[1], lv, heads, s_sorted=s_edge, want_probs=True)
     (out * w_out.to(DEV)).sum().backward()
     torch.cuda.synchronize()
     plan.check()
@@ -212,7 +220,7 @@ def test_gat_level_isolated_nodes_and_empty_graph():
     plan = GraphPlan([dict(kind="gat", name="l", dst=dst, src=src, n=n, n_loops=0)], DEV)
     h = torch.randn(n, 128, device=DEV)
     att = torch.randn(4, 192, device=DEV)
-    out = ops.gat_level(h, att, plan.levels["l"], 4, s_edge=torch.zeros(3, 4, device=DEV))
+    out = ops.gat_level(h, att, plan.levels["l"], 4, s_sorted=torch.zeros(3, 4, device=DEV))
     assert torch.equal(out[1:9], torch.zeros(8, 128, device=DEV))        # no in-edges => zero row, like scatter_add
     torch.testing.assert_close(out[9], h[3])                             # single in-edge => probability 1
     assert torch.isfinite(out).all()
