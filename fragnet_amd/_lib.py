@@ -53,6 +53,10 @@ SIGNATURES = {
     "fn_row_dots_sorted_bwd_f32": [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(GatPlan), vp, vp, ip, vp],
     "fn_sort_edge_attr_f32": [vp, C.c_int, C.POINTER(GatPlan), vp, vp],
     "fn_colsum_f32": [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp],
+    "fn_transpose_w_f32": [vp, C.c_int, vp, vp],
+    "fn_linear128_f32": [vp, C.c_int, vp, vp, vp, i64, vp],
+    "fn_linear128_wgrad_ws": [i64, C.c_int],
+    "fn_linear128_wgrad_f32": [vp, vp, C.c_int, i64, vp, vp, vp, vp],
     "fn_segment_sum_f32": [vp, i64, vp, vp, i32, vp, i64, i64, vp],
     "fn_gather_rows_f32": [vp, vp, vp, i64, i64, vp],
     "fn_segment_softmax_f32": [vp, vp, vp, i32, vp, i64, i64, vp],
@@ -85,7 +89,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "fn_last_error" else C.c_int
+        fn.restype = C.c_char_p if name == "fn_last_error" else (i64 if name.endswith("_ws") else C.c_int)
     if lib.fn_abi_version() != 1:
         raise FragnetHipError(f"ABI version mismatch: library {lib.fn_abi_version()}, binding 1")
     _lib = lib

@@ -933,6 +933,273 @@ __global__ void k_edge_concat(const float* __restrict__ x, const float* __restri
     }
 }
 
+// =====================================================================================
+// Projection GEMMs on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains, so the 1e-4
+// parity budget is untouched).  All three node projections have N = 128 outputs and K <= 168 inputs:
+//   forward    Y[M,128]  = X[M,K]   * Bt[K,128] + bias      (Bt = W^T, transposed once per step)
+//   input grad dX[M,128] = dY[M,128] * W[128,128]            (same kernel, Bt = W as stored, no bias)
+//   weight grad dW[128,K] = dY^T X, db = colsum(dY)           (split over row chunks, deterministic 2-stage sum)
+// =====================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kBtLd = 144;     // LDS leading dimension of the [K][128] operand: 144 % 32 == 16
+
+// A block = 8 waves = 64 rows x 128 columns: wave w owns rows 16*(w&3).. and columns 64*(w>>2).. (4 accumulator
+// tiles), so two waves share every SIMD and one wave's LDS reads hide under the other's MFMAs.  Bt is staged in
+// LDS once per block; blocks loop over row tiles.  The MFMA k index is "blocked": lane group kq supplies
+// k = kq*KQ + s at step s, so a lane's A operands are KQ consecutive floats of one row, loaded with 16-byte loads
+// straight from global memory (no LDS round trip for X) and prefetched one tile ahead.  The result tile goes
+// through LDS so that every lane stores whole 16-byte pieces of a row (scattered 4-byte stores cost 4 us a tile).
+constexpr int kLinOutLd = 68;      // LDS leading dimension of a wave's 16 x 64 result tile
+template <int KQ>
+__global__ __launch_bounds__(512) void k_linear128(const float* __restrict__ X, int K, const float* __restrict__ Bt,
+                                                   const float* __restrict__ bias, float* __restrict__ Y, int64_t M) {
+    extern __shared__ __attribute__((aligned(16))) float sBt[];        // [4*KQ][kBtLd] then 8 x [16][kLinOutLd]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
+    const int wr = w & 3, wc = w >> 2;
+    float* sOut = sBt + 4 * KQ * kBtLd + w * 16 * kLinOutLd;
+    {   // stage Bt [4*KQ][128] -> LDS with 16-byte loads, all loads of a thread in flight before the first LDS store
+        constexpr int N4 = 4 * KQ * 32;                 // float4 count
+        constexpr int PER = (N4 + 511) / 512;
+        float4 v[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int idx = tid + q * 512, k = idx >> 5, n4 = idx & 31;
+            v[q] = (idx < N4 && k < K) ? ld4(Bt + (size_t)k * 128 + n4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int idx = tid + q * 512, k = idx >> 5, n4 = idx & 31;
+            if (idx < N4) st4(sBt + k * kBtLd + n4 * 4, v[q]);
+        }
+    }
+    const int64_t tiles = (M + 63) / 64;
+    const bool vec = (K == 4 * KQ) && (KQ % 4 == 0);
+
+    auto load_rows = [&](int64_t tile, float (&xa)[KQ]) {
+        int64_t row = tile * 64 + wr * 16 + i;
+        row = row < M ? row : M - 1;
+        const float* src = X + row * K + kq * KQ;
+        if (vec) {
+#pragma unroll
+            for (int s = 0; s < KQ / 4; ++s) {
+                const float4 v = ld4(src + s * 4);
+                xa[4 * s + 0] = v.x; xa[4 * s + 1] = v.y; xa[4 * s + 2] = v.z; xa[4 * s + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KQ; ++s) xa[s] = (kq * KQ + s < K) ? src[s] : 0.f;
+        }
+    };
+
+    float cur[KQ], nxt[KQ];
+    int64_t tile = blockIdx.x;
+    if (tile < tiles) load_rows(tile, cur);
+    __syncthreads();
+    const float* bbase = sBt + (kq * KQ) * kBtLd + 64 * wc + i;
+    for (; tile < tiles; tile += gridDim.x) {
+        const int64_t ntile = tile + gridDim.x;
+        if (ntile < tiles) load_rows(ntile, nxt);
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float b0[4], b1[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b0[t] = bbase[16 * t];
+#pragma unroll
+        for (int s = 0; s < KQ; ++s) {                       // B operands of step s+1 are read while step s multiplies
+            if (s + 1 < KQ) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b1[t] = bbase[(s + 1) * kBtLd + 16 * t];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[s], b0[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b0[t] = b1[t];
+        }
+        // wave-private transpose through LDS: acc[t][r] is (row kq*4+r, col 16t+i) of the 16 x 64 tile
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float bv = bias ? bias[64 * wc + 16 * t + i] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sOut[(kq * 4 + r) * kLinOutLd + 16 * t + i] = acc[t][r] + bv;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the wave's own LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+        const int64_t r0 = tile * 64 + wr * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                        // 16 rows x 16 float4 = 256 pieces, 4 per lane
+            const int idx = lane + q * 64, rr = idx >> 4, c4 = idx & 15;
+            if (r0 + rr < M)
+                st4(Y + (r0 + rr) * 128 + 64 * wc + c4 * 4, *reinterpret_cast<const float4*>(sOut + rr * kLinOutLd + c4 * 4));
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < KQ; ++s) cur[s] = nxt[s];
+    }
+}
+
+// Bt[k][n] = W[n][k]  (W is nn.Linear.weight [128, K])
+__global__ void k_transpose_w(const float* __restrict__ W, int K, float* __restrict__ Bt) {
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 thr = 32x8
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = (k0 + tx < K) ? W[(size_t)(n0 + r) * K + k0 + tx] : 0.f;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (k0 + r < K) Bt[(size_t)(k0 + r) * 128 + n0 + tx] = tile[tx][r];
+}
+
+// Weight gradient: block = `rows_per_block` rows in chunks of 32 staged through double-buffered LDS.  Wave w owns
+// output rows o in [32(w&3), +32) and the (w>>2)-th group of CTW 16-column tiles of X, so NH = 2 column groups
+// put two waves on every SIMD.  part [grid][128*K + 128]: dW partial followed by the db partial.
+constexpr int kWgChunk = 32;
+template <int CTW, int NH>
+__global__ __launch_bounds__(256 * NH) void k_linear128_wgrad(const float* __restrict__ dY, const float* __restrict__ X,
+                                                              int K, int64_t M, int rows_per_block,
+                                                              float* __restrict__ part) {
+    constexpr int NT = 256 * NH;
+    constexpr int XW = 16 * CTW * NH;            // padded X width held in LDS
+    constexpr int XLD = XW + 16;                 // XW is a multiple of 32 for every instantiation but <1,1>
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sY = smem;                                   // [2][32][144]
+    float* sX = smem + 2 * kWgChunk * kBtLd;            // [2][32][XLD]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
+    const int wo = w & 3, wc = w >> 2;
+    const int64_t m_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t m_end = m_begin + rows_per_block < M ? m_begin + rows_per_block : M;
+    const int n_chunks = (int)((m_end - m_begin + kWgChunk - 1) / kWgChunk);
+
+    constexpr int YPT = 1024 / NT;                            // dY float4 per thread per chunk
+    constexpr int XPT = (kWgChunk * XW + NT - 1) / NT;        // X scalars per thread per chunk
+    float4 ry[YPT];
+    float rx[XPT];
+    auto fetch = [&](int c) {
+        const int64_t base = m_begin + (int64_t)c * kWgChunk;
+#pragma unroll
+        for (int q = 0; q < YPT; ++q) {
+            const int idx = tid + q * NT, r = idx >> 5, c4 = idx & 31;
+            ry[q] = (base + r < m_end) ? ld4(dY + (base + r) * 128 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < XPT; ++q) {
+            const int idx = tid + q * NT, r = idx / XW, cc = idx % XW;
+            rx[q] = (r < kWgChunk && base + r < m_end && cc < K) ? X[(base + r) * K + cc] : 0.f;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < YPT; ++q) {
+            const int idx = tid + q * NT, r = idx >> 5, c4 = idx & 31;
+            st4(sY + (buf * kWgChunk + r) * kBtLd + c4 * 4, ry[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < XPT; ++q) {
+            const int idx = tid + q * NT, r = idx / XW, cc = idx % XW;
+            if (r < kWgChunk) sX[(buf * kWgChunk + r) * XLD + cc] = rx[q];
+        }
+    };
+
+    f32x4 acc[2][CTW];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) acc[u][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[2] = {0.f, 0.f};
+
+    if (n_chunks > 0) { fetch(0); stash(0); }
+    __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) fetch(c + 1);
+#pragma unroll
+        for (int s = 0; s < kWgChunk / 4; ++s) {
+            const float* yrow = sY + (buf * kWgChunk + 4 * s + kq) * kBtLd + 32 * wo + i;
+            const float* xrow = sX + (buf * kWgChunk + 4 * s + kq) * XLD + 16 * CTW * wc + i;
+            const float a0 = yrow[0], a1 = yrow[16];
+            bsum[0] += a0;
+            bsum[1] += a1;
+            float bv[CTW];
+#pragma unroll
+            for (int cc = 0; cc < CTW; ++cc) bv[cc] = xrow[16 * cc];
+#pragma unroll
+            for (int cc = 0; cc < CTW; ++cc) {
+                acc[0][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv[cc], acc[0][cc], 0, 0, 0);
+                acc[1][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[cc], acc[1][cc], 0, 0, 0);
+            }
+        }
+        if (c + 1 < n_chunks) stash(buf ^ 1);
+        __syncthreads();
+    }
+    // partials are written in the accumulators' native layout: one coalesced 16-byte store per lane and tile;
+    // k_wgrad_reduce maps them back to dW[o][col] while summing over blocks
+    constexpr int PW = 128 * XW + 128;
+    float* pw = part + (size_t)blockIdx.x * PW;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int cc = 0; cc < CTW; ++cc)
+            st4(pw + ((size_t)((w * 2 + u) * CTW + cc) * 64 + lane) * 4,
+                make_float4(acc[u][cc][0], acc[u][cc][1], acc[u][cc][2], acc[u][cc][3]));
+    if (wc == 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float v = bsum[u];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (kq == 0) pw[(size_t)128 * XW + 32 * wo + 16 * u + i] = v;
+        }
+    }
+}
+
+// sums the native-layout partials over blocks and scatters them to dW [128][K] / db [128]
+template <int CTW, int NH>
+__global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__ part, int n_rows, int K,
+                                                       float* __restrict__ dW, float* __restrict__ db) {
+    constexpr int XW = 16 * CTW * NH;
+    constexpr int PW = 128 * XW + 128;
+    __shared__ float red[32][33];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + c;
+    float acc = 0.f;
+    if (col < PW)
+        for (int r = rg; r < n_rows; r += 32) acc += part[(size_t)r * PW + col];
+    red[rg][c] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32 && col < PW) {
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) v += red[g][threadIdx.x];
+        if (col >= 128 * XW) {
+            db[col - 128 * XW] = v;
+        } else {
+            const int r = col & 3, lane = (col >> 2) & 63, tile = col >> 8;        // tile = (w*2+u)*CTW + cc
+            const int cc = tile % CTW, wu = tile / CTW, u = wu & 1, w = wu >> 1;
+            const int o = 32 * (w & 3) + 16 * u + 4 * (lane >> 4) + r;
+            const int xc = 16 * (CTW * (w >> 2) + cc) + (lane & 15);
+            if (xc < K) dW[(size_t)o * K + xc] = v;
+        }
+    }
+}
+
+// column sums of part [n_rows][cols]: columns < split go to out0, the rest to out1.  1024 threads = 32 columns x 32 row groups
+__global__ __launch_bounds__(1024) void k_reduce_rows(const float* __restrict__ part, int n_rows, int64_t cols,
+                                                      float* __restrict__ out0, float* __restrict__ out1, int64_t split) {
+    __shared__ float red[32][33];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int64_t col = (int64_t)blockIdx.x * 32 + c;
+    float acc = 0.f;
+    if (col < cols)
+        for (int r = rg; r < n_rows; r += 32) acc += part[(size_t)r * cols + col];
+    red[rg][c] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32 && col < cols) {
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) v += red[g][threadIdx.x];
+        if (col < split) out0[col] = v;
+        else out1[col - split] = v;
+    }
+}
+
 #define FN_DISPATCH_H(heads, CALL)                         \
     switch (heads) {                                       \
         case 1: { constexpr int HH = 1; CALL; } break;     \
@@ -954,6 +1221,43 @@ bool bad_edge_term(const fn_edge_term* et) {
 // =====================================================================================
 // C-ABI
 // =====================================================================================
+namespace {
+template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail((int)e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); }
+    return 0;
+}
+template <int KQ>
+int launch_linear128(const float* X, int K, const float* Bt, const float* bias, float* Y, int64_t M, hipStream_t st) {
+    const size_t lds = ((size_t)4 * KQ * kBtLd + 8 * 16 * kLinOutLd) * sizeof(float);
+    if (int rc = allow_lds(k_linear128<KQ>, lds)) return rc;
+    const int64_t tiles = (M + 63) / 64;
+    const int grid = (int)(tiles < 256 ? tiles : 256);       // one block per CU: MFMA-bound, X prefetched a tile ahead
+    hipLaunchKernelGGL(k_linear128<KQ>, dim3(grid), dim3(512), lds, st, X, K, Bt, bias, Y, M);
+    return 0;
+}
+template <int CTW, int NH>
+int launch_wgrad(const float* dY, const float* X, int K, int64_t M, int rpb, int grid, float* part, float* dW, float* db,
+                 hipStream_t st) {
+    constexpr int XW = 16 * CTW * NH, XLD = XW + 16, PW = 128 * XW + 128;
+    const size_t lds = (size_t)2 * kWgChunk * (kBtLd + XLD) * sizeof(float);
+    if (int rc = allow_lds(k_linear128_wgrad<CTW, NH>, lds)) return rc;
+    hipLaunchKernelGGL((k_linear128_wgrad<CTW, NH>), dim3(grid), dim3(256 * NH), lds, st, dY, X, K, M, rpb, part);
+    hipLaunchKernelGGL((k_wgrad_reduce<CTW, NH>), dim3((PW + 31) / 32), dim3(1024), 0, st, part, grid, K, dW, db);
+    return 0;
+}
+inline int64_t wgrad_part_width(int K) {
+    const int xw = K <= 16 ? 16 : K <= 32 ? 32 : K <= 128 ? 128 : 192;
+    return (int64_t)128 * xw + 128;
+}
+inline int wgrad_rows_per_block(int64_t M) {
+    int64_t rpb = (M + 255) / 256;
+    rpb = (rpb + kWgChunk - 1) / kWgChunk * kWgChunk;
+    return (int)(rpb < kWgChunk ? kWgChunk : rpb);
+}
+}  // namespace
+
 extern "C" {
 
 int fn_abi_version(void) { return FN_ABI_VERSION; }
@@ -1135,6 +1439,52 @@ int fn_colsum_f32(const float* part, int n_rows, int cols, float* out, int ld, i
     if (!part || !out || n_rows < 0 || cols < 1) return fail(FN_EINVAL, "fn_colsum_f32: bad argument");
     hipLaunchKernelGGL(k_colsum, dim3((cols + 31) / 32), dim3(1024), 0, S(stream), part, n_rows, cols, out, ld, off);
     return launch_status("fn_colsum_f32");
+}
+
+int fn_transpose_w_f32(const float* W, int K, float* Bt, fn_stream_t stream) {
+    if (!W || !Bt || K < 1) return fail(FN_EINVAL, "fn_transpose_w_f32: bad argument");
+    hipLaunchKernelGGL(k_transpose_w, dim3((K + 31) / 32, 4), dim3(256), 0, S(stream), W, K, Bt);
+    return launch_status("fn_transpose_w_f32");
+}
+
+int fn_linear128_f32(const float* X, int K, const float* Bt, const float* bias, float* Y, int64_t M, fn_stream_t stream) {
+    if (K < 1 || M < 0) return fail(FN_EINVAL, "fn_linear128_f32: bad argument");
+    if (M == 0) return 0;
+    if (!X || !Bt || !Y || (((uintptr_t)X | (uintptr_t)Y) & 15)) return fail(FN_EINVAL, "fn_linear128_f32: null or misaligned buffer");
+    int rc;
+    if (K <= 8) rc = launch_linear128<2>(X, K, Bt, bias, Y, M, S(stream));
+    else if (K <= 20) rc = launch_linear128<5>(X, K, Bt, bias, Y, M, S(stream));
+    else if (K <= 128) rc = launch_linear128<32>(X, K, Bt, bias, Y, M, S(stream));
+    else if (K <= 168) rc = launch_linear128<42>(X, K, Bt, bias, Y, M, S(stream));
+    else return fail(FN_EUNSUPPORTED, "fn_linear128_f32: K > 168");
+    if (rc) return rc;
+    return launch_status("fn_linear128_f32");
+}
+
+int64_t fn_linear128_wgrad_ws(int64_t M, int K) {
+    const int rpb = wgrad_rows_per_block(M);
+    const int64_t grid = (M + rpb - 1) / rpb;
+    return (grid < 1 ? 1 : grid) * wgrad_part_width(K);
+}
+
+int fn_linear128_wgrad_f32(const float* dY, const float* X, int K, int64_t M, float* ws, float* dW, float* db, fn_stream_t stream) {
+    if (K < 1 || M < 0 || !dW || !db) return fail(FN_EINVAL, "fn_linear128_wgrad_f32: bad argument");
+    if (M == 0) {
+        hipError_t e = hipMemsetAsync(dW, 0, (size_t)128 * K * 4, S(stream));
+        if (e == hipSuccess) e = hipMemsetAsync(db, 0, 128 * 4, S(stream));
+        return e == hipSuccess ? 0 : fail((int)e, "fn_linear128_wgrad_f32: memset failed");
+    }
+    if (!dY || !X || !ws || ((uintptr_t)dY & 15)) return fail(FN_EINVAL, "fn_linear128_wgrad_f32: null or misaligned buffer");
+    const int rpb = wgrad_rows_per_block(M);
+    const int grid = (int)((M + rpb - 1) / rpb);
+    int rc;
+    if (K <= 16) rc = launch_wgrad<1, 1>(dY, X, K, M, rpb, grid, ws, dW, db, S(stream));
+    else if (K <= 32) rc = launch_wgrad<1, 2>(dY, X, K, M, rpb, grid, ws, dW, db, S(stream));
+    else if (K <= 128) rc = launch_wgrad<4, 2>(dY, X, K, M, rpb, grid, ws, dW, db, S(stream));
+    else if (K <= 192) rc = launch_wgrad<6, 2>(dY, X, K, M, rpb, grid, ws, dW, db, S(stream));
+    else return fail(FN_EUNSUPPORTED, "fn_linear128_wgrad_f32: K > 192");
+    if (rc) return rc;
+    return launch_status("fn_linear128_wgrad_f32");
 }
 
 int fn_segment_sum_f32(const float* src, int64_t src_ld, const int32_t* rowptr, const int32_t* perm, int32_t pos_base,

@@ -181,6 +181,50 @@ def row_dots_sorted(feat, A, off: int, level: Level):
 
 
 # ======================================================================================
+# node projections on the fp32 matrix cores
+# ======================================================================================
+class _Linear128(torch.autograd.Function):
+    """y = x @ W.T + b with W [128, K] (nn.Linear(K, 128)); K <= 168.  Input gradient only for K == 128."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, weight, bias = _f32c(x, "x"), _f32c(weight, "weight"), _f32c(bias, "bias")
+        M, K = x.shape
+        if weight.shape != (FN_D, K) or bias.shape != (FN_D,):
+            raise ValueError("linear128: weight must be [128, K], bias [128]")
+        st = _stream_ptr(x.device)
+        bt = torch.empty((K, FN_D), dtype=torch.float32, device=x.device)
+        _lib.call("fn_transpose_w_f32", weight.data_ptr(), K, bt.data_ptr(), st)
+        y = torch.empty((M, FN_D), dtype=torch.float32, device=x.device)
+        _lib.call("fn_linear128_f32", x.data_ptr(), K, bt.data_ptr(), bias.data_ptr(), y.data_ptr(), M, st)
+        ctx.save_for_backward(x, weight)
+        ctx.x_needs_grad = x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = _f32c(g, "g")
+        M, K = x.shape
+        st = _stream_ptr(x.device)
+        gx = None
+        if ctx.x_needs_grad:
+            if K != FN_D:
+                raise NotImplementedError("linear128: input gradient is implemented for K == 128 (layers >= 1)")
+            gx = torch.empty_like(x)
+            _lib.call("fn_linear128_f32", g.data_ptr(), FN_D, weight.data_ptr(), None, gx.data_ptr(), M, st)
+        ws = torch.empty(_lib.load().fn_linear128_wgrad_ws(M, K), dtype=torch.float32, device=x.device)
+        gw = torch.empty_like(weight)
+        gb = torch.empty(FN_D, dtype=torch.float32, device=x.device)
+        _lib.call("fn_linear128_wgrad_f32", g.data_ptr(), x.data_ptr(), K, M, ws.data_ptr(), gw.data_ptr(), gb.data_ptr(), st)
+        return gx, gw, gb
+
+
+def linear128(x, weight, bias):
+    return _Linear128.apply(x, weight, bias)
+
+
+# ======================================================================================
 # segment sum (scatter_add along dim 0) and its gather backward
 # ======================================================================================
 class _SegmentSum(torch.autograd.Function):

@@ -183,6 +183,20 @@ int fn_sort_edge_attr_f32(const float* x /*[m_real,K]*/, int K, const fn_gat_pla
 int fn_colsum_f32(const float* part, int n_rows, int cols, float* out, int ld, int off, fn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Node projections projection_b / projection_a / projection_fb (nn.Linear(K -> 128), gat2.py:142,189,247)
+ * on the fp32 matrix cores (exact fp32 FMA chains).  K <= 168.
+ *   fn_transpose_w_f32      Bt[K,128] = W[128,K]^T            (once per step per weight)
+ *   fn_linear128_f32        Y[M,128] = X[M,K] Bt + bias        (forward; input gradient with Bt = W, bias = NULL)
+ *   fn_linear128_wgrad_f32  dW[128,K] = dY^T X, db[128] = colsum(dY); ws holds fn_linear128_wgrad_ws(M,K) floats
+ * ------------------------------------------------------------------------------------------ */
+int fn_transpose_w_f32(const float* W, int K, float* Bt, fn_stream_t stream);
+int fn_linear128_f32(const float* X, int K, const float* Bt, const float* bias /*nullable*/, float* Y, int64_t M,
+                     fn_stream_t stream);
+int64_t fn_linear128_wgrad_ws(int64_t M, int K);
+int fn_linear128_wgrad_f32(const float* dY, const float* X, int K, int64_t M, float* ws, float* dW, float* db,
+                           fn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * torch_scatter.scatter_add / scatter_softmax along dim 0 on a CSR built by fn_plan_build
  * (gat2.py:234 atom->fragment sum; gat2.py:820-821 and pretrain_heads.py:93-94 pooling).
  * ------------------------------------------------------------------------------------------ */

@@ -142,6 +142,30 @@ def test_scatter_softmax_matches_oracle():
     torch.testing.assert_close(s.grad.cpu(), a.grad, atol=2e-6, rtol=1e-4)
 
 
+# ------------------------------------------------------------------------------- projections (fp32 MFMA)
+@pytest.mark.parametrize("M,K,xgrad", [(1000, 128, True), (26492, 128, True), (777, 17, False), (513, 167, False),
+                                       (64, 6, False), (1, 128, True), (4099, 100, False)])
+def test_linear128_matches_torch(M, K, xgrad):
+    from fragnet_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).to(DEV).requires_grad_(xgrad)
+    w = (torch.randn(128, K, generator=g) * 0.2).to(DEV).requires_grad_(True)
+    b = torch.randn(128, generator=g).to(DEV).requires_grad_(True)
+    gy = torch.randn(M, 128, generator=g).to(DEV)
+    y = ops.linear128(x, w, b)
+    y.backward(gy)
+    got = (y.detach(), w.grad.clone(), b.grad.clone(), x.grad.clone() if xgrad else None)
+    x2, w2, b2 = x.detach().double().requires_grad_(xgrad), w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    y2 = torch.nn.functional.linear(x2, w2, b2)
+    y2.backward(gy.double())
+    torch.testing.assert_close(got[0], y2.detach().float(), atol=2e-5, rtol=1e-5)
+    scale = max(1.0, float(w2.grad.abs().max()))
+    torch.testing.assert_close(got[1], w2.grad.float(), atol=2e-5 * scale, rtol=1e-5)
+    torch.testing.assert_close(got[2], b2.grad.float(), atol=2e-5 * max(1.0, float(b2.grad.abs().max())), rtol=1e-5)
+    if xgrad:
+        torch.testing.assert_close(got[3], x2.grad.float(), atol=2e-5, rtol=1e-5)
+
+
 # ------------------------------------------------------------------------------- one attention level
 def _level_case(n, m, heads, loops, seed, hub=False):
     g = torch.Generator().manual_seed(seed)
