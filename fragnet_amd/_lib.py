@@ -36,6 +36,28 @@ class GatPlan(C.Structure):
                 ("inv_d", vp), ("pos_base_d", i32), ("pos_base_s", i32), ("n", i64), ("m", i64), ("m_real", i64)]
 
 
+class SegPlan(C.Structure):
+    _fields_ = [("rowptr", vp), ("perm", vp), ("index", vp), ("n_seg", i64), ("n_items", i64), ("pos_base", i32), ("pad_", i32)]
+
+
+LAYER_FIELDS = ("proj_b_w", "proj_b_b", "proj_a_w", "proj_a_b", "proj_fb_w", "proj_fb_b", "emb_b_w", "emb_b_b",
+                "emb_fb_w", "emb_fb_b", "a_b", "a", "f", "f_a_b")
+FN_MAX_LAYERS = 8
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [(name, vp) for name in LAYER_FIELDS]
+
+
+class Encoder(C.Structure):
+    _fields_ = [("n_layers", i32), ("heads", i32), ("k_atom0", i32), ("k_bond0", i32), ("k_fbond0", i32), ("k_fattr", i32),
+                ("training", i32), ("pad_", i32), ("drop_p", f32), ("pad2_", f32), ("seed", u64), ("offset", u64),
+                ("N", i64), ("E", i64), ("F", i64), ("EF", i64),
+                ("bond", GatPlan), ("atom", GatPlan), ("fbond", GatPlan), ("frag", GatPlan), ("a2f", SegPlan),
+                ("x_atoms", vp), ("bond_nodes", vp), ("fbond_nodes", vp), ("cos_sorted", vp), ("fattr_sorted", vp),
+                ("w", LayerWeights * FN_MAX_LAYERS), ("ws", vp), ("ws_floats", i64)]
+
+
 # name -> argtypes; every function returns int (0 ok / <0 argument error / >0 hipError_t) unless noted.
 SIGNATURES = {
     "fn_abi_version": [],
@@ -57,6 +79,11 @@ SIGNATURES = {
     "fn_linear128_f32": [vp, C.c_int, vp, vp, vp, i64, vp],
     "fn_linear128_wgrad_ws": [i64, C.c_int],
     "fn_linear128_wgrad_f32": [vp, vp, C.c_int, i64, vp, vp, vp, vp],
+    "fn_encoder_ws_floats": [C.POINTER(Encoder)],
+    "fn_encoder_bwd_ws_floats": [C.POINTER(Encoder)],
+    "fn_encoder_rng_blocks": [C.POINTER(Encoder)],
+    "fn_encoder_forward": [C.POINTER(Encoder), vp, vp, vp, vp, vp],
+    "fn_encoder_backward": [C.POINTER(Encoder), vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(LayerWeights), vp, i64, vp],
     "fn_segment_sum_f32": [vp, i64, vp, vp, i32, vp, i64, i64, vp],
     "fn_gather_rows_f32": [vp, vp, vp, i64, i64, vp],
     "fn_segment_softmax_f32": [vp, vp, vp, i32, vp, i64, i64, vp],
@@ -89,7 +116,14 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "fn_last_error" else (i64 if name.endswith("_ws") else C.c_int)
+        if name == "fn_last_error":
+            fn.restype = C.c_char_p
+        elif name.endswith("_ws") or name.endswith("_ws_floats"):
+            fn.restype = i64
+        elif name == "fn_encoder_rng_blocks":
+            fn.restype = u64
+        else:
+            fn.restype = C.c_int
     if lib.fn_abi_version() != 1:
         raise FragnetHipError(f"ABI version mismatch: library {lib.fn_abi_version()}, binding 1")
     _lib = lib

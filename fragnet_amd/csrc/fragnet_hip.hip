@@ -9,6 +9,7 @@
 //   * a block is 256 threads = 8 rows; grids are capped and grid-strided so that the number of
 //     per-block partial-sum rows any backward kernel writes is bounded by FN_MAX_PART.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -697,8 +698,8 @@ __global__ __launch_bounds__(kBlock) void k_row_dots_sorted(const float* __restr
 __global__ __launch_bounds__(kBlock) void k_row_dots_sorted_bwd(const float* __restrict__ g_s_sorted,
                                                                 const float* __restrict__ feat,
                                                                 const float* __restrict__ A, int lda, int off, int J,
-                                                                fn_gat_plan pl, float* __restrict__ g_feat,
-                                                                float* __restrict__ part) {
+                                                                fn_gat_plan pl, float* g_feat,
+                                                                float* __restrict__ part, const float* addend) {
     __shared__ float sR[kRows][FN_D];
     const int lane = threadIdx.x & 31, hw = threadIdx.x >> 5;
     float4 a[8], q[8];
@@ -723,6 +724,7 @@ __global__ __launch_bounds__(kBlock) void k_row_dots_sorted_bwd(const float* __r
                 fma4(q[i], gs, v);
             }
         }
+        if (addend) { const float4 a0 = ld4(addend + e * FN_D + lane * 4); acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w; }
         st4(g_feat + e * FN_D + lane * 4, acc);
     }
 #pragma unroll
@@ -808,12 +810,15 @@ __global__ void k_segment_sum_any(const float* __restrict__ src, int64_t src_ld,
     }
 }
 
+// out[i,:] = table[index[i],:] (+ addend[i,:] when given; addend may alias out)
 __global__ void k_gather_rows4(const float* __restrict__ table, const int64_t* __restrict__ index,
-                               float* __restrict__ out, int64_t rows, int64_t w4) {
+                               float* out, int64_t rows, int64_t w4, const float* addend) {
     const int64_t total = rows * w4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / w4, c = i % w4;
-        st4(out + i * 4, ld4(table + ((size_t)index[r] * w4 + c) * 4));
+        float4 v = ld4(table + ((size_t)index[r] * w4 + c) * 4);
+        if (addend) { const float4 a = ld4(addend + i * 4); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+        st4(out + i * 4, v);
     }
 }
 
@@ -1423,7 +1428,7 @@ int fn_row_dots_sorted_bwd_f32(const float* g_s_sorted, const float* feat, const
     const int g = row_grid(plan->m_real, FN_MAX_PART);
     *n_part = g;
     hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(g), dim3(kBlock), 0, S(stream), g_s_sorted, feat, A, lda, off, J, *plan,
-                       g_feat, part);
+                       g_feat, part, (const float*)nullptr);
     return launch_status("fn_row_dots_sorted_bwd_f32");
 }
 
@@ -1507,7 +1512,7 @@ int fn_gather_rows_f32(const float* table, const int64_t* index, float* out, int
     if (!table || !index) return fail(FN_EINVAL, "fn_gather_rows_f32: null table/index");
     if ((width & 3) == 0 && (((uintptr_t)table | (uintptr_t)out) & 15) == 0)
         hipLaunchKernelGGL(k_gather_rows4, dim3(flat_grid(rows * (width / 4), kGridCap)), dim3(kBlock), 0, S(stream), table, index,
-                           out, rows, width / 4);
+                           out, rows, width / 4, (const float*)nullptr);
     else
         hipLaunchKernelGGL(k_gather_rows1, dim3(flat_grid(rows * width, kGridCap)), dim3(kBlock), 0, S(stream), table, index, out,
                            rows, width);
@@ -1562,6 +1567,345 @@ int fn_edge_concat_f32(const float* x, const float* e_attr, const int64_t* edge_
     if (!x || !e_attr || !edge_index || !out) return fail(FN_EINVAL, "fn_edge_concat_f32: null buffer");
     hipLaunchKernelGGL(k_edge_concat, dim3(flat_grid(E * 96, kGridCap)), dim3(kBlock), 0, S(stream), x, e_attr, edge_index, out, E);
     return launch_status("fn_edge_concat_f32");
+}
+
+}  // extern "C"
+
+// =====================================================================================
+// Encoder engine: FragNet.forward / its backward as ONE call each (reference gat2.py:381-442 and, per layer,
+// gat2.py:121-330).  The host only walks the layer list and enqueues kernels on the caller's stream; nothing is
+// allocated, nothing synchronises.  Activations the backward pass needs live in the caller's workspace.
+// =====================================================================================
+namespace {
+
+struct Bump {
+    float* base;
+    int64_t used = 0;
+    explicit Bump(float* b) : base(b) {}
+    float* take(int64_t n) {
+        float* p = base ? base + used : nullptr;
+        used += (n + 63) / 64 * 64;          // 256-byte granules keep every buffer 16-byte aligned
+        return p;
+    }
+};
+
+struct LayerActs {           // kept from forward for backward
+    float *h_b, *h_a, *h_fb, *frags, *new_bond, *new_fbond, *p_bond, *p_atom, *p_fbond, *p_frag;
+    float *y_atoms, *y_frags, *y_bond, *y_fbond;    // post dropout+ReLU outputs (null for the last layer: caller's buffers)
+};
+
+struct EncLayout {
+    LayerActs L[FN_MAX_LAYERS];
+    float* in_atoms0;        // dropout(x_atoms) when training with p > 0, else null (use x_atoms)
+    // forward scratch
+    float *atoms_new, *frags_new, *s_sorted, *s_dst, *s_src, *bt;
+    int64_t total;
+};
+
+inline int64_t max4(int64_t a, int64_t b, int64_t c, int64_t d) { return std::max(std::max(a, b), std::max(c, d)); }
+
+EncLayout enc_layout(const fn_encoder* e, float* ws) {
+    EncLayout o{};
+    Bump b(ws);
+    const int H = e->heads;
+    const bool drop = e->training && e->drop_p > 0.f;
+    for (int l = 0; l < e->n_layers; ++l) {
+        LayerActs& a = o.L[l];
+        a.h_b = b.take(e->E * FN_D);  a.h_a = b.take(e->N * FN_D);  a.h_fb = b.take(e->EF * FN_D);  a.frags = b.take(e->F * FN_D);
+        a.new_bond = b.take(e->E * FN_D);  a.new_fbond = b.take(e->EF * FN_D);
+        a.p_bond = b.take(e->bond.m * H);  a.p_atom = b.take(e->atom.m * H);
+        a.p_fbond = b.take(e->fbond.m * H);  a.p_frag = b.take(e->frag.m * H);
+        if (l + 1 < e->n_layers) {
+            a.y_atoms = b.take(e->N * FN_D);  a.y_frags = b.take(e->F * FN_D);
+            a.y_bond = b.take(e->E * FN_D);  a.y_fbond = b.take(e->EF * FN_D);
+        }
+    }
+    o.in_atoms0 = drop ? b.take(e->N * e->k_atom0) : nullptr;
+    o.atoms_new = b.take(e->N * FN_D);
+    o.frags_new = b.take(e->F * FN_D);
+    o.s_sorted = b.take(std::max(e->atom.m, e->frag.m) * H);
+    const int64_t nmax = max4(e->E, e->N, e->EF, e->F);
+    o.s_dst = b.take(nmax * H);
+    o.s_src = b.take(nmax * H);
+    o.bt = b.take(3 * 192 * FN_D);
+    o.total = b.used;
+    return o;
+}
+
+struct BwdLayout {
+    float *g_pre_atoms, *g_pre_frags, *g_pre_bond, *g_pre_fbond;   // grads w.r.t. pre-activation layer outputs
+    float *g_h, *g_frags, *dz, *g_s_dst, *part_a, *part_e, *part_rd, *wg_ws;
+    float *gy_atoms, *gy_bond, *gy_fbond;                          // grads flowing to the previous layer's outputs
+    int64_t total;
+};
+
+BwdLayout bwd_layout(const fn_encoder* e, float* ws) {
+    BwdLayout o{};
+    Bump b(ws);
+    const int H = e->heads;
+    const int64_t nmax = max4(e->E, e->N, e->EF, e->F), mmax = max4(e->bond.m, e->atom.m, e->fbond.m, e->frag.m);
+    o.g_pre_atoms = b.take(e->N * FN_D);  o.g_pre_frags = b.take(e->F * FN_D);
+    o.g_pre_bond = b.take(e->E * FN_D);   o.g_pre_fbond = b.take(e->EF * FN_D);
+    o.g_h = b.take(nmax * FN_D);          o.g_frags = b.take(e->F * FN_D);
+    o.dz = b.take(mmax * H);              o.g_s_dst = b.take(nmax * H);
+    o.part_a = b.take((int64_t)FN_MAX_PART * 2 * FN_D);
+    o.part_e = b.take((int64_t)FN_MAX_PART * H * (FN_MAX_EDGE_K + 1));
+    o.part_rd = b.take((int64_t)FN_MAX_PART * H * FN_D);
+    int64_t wg = 0;
+    const int ks[3] = {e->k_bond0 > FN_D ? e->k_bond0 : FN_D, e->k_atom0 > FN_D ? e->k_atom0 : FN_D, e->k_fbond0 > FN_D ? e->k_fbond0 : FN_D};
+    const int64_t ms[3] = {e->E, e->N, e->EF};
+    for (int i = 0; i < 3; ++i) wg = std::max(wg, fn_linear128_wgrad_ws(ms[i], ks[i]));
+    o.wg_ws = b.take(wg);
+    o.gy_atoms = b.take(e->N * FN_D);  o.gy_bond = b.take(e->E * FN_D);  o.gy_fbond = b.take(e->EF * FN_D);
+    o.total = b.used;
+    return o;
+}
+
+inline uint64_t blocks4(int64_t numel) { return (uint64_t)((numel + 3) / 4); }
+
+// Philox offsets consumed by the encoder, in order: input dropout of x_atoms, then per layer atoms, frags, bond, fbond
+struct RngPlan {
+    uint64_t in_atoms;
+    uint64_t y[FN_MAX_LAYERS][4];
+    uint64_t total;
+};
+RngPlan rng_plan(const fn_encoder* e) {
+    RngPlan r{};
+    uint64_t off = e->offset;
+    r.in_atoms = off;  off += blocks4(e->N * e->k_atom0);
+    for (int l = 0; l < e->n_layers; ++l) {
+        r.y[l][0] = off;  off += blocks4(e->N * FN_D);
+        r.y[l][1] = off;  off += blocks4(e->F * FN_D);
+        r.y[l][2] = off;  off += blocks4(e->E * FN_D);
+        r.y[l][3] = off;  off += blocks4(e->EF * FN_D);
+    }
+    r.total = off - e->offset;
+    return r;
+}
+
+int enc_check(const fn_encoder* e) {
+    if (!e) return fail(FN_EINVAL, "fn_encoder: null descriptor");
+    if (e->n_layers < 1 || e->n_layers > FN_MAX_LAYERS) return fail(FN_EINVAL, "fn_encoder: n_layers out of range");
+    if (e->heads != 1 && e->heads != 2 && e->heads != 4 && e->heads != 8) return fail(FN_EUNSUPPORTED, "fn_encoder: heads must be 1, 2, 4 or 8");
+    if (e->k_atom0 < 1 || e->k_atom0 > 168 || e->k_bond0 < 1 || e->k_bond0 > 168 || e->k_fbond0 < 1 || e->k_fbond0 > 168)
+        return fail(FN_EUNSUPPORTED, "fn_encoder: layer-0 feature widths must be in [1, 168]");
+    if (e->k_fattr < 1 || e->k_fattr > FN_MAX_EDGE_K) return fail(FN_EUNSUPPORTED, "fn_encoder: fragment-bond attribute width");
+    if (e->bond.n != e->E || e->atom.n != e->N || e->fbond.n != e->EF || e->frag.n != e->F || e->a2f.n_seg != e->F || e->a2f.n_items != e->N)
+        return fail(FN_EINVAL, "fn_encoder: plan sizes disagree with N/E/F/EF");
+    if (e->atom.m_real != e->E || e->frag.m_real != e->EF) return fail(FN_EINVAL, "fn_encoder: bond nodes must be the atom-graph edges");
+    if (!e->x_atoms || !e->bond_nodes || !e->fbond_nodes || !e->cos_sorted || !e->fattr_sorted || !e->ws)
+        return fail(FN_EINVAL, "fn_encoder: null input");
+    return 0;
+}
+
+#define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int64_t fn_encoder_ws_floats(const fn_encoder* e) { return e ? enc_layout(e, nullptr).total : 0; }
+int64_t fn_encoder_bwd_ws_floats(const fn_encoder* e) { return e ? bwd_layout(e, nullptr).total : 0; }
+uint64_t fn_encoder_rng_blocks(const fn_encoder* e) { return e ? rng_plan(e).total : 0; }
+
+int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, float* out_bond, float* out_fbond,
+                       fn_stream_t st) {
+    FN_TRY(enc_check(e));
+    if (!out_atoms || !out_frags || !out_bond || !out_fbond) return fail(FN_EINVAL, "fn_encoder_forward: null output");
+    const EncLayout lay = enc_layout(e, e->ws);
+    if (lay.total > e->ws_floats) return fail(FN_EINVAL, "fn_encoder_forward: workspace too small");
+    const RngPlan rng = rng_plan(e);
+    const int H = e->heads, d = FN_D / H;
+    const float p = e->training ? e->drop_p : 0.f;
+    const int wide = 2 * d + FN_D;             // width of a / f
+
+    const float* in_atoms = e->x_atoms;
+    if (lay.in_atoms0) {
+        FN_TRY(fn_dropout_act_f32(e->x_atoms, lay.in_atoms0, e->N * e->k_atom0, p, e->seed, rng.in_atoms, 0, st));
+        in_atoms = lay.in_atoms0;
+    }
+    const float* in_bond = e->bond_nodes;
+    const float* in_fbond = e->fbond_nodes;
+    int ka = e->k_atom0, kb = e->k_bond0, kfb = e->k_fbond0;
+
+    for (int l = 0; l < e->n_layers; ++l) {
+        const fn_layer_weights& w = e->w[l];
+        const LayerActs& a = lay.L[l];
+        const bool last = l + 1 == e->n_layers;
+        float* bt_b = lay.bt;
+        float* bt_a = lay.bt + 192 * FN_D;
+        float* bt_fb = lay.bt + 2 * 192 * FN_D;
+        FN_TRY(fn_transpose_w_f32(w.proj_b_w, kb, bt_b, st));
+        FN_TRY(fn_transpose_w_f32(w.proj_a_w, ka, bt_a, st));
+        FN_TRY(fn_transpose_w_f32(w.proj_fb_w, kfb, bt_fb, st));
+
+        // L1 bond graph
+        FN_TRY(fn_linear128_f32(in_bond, kb, bt_b, w.proj_b_b, a.h_b, e->E, st));
+        FN_TRY(fn_node_scalars_f32(a.h_b, w.a_b, 3 * d, 0, 2 * d, lay.s_dst, lay.s_src, e->E, H, st));
+        fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
+        FN_TRY(fn_gat_fwd_f32(a.h_b, lay.s_dst, lay.s_src, w.a_b, 3 * d, &et_b, &e->bond, 0.2f, a.new_bond, a.p_bond, nullptr, H, st));
+
+        // L2 atom graph (+ self loops), edge term = <new_bond, a[:, d:d+128]>
+        FN_TRY(fn_linear128_f32(in_atoms, ka, bt_a, w.proj_a_b, a.h_a, e->N, st));
+        FN_TRY(fn_row_dots_sorted_f32(a.new_bond, w.a, wide, d, H, &e->atom, lay.s_sorted, st));
+        FN_TRY(fn_node_scalars_f32(a.h_a, w.a, wide, 0, d + FN_D, lay.s_dst, lay.s_src, e->N, H, st));
+        fn_edge_term et_a{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
+        FN_TRY(fn_gat_fwd_f32(a.h_a, lay.s_dst, lay.s_src, w.a, wide, &et_a, &e->atom, 0.2f, lay.atoms_new, a.p_atom, nullptr, H, st));
+
+        // L3 atom -> fragment sum
+        FN_TRY(fn_segment_sum_f32(lay.atoms_new, FN_D, e->a2f.rowptr, e->a2f.perm, e->a2f.pos_base, a.frags, e->F, FN_D, st));
+
+        // L4a fragment-bond graph
+        FN_TRY(fn_linear128_f32(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, st));
+        FN_TRY(fn_node_scalars_f32(a.h_fb, w.f_a_b, 3 * d, 0, 2 * d, lay.s_dst, lay.s_src, e->EF, H, st));
+        fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
+        FN_TRY(fn_gat_fwd_f32(a.h_fb, lay.s_dst, lay.s_src, w.f_a_b, 3 * d, &et_fb, &e->fbond, 0.2f, a.new_fbond, a.p_fbond, nullptr, H, st));
+
+        // L4b fragment graph on the raw fragment sums
+        FN_TRY(fn_row_dots_sorted_f32(a.new_fbond, w.f, wide, d, H, &e->frag, lay.s_sorted, st));
+        FN_TRY(fn_node_scalars_f32(a.frags, w.f, wide, 0, d + FN_D, lay.s_dst, lay.s_src, e->F, H, st));
+        fn_edge_term et_f{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
+        FN_TRY(fn_gat_fwd_f32(a.frags, lay.s_dst, lay.s_src, w.f, wide, &et_f, &e->frag, 0.2f, lay.frags_new, a.p_frag, nullptr, H, st));
+
+        // act(dropout(.)) on the four outputs
+        float* y_atoms = last ? out_atoms : a.y_atoms;
+        float* y_frags = last ? out_frags : a.y_frags;
+        float* y_bond = last ? out_bond : a.y_bond;
+        float* y_fbond = last ? out_fbond : a.y_fbond;
+        FN_TRY(fn_dropout_act_f32(lay.atoms_new, y_atoms, e->N * FN_D, p, e->seed, rng.y[l][0], 1, st));
+        FN_TRY(fn_dropout_act_f32(lay.frags_new, y_frags, e->F * FN_D, p, e->seed, rng.y[l][1], 1, st));
+        FN_TRY(fn_dropout_act_f32(a.new_bond, y_bond, e->E * FN_D, p, e->seed, rng.y[l][2], 1, st));
+        FN_TRY(fn_dropout_act_f32(a.new_fbond, y_fbond, e->EF * FN_D, p, e->seed, rng.y[l][3], 1, st));
+        in_atoms = y_atoms;  in_bond = y_bond;  in_fbond = y_fbond;
+        ka = kb = kfb = FN_D;
+    }
+    return 0;
+}
+
+int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float* out_frags, const float* out_bond,
+                        const float* out_fbond, const float* g_atoms, const float* g_frags, const float* g_bond,
+                        const float* g_fbond, const fn_layer_weights* grads, float* scratch, int64_t scratch_floats,
+                        fn_stream_t st) {
+    FN_TRY(enc_check(e));
+    if (!grads || !scratch || !out_atoms || !out_frags || !out_bond || !out_fbond) return fail(FN_EINVAL, "fn_encoder_backward: null argument");
+    const EncLayout lay = enc_layout(e, e->ws);
+    const BwdLayout bw = bwd_layout(e, scratch);
+    if (bw.total > scratch_floats) return fail(FN_EINVAL, "fn_encoder_backward: scratch too small");
+    const RngPlan rng = rng_plan(e);
+    const int H = e->heads, d = FN_D / H;
+    const float p = e->training ? e->drop_p : 0.f;
+    const int wide = 2 * d + FN_D;
+    hipStream_t hs = S(st);
+
+    // gradients w.r.t. the current layer's post-activation outputs (null = zero)
+    const float* gy_atoms = g_atoms;
+    const float* gy_frags = g_frags;
+    const float* gy_bond = g_bond;
+    const float* gy_fbond = g_fbond;
+
+    for (int l = e->n_layers - 1; l >= 0; --l) {
+        const fn_layer_weights& w = e->w[l];
+        const fn_layer_weights& g = grads[l];
+        const LayerActs& a = lay.L[l];
+        const bool last = l + 1 == e->n_layers;
+        const float* y_atoms = last ? out_atoms : a.y_atoms;
+        const float* y_frags = last ? out_frags : a.y_frags;
+        const float* y_bond = last ? out_bond : a.y_bond;
+        const float* y_fbond = last ? out_fbond : a.y_fbond;
+        const float* in_atoms = l ? lay.L[l - 1].y_atoms : (lay.in_atoms0 ? lay.in_atoms0 : e->x_atoms);
+        const float* in_bond = l ? lay.L[l - 1].y_bond : e->bond_nodes;
+        const float* in_fbond = l ? lay.L[l - 1].y_fbond : e->fbond_nodes;
+        const int ka = l ? FN_D : e->k_atom0, kb = l ? FN_D : e->k_bond0, kfb = l ? FN_D : e->k_fbond0;
+        int n_a = 0, n_e = 0, n_rd = 0;
+
+        // ---- through act(dropout(.)): gradients of the pre-activation tensors
+        bool have_atoms = gy_atoms != nullptr, have_frags = gy_frags != nullptr, have_bond = gy_bond != nullptr, have_fbond = gy_fbond != nullptr;
+        if (have_atoms) FN_TRY(fn_dropout_act_bwd_f32(gy_atoms, y_atoms, bw.g_pre_atoms, e->N * FN_D, p, e->seed, rng.y[l][0], 1, st));
+        if (have_frags) FN_TRY(fn_dropout_act_bwd_f32(gy_frags, y_frags, bw.g_pre_frags, e->F * FN_D, p, e->seed, rng.y[l][1], 1, st));
+        if (have_bond) FN_TRY(fn_dropout_act_bwd_f32(gy_bond, y_bond, bw.g_pre_bond, e->E * FN_D, p, e->seed, rng.y[l][2], 1, st));
+        if (have_fbond) FN_TRY(fn_dropout_act_bwd_f32(gy_fbond, y_fbond, bw.g_pre_fbond, e->EF * FN_D, p, e->seed, rng.y[l][3], 1, st));
+
+        // ---- L4b fragment graph (only where its output is consumed: the last layer, reference fact SURVEY §0.8)
+        bool have_g_frags_h = false;
+        if (have_frags) {
+            fn_edge_term et_f{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_frags, a.frags, a.p_frag, &et_f, &e->frag, 0.2f, bw.dz, bw.g_s_dst, nullptr, &n_e, H, st));
+            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_frags, a.frags, a.p_frag, bw.dz, bw.g_s_dst, w.f, wide, 0, d + FN_D, &e->frag, bw.g_frags, bw.part_a, &n_a, H, st));
+            FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, nullptr, 0, &et_f, w.f, wide, 0, d + FN_D, g.f, nullptr, nullptr, H, st));
+            // edge term <new_fbond, f[:, d:d+128]>: dL/dnew_fbond accumulates into g_pre_fbond, dL/df mid block
+            if (e->frag.m_real > 0) {
+                const int gr = row_grid(e->frag.m_real, FN_MAX_PART);
+                hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(gr), dim3(kBlock), 0, hs, bw.dz, a.new_fbond, w.f, wide, d, H, e->frag,
+                                   bw.g_pre_fbond, bw.part_rd, have_fbond ? (const float*)bw.g_pre_fbond : (const float*)nullptr);
+                FN_TRY(launch_status("fn_encoder_backward: row_dots(frag)"));
+                FN_TRY(fn_colsum_f32(bw.part_rd, gr, H * FN_D, g.f, wide, d, st));
+                have_fbond = true;
+            }
+            have_g_frags_h = true;
+        }
+
+        // ---- L4a fragment-bond graph
+        const float* gy_fbond_prev = nullptr;
+        if (have_fbond) {
+            fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_fbond, a.h_fb, a.p_fbond, &et_fb, &e->fbond, 0.2f, bw.dz, bw.g_s_dst, bw.part_e, &n_e, H, st));
+            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_fbond, a.h_fb, a.p_fbond, bw.dz, bw.g_s_dst, w.f_a_b, 3 * d, 0, 2 * d, &e->fbond, bw.g_h, bw.part_a, &n_a, H, st));
+            FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, bw.part_e, n_e, &et_fb, w.f_a_b, 3 * d, 0, 2 * d, g.f_a_b, g.emb_fb_w, g.emb_fb_b, H, st));
+            FN_TRY(fn_linear128_wgrad_f32(bw.g_h, in_fbond, kfb, e->EF, bw.wg_ws, g.proj_fb_w, g.proj_fb_b, st));
+            if (l) {
+                FN_TRY(fn_linear128_f32(bw.g_h, FN_D, w.proj_fb_w, nullptr, bw.gy_fbond, e->EF, st));
+                gy_fbond_prev = bw.gy_fbond;
+            }
+        }
+
+        // ---- L3 atom -> fragment sum: dL/datoms_new += dL/dfrags[a2f]
+        if (have_g_frags_h) {
+            hipLaunchKernelGGL(k_gather_rows4, dim3(flat_grid(e->N * 32, kGridCap)), dim3(kBlock), 0, hs, bw.g_frags, e->a2f.index,
+                               bw.g_pre_atoms, e->N, (int64_t)32, have_atoms ? (const float*)bw.g_pre_atoms : (const float*)nullptr);
+            FN_TRY(launch_status("fn_encoder_backward: gather(a2f)"));
+            have_atoms = true;
+        }
+
+        // ---- L2 atom graph
+        const float* gy_atoms_prev = nullptr;
+        if (have_atoms) {
+            fn_edge_term et_a{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_atoms, a.h_a, a.p_atom, &et_a, &e->atom, 0.2f, bw.dz, bw.g_s_dst, nullptr, &n_e, H, st));
+            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_atoms, a.h_a, a.p_atom, bw.dz, bw.g_s_dst, w.a, wide, 0, d + FN_D, &e->atom, bw.g_h, bw.part_a, &n_a, H, st));
+            FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, nullptr, 0, &et_a, w.a, wide, 0, d + FN_D, g.a, nullptr, nullptr, H, st));
+            if (e->atom.m_real > 0) {
+                const int gr = row_grid(e->atom.m_real, FN_MAX_PART);
+                hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(gr), dim3(kBlock), 0, hs, bw.dz, a.new_bond, w.a, wide, d, H, e->atom,
+                                   bw.g_pre_bond, bw.part_rd, have_bond ? (const float*)bw.g_pre_bond : (const float*)nullptr);
+                FN_TRY(launch_status("fn_encoder_backward: row_dots(atom)"));
+                FN_TRY(fn_colsum_f32(bw.part_rd, gr, H * FN_D, g.a, wide, d, st));
+                have_bond = true;
+            }
+            FN_TRY(fn_linear128_wgrad_f32(bw.g_h, in_atoms, ka, e->N, bw.wg_ws, g.proj_a_w, g.proj_a_b, st));
+            if (l) {
+                FN_TRY(fn_linear128_f32(bw.g_h, FN_D, w.proj_a_w, nullptr, bw.gy_atoms, e->N, st));
+                gy_atoms_prev = bw.gy_atoms;
+            }
+        }
+
+        // ---- L1 bond graph
+        const float* gy_bond_prev = nullptr;
+        if (have_bond) {
+            fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_bond, a.h_b, a.p_bond, &et_b, &e->bond, 0.2f, bw.dz, bw.g_s_dst, bw.part_e, &n_e, H, st));
+            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_bond, a.h_b, a.p_bond, bw.dz, bw.g_s_dst, w.a_b, 3 * d, 0, 2 * d, &e->bond, bw.g_h, bw.part_a, &n_a, H, st));
+            FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, bw.part_e, n_e, &et_b, w.a_b, 3 * d, 0, 2 * d, g.a_b, g.emb_b_w, g.emb_b_b, H, st));
+            FN_TRY(fn_linear128_wgrad_f32(bw.g_h, in_bond, kb, e->E, bw.wg_ws, g.proj_b_w, g.proj_b_b, st));
+            if (l) {
+                FN_TRY(fn_linear128_f32(bw.g_h, FN_D, w.proj_b_w, nullptr, bw.gy_bond, e->E, st));
+                gy_bond_prev = bw.gy_bond;
+            }
+        }
+        (void)n_rd;
+        gy_atoms = gy_atoms_prev;  gy_bond = gy_bond_prev;  gy_fbond = gy_fbond_prev;
+        gy_frags = nullptr;        // a layer's x_frags input is dead in the reference (overwritten at gat2.py:234)
+    }
+    return 0;
 }
 
 }  // extern "C"

@@ -1,0 +1,124 @@
+"""The whole encoder (reference FragNet.forward, gat2.py:381-442) as one autograd node backed by two C calls:
+fn_encoder_forward / fn_encoder_backward walk the layers inside libfragnet_hip.so and enqueue every kernel
+(MFMA projections, node scalars, segmented softmax-aggregate, segment sum, dropout+ReLU) on the current
+stream.  Python does not see the per-level ops, so a training step costs two ctypes calls for the encoder
+instead of ~250 autograd nodes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import Encoder, FN_D, LAYER_FIELDS, LayerWeights, SegPlan
+from .plan import GraphPlan, _stream_ptr
+
+
+def layer_param_list(layer) -> List[torch.nn.Parameter]:
+    """Parameters of one FragNetLayerA in the order of fn_layer_weights."""
+    return [layer.projection_b.weight, layer.projection_b.bias, layer.projection_a.weight, layer.projection_a.bias,
+            layer.projection_fb.weight, layer.projection_fb.bias, layer.edge_attr_bond_embed.weight,
+            layer.edge_attr_bond_embed.bias, layer.edge_attr_fbond_embed.weight, layer.edge_attr_fbond_embed.bias,
+            layer.a_b, layer.a, layer.f, layer.f_a_b]
+
+
+NP = len(LAYER_FIELDS)
+F_IDX = LAYER_FIELDS.index("f")
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.FragnetHipError(f"{name}: the encoder engine needs GPU tensors (got {t.device}); there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _describe(plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, params: Sequence[torch.Tensor],
+              n_layers: int, heads: int, drop_p: float, training: bool, seed: int, offset: int) -> Encoder:
+    e = Encoder()
+    e.n_layers, e.heads = n_layers, heads
+    e.k_atom0, e.k_bond0, e.k_fbond0 = x_atoms.shape[1], bond_nodes.shape[1], fbond_nodes.shape[1]
+    e.k_fattr = fattr_sorted.shape[1]
+    e.training, e.drop_p = int(training), float(drop_p)
+    e.seed, e.offset = seed, offset
+    L = plan.levels
+    e.N, e.E, e.F, e.EF = L["atom"].n, L["bond"].n, L["frag"].n, L["fbond"].n
+    e.bond, e.atom, e.fbond, e.frag = L["bond"].c, L["atom"].c, L["fbond"].c, L["frag"].c
+    s = plan.segs["a2f"]
+    e.a2f = SegPlan(s.rowptr.data_ptr(), s.perm.data_ptr(), s.index.data_ptr(), s.n_seg, s.n_items, s.pos_base, 0)
+    e.x_atoms, e.bond_nodes, e.fbond_nodes = x_atoms.data_ptr(), bond_nodes.data_ptr(), fbond_nodes.data_ptr()
+    e.cos_sorted, e.fattr_sorted = cos_sorted.data_ptr(), fattr_sorted.data_ptr()
+    for l in range(n_layers):
+        for k, name in enumerate(LAYER_FIELDS):
+            setattr(e.w[l], name, params[l * NP + k].data_ptr())
+    return e
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, plan, n_layers, heads, drop_p, training,
+                seed, offset, *params):
+        x_atoms, bond_nodes, fbond_nodes = _f32(x_atoms, "x_atoms"), _f32(bond_nodes, "node_features_bonds"), _f32(fbond_nodes, "node_features_fbonds")
+        params = tuple(_f32(p, "parameter") for p in params)
+        dev = x_atoms.device
+        lib = _lib.load()
+        e = _describe(plan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, params, n_layers, heads, drop_p,
+                      training, seed, offset)
+        ws = torch.empty(lib.fn_encoder_ws_floats(C.byref(e)), dtype=torch.float32, device=dev)
+        e.ws, e.ws_floats = ws.data_ptr(), ws.numel()
+        outs = [torch.empty((n, FN_D), dtype=torch.float32, device=dev) for n in (e.N, e.F, e.E, e.EF)]
+        _lib.check(lib.fn_encoder_forward(C.byref(e), *(o.data_ptr() for o in outs), _stream_ptr(dev)), "fn_encoder_forward")
+        ctx.desc = e
+        ctx.keep = (plan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, ws)
+        ctx.n_layers = n_layers
+        ctx.save_for_backward(*params, *outs)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_atoms, g_frags, g_bond, g_fbond):
+        n_layers = ctx.n_layers
+        saved = ctx.saved_tensors
+        params, outs = saved[: n_layers * NP], saved[n_layers * NP:]
+        e = ctx.desc
+        dev = outs[0].device
+        lib = _lib.load()
+        gs = [None if g is None else _f32(g, "grad") for g in (g_atoms, g_frags, g_bond, g_fbond)]
+        grads = [torch.empty_like(p) for p in params]
+        gw = (LayerWeights * n_layers)()
+        for l in range(n_layers):
+            for k, name in enumerate(LAYER_FIELDS):
+                setattr(gw[l], name, grads[l * NP + k].data_ptr())
+        scratch = torch.empty(lib.fn_encoder_bwd_ws_floats(C.byref(e)), dtype=torch.float32, device=dev)
+        _lib.check(lib.fn_encoder_backward(C.byref(e), *(o.data_ptr() for o in outs),
+                                           *(None if g is None else g.data_ptr() for g in gs), gw, scratch.data_ptr(),
+                                           scratch.numel(), _stream_ptr(dev)), "fn_encoder_backward")
+        out = []
+        have_frags = gs[1] is not None
+        any_grad = any(g is not None for g in gs)
+        for l in range(n_layers):
+            for k in range(NP):
+                live = any_grad and not (k == F_IDX and not (l == n_layers - 1 and have_frags))
+                out.append(grads[l * NP + k] if live else None)
+        return (None,) * 12 + tuple(out)
+
+
+def encoder_forward(layers, plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, heads: int,
+                    drop_p: float, training: bool, rng) -> tuple:
+    """Runs all ``layers`` (FragNetLayerA modules) + the inter-layer act(dropout(.)); returns the four outputs."""
+    params = [p for layer in layers for p in layer_param_list(layer)]
+    n_layers = len(layers)
+    p_eff = float(drop_p) if training else 0.0
+    if p_eff > 0.0:
+        # reserve the Philox offsets the engine will consume (fn_encoder_rng_blocks): x_atoms + 4 tensors per layer
+        N, E = x_atoms.shape[0], bond_nodes.shape[0]
+        F, EF = plan.levels["frag"].n, fbond_nodes.shape[0]
+        blocks = (N * x_atoms.shape[1] + 3) // 4 + n_layers * sum((n * FN_D + 3) // 4 for n in (N, F, E, EF))
+        seed, offset = rng.take(4 * blocks)
+    else:
+        seed, offset = 0, 0
+    return _EncoderFn.apply(x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, plan, n_layers, heads, p_eff,
+                            bool(training), seed, offset, *params)

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import engine, ops
 from .plan import plan_for
 
 _ACTS = {
@@ -175,10 +175,18 @@ class FragNet(nn.Module):
                                              edge_in=emb_dim, edge_out=emb_dim, fedge_in=emb_dim,
                                              fbond_edge_in=fbond_edge_in, num_heads=num_heads))
         self.rng = ops.PhiloxStream()
+        self.use_engine = True      # False: one autograd node per level (same kernels, used by the per-op tests)
 
     def forward(self, batch):
         plan = plan_for(batch)
         p, train = self.dropout.p, self.training
+        if self.use_engine and not any(l.return_attentions or l.bond_mask is not None or l.frag_bond_mask is not None
+                                       or l.atom_mask_individual is not None for l in self.layers):
+            # whole encoder in two C calls (fragnet_amd/engine.py); masks / attention outputs use the per-level path
+            return engine.encoder_forward(self.layers, plan, batch["x_atoms"], batch["node_features_bonds"],
+                                          batch["node_features_fbonds"], plan.sorted_attr("bond", batch["edge_attr_bonds"]),
+                                          plan.sorted_attr("fbond", batch["edge_attr_fbonds"]), self.layers[0].num_heads,
+                                          p, train, self.rng)
         x_atoms = ops.dropout_act(batch["x_atoms"], p, train, False, self.rng)
         # batch["x_frags"] is dead in the reference too: every layer overwrites it with the atom->fragment
         # sum before first use (gat2.py:234); its dropout mask is drawn and discarded there (gat2.py:397).

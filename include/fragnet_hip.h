@@ -227,6 +227,60 @@ int fn_dropout_act_bwd_f32(const float* g_y, const float* y, float* g_x, int64_t
 int fn_edge_concat_f32(const float* x /*[N,128]*/, const float* e_attr /*[E,128]*/, const int64_t* edge_index /*[2,E]*/,
                        float* out /*[E,384]*/, int64_t E, fn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Encoder engine: the reference's FragNet.forward (gat2.py:381-442: L x FragNetLayerA + act(dropout(.))) and
+ * its backward pass as one call each.  The host side only walks the layers and enqueues kernels on `stream`;
+ * nothing is allocated, nothing synchronises.  `ws` keeps the activations the backward pass reads.
+ * Gradient pointers in `grads[l]` that the pass does not produce are left untouched: `f` for every layer but the
+ * last (the fragment-graph output of inner layers is dead in the reference).
+ * ------------------------------------------------------------------------------------------ */
+#define FN_MAX_LAYERS 8
+
+typedef struct fn_seg_plan {
+    const int32_t* rowptr;    /* [n_seg+1] global positions */
+    const int32_t* perm;      /* [n_items] */
+    const int64_t* index;     /* [n_items] the original key (for the gather backward) */
+    int64_t n_seg, n_items;
+    int32_t pos_base, pad_;
+} fn_seg_plan;
+
+typedef struct fn_layer_weights {          /* parameters of one FragNetLayerA, or their gradients */
+    float *proj_b_w, *proj_b_b;            /* projection_b  [128,Kb], [128]  (gat2.py:88)  */
+    float *proj_a_w, *proj_a_b;            /* projection_a  [128,Ka], [128]  (gat2.py:95)  */
+    float *proj_fb_w, *proj_fb_b;          /* projection_fb [128,Kfb], [128] (gat2.py:89)  */
+    float *emb_b_w, *emb_b_b;              /* edge_attr_bond_embed  [d,1], [d]  (gat2.py:91) */
+    float *emb_fb_w, *emb_fb_b;            /* edge_attr_fbond_embed [d,Kf], [d] (gat2.py:92) */
+    float *a_b, *a, *f, *f_a_b;            /* attention vectors (gat2.py:98-109) */
+} fn_layer_weights;
+
+typedef struct fn_encoder {
+    int32_t n_layers, heads;
+    int32_t k_atom0, k_bond0, k_fbond0;    /* layer-0 feature widths (167, 17, 6); 128 afterwards */
+    int32_t k_fattr;                       /* width of edge_attr_fbonds (6) */
+    int32_t training, pad_;
+    float drop_p, pad2_;
+    uint64_t seed, offset;                 /* Philox stream; fn_encoder_rng_blocks() offsets are consumed */
+    int64_t N, E, F, EF;
+    fn_gat_plan bond, atom, fbond, frag;
+    fn_seg_plan a2f;
+    const float *x_atoms, *bond_nodes, *fbond_nodes;     /* layer-0 inputs */
+    const float *cos_sorted, *fattr_sorted;              /* fn_sort_edge_attr_f32 outputs */
+    fn_layer_weights w[FN_MAX_LAYERS];
+    float* ws;
+    int64_t ws_floats;                     /* >= fn_encoder_ws_floats() */
+} fn_encoder;
+
+int64_t fn_encoder_ws_floats(const fn_encoder* e);
+int64_t fn_encoder_bwd_ws_floats(const fn_encoder* e);
+uint64_t fn_encoder_rng_blocks(const fn_encoder* e);
+int fn_encoder_forward(const fn_encoder* e, float* out_atoms /*[N,128]*/, float* out_frags /*[F,128]*/,
+                       float* out_bond /*[E,128]*/, float* out_fbond /*[EF,128]*/, fn_stream_t stream);
+/* g_* are dL/d(out_*) (nullable = zero); out_* are the forward outputs (needed for the ReLU mask). */
+int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float* out_frags, const float* out_bond,
+                        const float* out_fbond, const float* g_atoms, const float* g_frags, const float* g_bond,
+                        const float* g_fbond, const fn_layer_weights* grads /*[n_layers]*/, float* scratch,
+                        int64_t scratch_floats, fn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -268,11 +268,12 @@ def test_dropout_act_statistics_and_backward_mask():
 
 
 # ------------------------------------------------------------------------------- whole model vs the reference's outputs
-def _run_ft(case):
+def _run_ft(case, use_engine):
     from fragnet_amd.model import FragNetFineTune, pooled
     cfg, batch, out, grads, pkeys, psums = load_case(case)
     torch.manual_seed(cfg["seed"])
     model = FragNetFineTune(**cfg["ctor"]).to(DEV)
+    model.pretrain.use_engine = use_engine
     model.train()
     b = _to_dev(batch)
     traces = []
@@ -291,10 +292,12 @@ def _run_ft(case):
     return cfg, b, out, grads, model, logits, traces
 
 
+@pytest.mark.parametrize("use_engine", [True, False], ids=["engine", "per_level_ops"])
 @pytest.mark.parametrize("case", ["ft_esol_b8", "ft_tox21_b4", "ft_edge_b6"])
-def test_finetune_matches_reference_golden(case):
+def test_finetune_matches_reference_golden(case, use_engine):
     from oracle import fragnet_ref as ref
-    cfg, b, out, grads, model, logits, traces = _run_ft(case)
+    cfg, b, out, grads, model, logits, traces = _run_ft(case, use_engine)
+    assert bool(traces) != use_engine          # the engine never surfaces per-level tensors to Python
     for li, outs in enumerate(traces):
         for nm, t in zip(("x_atoms", "x_frags", "bond", "fbond"), outs):
             torch.testing.assert_close(t, torch.from_numpy(out[f"layer{li}/{nm}"]), atol=ATOL, rtol=1e-4,
@@ -311,12 +314,14 @@ def test_finetune_matches_reference_golden(case):
     check_grads(model, grads, atol=ATOL, rtol=2e-3)
 
 
-def test_pretrain_matches_reference_golden():
+@pytest.mark.parametrize("use_engine", [True, False], ids=["engine", "per_level_ops"])
+def test_pretrain_matches_reference_golden(use_engine):
     from fragnet_amd.model import FragNetPreTrain
     from oracle import fragnet_ref as ref
     cfg, batch, out, grads, pkeys, psums = load_case("pt_esol_b4")
     torch.manual_seed(cfg["seed"])
     model = FragNetPreTrain(**cfg["ctor"]).to(DEV)
+    model.pretrain.use_engine = use_engine
     model.train()
     b = _to_dev(batch)
     outs = model(b)
@@ -402,6 +407,27 @@ def test_b512_matches_oracle_on_a_64_molecule_slice_and_is_permutation_equivaria
     with torch.no_grad():
         want = gold(data.collate_fn(mols[:64]))
     torch.testing.assert_close(full[:64], want, atol=ATOL, rtol=1e-4)
+
+
+def test_engine_and_per_level_path_agree_with_dropout(esol512):
+    """Train mode, drop 0.1: both host paths draw the same Philox offsets, so they must agree to round-off
+    (the projections differ: fp32 MFMA kernel vs library GEMM)."""
+    res = []
+    for use_engine in (True, False):
+        model = _esol_model(drop=0.1)
+        model.pretrain.use_engine = use_engine
+        model.pretrain.rng.seed = 1234
+        model.fthead.dropout.p = 0.0           # torch's own generator drives the head's dropout: switch it off
+        model.train()
+        b = _to_dev(esol512)
+        out = model(b)
+        loss = torch.nn.functional.mse_loss(out.view(-1), b["y"])
+        loss.backward()
+        res.append((out.detach().cpu(), model.pretrain.layers[0].projection_a.weight.grad.cpu(),
+                    model.pretrain.layers[3].f.grad.cpu(), model.pretrain.layers[2].a_b.grad.cpu()))
+        assert model.pretrain.layers[1].f.grad is None
+    for a, c in zip(*res):
+        torch.testing.assert_close(a, c, atol=2e-5 * max(1.0, float(c.abs().max())), rtol=1e-4)
 
 
 def test_b512_training_step_is_bitwise_reproducible(esol512):
