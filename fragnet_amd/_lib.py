@@ -31,6 +31,10 @@ class EdgeTerm(C.Structure):
                 ("s_sorted", vp), ("x_sorted", vp), ("embW", vp), ("embb", vp)]
 
 
+class ActEpilogue(C.Structure):
+    _fields_ = [("y", vp), ("p", f32), ("relu", i32), ("seed", u64), ("offset", u64)]
+
+
 class GatPlan(C.Structure):
     _fields_ = [("rowptr_d", vp), ("eid_d", vp), ("src_d", vp), ("rowptr_s", vp), ("dst_s", vp), ("dpos_s", vp),
                 ("inv_d", vp), ("pos_base_d", i32), ("pos_base_s", i32), ("n", i64), ("m", i64), ("m_real", i64)]
@@ -65,7 +69,8 @@ SIGNATURES = {
     "fn_plan_layout": [C.POINTER(CsrTask), C.c_int, C.POINTER(i64), C.POINTER(i64)],
     "fn_plan_build": [C.POINTER(CsrTask), C.c_int, vp, vp, vp, vp, vp, vp],
     "fn_node_scalars_f32": [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, i64, C.c_int, vp],
-    "fn_gat_fwd_f32": [vp, vp, vp, vp, C.c_int, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp, C.c_int, vp],
+    "fn_gat_fwd_f32": [vp, vp, vp, vp, C.c_int, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp,
+                       C.POINTER(ActEpilogue), C.c_int, vp],
     "fn_gat_bwd_dst_f32": [vp, vp, vp, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp, ip, C.c_int, vp],
     "fn_gat_bwd_src_f32": [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(GatPlan), vp, vp, ip, C.c_int, vp],
     "fn_gat_bwd_finalize_f32": [vp, C.c_int, vp, C.c_int, C.POINTER(EdgeTerm), vp, C.c_int, C.c_int, C.c_int, vp, vp, vp,
@@ -84,12 +89,13 @@ SIGNATURES = {
     "fn_encoder_rng_blocks": [C.POINTER(Encoder)],
     "fn_encoder_forward": [C.POINTER(Encoder), vp, vp, vp, vp, vp],
     "fn_encoder_backward": [C.POINTER(Encoder), vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(LayerWeights), vp, i64, vp],
-    "fn_segment_sum_f32": [vp, i64, vp, vp, i32, vp, i64, i64, vp],
+    "fn_segment_sum_f32": [vp, i64, vp, vp, i32, vp, i64, i64, i64, vp],
     "fn_gather_rows_f32": [vp, vp, vp, i64, i64, vp],
     "fn_segment_softmax_f32": [vp, vp, vp, i32, vp, i64, i64, vp],
     "fn_segment_softmax_bwd_f32": [vp, vp, vp, vp, i32, vp, i64, i64, vp],
     "fn_dropout_act_f32": [vp, vp, i64, f32, u64, u64, C.c_int, vp],
     "fn_dropout_act_bwd_f32": [vp, vp, vp, i64, f32, u64, u64, C.c_int, vp],
+    "fn_adam_f32": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp],
     "fn_edge_concat_f32": [vp, vp, vp, vp, i64, vp],
 }
 

@@ -86,6 +86,25 @@ __device__ __forceinline__ void block_groups(int64_t n_rows, int rb, int64_t& be
     end = begin + per < groups ? begin + per : groups;
 }
 
+__device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t seed) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+__device__ __forceinline__ float keep_scale(uint32_t bits, float p, float inv_keep) {
+    const float u = (float)(bits >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? inv_keep : 0.f;
+}
+
 template <int W> __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
     for (int off = W / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -368,7 +387,7 @@ __global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h,
                                                     const float* __restrict__ s_src, const float* __restrict__ att,
                                                     int att_w, fn_edge_term et, fn_gat_plan pl, float slope,
                                                     float* __restrict__ out, float* __restrict__ p_sorted,
-                                                    float* __restrict__ probs_orig) {
+                                                    float* __restrict__ probs_orig, fn_act_epilogue ep) {
     constexpr int LPH = 32 / H;
     __shared__ float sWf[8][kWfLd];
     fold_edge_embed(et, att, att_w, H, sWf);
@@ -433,7 +452,18 @@ __global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h,
                 fma4(acc, p, ld4(h + (size_t)sk * FN_D + lane * 4));
             }
         }
-        st4(out + t * FN_D + lane * 4, acc);
+        if (out) st4(out + t * FN_D + lane * 4, acc);
+        if (ep.y) {          // fused act(dropout(.)): same Philox block index (element / 4) as k_dropout_act
+            float4 r = acc;
+            if (ep.p > 0.f) {
+                const uint4 rnd = philox4x32_10(ep.offset + (uint64_t)t * 32 + lane, ep.seed);
+                const float ik = ep.p < 1.f ? 1.f / (1.f - ep.p) : 0.f;
+                r.x *= keep_scale(rnd.x, ep.p, ik); r.y *= keep_scale(rnd.y, ep.p, ik);
+                r.z *= keep_scale(rnd.z, ep.p, ik); r.w *= keep_scale(rnd.w, ep.p, ik);
+            }
+            if (ep.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+            st4(ep.y + t * FN_D + lane * 4, r);
+        }
     }
 }
 
@@ -581,32 +611,37 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_src(const float* __restrict
         float a = 0.f;
 #pragma unroll
         for (int w = 0; w < RB; ++w) a += sA[w][c];
-        part_a[(size_t)blockIdx.x * (2 * FN_D) + c] = a;
+        part_a[(size_t)c * FN_MAX_PART + blockIdx.x] = a;          // column-major: finalize reads a column contiguously
     }
 }
 
-// blocks 0..7: column tiles (32 columns each) of the [n_a, 256] a_dst/a_src partials; block 8 (mode 2 only):
-// the [n_e, H*(K+1)] edge-embedding partials and the chain rule through the folded weights.
+// sum of up to 1024 values, one per thread (deterministic: wave butterflies, then 16 wave sums in order)
+__device__ __forceinline__ float block_sum_1024(float v, float* s16) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) s16[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += s16[w];
+    return t;
+}
+
+// blocks 0..255: one column each of the column-major [256][FN_MAX_PART] a_dst/a_src partials; block 256 (mode 2
+// only): the [n_e, H*(K+1)] edge-embedding partials and the chain rule through the folded weights.
 __global__ __launch_bounds__(1024) void k_gat_finalize(const float* __restrict__ part_a, int n_a,
                                                        const float* __restrict__ part_e, int n_e, fn_edge_term et,
                                                        const float* __restrict__ att, int att_w, int dst_off,
                                                        int src_off, float* __restrict__ g_att,
                                                        float* __restrict__ g_embW, float* __restrict__ g_embb, int H) {
-    __shared__ float red[32][33];
+    __shared__ float s16[16];
     __shared__ float redE[8][128];
     __shared__ float sE[128];
     const int tid = threadIdx.x;
-    if (blockIdx.x < 8) {
-        const int c = tid & 31, rg = tid >> 5;
-        const int col = blockIdx.x * 32 + c;
-        float acc = 0.f;
-        for (int r = rg; r < n_a; r += 32) acc += part_a[(size_t)r * (2 * FN_D) + col];
-        red[rg][c] = acc;
-        __syncthreads();
-        if (tid < 32) {
-            float v = 0.f;
-#pragma unroll
-            for (int g = 0; g < 32; ++g) v += red[g][tid];
+    if (blockIdx.x < 2 * FN_D) {
+        const int col = blockIdx.x;
+        const float v = block_sum_1024(tid < n_a ? part_a[(size_t)col * FN_MAX_PART + tid] : 0.f, s16);
+        if (tid == 0) {
             const int DH = FN_D / H;
             const int cc = col & 127, part = col >> 7;
             g_att[(cc / DH) * att_w + (part ? src_off : dst_off) + (cc % DH)] = v;
@@ -615,21 +650,24 @@ __global__ __launch_bounds__(1024) void k_gat_finalize(const float* __restrict__
     }
     const int K = et.K, d_e = et.d_e;
     const int ne = H * (K + 1);     // <= 72
-    {
-        const int col = tid & 127, grp = tid >> 7;
+    {   // column sums of part_e [n_e][ne]: the 1024 threads form (1024 / cp) row groups x cp columns, cp = pow2 >= ne
+        float* red = &redE[0][0];   // 1024 floats
+        int cp = 8;
+        while (cp < ne) cp <<= 1;
+        const int groups = 1024 / cp, col = tid % cp, grp = tid / cp;
         float acc = 0.f;
         if (col < ne)
-            for (int r = grp; r < n_e; r += 8) acc += part_e[(size_t)r * ne + col];
-        redE[grp][col] = acc;
+            for (int r = grp; r < n_e; r += groups) acc += part_e[(size_t)r * ne + col];
+        red[grp * cp + col] = acc;
+        __syncthreads();
+        if (tid < 128) {
+            float v = 0.f;
+            if (tid < ne)
+                for (int g = 0; g < groups; ++g) v += red[g * cp + tid];
+            sE[tid] = v;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (tid < 128) {
-        float v = 0.f;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) v += redE[g][tid];
-        sE[tid] = v;
-    }
-    __syncthreads();
     if (tid < H * d_e) {
         const int hh = tid / d_e, c = tid % d_e;
         float a = sE[hh * (K + 1) + K] * et.embb[c];
@@ -736,7 +774,7 @@ __global__ __launch_bounds__(kBlock) void k_row_dots_sorted_bwd(const float* __r
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < kRows; ++w) v += sR[w][threadIdx.x];
-                part[(size_t)blockIdx.x * (J * FN_D) + i * FN_D + threadIdx.x] = v;
+                part[(size_t)(i * FN_D + threadIdx.x) * FN_MAX_PART + blockIdx.x] = v;   // column-major
             }
             __syncthreads();
         }
@@ -754,23 +792,13 @@ __global__ void k_sort_edge_attr(const float* __restrict__ x, int K, fn_gat_plan
     }
 }
 
-// 1024 threads = 32 columns x 32 row groups; grid = ceil(cols / 32)
+// one block per column of the column-major partials [cols][FN_MAX_PART]
 __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ part, int n_rows, int cols,
                                                   float* __restrict__ out, int ld, int off) {
-    __shared__ float red[32][33];
-    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int col = blockIdx.x * 32 + c;
-    float acc = 0.f;
-    if (col < cols)
-        for (int r = rg; r < n_rows; r += 32) acc += part[(size_t)r * cols + col];
-    red[rg][c] = acc;
-    __syncthreads();
-    if (threadIdx.x < 32 && col < cols) {
-        float v = 0.f;
-#pragma unroll
-        for (int g = 0; g < 32; ++g) v += red[g][threadIdx.x];
-        out[(col / FN_D) * ld + off + (col % FN_D)] = v;
-    }
+    __shared__ float s16[16];
+    const int col = blockIdx.x;
+    const float v = block_sum_1024((int)threadIdx.x < n_rows ? part[(size_t)col * FN_MAX_PART + threadIdx.x] : 0.f, s16);
+    if (threadIdx.x == 0) out[(col / FN_D) * ld + off + (col % FN_D)] = v;
 }
 
 // =====================================================================================
@@ -794,6 +822,33 @@ __global__ __launch_bounds__(kBlock) void k_segment_sum128(const float* __restri
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
         st4(out + s * FN_D + lane * 4, acc);
+    }
+}
+
+// long segments (pooling: ~26 atoms per molecule, few hundred segments): one block per segment, its 8 half-waves
+// take rows hw, hw+8, ... and the 8 partial rows are added in a fixed order
+__global__ __launch_bounds__(kBlock) void k_segment_sum128_wide(const float* __restrict__ src, int64_t src_ld,
+                                                                const int32_t* __restrict__ rowptr,
+                                                                const int32_t* __restrict__ perm, int32_t pos_base,
+                                                                float* __restrict__ out, int64_t n_seg) {
+    __shared__ float sS[kRows][FN_D];
+    const int lane = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    for (int64_t s = blockIdx.x; s < n_seg; s += gridDim.x) {
+        const int beg = rowptr[s] - pos_base, deg = rowptr[s + 1] - rowptr[s];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = hw; i < deg; i += kRows) {
+            const float4 v = ld4(src + (size_t)perm[beg + i] * src_ld + lane * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        st4(&sS[hw][lane * 4], acc);
+        __syncthreads();
+        if (threadIdx.x < FN_D) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < kRows; ++w) v += sS[w][threadIdx.x];
+            out[s * FN_D + threadIdx.x] = v;
+        }
+        __syncthreads();
     }
 }
 
@@ -869,25 +924,6 @@ __global__ void k_segment_softmax_bwd(const float* __restrict__ probs, const flo
 // =====================================================================================
 // dropout + ReLU epilogue (Philox-4x32-10)
 // =====================================================================================
-__device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t seed) {
-    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return make_uint4(c0, c1, c2, c3);
-}
-
-__device__ __forceinline__ float keep_scale(uint32_t bits, float p, float inv_keep) {
-    const float u = (float)(bits >> 8) * (1.0f / 16777216.0f);
-    return u >= p ? inv_keep : 0.f;
-}
-
 template <bool BWD>
 __global__ void k_dropout_act(const float* __restrict__ a, const float* __restrict__ y_saved, float* __restrict__ o,
                               int64_t numel, float p, uint64_t seed, uint64_t offset, int relu) {
@@ -921,6 +957,32 @@ __global__ void k_dropout_act(const float* __restrict__ a, const float* __restri
                 o[e0 + q] = v;
             }
         }
+    }
+}
+
+// torch.optim.Adam's update rule (no amsgrad) on one flat tensor: the reference's optimiser, finetune_gat2.py:257
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                       int64_t n, float lr_over_bc1, float beta1, float beta2, float eps, float inv_sqrt_bc2, float wd) {
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 pp = ld4(p + i * 4), gg = ld4(g + i * 4), mm = ld4(m + i * 4), vv = ld4(v + i * 4);
+        float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float gq = G[q] + wd * P[q];
+            M[q] = M[q] + (gq - M[q]) * (1.f - beta1);
+            V[q] = V[q] * beta2 + (1.f - beta2) * gq * gq;
+            P[q] -= lr_over_bc1 * (M[q] / (sqrtf(V[q]) * inv_sqrt_bc2 + eps));
+        }
+        st4(p + i * 4, pp); st4(m + i * 4, mm); st4(v + i * 4, vv);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = n4 * 4 + threadIdx.x;
+        const float gq = g[i] + wd * p[i];
+        const float mq = m[i] + (gq - m[i]) * (1.f - beta1);
+        const float vq = v[i] * beta2 + (1.f - beta2) * gq * gq;
+        m[i] = mq; v[i] = vq;
+        p[i] -= lr_over_bc1 * (mq / (sqrtf(vq) * inv_sqrt_bc2 + eps));
     }
 }
 
@@ -1051,6 +1113,24 @@ __global__ void k_transpose_w(const float* __restrict__ W, int K, float* __restr
     __syncthreads();
     for (int r = ty; r < 32; r += 8)
         if (k0 + r < K) Bt[(size_t)(k0 + r) * 128 + n0 + tx] = tile[tx][r];
+}
+
+// all projection weights of the encoder in one launch: matrix z -> Bt base + z * 192 * 128
+struct TransposeMany {
+    const float* W[3 * FN_MAX_LAYERS];
+    int K[3 * FN_MAX_LAYERS];
+};
+__global__ void k_transpose_many(TransposeMany tm, float* __restrict__ bt_base) {
+    __shared__ float tile[32][33];
+    const int z = blockIdx.z, K = tm.K[z];
+    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (k0 >= K) return;
+    const float* W = tm.W[z];
+    float* Bt = bt_base + (size_t)z * 192 * FN_D;
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = (k0 + tx < K) ? W[(size_t)(n0 + r) * K + k0 + tx] : 0.f;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (k0 + r < K) Bt[(size_t)(k0 + r) * FN_D + n0 + tx] = tile[tx][r];
 }
 
 // Weight gradient: block = `rows_per_block` rows in chunks of 32 staged through double-buffered LDS.  Wave w owns
@@ -1349,13 +1429,16 @@ int fn_node_scalars_f32(const float* h, const float* att, int att_w, int dst_off
 
 int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const float* att, int att_w,
                    const fn_edge_term* et, const fn_gat_plan* plan, float neg_slope, float* out, float* p_sorted,
-                   float* probs_orig, int heads, fn_stream_t stream) {
-    if (!h || !s_dst || !s_src || !att || !plan || !out || bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_fwd_f32: bad argument");
+                   float* probs_orig, const fn_act_epilogue* act, int heads, fn_stream_t stream) {
+    if (!h || !s_dst || !s_src || !att || !plan || bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_fwd_f32: bad argument");
+    if (!out && !(act && act->y)) return fail(FN_EINVAL, "fn_gat_fwd_f32: no output buffer");
+    if (act && (act->p < 0.f || act->p > 1.f)) return fail(FN_EINVAL, "fn_gat_fwd_f32: dropout probability");
+    const fn_act_epilogue ep = act ? *act : fn_act_epilogue{nullptr, 0.f, 0, 0, 0};
     if (plan->m > 0 && !p_sorted) return fail(FN_EINVAL, "fn_gat_fwd_f32: null p_sorted");
     if (et->mode == 0 && plan->m > 0 && !et->s_sorted) return fail(FN_EINVAL, "fn_gat_fwd_f32: null s_sorted");
     if (plan->n == 0) return 0;
     FN_DISPATCH_H(heads, hipLaunchKernelGGL(k_gat_fwd<HH>, dim3(row_grid(plan->n, 8 * kGridCap)), dim3(kBlock), 0, S(stream),
-                                            h, s_dst, s_src, att, att_w, *et, *plan, neg_slope, out, p_sorted, probs_orig));
+                                            h, s_dst, s_src, att, att_w, *et, *plan, neg_slope, out, p_sorted, probs_orig, ep));
     return launch_status("fn_gat_fwd_f32");
 }
 
@@ -1396,7 +1479,7 @@ int fn_gat_bwd_finalize_f32(const float* part_a, int n_part_a, const float* part
     if (!part_a || n_part_a < 0 || n_part_e < 0 || !att || !g_att || bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_bwd_finalize_f32: bad argument");
     if (et->mode == 2 && (!part_e || !g_embW || !g_embb)) return fail(FN_EINVAL, "fn_gat_bwd_finalize_f32: null mode-2 buffer");
     if (heads != 1 && heads != 2 && heads != 4 && heads != 8) return fail(FN_EUNSUPPORTED, "heads must be 1, 2, 4 or 8");
-    hipLaunchKernelGGL(k_gat_finalize, dim3(et->mode == 2 ? 9 : 8), dim3(1024), 0, S(stream), part_a, n_part_a, part_e, n_part_e, *et, att,
+    hipLaunchKernelGGL(k_gat_finalize, dim3(2 * FN_D + (et->mode == 2 ? 1 : 0)), dim3(1024), 0, S(stream), part_a, n_part_a, part_e, n_part_e, *et, att,
                        att_w, dst_off, src_off, g_att, g_embW, g_embb, heads);
     return launch_status("fn_gat_bwd_finalize_f32");
 }
@@ -1441,8 +1524,8 @@ int fn_sort_edge_attr_f32(const float* x, int K, const fn_gat_plan* plan, float*
 }
 
 int fn_colsum_f32(const float* part, int n_rows, int cols, float* out, int ld, int off, fn_stream_t stream) {
-    if (!part || !out || n_rows < 0 || cols < 1) return fail(FN_EINVAL, "fn_colsum_f32: bad argument");
-    hipLaunchKernelGGL(k_colsum, dim3((cols + 31) / 32), dim3(1024), 0, S(stream), part, n_rows, cols, out, ld, off);
+    if (!part || !out || n_rows < 0 || n_rows > FN_MAX_PART || cols < 1) return fail(FN_EINVAL, "fn_colsum_f32: bad argument");
+    hipLaunchKernelGGL(k_colsum, dim3(cols), dim3(1024), 0, S(stream), part, n_rows, cols, out, ld, off);
     return launch_status("fn_colsum_f32");
 }
 
@@ -1493,13 +1576,18 @@ int fn_linear128_wgrad_f32(const float* dY, const float* X, int K, int64_t M, fl
 }
 
 int fn_segment_sum_f32(const float* src, int64_t src_ld, const int32_t* rowptr, const int32_t* perm, int32_t pos_base,
-                       float* out, int64_t n_seg, int64_t width, fn_stream_t stream) {
+                       float* out, int64_t n_seg, int64_t width, int64_t n_items, fn_stream_t stream) {
     if (!rowptr || !out || n_seg < 0 || width < 1 || src_ld < width) return fail(FN_EINVAL, "fn_segment_sum_f32: bad argument");
     if (n_seg == 0) return 0;
     if (!src || !perm) return fail(FN_EINVAL, "fn_segment_sum_f32: null src/perm");
-    if (width == FN_D && (src_ld & 3) == 0 && (((uintptr_t)src | (uintptr_t)out) & 15) == 0)
-        hipLaunchKernelGGL(k_segment_sum128, dim3(row_grid(n_seg, kGridCap)), dim3(kBlock), 0, S(stream), src, src_ld, rowptr,
-                           perm, pos_base, out, n_seg);
+    if (width == FN_D && (src_ld & 3) == 0 && (((uintptr_t)src | (uintptr_t)out) & 15) == 0) {
+        if (n_items >= 4 * n_seg)
+            hipLaunchKernelGGL(k_segment_sum128_wide, dim3((unsigned)(n_seg < 8 * kGridCap ? n_seg : 8 * kGridCap)), dim3(kBlock), 0,
+                               S(stream), src, src_ld, rowptr, perm, pos_base, out, n_seg);
+        else
+            hipLaunchKernelGGL(k_segment_sum128, dim3(row_grid(n_seg, kGridCap)), dim3(kBlock), 0, S(stream), src, src_ld, rowptr,
+                               perm, pos_base, out, n_seg);
+    }
     else
         hipLaunchKernelGGL(k_segment_sum_any, dim3(flat_grid(n_seg * width, kGridCap)), dim3(kBlock), 0, S(stream), src, src_ld,
                            rowptr, perm, pos_base, out, n_seg, width);
@@ -1558,6 +1646,18 @@ int fn_dropout_act_bwd_f32(const float* g_y, const float* y, float* g_x, int64_t
     hipLaunchKernelGGL(k_dropout_act<true>, dim3(flat_grid((numel + 3) / 4, kGridCap)), dim3(kBlock), 0, S(stream), g_y, y, g_x,
                        numel, p, seed, offset, relu);
     return launch_status("fn_dropout_act_bwd_f32");
+}
+
+int fn_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                float weight_decay, int64_t step, fn_stream_t stream) {
+    if (n < 0 || step < 1) return fail(FN_EINVAL, "fn_adam_f32: bad argument");
+    if (n == 0) return 0;
+    if (!p || !g || !m || !v || (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15))
+        return fail(FN_EINVAL, "fn_adam_f32: null or misaligned buffer");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(k_adam, dim3(flat_grid((n + 3) / 4, kGridCap)), dim3(kBlock), 0, S(stream), p, g, m, v, n,
+                       (float)((double)lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), weight_decay);
+    return launch_status("fn_adam_f32");
 }
 
 int fn_edge_concat_f32(const float* x, const float* e_attr, const int64_t* edge_index, float* out, int64_t E,
@@ -1627,7 +1727,7 @@ EncLayout enc_layout(const fn_encoder* e, float* ws) {
     const int64_t nmax = max4(e->E, e->N, e->EF, e->F);
     o.s_dst = b.take(nmax * H);
     o.s_src = b.take(nmax * H);
-    o.bt = b.take(3 * 192 * FN_D);
+    o.bt = b.take((int64_t)3 * e->n_layers * 192 * FN_D);
     o.total = b.used;
     return o;
 }
@@ -1728,54 +1828,61 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
     const float* in_fbond = e->fbond_nodes;
     int ka = e->k_atom0, kb = e->k_bond0, kfb = e->k_fbond0;
 
+    {   // W^T of every projection, one launch
+        TransposeMany tm{};
+        for (int l = 0; l < e->n_layers; ++l) {
+            tm.W[3 * l] = e->w[l].proj_b_w;       tm.K[3 * l] = l ? FN_D : e->k_bond0;
+            tm.W[3 * l + 1] = e->w[l].proj_a_w;   tm.K[3 * l + 1] = l ? FN_D : e->k_atom0;
+            tm.W[3 * l + 2] = e->w[l].proj_fb_w;  tm.K[3 * l + 2] = l ? FN_D : e->k_fbond0;
+            if (!tm.W[3 * l] || !tm.W[3 * l + 1] || !tm.W[3 * l + 2]) return fail(FN_EINVAL, "fn_encoder_forward: null projection weight");
+        }
+        hipLaunchKernelGGL(k_transpose_many, dim3(6, 4, 3 * e->n_layers), dim3(256), 0, S(st), tm, lay.bt);
+        FN_TRY(launch_status("fn_encoder_forward: transpose"));
+    }
+
     for (int l = 0; l < e->n_layers; ++l) {
         const fn_layer_weights& w = e->w[l];
         const LayerActs& a = lay.L[l];
         const bool last = l + 1 == e->n_layers;
-        float* bt_b = lay.bt;
-        float* bt_a = lay.bt + 192 * FN_D;
-        float* bt_fb = lay.bt + 2 * 192 * FN_D;
-        FN_TRY(fn_transpose_w_f32(w.proj_b_w, kb, bt_b, st));
-        FN_TRY(fn_transpose_w_f32(w.proj_a_w, ka, bt_a, st));
-        FN_TRY(fn_transpose_w_f32(w.proj_fb_w, kfb, bt_fb, st));
+        const float* bt_b = lay.bt + (size_t)(3 * l) * 192 * FN_D;
+        const float* bt_a = lay.bt + (size_t)(3 * l + 1) * 192 * FN_D;
+        const float* bt_fb = lay.bt + (size_t)(3 * l + 2) * 192 * FN_D;
 
         // L1 bond graph
         FN_TRY(fn_linear128_f32(in_bond, kb, bt_b, w.proj_b_b, a.h_b, e->E, st));
         FN_TRY(fn_node_scalars_f32(a.h_b, w.a_b, 3 * d, 0, 2 * d, lay.s_dst, lay.s_src, e->E, H, st));
         fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
-        FN_TRY(fn_gat_fwd_f32(a.h_b, lay.s_dst, lay.s_src, w.a_b, 3 * d, &et_b, &e->bond, 0.2f, a.new_bond, a.p_bond, nullptr, H, st));
+        float* y_atoms = last ? out_atoms : a.y_atoms;
+        float* y_frags = last ? out_frags : a.y_frags;
+        float* y_bond = last ? out_bond : a.y_bond;
+        float* y_fbond = last ? out_fbond : a.y_fbond;
+        // act(dropout(.)) of the four layer outputs rides in the producing kernels' epilogues
+        const fn_act_epilogue ep_atoms{y_atoms, p, 1, e->seed, rng.y[l][0]}, ep_frags{y_frags, p, 1, e->seed, rng.y[l][1]};
+        const fn_act_epilogue ep_bond{y_bond, p, 1, e->seed, rng.y[l][2]}, ep_fbond{y_fbond, p, 1, e->seed, rng.y[l][3]};
+        FN_TRY(fn_gat_fwd_f32(a.h_b, lay.s_dst, lay.s_src, w.a_b, 3 * d, &et_b, &e->bond, 0.2f, a.new_bond, a.p_bond, nullptr, &ep_bond, H, st));
 
         // L2 atom graph (+ self loops), edge term = <new_bond, a[:, d:d+128]>
         FN_TRY(fn_linear128_f32(in_atoms, ka, bt_a, w.proj_a_b, a.h_a, e->N, st));
         FN_TRY(fn_row_dots_sorted_f32(a.new_bond, w.a, wide, d, H, &e->atom, lay.s_sorted, st));
         FN_TRY(fn_node_scalars_f32(a.h_a, w.a, wide, 0, d + FN_D, lay.s_dst, lay.s_src, e->N, H, st));
         fn_edge_term et_a{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
-        FN_TRY(fn_gat_fwd_f32(a.h_a, lay.s_dst, lay.s_src, w.a, wide, &et_a, &e->atom, 0.2f, lay.atoms_new, a.p_atom, nullptr, H, st));
+        FN_TRY(fn_gat_fwd_f32(a.h_a, lay.s_dst, lay.s_src, w.a, wide, &et_a, &e->atom, 0.2f, lay.atoms_new, a.p_atom, nullptr, &ep_atoms, H, st));
 
         // L3 atom -> fragment sum
-        FN_TRY(fn_segment_sum_f32(lay.atoms_new, FN_D, e->a2f.rowptr, e->a2f.perm, e->a2f.pos_base, a.frags, e->F, FN_D, st));
+        FN_TRY(fn_segment_sum_f32(lay.atoms_new, FN_D, e->a2f.rowptr, e->a2f.perm, e->a2f.pos_base, a.frags, e->F, FN_D, e->N, st));
 
         // L4a fragment-bond graph
         FN_TRY(fn_linear128_f32(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, st));
         FN_TRY(fn_node_scalars_f32(a.h_fb, w.f_a_b, 3 * d, 0, 2 * d, lay.s_dst, lay.s_src, e->EF, H, st));
         fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
-        FN_TRY(fn_gat_fwd_f32(a.h_fb, lay.s_dst, lay.s_src, w.f_a_b, 3 * d, &et_fb, &e->fbond, 0.2f, a.new_fbond, a.p_fbond, nullptr, H, st));
+        FN_TRY(fn_gat_fwd_f32(a.h_fb, lay.s_dst, lay.s_src, w.f_a_b, 3 * d, &et_fb, &e->fbond, 0.2f, a.new_fbond, a.p_fbond, nullptr, &ep_fbond, H, st));
 
         // L4b fragment graph on the raw fragment sums
         FN_TRY(fn_row_dots_sorted_f32(a.new_fbond, w.f, wide, d, H, &e->frag, lay.s_sorted, st));
         FN_TRY(fn_node_scalars_f32(a.frags, w.f, wide, 0, d + FN_D, lay.s_dst, lay.s_src, e->F, H, st));
         fn_edge_term et_f{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
-        FN_TRY(fn_gat_fwd_f32(a.frags, lay.s_dst, lay.s_src, w.f, wide, &et_f, &e->frag, 0.2f, lay.frags_new, a.p_frag, nullptr, H, st));
+        FN_TRY(fn_gat_fwd_f32(a.frags, lay.s_dst, lay.s_src, w.f, wide, &et_f, &e->frag, 0.2f, nullptr, a.p_frag, nullptr, &ep_frags, H, st));
 
-        // act(dropout(.)) on the four outputs
-        float* y_atoms = last ? out_atoms : a.y_atoms;
-        float* y_frags = last ? out_frags : a.y_frags;
-        float* y_bond = last ? out_bond : a.y_bond;
-        float* y_fbond = last ? out_fbond : a.y_fbond;
-        FN_TRY(fn_dropout_act_f32(lay.atoms_new, y_atoms, e->N * FN_D, p, e->seed, rng.y[l][0], 1, st));
-        FN_TRY(fn_dropout_act_f32(lay.frags_new, y_frags, e->F * FN_D, p, e->seed, rng.y[l][1], 1, st));
-        FN_TRY(fn_dropout_act_f32(a.new_bond, y_bond, e->E * FN_D, p, e->seed, rng.y[l][2], 1, st));
-        FN_TRY(fn_dropout_act_f32(a.new_fbond, y_fbond, e->EF * FN_D, p, e->seed, rng.y[l][3], 1, st));
         in_atoms = y_atoms;  in_bond = y_bond;  in_fbond = y_fbond;
         ka = kb = kfb = FN_D;
     }

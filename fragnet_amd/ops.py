@@ -79,7 +79,7 @@ class _GatLevel(torch.autograd.Function):
         p_sorted = torch.empty((m, heads), dtype=torch.float32, device=dev)
         probs = torch.empty((m, heads), dtype=torch.float32, device=dev) if want_probs else None
         _lib.call("fn_gat_fwd_f32", h.data_ptr(), s_dst.data_ptr(), s_src.data_ptr(), att.data_ptr(), att_w,
-                  C.byref(et), C.byref(level.c), NEG_SLOPE, out.data_ptr(), p_sorted.data_ptr(), _ptr(probs), heads, st)
+                  C.byref(et), C.byref(level.c), NEG_SLOPE, out.data_ptr(), p_sorted.data_ptr(), _ptr(probs), None, heads, st)
         ctx.level, ctx.heads, ctx.mode = level, heads, mode
         ctx.offs = (dst_off, mid_off, src_off)
         ctx.save_for_backward(h, att, p_sorted, x_sorted, embW, embb)
@@ -240,7 +240,7 @@ class _SegmentSum(torch.autograd.Function):
         out = alloc((seg.n_seg,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
         if seg.n_seg and width and seg.n_items:
             _lib.call("fn_segment_sum_f32", src.data_ptr(), width, seg.rowptr.data_ptr(), seg.perm.data_ptr(),
-                      seg.pos_base, out.data_ptr(), seg.n_seg, width, _stream_ptr(src.device))
+                      seg.pos_base, out.data_ptr(), seg.n_seg, width, seg.n_items, _stream_ptr(src.device))
         ctx.seg, ctx.width, ctx.keep = seg, width, keep_plan
         return out
 
@@ -280,7 +280,7 @@ class _GatherRows(torch.autograd.Function):
         width = g.shape[1]
         out = torch.empty((ctx.rows, width), dtype=torch.float32, device=g.device)
         _lib.call("fn_segment_sum_f32", g.data_ptr(), width, seg.rowptr.data_ptr(), seg.perm.data_ptr(), seg.pos_base,
-                  out.data_ptr(), seg.n_seg, width, _stream_ptr(g.device))
+                  out.data_ptr(), seg.n_seg, width, seg.n_items, _stream_ptr(g.device))
         return out, None, None
 
 
@@ -423,9 +423,9 @@ class _EdgeConcat(torch.autograd.Function):
         s, d = plan.segs["edge_src"], plan.segs["edge_dst"]
         ld = 3 * FN_D
         _lib.call("fn_segment_sum_f32", g.data_ptr(), ld, s.rowptr.data_ptr(), s.perm.data_ptr(), s.pos_base,
-                  gx.data_ptr(), n, FN_D, st)
+                  gx.data_ptr(), n, FN_D, s.n_items, st)
         _lib.call("fn_segment_sum_f32", g.data_ptr() + 4 * FN_D, ld, d.rowptr.data_ptr(), d.perm.data_ptr(), d.pos_base,
-                  tmp.data_ptr(), n, FN_D, st)
+                  tmp.data_ptr(), n, FN_D, d.n_items, st)
         gx += tmp
         return gx, g[:, 2 * FN_D:].contiguous(), None, None
 

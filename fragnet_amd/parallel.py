@@ -139,11 +139,12 @@ class FlatAdam:
                 off += n
         self.flat = torch.nn.Parameter(flat)
         self.grad = torch.zeros_like(flat)
-        kw = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
-        try:
-            self.opt = torch.optim.Adam([self.flat], fused=flat.is_cuda, **kw)
-        except (RuntimeError, TypeError):
-            self.opt = torch.optim.Adam([self.flat], **kw)
+        self.hyper = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.steps = 0
+        if flat.is_cuda:      # one HIP kernel (fn_adam_f32) over the flat tensor
+            self.exp_avg, self.exp_avg_sq, self.opt = torch.zeros_like(flat), torch.zeros_like(flat), None
+        else:                 # CPU (gloo tests of the exchange logic): stock torch Adam on the flat tensor
+            self.opt = torch.optim.Adam([self.flat], **self.hyper)
 
     @classmethod
     def for_live_parameters(cls, model: torch.nn.Module, probe_backward, **kw) -> "FlatAdam":
@@ -182,5 +183,13 @@ class FlatAdam:
         """gather -> all-reduce (if distributed) -> Adam."""
         self.gather_grads()
         self.all_reduce(group)
-        self.flat.grad = self.grad
-        self.opt.step()
+        self.steps += 1
+        if self.opt is not None:
+            self.flat.grad = self.grad
+            self.opt.step()
+            return
+        from . import _lib
+        h = self.hyper
+        _lib.call("fn_adam_f32", self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                  self.flat.numel(), float(h["lr"]), float(h["betas"][0]), float(h["betas"][1]), float(h["eps"]),
+                  float(h["weight_decay"]), self.steps, torch.cuda.current_stream(self.flat.device).cuda_stream)

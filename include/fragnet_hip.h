@@ -132,13 +132,22 @@ typedef struct fn_gat_plan {          /* slices of the fn_plan_build outputs for
     int64_t m_real;           /* edges with an explicit attribute     */
 } fn_gat_plan;
 
+/* Optional fused epilogue of the forward kernel: y = relu?(dropout(out)) with the Philox stream of
+ * fn_dropout_act_f32 (block index = element / 4), so the standalone backward kernel applies to it. */
+typedef struct fn_act_epilogue {
+    float* y;                 /* [n,128]; NULL = no fused activation */
+    float p;                  /* dropout probability (0 = none)      */
+    int32_t relu;
+    uint64_t seed, offset;
+} fn_act_epilogue;
+
 /* p_sorted [m,H]: probabilities in destination-sorted order; the sign bit carries "z_e <= 0"
  * (the LeakyReLU branch) for the backward pass.  probs_orig (nullable) [m,H] in original edge
  * order, unsigned -- the reference's attn_probs. */
 int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const float* att, int att_w,
                    const fn_edge_term* et, const fn_gat_plan* plan, float neg_slope,
-                   float* out /*[n,128]*/, float* p_sorted /*[m,H]*/, float* probs_orig /*nullable*/,
-                   int heads, fn_stream_t stream);
+                   float* out /*[n,128], nullable when act->y is given*/, float* p_sorted /*[m,H]*/,
+                   float* probs_orig /*nullable*/, const fn_act_epilogue* act /*nullable*/, int heads, fn_stream_t stream);
 
 /* Backward, destination pass: dz_sorted [m,H] (= dL/ds_sorted, the gradient of the mode-0 edge term),
  * g_s_dst [n,H]; mode 2 writes per-block partial sums part_e [grid, H*(K+1)].
@@ -179,7 +188,7 @@ int fn_row_dots_sorted_bwd_f32(const float* g_s_sorted, const float* feat, const
 /* x_sorted[pos,:] = x[eid(pos),:] (0 at loop positions): once per batch for the raw edge attributes */
 int fn_sort_edge_attr_f32(const float* x /*[m_real,K]*/, int K, const fn_gat_plan* plan, float* x_sorted /*[m,K]*/,
                           fn_stream_t stream);
-/* out[(c / 128) * ld + off + c % 128] = sum_r part[r, c], c < cols */
+/* out[(c / 128) * ld + off + c % 128] = sum_{r < n_rows} part[c * FN_MAX_PART + r], c < cols (partials are column-major) */
 int fn_colsum_f32(const float* part, int n_rows, int cols, float* out, int ld, int off, fn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -202,7 +211,7 @@ int fn_linear128_wgrad_f32(const float* dY, const float* X, int K, int64_t M, fl
  * ------------------------------------------------------------------------------------------ */
 int fn_segment_sum_f32(const float* src /*[items, src_ld >= width]*/, int64_t src_ld, const int32_t* rowptr,
                        const int32_t* perm, int32_t pos_base, float* out /*[n_seg,width]*/, int64_t n_seg,
-                       int64_t width, fn_stream_t stream);
+                       int64_t width, int64_t n_items /*picks the long-segment kernel*/, fn_stream_t stream);
 /* backward of the above and of index_select: out[i,:] = table[index[i],:] */
 int fn_gather_rows_f32(const float* table, const int64_t* index, float* out, int64_t rows, int64_t width,
                        fn_stream_t stream);
@@ -222,6 +231,11 @@ int fn_dropout_act_f32(const float* x, float* y, int64_t numel, float p, uint64_
                        int relu, fn_stream_t stream);
 int fn_dropout_act_bwd_f32(const float* g_y, const float* y, float* g_x, int64_t numel, float p, uint64_t seed,
                            uint64_t offset, int relu, fn_stream_t stream);
+
+/* torch.optim.Adam step (no amsgrad) on one flat fp32 tensor: finetune_gat2.py:257, pretrain_gat2.py:165.
+ * `step` is the 1-based step count (bias corrections are computed on the host in double). */
+int fn_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                float weight_decay, int64_t step, fn_stream_t stream);
 
 /* cat(x[src_e], x[dst_e], e_attr[e]) -> [E, 384] for the bond-length head (pretrain_heads.py:67-70) */
 int fn_edge_concat_f32(const float* x /*[N,128]*/, const float* e_attr /*[E,128]*/, const int64_t* edge_index /*[2,E]*/,

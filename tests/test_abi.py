@@ -48,7 +48,7 @@ def test_plan_layout_is_host_side_and_validates():
 def test_argument_errors_do_not_touch_the_gpu():
     from fragnet_amd import _lib
     lib = _lib.load()
-    assert lib.fn_segment_sum_f32(None, 128, None, None, 0, None, 4, 128, None) == -1
+    assert lib.fn_segment_sum_f32(None, 128, None, None, 0, None, 4, 128, 16, None) == -1
     assert lib.fn_row_dots_sorted_f32(None, None, 128, 0, 9, None, None, None) == -1
     assert lib.fn_dropout_act_f32(None, None, 8, 1.5, 0, 0, 1, None) == -1
 

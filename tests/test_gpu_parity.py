@@ -267,6 +267,22 @@ def test_dropout_act_statistics_and_backward_mask():
     assert (z >= 0).all()
 
 
+def test_flat_adam_kernel_matches_torch_adam():
+    from fragnet_amd.parallel import FlatAdam
+    torch.manual_seed(0)
+    net1 = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.ReLU(), torch.nn.Linear(53, 3)).to(DEV)
+    import copy
+    net2 = copy.deepcopy(net1)
+    o1 = torch.optim.Adam(net1.parameters(), lr=1e-2)
+    o2 = FlatAdam(net2.parameters(), lr=1e-2)
+    x = torch.randn(64, 37, device=DEV)
+    for _ in range(7):
+        o1.zero_grad(); net1(x).pow(2).sum().backward(); o1.step()
+        o2.zero_grad(); net2(x).pow(2).sum().backward(); o2.step()
+    for a, b in zip(net1.parameters(), net2.parameters()):
+        torch.testing.assert_close(a, b, atol=1e-6, rtol=1e-5)
+
+
 # ------------------------------------------------------------------------------- whole model vs the reference's outputs
 def _run_ft(case, use_engine):
     from fragnet_amd.model import FragNetFineTune, pooled
