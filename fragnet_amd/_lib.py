@@ -81,7 +81,7 @@ SIGNATURES = {
     "fn_sort_edge_attr_f32": [vp, C.c_int, C.POINTER(GatPlan), vp, vp],
     "fn_colsum_f32": [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp],
     "fn_transpose_w_f32": [vp, C.c_int, vp, vp],
-    "fn_linear128_f32": [vp, C.c_int, vp, vp, vp, i64, vp],
+    "fn_linear128_f32": [vp, C.c_int, vp, vp, vp, i64, C.POINTER(ActEpilogue), vp],
     "fn_linear128_wgrad_ws": [i64, C.c_int],
     "fn_linear128_wgrad_f32": [vp, vp, C.c_int, i64, vp, vp, vp, vp],
     "fn_encoder_ws_floats": [C.POINTER(Encoder)],

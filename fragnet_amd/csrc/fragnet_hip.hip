@@ -1017,9 +1017,16 @@ constexpr int kBtLd = 144;     // LDS leading dimension of the [K][128] operand:
 // straight from global memory (no LDS round trip for X) and prefetched one tile ahead.  The result tile goes
 // through LDS so that every lane stores whole 16-byte pieces of a row (scattered 4-byte stores cost 4 us a tile).
 constexpr int kLinOutLd = 68;      // LDS leading dimension of a wave's 16 x 64 result tile
+struct NodeScalarEpi {             // optional fused epilogue: s_dst/s_src[row, head] = <Y[row, head cols], att blocks>
+    const float* att;
+    float* s_dst;
+    float* s_src;
+    int att_w, dst_off, src_off, heads;     // heads in {2, 4, 8}: a head's columns must lie inside one wave's 64
+};
 template <int KQ>
 __global__ __launch_bounds__(512) void k_linear128(const float* __restrict__ X, int K, const float* __restrict__ Bt,
-                                                   const float* __restrict__ bias, float* __restrict__ Y, int64_t M) {
+                                                   const float* __restrict__ bias, float* __restrict__ Y, int64_t M,
+                                                   fn_act_epilogue mk, NodeScalarEpi ns) {
     extern __shared__ __attribute__((aligned(16))) float sBt[];        // [4*KQ][kBtLd] then 8 x [16][kLinOutLd]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
     const int wr = w & 3, wc = w >> 2;
@@ -1096,8 +1103,45 @@ __global__ __launch_bounds__(512) void k_linear128(const float* __restrict__ X, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                        // 16 rows x 16 float4 = 256 pieces, 4 per lane
             const int idx = lane + q * 64, rr = idx >> 4, c4 = idx & 15;
-            if (r0 + rr < M)
-                st4(Y + (r0 + rr) * 128 + 64 * wc + c4 * 4, *reinterpret_cast<const float4*>(sOut + rr * kLinOutLd + c4 * 4));
+            if (r0 + rr < M) {
+                float4 o = *reinterpret_cast<const float4*>(sOut + rr * kLinOutLd + c4 * 4);
+                if (mk.y) {      // backward of act(dropout(.)) fused into the input-gradient GEMM: o *= mask * (y > 0)
+                    const int64_t e4 = (r0 + rr) * 32 + 16 * wc + c4;            // Philox block = element / 4
+                    if (mk.p > 0.f) {
+                        const uint4 rnd = philox4x32_10(mk.offset + (uint64_t)e4, mk.seed);
+                        const float ik = mk.p < 1.f ? 1.f / (1.f - mk.p) : 0.f;
+                        o.x *= keep_scale(rnd.x, mk.p, ik); o.y *= keep_scale(rnd.y, mk.p, ik);
+                        o.z *= keep_scale(rnd.z, mk.p, ik); o.w *= keep_scale(rnd.w, mk.p, ik);
+                    }
+                    if (mk.relu) {
+                        const float4 yy = ld4(mk.y + e4 * 4);
+                        o.x = yy.x > 0.f ? o.x : 0.f; o.y = yy.y > 0.f ? o.y : 0.f;
+                        o.z = yy.z > 0.f ? o.z : 0.f; o.w = yy.w > 0.f ? o.w : 0.f;
+                    }
+                }
+                st4(Y + (r0 + rr) * 128 + 64 * wc + c4 * 4, o);
+            }
+        }
+        if (ns.att) {        // node scalars of the finished rows straight from the LDS tile (lane = row rr, 16-column quarter q)
+            const int rr = lane >> 2, q = lane & 3, d = FN_D / ns.heads;
+            const int col0 = 64 * wc + 16 * q, head = col0 / d, within = col0 % d;
+            const float* ad = ns.att + head * ns.att_w + ns.dst_off + within;
+            const float* as = ns.att + head * ns.att_w + ns.src_off + within;
+            float pd = 0.f, ps = 0.f;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const float4 yv = *reinterpret_cast<const float4*>(sOut + rr * kLinOutLd + 16 * q + c4 * 4);
+                const float4 a4 = ld4(ad + c4 * 4), b4 = ld4(as + c4 * 4);
+                pd += dot4(yv, a4);
+                ps += dot4(yv, b4);
+            }
+            if (d >= 32) { pd += dpp_mov<kDppXor1>(pd); ps += dpp_mov<kDppXor1>(ps); }
+            if (d >= 64) { pd += dpp_mov<kDppXor2>(pd); ps += dpp_mov<kDppXor2>(ps); }
+            const int lanes_per_head = d / 16;               // 1, 2 or 4 quarters
+            if ((q % lanes_per_head) == 0 && r0 + rr < M) {
+                ns.s_dst[(r0 + rr) * ns.heads + head] = pd;
+                ns.s_src[(r0 + rr) * ns.heads + head] = ps;
+            }
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1314,12 +1358,13 @@ template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     return 0;
 }
 template <int KQ>
-int launch_linear128(const float* X, int K, const float* Bt, const float* bias, float* Y, int64_t M, hipStream_t st) {
+int launch_linear128(const float* X, int K, const float* Bt, const float* bias, float* Y, int64_t M, fn_act_epilogue mk,
+                     NodeScalarEpi ns, hipStream_t st) {
     const size_t lds = ((size_t)4 * KQ * kBtLd + 8 * 16 * kLinOutLd) * sizeof(float);
     if (int rc = allow_lds(k_linear128<KQ>, lds)) return rc;
     const int64_t tiles = (M + 63) / 64;
     const int grid = (int)(tiles < 256 ? tiles : 256);       // one block per CU: MFMA-bound, X prefetched a tile ahead
-    hipLaunchKernelGGL(k_linear128<KQ>, dim3(grid), dim3(512), lds, st, X, K, Bt, bias, Y, M);
+    hipLaunchKernelGGL(k_linear128<KQ>, dim3(grid), dim3(512), lds, st, X, K, Bt, bias, Y, M, mk, ns);
     return 0;
 }
 template <int CTW, int NH>
@@ -1535,18 +1580,25 @@ int fn_transpose_w_f32(const float* W, int K, float* Bt, fn_stream_t stream) {
     return launch_status("fn_transpose_w_f32");
 }
 
-int fn_linear128_f32(const float* X, int K, const float* Bt, const float* bias, float* Y, int64_t M, fn_stream_t stream) {
+static int linear128_impl(const float* X, int K, const float* Bt, const float* bias, float* Y, int64_t M,
+                          const fn_act_epilogue* act_bwd, NodeScalarEpi ns, fn_stream_t stream) {
     if (K < 1 || M < 0) return fail(FN_EINVAL, "fn_linear128_f32: bad argument");
+    const fn_act_epilogue mk = act_bwd ? *act_bwd : fn_act_epilogue{nullptr, 0.f, 0, 0, 0};
     if (M == 0) return 0;
     if (!X || !Bt || !Y || (((uintptr_t)X | (uintptr_t)Y) & 15)) return fail(FN_EINVAL, "fn_linear128_f32: null or misaligned buffer");
     int rc;
-    if (K <= 8) rc = launch_linear128<2>(X, K, Bt, bias, Y, M, S(stream));
-    else if (K <= 20) rc = launch_linear128<5>(X, K, Bt, bias, Y, M, S(stream));
-    else if (K <= 128) rc = launch_linear128<32>(X, K, Bt, bias, Y, M, S(stream));
-    else if (K <= 168) rc = launch_linear128<42>(X, K, Bt, bias, Y, M, S(stream));
+    if (K <= 8) rc = launch_linear128<2>(X, K, Bt, bias, Y, M, mk, ns, S(stream));
+    else if (K <= 20) rc = launch_linear128<5>(X, K, Bt, bias, Y, M, mk, ns, S(stream));
+    else if (K <= 128) rc = launch_linear128<32>(X, K, Bt, bias, Y, M, mk, ns, S(stream));
+    else if (K <= 168) rc = launch_linear128<42>(X, K, Bt, bias, Y, M, mk, ns, S(stream));
     else return fail(FN_EUNSUPPORTED, "fn_linear128_f32: K > 168");
     if (rc) return rc;
     return launch_status("fn_linear128_f32");
+}
+
+int fn_linear128_f32(const float* X, int K, const float* Bt, const float* bias, float* Y, int64_t M,
+                     const fn_act_epilogue* act_bwd, fn_stream_t stream) {
+    return linear128_impl(X, K, Bt, bias, Y, M, act_bwd, NodeScalarEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0}, stream);
 }
 
 int64_t fn_linear128_wgrad_ws(int64_t M, int K) {
@@ -1735,7 +1787,6 @@ EncLayout enc_layout(const fn_encoder* e, float* ws) {
 struct BwdLayout {
     float *g_pre_atoms, *g_pre_frags, *g_pre_bond, *g_pre_fbond;   // grads w.r.t. pre-activation layer outputs
     float *g_h, *g_frags, *dz, *g_s_dst, *part_a, *part_e, *part_rd, *wg_ws;
-    float *gy_atoms, *gy_bond, *gy_fbond;                          // grads flowing to the previous layer's outputs
     int64_t total;
 };
 
@@ -1756,7 +1807,6 @@ BwdLayout bwd_layout(const fn_encoder* e, float* ws) {
     const int64_t ms[3] = {e->E, e->N, e->EF};
     for (int i = 0; i < 3; ++i) wg = std::max(wg, fn_linear128_wgrad_ws(ms[i], ks[i]));
     o.wg_ws = b.take(wg);
-    o.gy_atoms = b.take(e->N * FN_D);  o.gy_bond = b.take(e->E * FN_D);  o.gy_fbond = b.take(e->EF * FN_D);
     o.total = b.used;
     return o;
 }
@@ -1849,8 +1899,14 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         const float* bt_fb = lay.bt + (size_t)(3 * l + 2) * 192 * FN_D;
 
         // L1 bond graph
-        FN_TRY(fn_linear128_f32(in_bond, kb, bt_b, w.proj_b_b, a.h_b, e->E, st));
-        FN_TRY(fn_node_scalars_f32(a.h_b, w.a_b, 3 * d, 0, 2 * d, lay.s_dst, lay.s_src, e->E, H, st));
+        const bool fuse_ns = H >= 2;         // a head's columns fit one wave's 64-column half for H >= 2
+        auto project = [&](const float* x, int k, const float* bt, const float* bias, float* hout, int64_t rows,
+                           const float* att, int att_w, int src_off) -> int {
+            if (fuse_ns) return linear128_impl(x, k, bt, bias, hout, rows, nullptr, NodeScalarEpi{att, lay.s_dst, lay.s_src, att_w, 0, src_off, H}, st);
+            FN_TRY(fn_linear128_f32(x, k, bt, bias, hout, rows, nullptr, st));
+            return fn_node_scalars_f32(hout, att, att_w, 0, src_off, lay.s_dst, lay.s_src, rows, H, st);
+        };
+        FN_TRY(project(in_bond, kb, bt_b, w.proj_b_b, a.h_b, e->E, w.a_b, 3 * d, 2 * d));
         fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
         float* y_atoms = last ? out_atoms : a.y_atoms;
         float* y_frags = last ? out_frags : a.y_frags;
@@ -1862,9 +1918,8 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         FN_TRY(fn_gat_fwd_f32(a.h_b, lay.s_dst, lay.s_src, w.a_b, 3 * d, &et_b, &e->bond, 0.2f, a.new_bond, a.p_bond, nullptr, &ep_bond, H, st));
 
         // L2 atom graph (+ self loops), edge term = <new_bond, a[:, d:d+128]>
-        FN_TRY(fn_linear128_f32(in_atoms, ka, bt_a, w.proj_a_b, a.h_a, e->N, st));
+        FN_TRY(project(in_atoms, ka, bt_a, w.proj_a_b, a.h_a, e->N, w.a, wide, d + FN_D));
         FN_TRY(fn_row_dots_sorted_f32(a.new_bond, w.a, wide, d, H, &e->atom, lay.s_sorted, st));
-        FN_TRY(fn_node_scalars_f32(a.h_a, w.a, wide, 0, d + FN_D, lay.s_dst, lay.s_src, e->N, H, st));
         fn_edge_term et_a{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
         FN_TRY(fn_gat_fwd_f32(a.h_a, lay.s_dst, lay.s_src, w.a, wide, &et_a, &e->atom, 0.2f, lay.atoms_new, a.p_atom, nullptr, &ep_atoms, H, st));
 
@@ -1872,17 +1927,19 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         FN_TRY(fn_segment_sum_f32(lay.atoms_new, FN_D, e->a2f.rowptr, e->a2f.perm, e->a2f.pos_base, a.frags, e->F, FN_D, e->N, st));
 
         // L4a fragment-bond graph
-        FN_TRY(fn_linear128_f32(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, st));
-        FN_TRY(fn_node_scalars_f32(a.h_fb, w.f_a_b, 3 * d, 0, 2 * d, lay.s_dst, lay.s_src, e->EF, H, st));
+        FN_TRY(project(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, w.f_a_b, 3 * d, 2 * d));
         fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
         FN_TRY(fn_gat_fwd_f32(a.h_fb, lay.s_dst, lay.s_src, w.f_a_b, 3 * d, &et_fb, &e->fbond, 0.2f, a.new_fbond, a.p_fbond, nullptr, &ep_fbond, H, st));
 
-        // L4b fragment graph on the raw fragment sums
-        FN_TRY(fn_row_dots_sorted_f32(a.new_fbond, w.f, wide, d, H, &e->frag, lay.s_sorted, st));
-        FN_TRY(fn_node_scalars_f32(a.frags, w.f, wide, 0, d + FN_D, lay.s_dst, lay.s_src, e->F, H, st));
-        fn_edge_term et_f{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
-        FN_TRY(fn_gat_fwd_f32(a.frags, lay.s_dst, lay.s_src, w.f, wide, &et_f, &e->frag, 0.2f, nullptr, a.p_frag, nullptr, &ep_frags, H, st));
-
+        // L4b fragment graph on the raw fragment sums.  Only the last layer's result is ever read: the next layer
+        // overwrites x_frags with its own atom->fragment sum before first use (gat2.py:234), so inner
+        // layers skip this level entirely (the reference computes it and throws it away).
+        if (last) {
+            FN_TRY(fn_row_dots_sorted_f32(a.new_fbond, w.f, wide, d, H, &e->frag, lay.s_sorted, st));
+            FN_TRY(fn_node_scalars_f32(a.frags, w.f, wide, 0, d + FN_D, lay.s_dst, lay.s_src, e->F, H, st));
+            fn_edge_term et_f{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
+            FN_TRY(fn_gat_fwd_f32(a.frags, lay.s_dst, lay.s_src, w.f, wide, &et_f, &e->frag, 0.2f, nullptr, a.p_frag, nullptr, &ep_frags, H, st));
+        }
         in_atoms = y_atoms;  in_bond = y_bond;  in_fbond = y_fbond;
         ka = kb = kfb = FN_D;
     }
@@ -1905,6 +1962,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
     hipStream_t hs = S(st);
 
     // gradients w.r.t. the current layer's post-activation outputs (null = zero)
+    bool pre_atoms = false, pre_bond = false, pre_fbond = false;   // g_pre_* already hold layer l's pre-activation grads
     const float* gy_atoms = g_atoms;
     const float* gy_frags = g_frags;
     const float* gy_bond = g_bond;
@@ -1925,12 +1983,16 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         const int ka = l ? FN_D : e->k_atom0, kb = l ? FN_D : e->k_bond0, kfb = l ? FN_D : e->k_fbond0;
         int n_a = 0, n_e = 0, n_rd = 0;
 
-        // ---- through act(dropout(.)): gradients of the pre-activation tensors
-        bool have_atoms = gy_atoms != nullptr, have_frags = gy_frags != nullptr, have_bond = gy_bond != nullptr, have_fbond = gy_fbond != nullptr;
-        if (have_atoms) FN_TRY(fn_dropout_act_bwd_f32(gy_atoms, y_atoms, bw.g_pre_atoms, e->N * FN_D, p, e->seed, rng.y[l][0], 1, st));
-        if (have_frags) FN_TRY(fn_dropout_act_bwd_f32(gy_frags, y_frags, bw.g_pre_frags, e->F * FN_D, p, e->seed, rng.y[l][1], 1, st));
-        if (have_bond) FN_TRY(fn_dropout_act_bwd_f32(gy_bond, y_bond, bw.g_pre_bond, e->E * FN_D, p, e->seed, rng.y[l][2], 1, st));
-        if (have_fbond) FN_TRY(fn_dropout_act_bwd_f32(gy_fbond, y_fbond, bw.g_pre_fbond, e->EF * FN_D, p, e->seed, rng.y[l][3], 1, st));
+        // ---- through act(dropout(.)): gradients of the pre-activation tensors.  For the last layer they come from
+        // the caller's output gradients; for inner layers the input-gradient GEMMs of layer l+1 already wrote them
+        // (mask and ReLU gate fused into their epilogue), flagged by pre_* below.
+        bool have_atoms = gy_atoms != nullptr || pre_atoms, have_frags = gy_frags != nullptr;
+        bool have_bond = gy_bond != nullptr || pre_bond, have_fbond = gy_fbond != nullptr || pre_fbond;
+        if (gy_atoms) FN_TRY(fn_dropout_act_bwd_f32(gy_atoms, y_atoms, bw.g_pre_atoms, e->N * FN_D, p, e->seed, rng.y[l][0], 1, st));
+        if (gy_frags) FN_TRY(fn_dropout_act_bwd_f32(gy_frags, y_frags, bw.g_pre_frags, e->F * FN_D, p, e->seed, rng.y[l][1], 1, st));
+        if (gy_bond) FN_TRY(fn_dropout_act_bwd_f32(gy_bond, y_bond, bw.g_pre_bond, e->E * FN_D, p, e->seed, rng.y[l][2], 1, st));
+        if (gy_fbond) FN_TRY(fn_dropout_act_bwd_f32(gy_fbond, y_fbond, bw.g_pre_fbond, e->EF * FN_D, p, e->seed, rng.y[l][3], 1, st));
+        bool nxt_atoms = false, nxt_bond = false, nxt_fbond = false;     // what this layer hands to layer l-1
 
         // ---- L4b fragment graph (only where its output is consumed: the last layer, reference fact SURVEY §0.8)
         bool have_g_frags_h = false;
@@ -1952,16 +2014,16 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         }
 
         // ---- L4a fragment-bond graph
-        const float* gy_fbond_prev = nullptr;
         if (have_fbond) {
             fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
             FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_fbond, a.h_fb, a.p_fbond, &et_fb, &e->fbond, 0.2f, bw.dz, bw.g_s_dst, bw.part_e, &n_e, H, st));
             FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_fbond, a.h_fb, a.p_fbond, bw.dz, bw.g_s_dst, w.f_a_b, 3 * d, 0, 2 * d, &e->fbond, bw.g_h, bw.part_a, &n_a, H, st));
             FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, bw.part_e, n_e, &et_fb, w.f_a_b, 3 * d, 0, 2 * d, g.f_a_b, g.emb_fb_w, g.emb_fb_b, H, st));
             FN_TRY(fn_linear128_wgrad_f32(bw.g_h, in_fbond, kfb, e->EF, bw.wg_ws, g.proj_fb_w, g.proj_fb_b, st));
-            if (l) {
-                FN_TRY(fn_linear128_f32(bw.g_h, FN_D, w.proj_fb_w, nullptr, bw.gy_fbond, e->EF, st));
-                gy_fbond_prev = bw.gy_fbond;
+            if (l) {     // dL/d(pre-activation fbond output of layer l-1), gated by that layer's dropout mask and ReLU
+                const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_fbond), p, 1, e->seed, rng.y[l - 1][3]};
+                FN_TRY(fn_linear128_f32(bw.g_h, FN_D, w.proj_fb_w, nullptr, bw.g_pre_fbond, e->EF, &mk, st));
+                nxt_fbond = true;
             }
         }
 
@@ -1974,7 +2036,6 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         }
 
         // ---- L2 atom graph
-        const float* gy_atoms_prev = nullptr;
         if (have_atoms) {
             fn_edge_term et_a{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
             FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_atoms, a.h_a, a.p_atom, &et_a, &e->atom, 0.2f, bw.dz, bw.g_s_dst, nullptr, &n_e, H, st));
@@ -1990,13 +2051,13 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             }
             FN_TRY(fn_linear128_wgrad_f32(bw.g_h, in_atoms, ka, e->N, bw.wg_ws, g.proj_a_w, g.proj_a_b, st));
             if (l) {
-                FN_TRY(fn_linear128_f32(bw.g_h, FN_D, w.proj_a_w, nullptr, bw.gy_atoms, e->N, st));
-                gy_atoms_prev = bw.gy_atoms;
+                const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_atoms), p, 1, e->seed, rng.y[l - 1][0]};
+                FN_TRY(fn_linear128_f32(bw.g_h, FN_D, w.proj_a_w, nullptr, bw.g_pre_atoms, e->N, &mk, st));
+                nxt_atoms = true;
             }
         }
 
         // ---- L1 bond graph
-        const float* gy_bond_prev = nullptr;
         if (have_bond) {
             fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
             FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_bond, a.h_b, a.p_bond, &et_b, &e->bond, 0.2f, bw.dz, bw.g_s_dst, bw.part_e, &n_e, H, st));
@@ -2004,12 +2065,14 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, bw.part_e, n_e, &et_b, w.a_b, 3 * d, 0, 2 * d, g.a_b, g.emb_b_w, g.emb_b_b, H, st));
             FN_TRY(fn_linear128_wgrad_f32(bw.g_h, in_bond, kb, e->E, bw.wg_ws, g.proj_b_w, g.proj_b_b, st));
             if (l) {
-                FN_TRY(fn_linear128_f32(bw.g_h, FN_D, w.proj_b_w, nullptr, bw.gy_bond, e->E, st));
-                gy_bond_prev = bw.gy_bond;
+                const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_bond), p, 1, e->seed, rng.y[l - 1][2]};
+                FN_TRY(fn_linear128_f32(bw.g_h, FN_D, w.proj_b_w, nullptr, bw.g_pre_bond, e->E, &mk, st));
+                nxt_bond = true;
             }
         }
         (void)n_rd;
-        gy_atoms = gy_atoms_prev;  gy_bond = gy_bond_prev;  gy_fbond = gy_fbond_prev;
+        pre_atoms = nxt_atoms;  pre_bond = nxt_bond;  pre_fbond = nxt_fbond;
+        gy_atoms = gy_bond = gy_fbond = nullptr;
         gy_frags = nullptr;        // a layer's x_frags input is dead in the reference (overwritten at gat2.py:234)
     }
     return 0;

@@ -196,7 +196,7 @@ class _Linear128(torch.autograd.Function):
         bt = torch.empty((K, FN_D), dtype=torch.float32, device=x.device)
         _lib.call("fn_transpose_w_f32", weight.data_ptr(), K, bt.data_ptr(), st)
         y = torch.empty((M, FN_D), dtype=torch.float32, device=x.device)
-        _lib.call("fn_linear128_f32", x.data_ptr(), K, bt.data_ptr(), bias.data_ptr(), y.data_ptr(), M, st)
+        _lib.call("fn_linear128_f32", x.data_ptr(), K, bt.data_ptr(), bias.data_ptr(), y.data_ptr(), M, None, st)
         ctx.save_for_backward(x, weight)
         ctx.x_needs_grad = x.requires_grad
         return y
@@ -212,7 +212,7 @@ class _Linear128(torch.autograd.Function):
             if K != FN_D:
                 raise NotImplementedError("linear128: input gradient is implemented for K == 128 (layers >= 1)")
             gx = torch.empty_like(x)
-            _lib.call("fn_linear128_f32", g.data_ptr(), FN_D, weight.data_ptr(), None, gx.data_ptr(), M, st)
+            _lib.call("fn_linear128_f32", g.data_ptr(), FN_D, weight.data_ptr(), None, gx.data_ptr(), M, None, st)
         ws = torch.empty(_lib.load().fn_linear128_wgrad_ws(M, K), dtype=torch.float32, device=x.device)
         gw = torch.empty_like(weight)
         gb = torch.empty(FN_D, dtype=torch.float32, device=x.device)

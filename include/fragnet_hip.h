@@ -200,7 +200,8 @@ int fn_colsum_f32(const float* part, int n_rows, int cols, float* out, int ld, i
  * ------------------------------------------------------------------------------------------ */
 int fn_transpose_w_f32(const float* W, int K, float* Bt, fn_stream_t stream);
 int fn_linear128_f32(const float* X, int K, const float* Bt, const float* bias /*nullable*/, float* Y, int64_t M,
-                     fn_stream_t stream);
+                     const fn_act_epilogue* act_bwd /*nullable: Y *= dropout mask * (act_bwd->y > 0), the backward of
+                     act(dropout(.)) fused into an input-gradient GEMM*/, fn_stream_t stream);
 int64_t fn_linear128_wgrad_ws(int64_t M, int K);
 int fn_linear128_wgrad_f32(const float* dY, const float* X, int K, int64_t M, float* ws, float* dW, float* db,
                            fn_stream_t stream);

@@ -24,7 +24,7 @@ for M, K in ((26492, 128), (13334, 128), (2500, 128), (26492, 17), (13334, 167))
     st = _stream_ptr(torch.device(dev))
     bt = w.t().contiguous(); y = torch.empty(M, 128, device=dev)
     ws = torch.empty(_lib.load().fn_linear128_wgrad_ws(M, K), device=dev); gw = torch.empty_like(w); gb = torch.empty(128, device=dev)
-    t_f = timeit(lambda: _lib.call("fn_linear128_f32", x.data_ptr(), K, bt.data_ptr(), b.data_ptr(), y.data_ptr(), M, st))
+    t_f = timeit(lambda: _lib.call("fn_linear128_f32", x.data_ptr(), K, bt.data_ptr(), b.data_ptr(), y.data_ptr(), M, None, st))
     t_w = timeit(lambda: _lib.call("fn_linear128_wgrad_f32", g.data_ptr(), x.data_ptr(), K, M, ws.data_ptr(), gw.data_ptr(), gb.data_ptr(), st))
     t_tf = timeit(lambda: torch.nn.functional.linear(x, w, b))
     t_tw = timeit(lambda: (g.t() @ x, g.sum(0)))

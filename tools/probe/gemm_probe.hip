@@ -22,7 +22,7 @@ int main() {
             (void)hipMalloc(&X, M * K * 4); (void)hipMalloc(&Bt, K * 128 * 4); (void)hipMalloc(&bias, 512); (void)hipMalloc(&Y, M * 128 * 4);
             (void)hipMalloc(&ws, fn_linear128_wgrad_ws(M, K) * 4); (void)hipMalloc(&dW, 128 * K * 4); (void)hipMalloc(&db, 512);
             (void)hipMemset(X, 0, M * K * 4); (void)hipMemset(Bt, 0, K * 128 * 4); (void)hipMemset(bias, 0, 512); (void)hipMemset(Y, 0, M * 128 * 4);
-            float t4 = time_us([&] { fn_linear128_f32(X, K, Bt, bias, Y, M, nullptr); });
+            float t4 = time_us([&] { fn_linear128_f32(X, K, Bt, bias, Y, M, nullptr, nullptr); });
             float t5 = time_us([&] { fn_linear128_wgrad_f32(Y, X, K, M, ws, dW, db, nullptr); });
             printf("K=%d M=%ld: fwd %.1f us   wgrad(+2 reduces) %.1f us   [%s]\n", K, (long)M, t4, t5, fn_last_error());
             (void)hipFree(X); (void)hipFree(Bt); (void)hipFree(bias); (void)hipFree(Y); (void)hipFree(ws); (void)hipFree(dW); (void)hipFree(db);
