@@ -127,7 +127,8 @@ def kernel_roofline(batch, model, iters=50):
     s_dst, s_src = torch.empty(n, H, **f32), torch.empty(n, H, **f32)
     out, p_sorted, dz = torch.empty(n, 128, **f32), torch.empty(m, H, **f32), torch.empty(m, H, **f32)
     g_s_dst, g_h = torch.empty(n, H, **f32), torch.empty(n, 128, **f32)
-    part_e, part_a = torch.empty(1024, H * 2, **f32), torch.empty(1024, 256, **f32)
+    pz = torch.empty(m, H, 2, **f32)
+    part_e, part_a = torch.empty(4096, H * 2, **f32), torch.empty(4096, 256, **f32)
     n_e, n_a = C.c_int(0), C.c_int(0)
     st = _stream_ptr(dev)
     _lib.call("fn_node_scalars_f32", h.data_ptr(), att.data_ptr(), 96, 0, 64, s_dst.data_ptr(), s_src.data_ptr(), n, H, st)
@@ -138,16 +139,16 @@ def kernel_roofline(batch, model, iters=50):
 
     def bwd_dst():
         _lib.call("fn_gat_bwd_dst_f32", gout.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), C.byref(et), C.byref(lv.c), 0.2,
-                  dz.data_ptr(), g_s_dst.data_ptr(), part_e.data_ptr(), C.byref(n_e), H, st)
+                  dz.data_ptr(), pz.data_ptr(), g_s_dst.data_ptr(), part_e.data_ptr(), C.byref(n_e), H, st)
 
     def bwd_src():
-        _lib.call("fn_gat_bwd_src_f32", gout.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), dz.data_ptr(), g_s_dst.data_ptr(),
+        _lib.call("fn_gat_bwd_src_f32", gout.data_ptr(), h.data_ptr(), pz.data_ptr(), g_s_dst.data_ptr(),
                   att.data_ptr(), 96, 0, 64, C.byref(lv.c), g_h.data_ptr(), part_a.data_ptr(), C.byref(n_a), H, st)
 
     D = 128
     fwd_b = 4 * ((n + 1) + m + m * H + 2 * n * H + n * D + n * D + m * H)
     # backward split of B_agg' (§8d) over the two passes: each operand read once, each result written once
-    bwd_dst_b = 4 * (2 * n * D + m * H + m + m * H + n * H)            # g_out, h, probs, idx -> dz, g_s_dst
+    bwd_dst_b = 4 * (2 * n * D + m * H + m + m * H + n * H)            # g_out, h, probs, idx -> dz, g_s_dst (as in §8d)
     bwd_src_b = 4 * (2 * n * D + 2 * m * H + m + n * H + n * D)        # g_out, h, probs, dz, idx, g_s_dst -> g_h
     res = {}
     fwd()

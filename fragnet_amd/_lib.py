@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfragnet_hip.so")
 FN_D = 128
 FN_MAX_TASKS = 16
 FN_MAX_EDGE_K = 8
-FN_MAX_PART = 1024
+FN_MAX_PART = 4096
 ROLE_PLAIN, ROLE_DST, ROLE_SRC = 0, 1, 2
 
 i32, i64, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
@@ -37,7 +37,7 @@ class ActEpilogue(C.Structure):
 
 class GatPlan(C.Structure):
     _fields_ = [("rowptr_d", vp), ("eid_d", vp), ("src_d", vp), ("rowptr_s", vp), ("dst_s", vp), ("dpos_s", vp),
-                ("inv_d", vp), ("pos_base_d", i32), ("pos_base_s", i32), ("n", i64), ("m", i64), ("m_real", i64)]
+                ("inv_d", vp), ("spos_d", vp), ("pos_base_d", i32), ("pos_base_s", i32), ("n", i64), ("m", i64), ("m_real", i64)]
 
 
 class SegPlan(C.Structure):
@@ -67,12 +67,12 @@ SIGNATURES = {
     "fn_abi_version": [],
     "fn_last_error": [],
     "fn_plan_layout": [C.POINTER(CsrTask), C.c_int, C.POINTER(i64), C.POINTER(i64)],
-    "fn_plan_build": [C.POINTER(CsrTask), C.c_int, vp, vp, vp, vp, vp, vp],
+    "fn_plan_build": [C.POINTER(CsrTask), C.c_int, vp, vp, vp, vp, vp, vp, vp],
     "fn_node_scalars_f32": [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, i64, C.c_int, vp],
     "fn_gat_fwd_f32": [vp, vp, vp, vp, C.c_int, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp,
                        C.POINTER(ActEpilogue), C.c_int, vp],
-    "fn_gat_bwd_dst_f32": [vp, vp, vp, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp, ip, C.c_int, vp],
-    "fn_gat_bwd_src_f32": [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(GatPlan), vp, vp, ip, C.c_int, vp],
+    "fn_gat_bwd_dst_f32": [vp, vp, vp, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp, vp, ip, C.c_int, vp],
+    "fn_gat_bwd_src_f32": [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(GatPlan), vp, vp, ip, C.c_int, vp],
     "fn_gat_bwd_finalize_f32": [vp, C.c_int, vp, C.c_int, C.POINTER(EdgeTerm), vp, C.c_int, C.c_int, C.c_int, vp, vp, vp,
                                 C.c_int, vp],
     "fn_attn_by_src_f32": [vp, C.POINTER(GatPlan), vp, C.c_int, vp],

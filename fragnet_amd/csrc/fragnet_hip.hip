@@ -39,7 +39,7 @@ inline hipStream_t S(fn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 constexpr int kBlock = 256;
 constexpr int kRows = 8;          // rows (half-waves) per block
 constexpr int kGridCap = 2048;    // memory-bound kernels: ~8 blocks per CU, grid-stride the rest
-constexpr int kBwdRows = 16;      // rows (half-waves) per block in the attention backward kernels
+constexpr int kBwdRows = 8;       // rows (half-waves) per block in the attention backward kernels
 
 inline int bwd_grid(int64_t rows) {
     int64_t g = (rows + kBwdRows - 1) / kBwdRows;
@@ -267,7 +267,7 @@ __global__ void k_plan_ranksort(const int32_t* __restrict__ rowptr_all, const in
 
 template <int ROLE>
 __global__ void k_plan_aux(PlanTasks P, const int32_t* __restrict__ perm_all, int32_t* __restrict__ aux_a,
-                           int32_t* __restrict__ aux_b) {
+                           int32_t* __restrict__ aux_b, int32_t* __restrict__ aux_c) {
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < P.total_items;
          g += (int64_t)gridDim.x * blockDim.x) {
         const fn_csr_task& T = P.t[find_task(P, g)];
@@ -276,7 +276,12 @@ __global__ void k_plan_aux(PlanTasks P, const int32_t* __restrict__ perm_all, in
         if (item < 0 || item >= T.n_real + T.n_loops) continue;      // unfilled slot (some key was out of range)
         aux_a[g] = (int32_t)item_other(T, item);
         if (ROLE == FN_ROLE_DST) aux_b[T.item_base + item] = (int32_t)(g - T.item_base);   // inverse permutation
-        else aux_b[g] = aux_b[P.t[T.partner].item_base + item];
+        else {
+            const fn_csr_task& D = P.t[T.partner];
+            const int32_t dpos = aux_b[D.item_base + item];
+            aux_b[g] = dpos;                                          // position of this edge in the DST order
+            aux_c[D.item_base + dpos] = (int32_t)(g - T.item_base);   // and, for that DST position, its SRC position
+        }
     }
 }
 
@@ -472,7 +477,8 @@ template <int H, int RB>
 __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(const float* __restrict__ g_out, const float* __restrict__ h,
                                                          const float* __restrict__ p_sorted, fn_edge_term et,
                                                          fn_gat_plan pl, float slope, float* __restrict__ dz_sorted,
-                                                         float* __restrict__ g_s_dst, float* __restrict__ part_e) {
+                                                         float* __restrict__ pz_src, float* __restrict__ g_s_dst,
+                                                         float* __restrict__ part_e) {
     constexpr int LPH = 32 / H;
     __shared__ float sP[RB][8][kWfLd];
     const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH, hw = threadIdx.x >> 5;
@@ -480,8 +486,11 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(const float* __restrict
 #pragma unroll
     for (int k = 0; k < kWfLd; ++k) pw[k] = 0.f;
 
-    auto emit = [&](int pos, float dz) {
-        dz_sorted[(size_t)pos * H + head] = dz;
+    // (|p|, dz) of every edge goes to its slot in SOURCE order, so the source pass streams them instead of
+    // gathering through dpos; dz in destination order is only kept where it is a gradient itself (mode 0)
+    auto emit = [&](int pos, float dz, float pabs) {
+        *reinterpret_cast<float2*>(pz_src + ((size_t)pl.spos_d[pos] * H + head) * 2) = make_float2(pabs, dz);
+        if (et.mode == 0) dz_sorted[(size_t)pos * H + head] = dz;
         if (et.mode == 2) {
             pw[FN_MAX_EDGE_K] += dz;
 #pragma unroll
@@ -490,7 +499,7 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(const float* __restrict
         }
     };
 
-    for (int64_t t = (int64_t)blockIdx.x * RB + hw; t < pl.n; t += (int64_t)gridDim.x * RB) {
+    for (int64_t t = (int64_t)xcd_block(blockIdx.x, gridDim.x) * RB + hw; t < pl.n; t += (int64_t)gridDim.x * RB) {
         const int beg = pl.rowptr_d[t] - pl.pos_base_d;
         const int deg = pl.rowptr_d[t + 1] - pl.rowptr_d[t];
         const float4 g = ld4(g_out + t * FN_D + lane * 4);
@@ -518,8 +527,8 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(const float* __restrict
             const float c = head_sum<LPH>(pA * dpA + pB * dpB);
             const float dzA = pA * (dpA - c) * ((__float_as_uint(psA) >> 31) ? slope : 1.f);
             const float dzB = pB * (dpB - c) * ((__float_as_uint(psB) >> 31) ? slope : 1.f);
-            if (hasA) emit(beg + j, dzA);
-            if (hasB) emit(beg + LPH + j, dzB);
+            if (hasA) emit(beg + j, dzA, pA);
+            if (hasB) emit(beg + LPH + j, dzB, pB);
             const float gs = head_sum<LPH>(dzA + dzB);
             if (j == 0) g_s_dst[t * H + head] = gs;
         } else {
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(const float* __restrict
                 const float d = head_sum<LPH>(dot4(g, ld4(h + (size_t)sk * FN_D + lane * 4)));
                 const float ps = p_sorted[(size_t)(beg + k) * H + head];
                 const float dz = fabsf(ps) * (d - c) * ((__float_as_uint(ps) >> 31) ? slope : 1.f);
-                if (j == 0) emit(beg + k, dz);
+                if (j == 0) emit(beg + k, dz, fabsf(ps));
                 gs += dz;
             }
             if (j == 0) g_s_dst[t * H + head] = gs;
@@ -564,8 +573,7 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(const float* __restrict
 
 template <int H, int RB>
 __global__ __launch_bounds__(RB * 32) void k_gat_bwd_src(const float* __restrict__ g_out, const float* __restrict__ h,
-                                                         const float* __restrict__ p_sorted,
-                                                         const float* __restrict__ dz_sorted,
+                                                         const float* __restrict__ pz_src,
                                                          const float* __restrict__ g_s_dst, const float* __restrict__ att,
                                                          int att_w, int dst_off, int src_off, fn_gat_plan pl,
                                                          float* __restrict__ g_h, float* __restrict__ part_a) {
@@ -575,7 +583,7 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_src(const float* __restrict
     const float4 ad = ld4(att + head * att_w + dst_off + j * 4);
     const float4 as = ld4(att + head * att_w + src_off + j * 4);
     float4 qd = make_float4(0.f, 0.f, 0.f, 0.f), qs = qd;
-    for (int64_t s = (int64_t)blockIdx.x * RB + hw; s < pl.n; s += (int64_t)gridDim.x * RB) {
+    for (int64_t s = (int64_t)xcd_block(blockIdx.x, gridDim.x) * RB + hw; s < pl.n; s += (int64_t)gridDim.x * RB) {
         const int beg = pl.rowptr_s[s] - pl.pos_base_s;
         const int deg = pl.rowptr_s[s + 1] - pl.rowptr_s[s];
         const float gsd = g_s_dst[s * H + head];
@@ -590,9 +598,9 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_src(const float* __restrict
                 const bool ok = i0 + i < deg;
                 const int ii = ok ? i0 + i : deg - 1;
                 const int t = pl.dst_s[beg + ii];
-                const size_t pos = (size_t)pl.dpos_s[beg + ii] * H + head;
-                pk[i] = ok ? fabsf(p_sorted[pos]) : 0.f;
-                dk[i] = ok ? dz_sorted[pos] : 0.f;
+                const float2 pz = *reinterpret_cast<const float2*>(pz_src + ((size_t)(beg + ii) * H + head) * 2);
+                pk[i] = ok ? pz.x : 0.f;
+                dk[i] = ok ? pz.y : 0.f;
                 r[i] = ld4(g_out + (size_t)t * FN_D + lane * 4);
             }
 #pragma unroll
@@ -640,7 +648,9 @@ __global__ __launch_bounds__(1024) void k_gat_finalize(const float* __restrict__
     const int tid = threadIdx.x;
     if (blockIdx.x < 2 * FN_D) {
         const int col = blockIdx.x;
-        const float v = block_sum_1024(tid < n_a ? part_a[(size_t)col * FN_MAX_PART + tid] : 0.f, s16);
+        float mine = 0.f;
+        for (int r = tid; r < n_a; r += 1024) mine += part_a[(size_t)col * FN_MAX_PART + r];
+        const float v = block_sum_1024(mine, s16);
         if (tid == 0) {
             const int DH = FN_D / H;
             const int cc = col & 127, part = col >> 7;
@@ -797,7 +807,9 @@ __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ part,
                                                   float* __restrict__ out, int ld, int off) {
     __shared__ float s16[16];
     const int col = blockIdx.x;
-    const float v = block_sum_1024((int)threadIdx.x < n_rows ? part[(size_t)col * FN_MAX_PART + threadIdx.x] : 0.f, s16);
+    float mine = 0.f;
+    for (int r = threadIdx.x; r < n_rows; r += 1024) mine += part[(size_t)col * FN_MAX_PART + r];
+    const float v = block_sum_1024(mine, s16);
     if (threadIdx.x == 0) out[(col / FN_D) * ld + off + (col % FN_D)] = v;
 }
 
@@ -1413,8 +1425,8 @@ int fn_plan_layout(fn_csr_task* tasks, int n_tasks, int64_t* total_items, int64_
 }
 
 int fn_plan_build(const fn_csr_task* tasks, int n_tasks, int32_t* rowptr_all, int32_t* perm_all, int32_t* aux_a,
-                  int32_t* aux_b, int32_t* ws_i32, fn_stream_t stream) {
-    if (!tasks || n_tasks < 1 || !rowptr_all || !perm_all || !aux_a || !aux_b || !ws_i32)
+                  int32_t* aux_b, int32_t* aux_c, int32_t* ws_i32, fn_stream_t stream) {
+    if (!tasks || n_tasks < 1 || !rowptr_all || !perm_all || !aux_a || !aux_b || !aux_c || !ws_i32)
         return fail(FN_EINVAL, "fn_plan_build: null argument");
     if (n_tasks > FN_MAX_TASKS) return fail(FN_ETOOMANY, "fn_plan_build: more than FN_MAX_TASKS tasks");
     PlanTasks P;
@@ -1455,8 +1467,8 @@ int fn_plan_build(const fn_csr_task* tasks, int n_tasks, int32_t* rowptr_all, in
         hipLaunchKernelGGL(k_plan_fill, dim3(g), dim3(kBlock), 0, st, P, rowptr_all, cursor, tmp, aux_a);
         hipLaunchKernelGGL(k_plan_ranksort, dim3(g), dim3(kBlock), 0, st, rowptr_all, tmp, aux_a, perm_all, items, segs);
         if (any_pair) {
-            hipLaunchKernelGGL(k_plan_aux<FN_ROLE_DST>, dim3(g), dim3(kBlock), 0, st, P, perm_all, aux_a, aux_b);
-            hipLaunchKernelGGL(k_plan_aux<FN_ROLE_SRC>, dim3(g), dim3(kBlock), 0, st, P, perm_all, aux_a, aux_b);
+            hipLaunchKernelGGL(k_plan_aux<FN_ROLE_DST>, dim3(g), dim3(kBlock), 0, st, P, perm_all, aux_a, aux_b, aux_c);
+            hipLaunchKernelGGL(k_plan_aux<FN_ROLE_SRC>, dim3(g), dim3(kBlock), 0, st, P, perm_all, aux_a, aux_b, aux_c);
         }
     }
     return launch_status("fn_plan_build");
@@ -1488,33 +1500,34 @@ int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const
 }
 
 int fn_gat_bwd_dst_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et,
-                       const fn_gat_plan* plan, float neg_slope, float* dz_sorted, float* g_s_dst, float* part_e,
-                       int* n_part_e, int heads, fn_stream_t stream) {
+                       const fn_gat_plan* plan, float neg_slope, float* dz_sorted, float* pz_src, float* g_s_dst,
+                       float* part_e, int* n_part_e, int heads, fn_stream_t stream) {
     if (!g_out || !h || !plan || !g_s_dst || !n_part_e || !et) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: bad argument");
     if (et->mode != 0 && bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: bad edge term");
-    if (plan->m > 0 && (!p_sorted || !dz_sorted)) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: null edge buffer");
+    if (plan->m > 0 && (!p_sorted || !pz_src || !plan->spos_d || (et->mode == 0 && !dz_sorted)))
+        return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: null edge buffer");
     if (et->mode == 2 && !part_e) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: null part_e");
     *n_part_e = 0;
     if (plan->n == 0) return 0;
     const int g = bwd_grid(plan->n);
     *n_part_e = (et->mode == 2) ? g : 0;
     FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_dst<HH, kBwdRows>), dim3(g), dim3(kBwdRows * 32), 0, S(stream), g_out, h,
-                                            p_sorted, *et, *plan, neg_slope, dz_sorted, g_s_dst, part_e));
+                                            p_sorted, *et, *plan, neg_slope, dz_sorted, pz_src, g_s_dst, part_e));
     return launch_status("fn_gat_bwd_dst_f32");
 }
 
-int fn_gat_bwd_src_f32(const float* g_out, const float* h, const float* p_sorted, const float* dz_sorted,
+int fn_gat_bwd_src_f32(const float* g_out, const float* h, const float* pz_src,
                        const float* g_s_dst, const float* att, int att_w, int dst_off, int src_off,
                        const fn_gat_plan* plan, float* g_h, float* part_a, int* n_part_a, int heads, fn_stream_t stream) {
     if (!g_out || !h || !g_s_dst || !att || !plan || !g_h || !part_a || !n_part_a) return fail(FN_EINVAL, "fn_gat_bwd_src_f32: bad argument");
-    if (plan->m > 0 && (!p_sorted || !dz_sorted)) return fail(FN_EINVAL, "fn_gat_bwd_src_f32: null edge buffer");
+    if (plan->m > 0 && !pz_src) return fail(FN_EINVAL, "fn_gat_bwd_src_f32: null edge buffer");
     if ((att_w | dst_off | src_off) & 3) return fail(FN_EINVAL, "fn_gat_bwd_src_f32: att blocks must be 16-byte aligned");
     *n_part_a = 0;
     if (plan->n == 0) return 0;
     const int g = bwd_grid(plan->n);
     *n_part_a = g;
-    FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src<HH, kBwdRows>), dim3(g), dim3(kBwdRows * 32), 0, S(stream), g_out, h, p_sorted,
-                                            dz_sorted, g_s_dst, att, att_w, dst_off, src_off, *plan, g_h, part_a));
+    FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src<HH, kBwdRows>), dim3(g), dim3(kBwdRows * 32), 0, S(stream), g_out, h, pz_src,
+                                            g_s_dst, att, att_w, dst_off, src_off, *plan, g_h, part_a));
     return launch_status("fn_gat_bwd_src_f32");
 }
 
@@ -1786,7 +1799,7 @@ EncLayout enc_layout(const fn_encoder* e, float* ws) {
 
 struct BwdLayout {
     float *g_pre_atoms, *g_pre_frags, *g_pre_bond, *g_pre_fbond;   // grads w.r.t. pre-activation layer outputs
-    float *g_h, *g_frags, *dz, *g_s_dst, *part_a, *part_e, *part_rd, *wg_ws;
+    float *g_h, *g_frags, *dz, *pz, *g_s_dst, *part_a, *part_e, *part_rd, *wg_ws;
     int64_t total;
 };
 
@@ -1799,6 +1812,7 @@ BwdLayout bwd_layout(const fn_encoder* e, float* ws) {
     o.g_pre_bond = b.take(e->E * FN_D);   o.g_pre_fbond = b.take(e->EF * FN_D);
     o.g_h = b.take(nmax * FN_D);          o.g_frags = b.take(e->F * FN_D);
     o.dz = b.take(mmax * H);              o.g_s_dst = b.take(nmax * H);
+    o.pz = b.take(2 * mmax * H);
     o.part_a = b.take((int64_t)FN_MAX_PART * 2 * FN_D);
     o.part_e = b.take((int64_t)FN_MAX_PART * H * (FN_MAX_EDGE_K + 1));
     o.part_rd = b.take((int64_t)FN_MAX_PART * H * FN_D);
@@ -1998,8 +2012,8 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         bool have_g_frags_h = false;
         if (have_frags) {
             fn_edge_term et_f{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_frags, a.frags, a.p_frag, &et_f, &e->frag, 0.2f, bw.dz, bw.g_s_dst, nullptr, &n_e, H, st));
-            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_frags, a.frags, a.p_frag, bw.dz, bw.g_s_dst, w.f, wide, 0, d + FN_D, &e->frag, bw.g_frags, bw.part_a, &n_a, H, st));
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_frags, a.frags, a.p_frag, &et_f, &e->frag, 0.2f, bw.dz, bw.pz, bw.g_s_dst, nullptr, &n_e, H, st));
+            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_frags, a.frags, bw.pz, bw.g_s_dst, w.f, wide, 0, d + FN_D, &e->frag, bw.g_frags, bw.part_a, &n_a, H, st));
             FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, nullptr, 0, &et_f, w.f, wide, 0, d + FN_D, g.f, nullptr, nullptr, H, st));
             // edge term <new_fbond, f[:, d:d+128]>: dL/dnew_fbond accumulates into g_pre_fbond, dL/df mid block
             if (e->frag.m_real > 0) {
@@ -2016,8 +2030,8 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         // ---- L4a fragment-bond graph
         if (have_fbond) {
             fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_fbond, a.h_fb, a.p_fbond, &et_fb, &e->fbond, 0.2f, bw.dz, bw.g_s_dst, bw.part_e, &n_e, H, st));
-            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_fbond, a.h_fb, a.p_fbond, bw.dz, bw.g_s_dst, w.f_a_b, 3 * d, 0, 2 * d, &e->fbond, bw.g_h, bw.part_a, &n_a, H, st));
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_fbond, a.h_fb, a.p_fbond, &et_fb, &e->fbond, 0.2f, bw.dz, bw.pz, bw.g_s_dst, bw.part_e, &n_e, H, st));
+            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_fbond, a.h_fb, bw.pz, bw.g_s_dst, w.f_a_b, 3 * d, 0, 2 * d, &e->fbond, bw.g_h, bw.part_a, &n_a, H, st));
             FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, bw.part_e, n_e, &et_fb, w.f_a_b, 3 * d, 0, 2 * d, g.f_a_b, g.emb_fb_w, g.emb_fb_b, H, st));
             FN_TRY(fn_linear128_wgrad_f32(bw.g_h, in_fbond, kfb, e->EF, bw.wg_ws, g.proj_fb_w, g.proj_fb_b, st));
             if (l) {     // dL/d(pre-activation fbond output of layer l-1), gated by that layer's dropout mask and ReLU
@@ -2038,8 +2052,8 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         // ---- L2 atom graph
         if (have_atoms) {
             fn_edge_term et_a{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_atoms, a.h_a, a.p_atom, &et_a, &e->atom, 0.2f, bw.dz, bw.g_s_dst, nullptr, &n_e, H, st));
-            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_atoms, a.h_a, a.p_atom, bw.dz, bw.g_s_dst, w.a, wide, 0, d + FN_D, &e->atom, bw.g_h, bw.part_a, &n_a, H, st));
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_atoms, a.h_a, a.p_atom, &et_a, &e->atom, 0.2f, bw.dz, bw.pz, bw.g_s_dst, nullptr, &n_e, H, st));
+            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_atoms, a.h_a, bw.pz, bw.g_s_dst, w.a, wide, 0, d + FN_D, &e->atom, bw.g_h, bw.part_a, &n_a, H, st));
             FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, nullptr, 0, &et_a, w.a, wide, 0, d + FN_D, g.a, nullptr, nullptr, H, st));
             if (e->atom.m_real > 0) {
                 const int gr = row_grid(e->atom.m_real, FN_MAX_PART);
@@ -2060,8 +2074,8 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         // ---- L1 bond graph
         if (have_bond) {
             fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_bond, a.h_b, a.p_bond, &et_b, &e->bond, 0.2f, bw.dz, bw.g_s_dst, bw.part_e, &n_e, H, st));
-            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_bond, a.h_b, a.p_bond, bw.dz, bw.g_s_dst, w.a_b, 3 * d, 0, 2 * d, &e->bond, bw.g_h, bw.part_a, &n_a, H, st));
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_bond, a.h_b, a.p_bond, &et_b, &e->bond, 0.2f, bw.dz, bw.pz, bw.g_s_dst, bw.part_e, &n_e, H, st));
+            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_bond, a.h_b, bw.pz, bw.g_s_dst, w.a_b, 3 * d, 0, 2 * d, &e->bond, bw.g_h, bw.part_a, &n_a, H, st));
             FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, bw.part_e, n_e, &et_b, w.a_b, 3 * d, 0, 2 * d, g.a_b, g.emb_b_w, g.emb_b_b, H, st));
             FN_TRY(fn_linear128_wgrad_f32(bw.g_h, in_bond, kb, e->E, bw.wg_ws, g.proj_b_w, g.proj_b_b, st));
             if (l) {

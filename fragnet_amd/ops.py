@@ -108,15 +108,15 @@ class _GatLevel(torch.autograd.Function):
             K = x_sorted.shape[1]
             et = EdgeTerm(2, K, FN_D // heads, mid_off, None, x_sorted.data_ptr(), embW.data_ptr(), embb.data_ptr())
             part_e = torch.empty((FN_MAX_PART, heads * (K + 1)), dtype=torch.float32, device=dev)
-        dz = torch.empty((m, heads), dtype=torch.float32, device=dev)
+        dz = torch.empty((m, heads), dtype=torch.float32, device=dev) if mode == 0 else None
+        pz = torch.empty((m, heads, 2), dtype=torch.float32, device=dev)
         g_s_dst = torch.empty((n, heads), dtype=torch.float32, device=dev)
         n_e, n_a = C.c_int(0), C.c_int(0)
         _lib.call("fn_gat_bwd_dst_f32", g_out.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), C.byref(et),
-                  C.byref(level.c), NEG_SLOPE, dz.data_ptr(), g_s_dst.data_ptr(), _ptr(part_e), C.byref(n_e), heads, st)
+                  C.byref(level.c), NEG_SLOPE, _ptr(dz), pz.data_ptr(), g_s_dst.data_ptr(), _ptr(part_e), C.byref(n_e), heads, st)
         g_h = torch.empty((n, FN_D), dtype=torch.float32, device=dev)
         part_a = torch.empty((FN_MAX_PART, 2 * FN_D), dtype=torch.float32, device=dev)
-        _lib.call("fn_gat_bwd_src_f32", g_out.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), dz.data_ptr(),
-                  g_s_dst.data_ptr(), att.data_ptr(), att_w, dst_off, src_off, C.byref(level.c), g_h.data_ptr(),
+        _lib.call("fn_gat_bwd_src_f32", g_out.data_ptr(), h.data_ptr(), pz.data_ptr(), g_s_dst.data_ptr(), att.data_ptr(), att_w, dst_off, src_off, C.byref(level.c), g_h.data_ptr(),
                   part_a.data_ptr(), C.byref(n_a), heads, st)
         g_att = torch.zeros_like(att)
         g_embW = torch.empty_like(embW) if mode == 2 else None

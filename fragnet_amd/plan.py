@@ -85,18 +85,20 @@ class GraphPlan:
         tot_items, tot_segs = C.c_int64(), C.c_int64()
         _lib.check(lib.fn_plan_layout(tasks, nt, C.byref(tot_items), C.byref(tot_segs)), "fn_plan_layout")
         ti, ts = tot_items.value, tot_segs.value
-        # one int32 arena: rowptr | perm | aux_a | aux_b | workspace(cursor, inv, status)
+        # one int32 arena: rowptr | perm | aux_a | aux_b | aux_c | workspace(cursor, tmp, status, block sums)
         ta = max(ti, 1)                 # keep every region non-empty so its pointer is never null
-        arena = torch.empty(ts + 1 + 3 * ta + (ts + ti + 4 + ts // 2048 + 1), dtype=torch.int32, device=device)
+        arena = torch.empty(ts + 1 + 4 * ta + (ts + ti + 4 + ts // 2048 + 1), dtype=torch.int32, device=device)
         self._arena = arena
         self.rowptr = arena[: ts + 1]
         self.perm = arena[ts + 1: ts + 1 + ta]
         self.aux_a = arena[ts + 1 + ta: ts + 1 + 2 * ta]
         self.aux_b = arena[ts + 1 + 2 * ta: ts + 1 + 3 * ta]
-        ws = arena[ts + 1 + 3 * ta:]
+        self.aux_c = arena[ts + 1 + 3 * ta: ts + 1 + 4 * ta]
+        ws = arena[ts + 1 + 4 * ta:]
         self._status = ws[ts + ti: ts + ti + 1]
         _lib.check(lib.fn_plan_build(tasks, nt, self.rowptr.data_ptr(), self.perm.data_ptr(), self.aux_a.data_ptr(),
-                                     self.aux_b.data_ptr(), ws.data_ptr(), _stream_ptr(device)), "fn_plan_build")
+                                     self.aux_b.data_ptr(), self.aux_c.data_ptr(), ws.data_ptr(), _stream_ptr(device)),
+                   "fn_plan_build")
         self._keep = keep
         self._sorted = {}
         self.levels: Dict[str, Level] = {}
@@ -109,7 +111,8 @@ class GraphPlan:
                 c = GatPlan(self.rowptr.data_ptr() + 4 * d.seg_base, self.perm.data_ptr() + 4 * d.item_base,
                             self.aux_a.data_ptr() + 4 * d.item_base, self.rowptr.data_ptr() + 4 * s.seg_base,
                             self.aux_a.data_ptr() + 4 * s.item_base, self.aux_b.data_ptr() + 4 * s.item_base,
-                            self.aux_b.data_ptr() + 4 * d.item_base, int(d.item_base), int(s.item_base), int(d.n_seg), m, int(d.n_real))
+                            self.aux_b.data_ptr() + 4 * d.item_base, self.aux_c.data_ptr() + 4 * d.item_base,
+                            int(d.item_base), int(s.item_base), int(d.n_seg), m, int(d.n_real))
                 self.levels[name] = Level(c, int(d.n_seg), m, int(d.n_real), (self,))
             else:
                 _, name, t0, sp, key = ent

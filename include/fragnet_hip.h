@@ -56,6 +56,7 @@ const char* fn_last_error(void);
  *                                       a segment (=> deterministic, reference summation order)
  * For a GAT level, two tasks are paired (role DST keyed by destination, role SRC keyed by source):
  *   DST task: aux_a[pos] = source node of the edge at pos; aux_b[item] = position of edge `item` (inverse perm)
+ *             aux_c[pos] = position of the same edge in the paired SRC task
  *   SRC task: aux_a[pos] = destination node; aux_b[pos] = that edge's position (task-local) in the
  *             paired DST task
  * ------------------------------------------------------------------------------------------ */
@@ -83,7 +84,7 @@ int fn_plan_layout(fn_csr_task* tasks, int n_tasks, int64_t* total_items, int64_
 #define FN_PLAN_WS(total_segs, total_items) ((total_segs) + (total_items) + 4 + (total_segs) / 2048 + 1)
 int fn_plan_build(const fn_csr_task* tasks, int n_tasks,
                   int32_t* rowptr_all /*[total_segs+1]*/, int32_t* perm_all /*[total_items]*/,
-                  int32_t* aux_a /*[total_items]*/, int32_t* aux_b /*[total_items]*/,
+                  int32_t* aux_a /*[total_items]*/, int32_t* aux_b /*[total_items]*/, int32_t* aux_c /*[total_items]*/,
                   int32_t* ws_i32, fn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -125,6 +126,7 @@ typedef struct fn_gat_plan {          /* slices of the fn_plan_build outputs for
     const int32_t* dst_s;     /* [m]   destination node               */
     const int32_t* dpos_s;    /* [m]   position in the DST order      */
     const int32_t* inv_d;     /* [m]   original edge id -> position in the DST order */
+    const int32_t* spos_d;    /* [m]   DST position -> position in the SRC order     */
     int32_t pos_base_d;       /* item_base of the DST task            */
     int32_t pos_base_s;       /* item_base of the SRC task            */
     int64_t n;                /* nodes                                */
@@ -149,18 +151,19 @@ int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const
                    float* out /*[n,128], nullable when act->y is given*/, float* p_sorted /*[m,H]*/,
                    float* probs_orig /*nullable*/, const fn_act_epilogue* act /*nullable*/, int heads, fn_stream_t stream);
 
-/* Backward, destination pass: dz_sorted [m,H] (= dL/ds_sorted, the gradient of the mode-0 edge term),
- * g_s_dst [n,H]; mode 2 writes per-block partial sums part_e [grid, H*(K+1)].
+/* Backward, destination pass.  Writes, per edge, (|p|, dz) into pz_src [m,H,2] at the edge's slot in SOURCE
+ * order (so the source pass streams them), dz_sorted [m,H] in mode 0 (= dL/ds_sorted, the gradient of the edge
+ * term), g_s_dst [n,H]; mode 2 writes per-block partial sums part_e [grid, H*(K+1)].
  * Returns the grid size used through *n_part_e. */
 int fn_gat_bwd_dst_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et,
                        const fn_gat_plan* plan, float neg_slope,
-                       float* dz_sorted, float* g_s_dst,
+                       float* dz_sorted /*mode 0*/, float* pz_src, float* g_s_dst,
                        float* part_e /*mode2: [FN_MAX_PART, H*(K+1)]*/, int* n_part_e,
                        int heads, fn_stream_t stream);
 
 /* Backward, source pass: g_h [n,128] = sum_{e: src=n} p_e g_out[dst] + g_s_dst*a_dst + g_s_src*a_src,
- * and per-block partial sums of dL/da_dst, dL/da_src: part_a [grid, 256]. */
-int fn_gat_bwd_src_f32(const float* g_out, const float* h, const float* p_sorted, const float* dz_sorted,
+ * and per-block partial sums of dL/da_dst, dL/da_src: part_a (column-major [256][FN_MAX_PART]). */
+int fn_gat_bwd_src_f32(const float* g_out, const float* h, const float* pz_src,
                        const float* g_s_dst, const float* att, int att_w, int dst_off, int src_off,
                        const fn_gat_plan* plan, float* g_h, float* part_a, int* n_part_a,
                        int heads, fn_stream_t stream);
@@ -171,7 +174,7 @@ int fn_gat_bwd_finalize_f32(const float* part_a, int n_part_a, const float* part
                             const fn_edge_term* et, const float* att, int att_w, int dst_off, int src_off,
                             float* g_att, float* g_embW, float* g_embb, int heads, fn_stream_t stream);
 
-#define FN_MAX_PART 1024      /* upper bound on partial rows any kernel writes */
+#define FN_MAX_PART 4096      /* upper bound on partial rows any kernel writes */
 
 /* attention mass per SOURCE node: scatter_add(attn_probs, source) at gat2.py:165,219,268,312 */
 int fn_attn_by_src_f32(const float* p_sorted, const fn_gat_plan* plan, float* attn /*[n,H]*/, int heads,

@@ -83,6 +83,10 @@ def test_plan_matches_stable_argsort():
     assert np.array_equal(dpos, inv[order_s])
     inv_d = arena[off(c.inv_d): off(c.inv_d) + lv.m]
     assert np.array_equal(inv_d, inv)
+    spos = arena[off(c.spos_d): off(c.spos_d) + lv.m]
+    want_spos = np.empty(lv.m, dtype=np.int64)
+    want_spos[dpos] = np.arange(lv.m)                      # inverse of dpos_s
+    assert np.array_equal(spos, want_spos)
     # raw edge attributes permuted into destination order, zeros on the loop positions
     attr = torch.arange(ei.shape[1] * 3, dtype=torch.float32, device=DEV).view(-1, 3)
     got = plan.sorted_attr("atom", attr).cpu().numpy()
