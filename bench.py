@@ -127,7 +127,7 @@ def kernel_roofline(batch, model, iters=50):
     s_dst, s_src = torch.empty(n, H, **f32), torch.empty(n, H, **f32)
     out, p_sorted, dz = torch.empty(n, 128, **f32), torch.empty(m, H, **f32), torch.empty(m, H, **f32)
     g_s_dst, g_h = torch.empty(n, H, **f32), torch.empty(n, 128, **f32)
-    pz = torch.empty(m, H, 2, **f32)
+    pz = torch.empty(H, m, 2, **f32)
     part_e, part_a = torch.empty(4096, H * 2, **f32), torch.empty(4096, 256, **f32)
     n_e, n_a = C.c_int(0), C.c_int(0)
     st = _stream_ptr(dev)

@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "fragnet_hip.h"
 
@@ -321,29 +322,40 @@ template <int W> __device__ __forceinline__ float head_max(float v) {
 // folded edge-embedding weights: Wf[h][k] = sum_c att[h, mid+c] * embW[c,k],  Wf[h][K] = sum_c att[h, mid+c] * embb[c]
 __device__ __forceinline__ void fold_edge_embed(const fn_edge_term& et, const float* att, int att_w, int H,
                                                 float (*sWf)[kWfLd]) {
+    // one wave per output scalar, lanes over the d_e-long dot product (two loads per lane, no serial chain: every
+    // block of the launch pays this prologue before its first node)
     if (et.mode == 2) {
         const int ne = H * (et.K + 1);
-        for (int i = threadIdx.x; i < ne; i += blockDim.x) {
+        const int wid = threadIdx.x >> 6, l64 = threadIdx.x & 63, nw = blockDim.x >> 6;
+        for (int i = wid; i < ne; i += nw) {
             const int hh = i / (et.K + 1), k = i % (et.K + 1);
-            float acc = 0.f;
-            for (int c = 0; c < et.d_e; ++c) {
-                const float a = att[hh * att_w + et.mid_off + c];
-                acc = fmaf(a, (k < et.K) ? et.embW[c * et.K + k] : et.embb[c], acc);
-            }
-            sWf[hh][k] = acc;
+            float part = 0.f;
+            for (int c = l64; c < et.d_e; c += 64)
+                part = fmaf(att[hh * att_w + et.mid_off + c], (k < et.K) ? et.embW[c * et.K + k] : et.embb[c], part);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (l64 == 0) sWf[hh][k] = part;
         }
     }
     __syncthreads();
 }
 
-// edge term of the logit for the edge at destination-sorted position pos (both forms are coalesced reads)
+// edge term of the logit for the edge at destination-sorted position pos.  Per-edge arrays are HEAD-MAJOR
+// ([H][m], [K][m]) so that the two consecutive edges a lane owns are one 8-byte load.
 template <int H>
-__device__ __forceinline__ float edge_term_at(int pos, int head, const fn_edge_term& et, const float (*sWf)[kWfLd]) {
-    if (et.mode == 0) return et.s_sorted[(size_t)pos * H + head];
+__device__ __forceinline__ float edge_term_at(int pos, int head, int64_t m, const fn_edge_term& et, const float (*sWf)[kWfLd]) {
+    if (et.mode == 0) return et.s_sorted[(size_t)head * m + pos];
     float e = sWf[head][et.K];
-    for (int k = 0; k < et.K; ++k) e = fmaf(et.x_sorted[(size_t)pos * et.K + k], sWf[head][k], e);
+    for (int k = 0; k < et.K; ++k) e = fmaf(et.x_sorted[(size_t)k * m + pos], sWf[head][k], e);
     return e;
 }
+
+struct __attribute__((packed, aligned(4))) i32x2u { int x, y; };       // 4-byte aligned pairs: one dwordx2 load
+struct __attribute__((packed, aligned(4))) f32x2u { float x, y; };
+struct __attribute__((packed, aligned(4))) f32x4u { float x, y, z, w; };
+__device__ __forceinline__ i32x2u ldp(const int32_t* p) { return *reinterpret_cast<const i32x2u*>(p); }
+__device__ __forceinline__ f32x2u ldp(const float* p) { return *reinterpret_cast<const f32x2u*>(p); }
+__device__ __forceinline__ void stp(float* p, float a, float b) { f32x2u v; v.x = a; v.y = b; *reinterpret_cast<f32x2u*>(p) = v; }
 
 template <int H>
 __global__ __launch_bounds__(kBlock) void k_node_scalars(const float* __restrict__ h, const float* __restrict__ att,
@@ -365,28 +377,11 @@ __global__ __launch_bounds__(kBlock) void k_node_scalars(const float* __restrict
     }
 }
 
-// acc += sum_{k < cnt} p_k * h[src_k], p/src held by lane k of each head group; four row gathers in flight
-template <int H>
-__device__ __forceinline__ void gather_accumulate(float4& acc, const float* __restrict__ h, float pv, int srcv,
-                                                  int cnt, int lane) {
-    constexpr int LPH = 32 / H;
-    for (int k0 = 0; k0 < cnt; k0 += 4) {
-        float4 r[4];
-        float pk[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = k0 + i;
-            const int kk = k < cnt ? k : cnt - 1;
-            const int sk = __shfl(srcv, kk, LPH);
-            const float p = __shfl(pv, kk, LPH);
-            pk[i] = k < cnt ? p : 0.f;
-            r[i] = ld4(h + (size_t)sk * FN_D + lane * 4);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fma4(acc, pk[i], r[i]);
-    }
-}
-
+// The vector memory pipe serves one wave instruction per ~16 cycles whatever its width, and these kernels are
+// bound by it (TA busy ~60 %, rocprofv3 r01b).  So every per-edge scalar is fetched ONCE by the lane that owns the
+// edge -- lane j of a head group owns the consecutive in-edges 2j and 2j+1, one 8-byte load per array -- and handed
+// to the other lanes through LDS-crossbar broadcasts (__shfl), never through repeated uniform global loads.
+// Row gathers are issued four at a time and only for edges that exist.
 template <int H>
 __global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h, const float* __restrict__ s_dst,
                                                     const float* __restrict__ s_src, const float* __restrict__ att,
@@ -397,49 +392,91 @@ __global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h,
     __shared__ float sWf[8][kWfLd];
     fold_edge_embed(et, att, att_w, H, sWf);
     const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH;
+    const int64_t m = pl.m;
     int64_t g0, g1;
     block_groups(pl.n, kRows, g0, g1);
     for (int64_t gi = g0; gi < g1; ++gi) {
         const int64_t t = gi * kRows + (threadIdx.x >> 5);
         if (t >= pl.n) continue;
-        const int beg = pl.rowptr_d[t] - pl.pos_base_d;
-        const int deg = pl.rowptr_d[t + 1] - pl.rowptr_d[t];
+        const i32x2u rp = ldp(pl.rowptr_d + t);
+        const int beg = rp.x - pl.pos_base_d, deg = rp.y - rp.x;
         const float sd = s_dst[t * H + head];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (deg <= 2 * LPH) {
-            // lane j of each head group owns in-edges j and LPH + j: the scalar gathers of a node go out in one
-            // round; probabilities and source ids are then broadcast edge by edge for the row gathers
-            const bool hasA = j < deg, hasB = j + LPH < deg;
-            const int posA = beg + j, posB = beg + LPH + j;
-            int srcA = 0, srcB = 0;
-            float zA = 0.f, zB = 0.f;
-            if (hasA) { srcA = pl.src_d[posA]; zA = edge_term_at<H>(posA, head, et, sWf); }
-            if (hasB) { srcB = pl.src_d[posB]; zB = edge_term_at<H>(posB, head, et, sWf); }
-            if (hasA) zA += sd + s_src[(size_t)srcA * H + head];
-            if (hasB) zB += sd + s_src[(size_t)srcB * H + head];
-            const float lA = hasA ? (zA > 0.f ? zA : slope * zA) : -INFINITY;
-            const float lB = hasB ? (zB > 0.f ? zB : slope * zB) : -INFINITY;
-            const float mx = head_max<LPH>(fmaxf(lA, lB));
-            const float eA = hasA ? expf(lA - mx) : 0.f;
-            const float eB = hasB ? expf(lB - mx) : 0.f;
-            const float den = head_sum<LPH>(eA + eB);
-            const float pA = hasA ? eA / den : 0.f;
-            const float pB = hasB ? eB / den : 0.f;
-            if (hasA) {
-                p_sorted[(size_t)posA * H + head] = lA > 0.f ? pA : -pA;
-                if (probs_orig) probs_orig[(size_t)pl.eid_d[posA] * H + head] = pA;
+            const int pos0 = beg + 2 * j;
+            const bool has0 = 2 * j < deg, has1 = 2 * j + 1 < deg;
+            int src0 = 0, src1 = 0;
+            float z0 = 0.f, z1 = 0.f;
+            if (has0 && pos0 + 1 < m) {                   // paired loads even when only edge 2j exists (the second
+                const i32x2u sp = ldp(pl.src_d + pos0);   // value then belongs to the next node and is ignored):
+                src0 = sp.x; src1 = sp.y;                 // one code path = one instruction per array
+                if (et.mode == 0) {
+                    const f32x2u e2 = ldp(et.s_sorted + (size_t)head * m + pos0);
+                    z0 = e2.x; z1 = e2.y;
+                } else {
+                    z0 = z1 = sWf[head][et.K];
+                    for (int k = 0; k < et.K; ++k) {
+                        const f32x2u x2 = ldp(et.x_sorted + (size_t)k * m + pos0);
+                        z0 = fmaf(x2.x, sWf[head][k], z0);
+                        z1 = fmaf(x2.y, sWf[head][k], z1);
+                    }
+                }
+            } else if (has0) {                            // very last edge of the level
+                src0 = pl.src_d[pos0];
+                z0 = edge_term_at<H>(pos0, head, m, et, sWf);
             }
-            if (hasB) {
-                p_sorted[(size_t)posB * H + head] = lB > 0.f ? pB : -pB;
-                if (probs_orig) probs_orig[(size_t)pl.eid_d[posB] * H + head] = pB;
+            if (!has1) src1 = src0;
+            // the first four source rows depend only on the source ids: issue their gathers now, so that they fly
+            // together with the s_src gathers instead of after the softmax (one round trip less per node)
+            const int slast = deg ? __shfl(((deg - 1) & 1) ? src1 : src0, (deg - 1) >> 1, LPH) : 0;
+            float4 r0[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int sk = __shfl((i & 1) ? src1 : src0, i >> 1, LPH);
+                if (i >= deg) sk = slast;
+                r0[i] = deg ? ld4(h + (size_t)sk * FN_D + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            gather_accumulate<H>(acc, h, pA, srcA, deg < LPH ? deg : LPH, lane);
-            if (deg > LPH) gather_accumulate<H>(acc, h, pB, srcB, deg - LPH, lane);
+            if (has0) z0 += sd + s_src[(size_t)src0 * H + head];
+            if (has1) z1 += sd + s_src[(size_t)src1 * H + head];
+            const float l0 = has0 ? (z0 > 0.f ? z0 : slope * z0) : -INFINITY;
+            const float l1 = has1 ? (z1 > 0.f ? z1 : slope * z1) : -INFINITY;
+            const float mx = head_max<LPH>(fmaxf(l0, l1));
+            const float e0 = has0 ? expf(l0 - mx) : 0.f;
+            const float e1 = has1 ? expf(l1 - mx) : 0.f;
+            const float den = head_sum<LPH>(e0 + e1);
+            const float p0 = has0 ? e0 / den : 0.f;
+            const float p1 = has1 ? e1 / den : 0.f;
+            float* pdst = p_sorted + (size_t)head * m + pos0;
+            if (has1) stp(pdst, l0 > 0.f ? p0 : -p0, l1 > 0.f ? p1 : -p1);
+            else if (has0) pdst[0] = l0 > 0.f ? p0 : -p0;
+            if (probs_orig) {
+                if (has0) probs_orig[(size_t)pl.eid_d[pos0] * H + head] = p0;
+                if (has1) probs_orig[(size_t)pl.eid_d[pos0 + 1] * H + head] = p1;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float pk = __shfl((i & 1) ? p1 : p0, i >> 1, LPH);
+                fma4(acc, i < deg ? pk : 0.f, r0[i]);
+            }
+            for (int k0 = 4; k0 < deg; k0 += 4) {
+                float4 r[4];
+                float pk[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = k0 + i;
+                    int sk = __shfl((i & 1) ? src1 : src0, k >> 1, LPH);
+                    pk[i] = __shfl((i & 1) ? p1 : p0, k >> 1, LPH);
+                    if (k >= deg) { sk = slast; pk[i] = 0.f; }
+                    r[i] = ld4(h + (size_t)sk * FN_D + lane * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fma4(acc, pk[i], r[i]);
+            }
         } else {
             // rare high in-degree node: every lane walks the edge list (three passes)
             auto logit = [&](int pos, int& sk) {
                 sk = pl.src_d[pos];
-                const float z = sd + s_src[(size_t)sk * H + head] + edge_term_at<H>(pos, head, et, sWf);
+                const float z = sd + s_src[(size_t)sk * H + head] + edge_term_at<H>(pos, head, m, et, sWf);
                 return z > 0.f ? z : slope * z;
             };
             int sk = 0;
@@ -451,7 +488,7 @@ __global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h,
                 const float l = logit(beg + i, sk);
                 const float p = expf(l - mx) / den;
                 if (j == 0) {
-                    p_sorted[(size_t)(beg + i) * H + head] = l > 0.f ? p : -p;
+                    p_sorted[(size_t)head * m + beg + i] = l > 0.f ? p : -p;
                     if (probs_orig) probs_orig[(size_t)pl.eid_d[beg + i] * H + head] = p;
                 }
                 fma4(acc, p, ld4(h + (size_t)sk * FN_D + lane * 4));
@@ -472,7 +509,7 @@ __global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h,
     }
 }
 
-// Backward kernels use RB rows (half-waves) per block so that the per-block partial rows stay few.
+// Backward kernels use RB rows (half-waves) per block.
 template <int H, int RB>
 __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(const float* __restrict__ g_out, const float* __restrict__ h,
                                                          const float* __restrict__ p_sorted, fn_edge_term et,
@@ -482,69 +519,93 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(const float* __restrict
     constexpr int LPH = 32 / H;
     __shared__ float sP[RB][8][kWfLd];
     const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH, hw = threadIdx.x >> 5;
+    const int64_t m = pl.m;
     float pw[kWfLd];
 #pragma unroll
     for (int k = 0; k < kWfLd; ++k) pw[k] = 0.f;
 
-    // (|p|, dz) of every edge goes to its slot in SOURCE order, so the source pass streams them instead of
-    // gathering through dpos; dz in destination order is only kept where it is a gradient itself (mode 0)
+    // (|p|, dz) of every edge goes to its slot in SOURCE order ([H][m][2]), so the source pass streams them;
+    // dz in destination order is only kept where it is a gradient itself (mode 0: dL/ds_sorted)
     auto emit = [&](int pos, float dz, float pabs) {
-        *reinterpret_cast<float2*>(pz_src + ((size_t)pl.spos_d[pos] * H + head) * 2) = make_float2(pabs, dz);
-        if (et.mode == 0) dz_sorted[(size_t)pos * H + head] = dz;
-        if (et.mode == 2) {
-            pw[FN_MAX_EDGE_K] += dz;
+        stp(pz_src + ((size_t)head * m + pl.spos_d[pos]) * 2, pabs, dz);
+        if (et.mode == 0) dz_sorted[(size_t)head * m + pos] = dz;
+    };
+    auto edge_partials = [&](int pos, float dz) {
+        pw[FN_MAX_EDGE_K] += dz;
 #pragma unroll
-            for (int k = 0; k < FN_MAX_EDGE_K; ++k)
-                if (k < et.K) pw[k] = fmaf(dz, et.x_sorted[(size_t)pos * et.K + k], pw[k]);
-        }
+        for (int k = 0; k < FN_MAX_EDGE_K; ++k)
+            if (k < et.K) pw[k] = fmaf(dz, et.x_sorted[(size_t)k * m + pos], pw[k]);
     };
 
     for (int64_t t = (int64_t)xcd_block(blockIdx.x, gridDim.x) * RB + hw; t < pl.n; t += (int64_t)gridDim.x * RB) {
-        const int beg = pl.rowptr_d[t] - pl.pos_base_d;
-        const int deg = pl.rowptr_d[t + 1] - pl.rowptr_d[t];
+        const i32x2u rp = ldp(pl.rowptr_d + t);
+        const int beg = rp.x - pl.pos_base_d, deg = rp.y - rp.x;
         const float4 g = ld4(g_out + t * FN_D + lane * 4);
         if (deg <= 2 * LPH) {
-            const bool hasA = j < deg, hasB = j + LPH < deg;
-            const float psA = hasA ? p_sorted[(size_t)(beg + j) * H + head] : 0.f;
-            const float psB = hasB ? p_sorted[(size_t)(beg + LPH + j) * H + head] : 0.f;
-            float dpA = 0.f, dpB = 0.f;
+            const int pos0 = beg + 2 * j;
+            const bool has0 = 2 * j < deg, has1 = 2 * j + 1 < deg;
+            int src0 = 0, src1 = 0;
+            float ps0 = 0.f, ps1 = 0.f;
+            if (has0 && pos0 + 1 < m) {
+                const i32x2u sp = ldp(pl.src_d + pos0);
+                const f32x2u pp = ldp(p_sorted + (size_t)head * m + pos0);
+                src0 = sp.x; src1 = sp.y; ps0 = pp.x; ps1 = has1 ? pp.y : 0.f;
+            } else if (has0) {
+                src0 = pl.src_d[pos0];
+                ps0 = p_sorted[(size_t)head * m + pos0];
+            }
+            if (!has1) src1 = src0;
+            float dp0 = 0.f, dp1 = 0.f;
+            const int slast = deg ? __shfl(((deg - 1) & 1) ? src1 : src0, (deg - 1) >> 1, LPH) : 0;
             for (int k0 = 0; k0 < deg; k0 += 4) {
                 float4 r[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int kk = (k0 + i < deg) ? k0 + i : deg - 1;
-                    r[i] = ld4(h + (size_t)pl.src_d[beg + kk] * FN_D + lane * 4);
+                    const int k = k0 + i;
+                    int sk = __shfl((i & 1) ? src1 : src0, k >> 1, LPH);
+                    if (k >= deg) sk = slast;
+                    r[i] = ld4(h + (size_t)sk * FN_D + lane * 4);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float d = head_sum<LPH>(dot4(g, r[i]));
-                    const int k = k0 + i;                    // k >= deg never matches an owned slot that is used
-                    if (k == j) dpA = d;
-                    if (k == j + LPH) dpB = d;
+                    const int k = k0 + i;
+                    if ((k >> 1) == j && k < deg) { if (i & 1) dp1 = d; else dp0 = d; }
                 }
             }
-            const float pA = fabsf(psA), pB = fabsf(psB);
-            const float c = head_sum<LPH>(pA * dpA + pB * dpB);
-            const float dzA = pA * (dpA - c) * ((__float_as_uint(psA) >> 31) ? slope : 1.f);
-            const float dzB = pB * (dpB - c) * ((__float_as_uint(psB) >> 31) ? slope : 1.f);
-            if (hasA) emit(beg + j, dzA, pA);
-            if (hasB) emit(beg + LPH + j, dzB, pB);
-            const float gs = head_sum<LPH>(dzA + dzB);
+            const float p0 = fabsf(ps0), p1 = fabsf(ps1);
+            const float c = head_sum<LPH>(p0 * dp0 + p1 * dp1);
+            const float dz0 = p0 * (dp0 - c) * ((__float_as_uint(ps0) >> 31) ? slope : 1.f);
+            const float dz1 = p1 * (dp1 - c) * ((__float_as_uint(ps1) >> 31) ? slope : 1.f);
+            if (has1) {
+                const i32x2u sq = ldp(pl.spos_d + pos0);
+                stp(pz_src + ((size_t)head * m + sq.x) * 2, p0, dz0);
+                stp(pz_src + ((size_t)head * m + sq.y) * 2, p1, dz1);
+                if (et.mode == 0) stp(dz_sorted + (size_t)head * m + pos0, dz0, dz1);
+                else { edge_partials(pos0, dz0); edge_partials(pos0 + 1, dz1); }
+            } else if (has0) {
+                emit(pos0, dz0, p0);
+                if (et.mode == 2) edge_partials(pos0, dz0);
+            }
+            const float gs = head_sum<LPH>(dz0 + dz1);
             if (j == 0) g_s_dst[t * H + head] = gs;
         } else {
             float c = 0.f;
             for (int k = 0; k < deg; ++k) {
                 const int sk = pl.src_d[beg + k];
                 const float d = head_sum<LPH>(dot4(g, ld4(h + (size_t)sk * FN_D + lane * 4)));
-                c = fmaf(fabsf(p_sorted[(size_t)(beg + k) * H + head]), d, c);
+                c = fmaf(fabsf(p_sorted[(size_t)head * m + beg + k]), d, c);
             }
             float gs = 0.f;
             for (int k = 0; k < deg; ++k) {
                 const int sk = pl.src_d[beg + k];
                 const float d = head_sum<LPH>(dot4(g, ld4(h + (size_t)sk * FN_D + lane * 4)));
-                const float ps = p_sorted[(size_t)(beg + k) * H + head];
+                const float ps = p_sorted[(size_t)head * m + beg + k];
                 const float dz = fabsf(ps) * (d - c) * ((__float_as_uint(ps) >> 31) ? slope : 1.f);
-                if (j == 0) emit(beg + k, dz, fabsf(ps));
+                if (j == 0) {
+                    emit(beg + k, dz, fabsf(ps));
+                    if (et.mode == 2) edge_partials(beg + k, dz);
+                }
                 gs += dz;
             }
             if (j == 0) g_s_dst[t * H + head] = gs;
@@ -580,31 +641,56 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_src(const float* __restrict
     constexpr int LPH = 32 / H;
     __shared__ float sA[RB][2 * FN_D];
     const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH, hw = threadIdx.x >> 5;
+    const int64_t m = pl.m;
     const float4 ad = ld4(att + head * att_w + dst_off + j * 4);
     const float4 as = ld4(att + head * att_w + src_off + j * 4);
     float4 qd = make_float4(0.f, 0.f, 0.f, 0.f), qs = qd;
     for (int64_t s = (int64_t)xcd_block(blockIdx.x, gridDim.x) * RB + hw; s < pl.n; s += (int64_t)gridDim.x * RB) {
-        const int beg = pl.rowptr_s[s] - pl.pos_base_s;
-        const int deg = pl.rowptr_s[s + 1] - pl.rowptr_s[s];
+        const i32x2u rp = ldp(pl.rowptr_s + s);
+        const int beg = rp.x - pl.pos_base_s, deg = rp.y - rp.x;
         const float gsd = g_s_dst[s * H + head];
         const float4 hr = ld4(h + s * FN_D + lane * 4);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         float gss = 0.f;
-        for (int i0 = 0; i0 < deg; i0 += 4) {
-            float4 r[4];
-            float pk[4], dk[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool ok = i0 + i < deg;
-                const int ii = ok ? i0 + i : deg - 1;
-                const int t = pl.dst_s[beg + ii];
-                const float2 pz = *reinterpret_cast<const float2*>(pz_src + ((size_t)(beg + ii) * H + head) * 2);
-                pk[i] = ok ? pz.x : 0.f;
-                dk[i] = ok ? pz.y : 0.f;
-                r[i] = ld4(g_out + (size_t)t * FN_D + lane * 4);
+        if (deg <= 2 * LPH) {
+            const int pos0 = beg + 2 * j;
+            const bool has0 = 2 * j < deg, has1 = 2 * j + 1 < deg;
+            int t0 = 0, t1 = 0;
+            float p0 = 0.f, p1 = 0.f, z0 = 0.f, z1 = 0.f;
+            const float* pzp = pz_src + ((size_t)head * m + pos0) * 2;
+            if (has0 && pos0 + 1 < m) {
+                const i32x2u tp = ldp(pl.dst_s + pos0);
+                const f32x4u v = *reinterpret_cast<const f32x4u*>(pzp);
+                t0 = tp.x; t1 = has1 ? tp.y : tp.x; p0 = v.x; z0 = v.y;
+                if (has1) { p1 = v.z; z1 = v.w; }
+            } else if (has0) {
+                t0 = t1 = pl.dst_s[pos0];
+                const f32x2u v = ldp(pzp);
+                p0 = v.x; z0 = v.y;
             }
+            gss = head_sum<LPH>(z0 + z1);
+            for (int k0 = 0; k0 < deg; k0 += 4) {
+                float4 r[4];
+                float pk[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { fma4(acc, pk[i], r[i]); gss += dk[i]; }
+                for (int i = 0; i < 4; ++i) {
+                    const int k = k0 + i;
+                    const int tk = __shfl((i & 1) ? t1 : t0, k >> 1, LPH);
+                    pk[i] = __shfl((i & 1) ? p1 : p0, k >> 1, LPH);
+                    r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k < deg) r[i] = ld4(g_out + (size_t)tk * FN_D + lane * 4);
+                    else pk[i] = 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fma4(acc, pk[i], r[i]);
+            }
+        } else {
+            for (int i = 0; i < deg; ++i) {
+                const int t = pl.dst_s[beg + i];
+                const f32x2u v = ldp(pz_src + ((size_t)head * m + beg + i) * 2);
+                fma4(acc, v.x, ld4(g_out + (size_t)t * FN_D + lane * 4));
+                gss += v.y;
+            }
         }
         fma4(acc, gsd, ad);
         fma4(acc, gss, as);
@@ -705,7 +791,7 @@ __global__ void k_attn_by_src(const float* __restrict__ p_sorted, fn_gat_plan pl
         const int head = (int)(i % H);
         const int beg = pl.rowptr_s[s] - pl.pos_base_s, deg = pl.rowptr_s[s + 1] - pl.rowptr_s[s];
         float a = 0.f;
-        for (int k = 0; k < deg; ++k) a += fabsf(p_sorted[(size_t)pl.dpos_s[beg + k] * H + head]);
+        for (int k = 0; k < deg; ++k) a += fabsf(p_sorted[(size_t)head * pl.m + pl.dpos_s[beg + k]]);
         attn[i] = a;
     }
 }
@@ -738,7 +824,7 @@ __global__ __launch_bounds__(kBlock) void k_row_dots_sorted(const float* __restr
                 }
             }
         }
-        if (lane < J) s_sorted[pos * J + lane] = mine;
+        if (lane < J) s_sorted[(size_t)lane * pl.m + pos] = mine;        // head-major [J][m]
     }
 }
 
@@ -767,7 +853,7 @@ __global__ __launch_bounds__(kBlock) void k_row_dots_sorted_bwd(const float* __r
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if (i < J) {
-                const float gs = g_s_sorted[pos * J + i];
+                const float gs = g_s_sorted[(size_t)i * pl.m + pos];
                 fma4(acc, gs, a[i]);
                 fma4(q[i], gs, v);
             }
@@ -798,7 +884,7 @@ __global__ void k_sort_edge_attr(const float* __restrict__ x, int K, fn_gat_plan
         const int64_t pos = i / K;
         const int k = (int)(i % K);
         const int eid = pl.eid_d[pos];
-        x_sorted[i] = eid < pl.m_real ? x[(size_t)eid * K + k] : 0.f;
+        x_sorted[(size_t)k * pl.m + pos] = eid < pl.m_real ? x[(size_t)eid * K + k] : 0.f;   // [K][m]
     }
 }
 
@@ -1494,7 +1580,8 @@ int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const
     if (plan->m > 0 && !p_sorted) return fail(FN_EINVAL, "fn_gat_fwd_f32: null p_sorted");
     if (et->mode == 0 && plan->m > 0 && !et->s_sorted) return fail(FN_EINVAL, "fn_gat_fwd_f32: null s_sorted");
     if (plan->n == 0) return 0;
-    FN_DISPATCH_H(heads, hipLaunchKernelGGL(k_gat_fwd<HH>, dim3(row_grid(plan->n, 8 * kGridCap)), dim3(kBlock), 0, S(stream),
+    static const int fwd_cap = getenv("FN_FWD_CAP") ? atoi(getenv("FN_FWD_CAP")) : 8 * kGridCap;
+    FN_DISPATCH_H(heads, hipLaunchKernelGGL(k_gat_fwd<HH>, dim3(row_grid(plan->n, fwd_cap)), dim3(kBlock), 0, S(stream),
                                             h, s_dst, s_src, att, att_w, *et, *plan, neg_slope, out, p_sorted, probs_orig, ep));
     return launch_status("fn_gat_fwd_f32");
 }

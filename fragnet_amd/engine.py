@@ -41,7 +41,7 @@ def _describe(plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fat
     e = Encoder()
     e.n_layers, e.heads = n_layers, heads
     e.k_atom0, e.k_bond0, e.k_fbond0 = x_atoms.shape[1], bond_nodes.shape[1], fbond_nodes.shape[1]
-    e.k_fattr = fattr_sorted.shape[1]
+    e.k_fattr = fattr_sorted.shape[0]
     e.training, e.drop_p = int(training), float(drop_p)
     e.seed, e.offset = seed, offset
     L = plan.levels

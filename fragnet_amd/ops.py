@@ -44,9 +44,9 @@ def _part_rows(n: int) -> int:
 class _GatLevel(torch.autograd.Function):
     """out[n,128] = sum_e softmax_dst(LeakyReLU(s_dst + s_src + s_edge))_e * h[src_e].
 
-    Inputs (differentiable): h [n,128]; att [H, att_w]; then either s_sorted [m,H] (mode 0: the edge term in
-    destination-sorted order, from row_dots_sorted) or x_sorted [m,K] (mode 2: the raw edge attribute in
-    destination-sorted order, not differentiated) with embW [d,K], embb [d]."""
+    Inputs (differentiable): h [n,128]; att [H, att_w]; then either s_sorted [H,m] (mode 0: the edge term in
+    destination-sorted order, head-major, from row_dots_sorted) or x_sorted [K,m] (mode 2: the raw edge attribute
+    in destination-sorted order, not differentiated) with embW [d,K], embb [d]."""
 
     @staticmethod
     def forward(ctx, h, att, s_sorted, x_sorted, embW, embb, level: Level, heads: int, dst_off: int, mid_off: int,
@@ -61,13 +61,13 @@ class _GatLevel(torch.autograd.Function):
         mode = 0 if x_sorted is None else 2
         if mode == 0:
             s_sorted = _f32c(s_sorted, "s_sorted")
-            if s_sorted.shape != (m, heads):
-                raise ValueError(f"s_sorted must be [{m}, {heads}], got {tuple(s_sorted.shape)}")
+            if s_sorted.shape != (heads, m):
+                raise ValueError(f"s_sorted must be head-major [{heads}, {m}], got {tuple(s_sorted.shape)}")
             et = EdgeTerm(0, 0, 0, 0, s_sorted.data_ptr(), None, None, None)
         else:
             x_sorted, embW, embb = _f32c(x_sorted, "x_sorted"), _f32c(embW, "embW"), _f32c(embb, "embb")
-            K = x_sorted.shape[1]
-            if x_sorted.shape[0] != m or embW.shape != (FN_D // heads, K):
+            K = x_sorted.shape[0]
+            if x_sorted.shape[1] != m or embW.shape != (FN_D // heads, K):
                 raise ValueError("edge attribute / embedding shapes do not match the plan")
             et = EdgeTerm(2, K, FN_D // heads, mid_off, None, x_sorted.data_ptr(), embW.data_ptr(), embb.data_ptr())
         st = _stream_ptr(dev)
@@ -76,7 +76,7 @@ class _GatLevel(torch.autograd.Function):
         _lib.call("fn_node_scalars_f32", h.data_ptr(), att.data_ptr(), att_w, dst_off, src_off, s_dst.data_ptr(),
                   s_src.data_ptr(), n, heads, st)
         out = torch.empty((n, FN_D), dtype=torch.float32, device=dev)
-        p_sorted = torch.empty((m, heads), dtype=torch.float32, device=dev)
+        p_sorted = torch.empty((heads, m), dtype=torch.float32, device=dev)      # head-major
         probs = torch.empty((m, heads), dtype=torch.float32, device=dev) if want_probs else None
         _lib.call("fn_gat_fwd_f32", h.data_ptr(), s_dst.data_ptr(), s_src.data_ptr(), att.data_ptr(), att_w,
                   C.byref(et), C.byref(level.c), NEG_SLOPE, out.data_ptr(), p_sorted.data_ptr(), _ptr(probs), None, heads, st)
@@ -105,11 +105,11 @@ class _GatLevel(torch.autograd.Function):
             et = EdgeTerm(0, 0, 0, 0, None, None, None, None)
             part_e = None
         else:
-            K = x_sorted.shape[1]
+            K = x_sorted.shape[0]
             et = EdgeTerm(2, K, FN_D // heads, mid_off, None, x_sorted.data_ptr(), embW.data_ptr(), embb.data_ptr())
             part_e = torch.empty((FN_MAX_PART, heads * (K + 1)), dtype=torch.float32, device=dev)
-        dz = torch.empty((m, heads), dtype=torch.float32, device=dev) if mode == 0 else None
-        pz = torch.empty((m, heads, 2), dtype=torch.float32, device=dev)
+        dz = torch.empty((heads, m), dtype=torch.float32, device=dev) if mode == 0 else None
+        pz = torch.empty((heads, m, 2), dtype=torch.float32, device=dev)
         g_s_dst = torch.empty((n, heads), dtype=torch.float32, device=dev)
         n_e, n_a = C.c_int(0), C.c_int(0)
         _lib.call("fn_gat_bwd_dst_f32", g_out.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), C.byref(et),
@@ -151,7 +151,7 @@ class _RowDotsSorted(torch.autograd.Function):
         J = A.shape[0]
         if feat.shape != (level.m_real, FN_D):
             raise ValueError(f"feat must be [{level.m_real}, {FN_D}], got {tuple(feat.shape)}")
-        s = torch.empty((level.m, J), dtype=torch.float32, device=feat.device)
+        s = torch.empty((J, level.m), dtype=torch.float32, device=feat.device)      # head-major
         _lib.call("fn_row_dots_sorted_f32", feat.data_ptr(), A.data_ptr(), A.shape[1], off, J, C.byref(level.c), s.data_ptr(),
                   _stream_ptr(feat.device))
         ctx.off, ctx.level = off, level

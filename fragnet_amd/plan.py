@@ -135,7 +135,7 @@ class GraphPlan:
         K = x.shape[1] if x.dim() == 2 else 1
         if x.numel() != lv.m_real * K:
             raise ValueError(f"edge attribute of level {name} has {x.shape[0]} rows, the plan has {lv.m_real} edges")
-        out = torch.empty((lv.m, K), dtype=torch.float32, device=x.device)
+        out = torch.empty((K, lv.m), dtype=torch.float32, device=x.device)      # [K][m]: a lane's two edges are adjacent
         _lib.call("fn_sort_edge_attr_f32", x.data_ptr(), K, C.byref(lv.c), out.data_ptr(), _stream_ptr(x.device))
         self._sorted[name] = (key, out)
         return out

@@ -103,7 +103,9 @@ int fn_node_scalars_f32(const float* h /*[n,128]*/, const float* att, int att_w,
                         float* s_dst /*[n,H]*/, float* s_src /*[n,H]*/, int64_t n, int heads, fn_stream_t stream);
 
 /* Edge term of the logit, always addressed by DESTINATION-SORTED edge position (coalesced, no
- * dependent gather).  mode 0: s_sorted [m,H] given (fn_row_dots_sorted_f32; 0 at loop positions).
+ * dependent gather).  All per-edge arrays of a level are HEAD-MAJOR ([H][m], [K][m]): the two consecutive
+ * in-edges a lane owns are then one 8-byte load.
+ * mode 0: s_sorted [H,m] given (fn_row_dots_sorted_f32; 0 at loop positions).
  * mode 2: s[pos,h] = <embW x_sorted[pos] + embb, att[h, mid_off:+d_e]> folded in-kernel (the reference's
  * edge_attr_bond_embed / edge_attr_fbond_embed Linear(K -> d_e), gat2.py:139,242); x_sorted is the raw
  * attribute permuted once per batch by fn_sort_edge_attr_f32 (it is the same in every layer). */
@@ -112,8 +114,8 @@ typedef struct fn_edge_term {
     int32_t K;                /* mode 2: raw attribute width (1 or 6) */
     int32_t d_e;              /* mode 2: embed width (= head_dim)     */
     int32_t mid_off;          /* mode 2: offset of the edge block in att */
-    const float* s_sorted;    /* mode 0: [m, H] */
-    const float* x_sorted;    /* mode 2: [m, K] */
+    const float* s_sorted;    /* mode 0: [H, m] */
+    const float* x_sorted;    /* mode 2: [K, m] */
     const float* embW;        /* mode 2: [d_e, K]    */
     const float* embb;        /* mode 2: [d_e]       */
 } fn_edge_term;
@@ -143,7 +145,7 @@ typedef struct fn_act_epilogue {
     uint64_t seed, offset;
 } fn_act_epilogue;
 
-/* p_sorted [m,H]: probabilities in destination-sorted order; the sign bit carries "z_e <= 0"
+/* p_sorted [H,m] (head-major): probabilities in destination-sorted order; the sign bit carries "z_e <= 0"
  * (the LeakyReLU branch) for the backward pass.  probs_orig (nullable) [m,H] in original edge
  * order, unsigned -- the reference's attn_probs. */
 int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const float* att, int att_w,

@@ -89,7 +89,7 @@ def test_plan_matches_stable_argsort():
     assert np.array_equal(spos, want_spos)
     # raw edge attributes permuted into destination order, zeros on the loop positions
     attr = torch.arange(ei.shape[1] * 3, dtype=torch.float32, device=DEV).view(-1, 3)
-    got = plan.sorted_attr("atom", attr).cpu().numpy()
+    got = plan.sorted_attr("atom", attr).cpu().numpy().T          # stored [K][m]
     want = np.concatenate([attr.cpu().numpy(), np.zeros((N, 3), np.float32)])[order]
     assert np.array_equal(got, want)
     assert np.array_equal(rps, np.concatenate([[0], np.cumsum(np.bincount(src, minlength=N))]))
@@ -248,7 +248,7 @@ def test_gat_level_isolated_nodes_and_empty_graph():
     plan = GraphPlan([dict(kind="gat", name="l", dst=dst, src=src, n=n, n_loops=0)], DEV)
     h = torch.randn(n, 128, device=DEV)
     att = torch.randn(4, 192, device=DEV)
-    out = ops.gat_level(h, att, plan.levels["l"], 4, s_sorted=torch.zeros(3, 4, device=DEV))
+    out = ops.gat_level(h, att, plan.levels["l"], 4, s_sorted=torch.zeros(4, 3, device=DEV))
     assert torch.equal(out[1:9], torch.zeros(8, 128, device=DEV))        # no in-edges => zero row, like scatter_add
     torch.testing.assert_close(out[9], h[3])                             # single in-edge => probability 1
     assert torch.isfinite(out).all()
