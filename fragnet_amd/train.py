@@ -1,0 +1,261 @@
+"""Training loops, config and checkpoint handling with the reference's semantics.
+
+Counterparts of
+  fragnet/train/utils.py:13-56      EarlyStopping (checkpoint = plain ``state_dict`` on every improvement)
+  fragnet/train/utils.py:297-304    compute_bce_loss (masked BCE-with-logits)
+  fragnet/train/utils.py:307-492    TrainerFineTune (train_regr / train_clsf_bce / validate / test)
+  fragnet/train/pretrain/pretrain_utils.py:4-56   pretrain Trainer (2*MSE(dihedral)+MSE(angle)+MSE(energy): the
+                                    bond-length term is overwritten before use there, reproduced here)
+  fragnet/train/finetune/finetune_gat2.py:17-26,68-288 / pretrain/pretrain_gat2.py:79-183   drivers (see scripts/)
+Config: one YAML per run with ``${key}`` interpolation and attribute + item access (the reference uses OmegaConf,
+which is not installed in the build image; PyYAML + a 20-line resolver cover the schema of exps/**.yaml).
+
+Loss values returned by ``train`` follow the reference's normalisation quirk: the sum of per-batch MEAN losses
+divided by the number of molecules in the dataset (train/utils.py:351).
+"""
+from __future__ import annotations
+
+import os
+import pickle
+import random
+import re
+from typing import Dict, Iterable, Optional
+
+import numpy as np
+import torch
+import yaml
+
+from . import parallel
+from .dataset import BatchSampler, FlatMolStore
+
+
+# ------------------------------------------------------------------------------------ config
+class Config(dict):
+    """dict with attribute access, recursively (args.finetune.model.h1 and args['exp_dir'] both work)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _wrap(node):
+    if isinstance(node, dict):
+        return Config({k: _wrap(v) for k, v in node.items()})
+    if isinstance(node, list):
+        return [_wrap(v) for v in node]
+    return node
+
+
+def _resolve(node, root):
+    if isinstance(node, dict):
+        for k in node:
+            node[k] = _resolve(node[k], root)
+    elif isinstance(node, list):
+        return [_resolve(v, root) for v in node]
+    elif isinstance(node, str):
+        def sub(mt):
+            cur = root
+            for part in mt.group(1).split("."):
+                cur = cur[part]
+            return str(cur)
+        for _ in range(8):
+            new = re.sub(r"\$\{([^}]+)\}", sub, node)
+            if new == node:
+                break
+            node = new
+    return node
+
+
+def load_config(path: str, **overrides) -> Config:
+    with open(path) as f:
+        cfg = _wrap(yaml.safe_load(f))
+    cfg.update(overrides)
+    return _resolve(cfg, cfg)
+
+
+def seed_everything(seed: int):
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------------ early stopping / checkpoints
+class EarlyStopping:
+    def __init__(self, patience=7, verbose=False, delta=0, chkpoint_name="gnn_best.pt"):
+        self.patience, self.verbose, self.delta, self.chkpoint_name = patience, verbose, delta, chkpoint_name
+        self.counter, self.best_score, self.early_stop, self.val_loss_min = 0, None, False, float("inf")
+
+    def __call__(self, val_loss, model):
+        score = -val_loss
+        if self.best_score is None or not (score < self.best_score + self.delta):
+            self.best_score = score
+            self.save_checkpoint(val_loss, model)
+            self.counter = 0
+        else:
+            self.counter += 1
+            if self.verbose:
+                print(f"EarlyStopping counter: {self.counter} out of {self.patience}")
+            if self.counter >= self.patience:
+                self.early_stop = True
+
+    def save_checkpoint(self, val_loss, model):
+        if self.verbose:
+            print(f"Validation loss decreased ({self.val_loss_min:.6f} --> {val_loss:.6f}).  Saving model ...")
+        os.makedirs(os.path.dirname(os.path.abspath(self.chkpoint_name)), exist_ok=True)
+        torch.save(model.state_dict(), self.chkpoint_name)
+        self.val_loss_min = val_loss
+
+
+# ------------------------------------------------------------------------------------ losses
+def compute_bce_loss(prediction, target):
+    valid = target > -0.5
+    mat = torch.nn.functional.binary_cross_entropy_with_logits(prediction, target, reduction="none")
+    return torch.where(valid, mat, torch.zeros_like(mat)).sum() / valid.sum()
+
+
+def pretrain_loss(outputs, batch, scales=(1.0, 1.0)):
+    """loss_lngth(:= MSE(dihedral)) + loss_angle + loss_lngth + loss_E.  ``scales`` = (per-edge, per-atom) weights
+    that make rank-averaged gradients equal the global-mean gradients (parallel.weighted_loss_scale)."""
+    _, ba, da, graph_rep = outputs
+    mse = torch.nn.functional.mse_loss
+    l_dh = mse(da, batch["dh_angl"]) * scales[0]
+    return l_dh + mse(ba, batch["bnd_angl"]) * scales[1] + l_dh + mse(graph_rep.view(-1), batch["y"])
+
+
+# ------------------------------------------------------------------------------------ loaders
+class StoreLoader:
+    """Iterates batch dicts from a FlatMolStore (on the GPU when the store lives there)."""
+
+    def __init__(self, store: FlatMolStore, batch_size: int, shuffle=False, drop_last=False, pretrain=False, seed=0,
+                 device=None, rank=0, world=1):
+        self.store, self.pretrain, self.device = store, pretrain, device
+        self.sampler = BatchSampler(len(store), batch_size, shuffle, drop_last, seed, rank, world)
+        self.dataset = store            # len(loader.dataset) is what the reference normalises losses by
+
+    def __iter__(self):
+        for idx in self.sampler:
+            batch = self.store.collate(idx.to(self.store.device), pretrain=self.pretrain)
+            if self.device is not None and batch["x_atoms"].device != torch.device(self.device):
+                batch = {k: v.to(self.device, non_blocking=True) for k, v in batch.items()}
+            yield batch
+
+    def __len__(self):
+        return len(self.sampler)
+
+
+# ------------------------------------------------------------------------------------ trainers
+class TrainerFineTune:
+    def __init__(self, target_pos=None, target_type="regr", n_multi_task_heads=0):
+        self.target_type = target_type
+        if target_type == "regr":
+            self.loss_fn = torch.nn.MSELoss()
+        elif target_type == "clsf":
+            self.loss_fn = compute_bce_loss
+        else:
+            raise NotImplementedError(f"target_type {target_type!r} is outside the FragNet gat2 hot path")
+
+    def _loss(self, model, batch):
+        out = model(batch)
+        if self.target_type == "regr":
+            return self.loss_fn(out.view(-1), batch["y"])
+        return self.loss_fn(out, batch["y"].view(out.shape))
+
+    def train(self, model, loader, optimizer, scheduler=None, device=None, val_loader=None):
+        """``optimizer``: torch.optim.Optimizer or parallel.FlatAdam."""
+        model.train()
+        total = 0.0
+        losses = []
+        for batch in loader:
+            optimizer.zero_grad()
+            loss = self._loss(model, batch)
+            loss.backward()
+            optimizer.step()
+            losses.append(loss.detach())
+        if losses:
+            total = float(torch.stack(losses).sum())        # one synchronisation per epoch, not per step
+        if scheduler:
+            scheduler.step()
+        return total / len(loader.dataset)
+
+    @torch.no_grad()
+    def validate(self, model, loader, device=None):
+        model.eval()
+        losses = [self._loss(model, batch) for batch in loader]
+        return float(torch.stack(losses).sum()) / len(loader.dataset) if losses else 0.0
+
+    @torch.no_grad()
+    def test(self, model, loader, device=None):
+        """regr: (mse, true, pred); clsf: (mean ROC-AUC over tasks with both classes, true, pred)."""
+        model.eval()
+        true, pred = [], []
+        for batch in loader:
+            out = model(batch)
+            true.append(batch["y"].reshape(out.shape[0], -1).cpu())
+            pred.append(out.reshape(out.shape[0], -1).cpu())
+        t, p = torch.cat(true).numpy(), torch.cat(pred).numpy()
+        if self.target_type == "regr":
+            return float(((t.ravel() - p.ravel()) ** 2).mean()), t.ravel(), p.ravel()
+        from sklearn.metrics import roc_auc_score
+        aucs = []
+        for c in range(t.shape[1]):
+            ok = t[:, c] > -0.5
+            if ok.any() and len(np.unique(t[ok, c])) == 2:
+                aucs.append(roc_auc_score(t[ok, c], p[ok, c]))
+        return float(np.mean(aucs)) if aucs else float("nan"), t, p
+
+
+class PretrainTrainer:
+    def __init__(self, loss_fn=None):
+        self.loss_fn = loss_fn
+
+    def train(self, model, loader, optimizer, device=None):
+        model.train()
+        losses = []
+        for batch in loader:
+            optimizer.zero_grad()
+            scales = (1.0, 1.0)
+            if parallel.dist.is_available() and parallel.dist.is_initialized() and parallel.dist.get_world_size() > 1:
+                dev = batch["x_atoms"].device
+                scales = (parallel.weighted_loss_scale(batch["dh_angl"].shape[0], dev),
+                          parallel.weighted_loss_scale(batch["bnd_angl"].shape[0], dev))
+            loss = pretrain_loss(model(batch), batch, scales)
+            loss.backward()
+            optimizer.step()
+            losses.append(loss.detach())
+        return float(torch.stack(losses).sum()) / len(loader.dataset) if losses else 0.0
+
+    @torch.no_grad()
+    def validate(self, loader, model, device=None):
+        model.eval()
+        losses = [pretrain_loss(model(batch), batch) for batch in loader]
+        return float(torch.stack(losses).sum()) / len(loader.dataset) if losses else 0.0
+
+
+def make_optimizer(model, lr: float, probe_batch: Optional[Dict[str, torch.Tensor]] = None, loss_of=None):
+    """parallel.FlatAdam over the live parameters when a probe batch is given (GPU path), else torch Adam."""
+    if probe_batch is None:
+        return torch.optim.Adam(model.parameters(), lr=lr)
+
+    def probe():
+        was = model.training
+        model.train()
+        loss_of(model, probe_batch).backward()
+        model.train(was)
+    return parallel.FlatAdam.for_live_parameters(model, probe, lr=lr)
+
+
+def save_predictions(trainer, loader, model, exp_dir, save_name="test_res", loss_type="mse", seed=123):
+    score, true, pred = trainer.test(model=model, loader=loader)
+    acc = score ** 0.5 if loss_type == "mse" else score
+    os.makedirs(exp_dir, exist_ok=True)
+    with open(os.path.join(exp_dir, f"{save_name}_{seed}.pkl"), "wb") as f:
+        pickle.dump({"acc": acc, "true": true, "pred": pred, "smiles": getattr(loader.dataset, "smiles", None)}, f)
+    return acc

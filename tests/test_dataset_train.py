@@ -1,0 +1,64 @@
+"""Flat store / sampler / config / early-stopping host logic (CPU)."""
+import os
+
+import pytest
+import torch
+
+from fragnet_amd import data as fdata, synth, train
+from fragnet_amd.dataset import BatchSampler, FlatMolStore
+
+
+@pytest.mark.parametrize("profile,pt", [("esol", False), ("tox21", False), ("esol", True)])
+def test_flat_store_collate_equals_record_collate(profile, pt, tmp_path):
+    mols = synth.synth_molecules(23, seed=5, profile=profile, pretrain_targets=pt, p_salt=0.2)
+    store = FlatMolStore.from_records(mols)
+    path = tmp_path / "s.pt"
+    store.save(str(path))
+    store = FlatMolStore.load(str(path))
+    idx = [7, 0, 22, 3, 3, 11]
+    got = store.collate(idx, pretrain=pt)
+    want = (fdata.collate_fn_pt if pt else fdata.collate_fn)([mols[i] for i in idx])
+    assert list(got.keys()) == list(want.keys())
+    for k in want:
+        assert got[k].dtype == want[k].dtype, k
+        assert torch.equal(got[k], want[k]), k
+
+
+def test_batch_sampler_semantics():
+    s = BatchSampler(10, 4, shuffle=False, drop_last=True)
+    assert [b.tolist() for b in s] == [[0, 1, 2, 3], [4, 5, 6, 7]] and len(s) == 2
+    s = BatchSampler(10, 4, shuffle=False, drop_last=False)
+    assert [b.tolist() for b in s][-1] == [8, 9] and len(s) == 3
+    a = BatchSampler(16, 8, shuffle=True, drop_last=True, seed=3, rank=0, world=2)
+    b = BatchSampler(16, 8, shuffle=True, drop_last=True, seed=3, rank=1, world=2)
+    for x, y in zip(a, b):           # two ranks split every global batch, no overlap
+        assert len(x) == len(y) == 4 and not set(x.tolist()) & set(y.tolist())
+
+
+def test_config_interpolation_and_access(tmp_path):
+    p = tmp_path / "c.yaml"
+    p.write_text("seed: 1\nexp_dir: runs/x\nfinetune:\n  chkpoint_name: ${exp_dir}/ft.pt\n  model:\n    h1: 128\n")
+    cfg = train.load_config(str(p), config=str(p))
+    assert cfg.finetune.chkpoint_name == "runs/x/ft.pt" and cfg["exp_dir"] == "runs/x" and cfg.finetune.model.h1 == 128
+    for shipped in ("exps/ft/esol_synth/config.yaml", "exps/pt/synth/config.yaml"):
+        c = train.load_config(os.path.join(os.path.dirname(os.path.dirname(__file__)), shipped))
+        assert c.pretrain.num_layer == 4 and "${" not in str(c.pretrain.chkpoint_name)
+
+
+def test_early_stopping_matches_reference_rule(tmp_path):
+    net = torch.nn.Linear(2, 1)
+    es = train.EarlyStopping(patience=2, chkpoint_name=str(tmp_path / "best.pt"))
+    for v in (1.0, 0.8, 0.9, 0.85):
+        es(v, net)
+    assert es.early_stop and es.val_loss_min == 0.8 and os.path.exists(tmp_path / "best.pt")
+
+
+def test_masked_bce_and_pretrain_loss_match_oracle():
+    from oracle import fragnet_ref as ref
+    g = torch.Generator().manual_seed(0)
+    out = torch.randn(5, 12, generator=g)
+    y = torch.randint(-1, 2, (5, 12), generator=g).float()
+    assert torch.equal(train.compute_bce_loss(out, y), ref.finetune_bce_loss(out, y))
+    outs = tuple(torch.randn(n, 1, generator=g) for n in (9, 6, 9, 3))
+    batch = {"dh_angl": torch.randn(9, 1, generator=g), "bnd_angl": torch.randn(6, 1, generator=g), "y": torch.randn(3, generator=g)}
+    assert torch.equal(train.pretrain_loss(outs, batch), ref.pretrain_loss(outs, batch))
