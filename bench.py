@@ -139,7 +139,7 @@ def kernel_roofline(batch, model, iters=50):
 
     def bwd_dst():
         _lib.call("fn_gat_bwd_dst_f32", gout.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), C.byref(et), C.byref(lv.c), 0.2,
-                  dz.data_ptr(), pz.data_ptr(), g_s_dst.data_ptr(), part_e.data_ptr(), C.byref(n_e), H, st)
+                  dz.data_ptr(), None, pz.data_ptr(), g_s_dst.data_ptr(), part_e.data_ptr(), C.byref(n_e), H, st)
 
     def bwd_src():
         _lib.call("fn_gat_bwd_src_f32", gout.data_ptr(), h.data_ptr(), pz.data_ptr(), g_s_dst.data_ptr(),

@@ -71,7 +71,7 @@ SIGNATURES = {
     "fn_node_scalars_f32": [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, i64, C.c_int, vp],
     "fn_gat_fwd_f32": [vp, vp, vp, vp, C.c_int, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp,
                        C.POINTER(ActEpilogue), C.c_int, vp],
-    "fn_gat_bwd_dst_f32": [vp, vp, vp, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp, vp, ip, C.c_int, vp],
+    "fn_gat_bwd_dst_f32": [vp, vp, vp, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp, vp, vp, ip, C.c_int, vp],
     "fn_gat_bwd_src_f32": [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(GatPlan), vp, vp, ip, C.c_int, vp],
     "fn_gat_bwd_finalize_f32": [vp, C.c_int, vp, C.c_int, C.POINTER(EdgeTerm), vp, C.c_int, C.c_int, C.c_int, vp, vp, vp,
                                 C.c_int, vp],

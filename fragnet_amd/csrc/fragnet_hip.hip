@@ -514,8 +514,8 @@ template <int H, int RB>
 __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(const float* __restrict__ g_out, const float* __restrict__ h,
                                                          const float* __restrict__ p_sorted, fn_edge_term et,
                                                          fn_gat_plan pl, float slope, float* __restrict__ dz_sorted,
-                                                         float* __restrict__ pz_src, float* __restrict__ g_s_dst,
-                                                         float* __restrict__ part_e) {
+                                                         float* __restrict__ g_s_orig, float* __restrict__ pz_src,
+                                                         float* __restrict__ g_s_dst, float* __restrict__ part_e) {
     constexpr int LPH = 32 / H;
     __shared__ float sP[RB][8][kWfLd];
     const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH, hw = threadIdx.x >> 5;
@@ -528,7 +528,10 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(const float* __restrict
     // dz in destination order is only kept where it is a gradient itself (mode 0: dL/ds_sorted)
     auto emit = [&](int pos, float dz, float pabs) {
         stp(pz_src + ((size_t)head * m + pl.spos_d[pos]) * 2, pabs, dz);
-        if (et.mode == 0) dz_sorted[(size_t)head * m + pos] = dz;
+        if (et.mode == 0) {
+            if (dz_sorted) dz_sorted[(size_t)head * m + pos] = dz;
+            if (g_s_orig) { const int eid = pl.eid_d[pos]; if (eid < pl.m_real) g_s_orig[(size_t)eid * H + head] = dz; }
+        }
     };
     auto edge_partials = [&](int pos, float dz) {
         pw[FN_MAX_EDGE_K] += dz;
@@ -581,8 +584,14 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(const float* __restrict
                 const i32x2u sq = ldp(pl.spos_d + pos0);
                 stp(pz_src + ((size_t)head * m + sq.x) * 2, p0, dz0);
                 stp(pz_src + ((size_t)head * m + sq.y) * 2, p1, dz1);
-                if (et.mode == 0) stp(dz_sorted + (size_t)head * m + pos0, dz0, dz1);
-                else { edge_partials(pos0, dz0); edge_partials(pos0 + 1, dz1); }
+                if (et.mode == 0) {
+                    if (dz_sorted) stp(dz_sorted + (size_t)head * m + pos0, dz0, dz1);
+                    if (g_s_orig) {                         // gradient of the edge term in ORIGINAL edge order, [m_real][H]
+                        const i32x2u eq = ldp(pl.eid_d + pos0);
+                        if (eq.x < pl.m_real) g_s_orig[(size_t)eq.x * H + head] = dz0;
+                        if (eq.y < pl.m_real) g_s_orig[(size_t)eq.y * H + head] = dz1;
+                    }
+                } else { edge_partials(pos0, dz0); edge_partials(pos0 + 1, dz1); }
             } else if (has0) {
                 emit(pos0, dz0, p0);
                 if (et.mode == 2) edge_partials(pos0, dz0);
@@ -833,7 +842,8 @@ __global__ __launch_bounds__(kBlock) void k_row_dots_sorted_bwd(const float* __r
                                                                 const float* __restrict__ feat,
                                                                 const float* __restrict__ A, int lda, int off, int J,
                                                                 fn_gat_plan pl, float* g_feat,
-                                                                float* __restrict__ part, const float* addend) {
+                                                                float* __restrict__ part, const float* addend,
+                                                                int g_is_orig) {
     __shared__ float sR[kRows][FN_D];
     const int lane = threadIdx.x & 31, hw = threadIdx.x >> 5;
     float4 a[8], q[8];
@@ -842,18 +852,21 @@ __global__ __launch_bounds__(kBlock) void k_row_dots_sorted_bwd(const float* __r
         a[i] = (i < J) ? ld4(A + i * lda + off + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // rows are walked in original edge order (sequential feat / g_feat rows).  The per-head gradient comes either in
+    // original order, edge-major [m_real][J] (written that way by the destination pass: one 16-byte read), or in
+    // destination-sorted head-major order [J][m] through the inverse permutation (autograd path)
     int64_t g0, g1;
     block_groups(pl.m_real, kRows, g0, g1);
     for (int64_t gi = g0; gi < g1; ++gi) {
         const int64_t e = gi * kRows + hw;
         if (e >= pl.m_real) continue;
-        const size_t pos = (size_t)pl.inv_d[e];
+        const size_t pos = g_is_orig ? 0 : (size_t)pl.inv_d[e];
         const float4 v = ld4(feat + e * FN_D + lane * 4);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if (i < J) {
-                const float gs = g_s_sorted[(size_t)i * pl.m + pos];
+                const float gs = g_is_orig ? g_s_sorted[(size_t)e * J + i] : g_s_sorted[(size_t)i * pl.m + pos];
                 fma4(acc, gs, a[i]);
                 fma4(q[i], gs, v);
             }
@@ -1587,11 +1600,11 @@ int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const
 }
 
 int fn_gat_bwd_dst_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et,
-                       const fn_gat_plan* plan, float neg_slope, float* dz_sorted, float* pz_src, float* g_s_dst,
-                       float* part_e, int* n_part_e, int heads, fn_stream_t stream) {
+                       const fn_gat_plan* plan, float neg_slope, float* dz_sorted, float* g_s_orig, float* pz_src,
+                       float* g_s_dst, float* part_e, int* n_part_e, int heads, fn_stream_t stream) {
     if (!g_out || !h || !plan || !g_s_dst || !n_part_e || !et) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: bad argument");
     if (et->mode != 0 && bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: bad edge term");
-    if (plan->m > 0 && (!p_sorted || !pz_src || !plan->spos_d || (et->mode == 0 && !dz_sorted)))
+    if (plan->m > 0 && (!p_sorted || !pz_src || !plan->spos_d || (et->mode == 0 && !dz_sorted && !g_s_orig)))
         return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: null edge buffer");
     if (et->mode == 2 && !part_e) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: null part_e");
     *n_part_e = 0;
@@ -1599,7 +1612,7 @@ int fn_gat_bwd_dst_f32(const float* g_out, const float* h, const float* p_sorted
     const int g = bwd_grid(plan->n);
     *n_part_e = (et->mode == 2) ? g : 0;
     FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_dst<HH, kBwdRows>), dim3(g), dim3(kBwdRows * 32), 0, S(stream), g_out, h,
-                                            p_sorted, *et, *plan, neg_slope, dz_sorted, pz_src, g_s_dst, part_e));
+                                            p_sorted, *et, *plan, neg_slope, dz_sorted, g_s_orig, pz_src, g_s_dst, part_e));
     return launch_status("fn_gat_bwd_dst_f32");
 }
 
@@ -1611,7 +1624,9 @@ int fn_gat_bwd_src_f32(const float* g_out, const float* h, const float* pz_src,
     if ((att_w | dst_off | src_off) & 3) return fail(FN_EINVAL, "fn_gat_bwd_src_f32: att blocks must be 16-byte aligned");
     *n_part_a = 0;
     if (plan->n == 0) return 0;
-    const int g = bwd_grid(plan->n);
+    // every block writes 256 partial sums: keep the block count (= scattered partial writes, finalize work) moderate
+    int g = bwd_grid(plan->n);
+    if (g > 1024) g = 1024;
     *n_part_a = g;
     FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src<HH, kBwdRows>), dim3(g), dim3(kBwdRows * 32), 0, S(stream), g_out, h, pz_src,
                                             g_s_dst, att, att_w, dst_off, src_off, *plan, g_h, part_a));
@@ -1653,10 +1668,10 @@ int fn_row_dots_sorted_bwd_f32(const float* g_s_sorted, const float* feat, const
         return fail(FN_EINVAL, "fn_row_dots_sorted_bwd_f32: bad argument");
     if (plan->m_real > 0 && (!g_s_sorted || !feat || !g_feat || !plan->inv_d))
         return fail(FN_EINVAL, "fn_row_dots_sorted_bwd_f32: null buffer");
-    const int g = row_grid(plan->m_real, FN_MAX_PART);
+    const int g = row_grid(plan->m_real, 512);
     *n_part = g;
     hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(g), dim3(kBlock), 0, S(stream), g_s_sorted, feat, A, lda, off, J, *plan,
-                       g_feat, part, (const float*)nullptr);
+                       g_feat, part, (const float*)nullptr, 0);
     return launch_status("fn_row_dots_sorted_bwd_f32");
 }
 
@@ -2099,14 +2114,14 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         bool have_g_frags_h = false;
         if (have_frags) {
             fn_edge_term et_f{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_frags, a.frags, a.p_frag, &et_f, &e->frag, 0.2f, bw.dz, bw.pz, bw.g_s_dst, nullptr, &n_e, H, st));
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_frags, a.frags, a.p_frag, &et_f, &e->frag, 0.2f, nullptr, bw.dz, bw.pz, bw.g_s_dst, nullptr, &n_e, H, st));
             FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_frags, a.frags, bw.pz, bw.g_s_dst, w.f, wide, 0, d + FN_D, &e->frag, bw.g_frags, bw.part_a, &n_a, H, st));
             FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, nullptr, 0, &et_f, w.f, wide, 0, d + FN_D, g.f, nullptr, nullptr, H, st));
             // edge term <new_fbond, f[:, d:d+128]>: dL/dnew_fbond accumulates into g_pre_fbond, dL/df mid block
             if (e->frag.m_real > 0) {
-                const int gr = row_grid(e->frag.m_real, FN_MAX_PART);
+                const int gr = row_grid(e->frag.m_real, 512);
                 hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(gr), dim3(kBlock), 0, hs, bw.dz, a.new_fbond, w.f, wide, d, H, e->frag,
-                                   bw.g_pre_fbond, bw.part_rd, have_fbond ? (const float*)bw.g_pre_fbond : (const float*)nullptr);
+                                   bw.g_pre_fbond, bw.part_rd, have_fbond ? (const float*)bw.g_pre_fbond : (const float*)nullptr, 1);
                 FN_TRY(launch_status("fn_encoder_backward: row_dots(frag)"));
                 FN_TRY(fn_colsum_f32(bw.part_rd, gr, H * FN_D, g.f, wide, d, st));
                 have_fbond = true;
@@ -2117,7 +2132,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         // ---- L4a fragment-bond graph
         if (have_fbond) {
             fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_fbond, a.h_fb, a.p_fbond, &et_fb, &e->fbond, 0.2f, bw.dz, bw.pz, bw.g_s_dst, bw.part_e, &n_e, H, st));
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_fbond, a.h_fb, a.p_fbond, &et_fb, &e->fbond, 0.2f, nullptr, nullptr, bw.pz, bw.g_s_dst, bw.part_e, &n_e, H, st));
             FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_fbond, a.h_fb, bw.pz, bw.g_s_dst, w.f_a_b, 3 * d, 0, 2 * d, &e->fbond, bw.g_h, bw.part_a, &n_a, H, st));
             FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, bw.part_e, n_e, &et_fb, w.f_a_b, 3 * d, 0, 2 * d, g.f_a_b, g.emb_fb_w, g.emb_fb_b, H, st));
             FN_TRY(fn_linear128_wgrad_f32(bw.g_h, in_fbond, kfb, e->EF, bw.wg_ws, g.proj_fb_w, g.proj_fb_b, st));
@@ -2139,13 +2154,13 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         // ---- L2 atom graph
         if (have_atoms) {
             fn_edge_term et_a{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_atoms, a.h_a, a.p_atom, &et_a, &e->atom, 0.2f, bw.dz, bw.pz, bw.g_s_dst, nullptr, &n_e, H, st));
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_atoms, a.h_a, a.p_atom, &et_a, &e->atom, 0.2f, nullptr, bw.dz, bw.pz, bw.g_s_dst, nullptr, &n_e, H, st));
             FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_atoms, a.h_a, bw.pz, bw.g_s_dst, w.a, wide, 0, d + FN_D, &e->atom, bw.g_h, bw.part_a, &n_a, H, st));
             FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, nullptr, 0, &et_a, w.a, wide, 0, d + FN_D, g.a, nullptr, nullptr, H, st));
             if (e->atom.m_real > 0) {
-                const int gr = row_grid(e->atom.m_real, FN_MAX_PART);
+                const int gr = row_grid(e->atom.m_real, 512);
                 hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(gr), dim3(kBlock), 0, hs, bw.dz, a.new_bond, w.a, wide, d, H, e->atom,
-                                   bw.g_pre_bond, bw.part_rd, have_bond ? (const float*)bw.g_pre_bond : (const float*)nullptr);
+                                   bw.g_pre_bond, bw.part_rd, have_bond ? (const float*)bw.g_pre_bond : (const float*)nullptr, 1);
                 FN_TRY(launch_status("fn_encoder_backward: row_dots(atom)"));
                 FN_TRY(fn_colsum_f32(bw.part_rd, gr, H * FN_D, g.a, wide, d, st));
                 have_bond = true;
@@ -2161,7 +2176,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         // ---- L1 bond graph
         if (have_bond) {
             fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_bond, a.h_b, a.p_bond, &et_b, &e->bond, 0.2f, bw.dz, bw.pz, bw.g_s_dst, bw.part_e, &n_e, H, st));
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_bond, a.h_b, a.p_bond, &et_b, &e->bond, 0.2f, nullptr, nullptr, bw.pz, bw.g_s_dst, bw.part_e, &n_e, H, st));
             FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_bond, a.h_b, bw.pz, bw.g_s_dst, w.a_b, 3 * d, 0, 2 * d, &e->bond, bw.g_h, bw.part_a, &n_a, H, st));
             FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, bw.part_e, n_e, &et_b, w.a_b, 3 * d, 0, 2 * d, g.a_b, g.emb_b_w, g.emb_b_b, H, st));
             FN_TRY(fn_linear128_wgrad_f32(bw.g_h, in_bond, kb, e->E, bw.wg_ws, g.proj_b_w, g.proj_b_b, st));

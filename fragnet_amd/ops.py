@@ -113,7 +113,7 @@ class _GatLevel(torch.autograd.Function):
         g_s_dst = torch.empty((n, heads), dtype=torch.float32, device=dev)
         n_e, n_a = C.c_int(0), C.c_int(0)
         _lib.call("fn_gat_bwd_dst_f32", g_out.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), C.byref(et),
-                  C.byref(level.c), NEG_SLOPE, _ptr(dz), pz.data_ptr(), g_s_dst.data_ptr(), _ptr(part_e), C.byref(n_e), heads, st)
+                  C.byref(level.c), NEG_SLOPE, _ptr(dz), None, pz.data_ptr(), g_s_dst.data_ptr(), _ptr(part_e), C.byref(n_e), heads, st)
         g_h = torch.empty((n, FN_D), dtype=torch.float32, device=dev)
         part_a = torch.empty((FN_MAX_PART, 2 * FN_D), dtype=torch.float32, device=dev)
         _lib.call("fn_gat_bwd_src_f32", g_out.data_ptr(), h.data_ptr(), pz.data_ptr(), g_s_dst.data_ptr(), att.data_ptr(), att_w, dst_off, src_off, C.byref(level.c), g_h.data_ptr(),

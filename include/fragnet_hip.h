@@ -159,7 +159,9 @@ int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const
  * Returns the grid size used through *n_part_e. */
 int fn_gat_bwd_dst_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et,
                        const fn_gat_plan* plan, float neg_slope,
-                       float* dz_sorted /*mode 0*/, float* pz_src, float* g_s_dst,
+                       float* dz_sorted /*mode 0, nullable: [H,m] destination-sorted (autograd path)*/,
+                       float* g_s_orig /*mode 0, nullable: [m_real,H] original edge order (engine path)*/,
+                       float* pz_src, float* g_s_dst,
                        float* part_e /*mode2: [FN_MAX_PART, H*(K+1)]*/, int* n_part_e,
                        int heads, fn_stream_t stream);
 
@@ -187,7 +189,7 @@ int fn_attn_by_src_f32(const float* p_sorted, const fn_gat_plan* plan, float* at
  * written directly in destination-sorted order. */
 int fn_row_dots_sorted_f32(const float* feat /*[m_real,128]*/, const float* A, int lda, int off, int J,
                            const fn_gat_plan* plan, float* s_sorted /*[m,J]*/, fn_stream_t stream);
-/* g_feat[e,:] = sum_j g_s_sorted[inv_d[e], j] A[j]; part [grid, J*128] partial sums of g_A[j,:] */
+/* g_feat[e,:] = sum_j g_s_sorted[j, inv_d[e]] A[j]; part: column-major partial sums of g_A[j,:] */
 int fn_row_dots_sorted_bwd_f32(const float* g_s_sorted, const float* feat, const float* A, int lda, int off, int J,
                                const fn_gat_plan* plan, float* g_feat, float* part, int* n_part, fn_stream_t stream);
 /* x_sorted[pos,:] = x[eid(pos),:] (0 at loop positions): once per batch for the raw edge attributes */
