@@ -180,8 +180,10 @@ def main():
     ap.add_argument("--kbatch", type=int, default=PER_GPU_BATCH, help="molecules per batch for --kernels-only")
     args = ap.parse_args()
 
+    import fragnet_amd
     from fragnet_amd import parallel
     from fragnet_amd.model import FragNetFineTune
+    fragnet_amd.prefer_rocblas_for_dense_heads()
     from fragnet_amd.plan import PLAN_KEY
 
     if not torch.cuda.is_available():

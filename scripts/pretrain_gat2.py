@@ -19,6 +19,8 @@ if __name__ == "__main__":
     cli = ap.parse_args()
     args = train.load_config(cli.config, config=cli.config)
     train.seed_everything(args.seed)
+    import fragnet_amd
+    fragnet_amd.prefer_rocblas_for_dense_heads()
     rank, local_rank, world = parallel.init_distributed()
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)

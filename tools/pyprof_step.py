@@ -8,6 +8,7 @@ from fragnet_amd import parallel
 from fragnet_amd.model import FragNetFineTune
 from fragnet_amd.plan import PLAN_KEY
 
+import fragnet_amd; fragnet_amd.prefer_rocblas_for_dense_heads()
 dev = torch.device("cuda", 0)
 pool = bench.make_pool(4, 0, dev)
 torch.manual_seed(0)
