@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-collated batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager-head", action="store_true", help="do not HIP-graph-capture the prediction head")
     ap.add_argument("--kernels-only", action="store_true", help="only time the bond-level scatter kernels (dev loop)")
     ap.add_argument("--kbatch", type=int, default=PER_GPU_BATCH, help="molecules per batch for --kernels-only")
     args = ap.parse_args()
@@ -211,6 +212,7 @@ def main():
 
     opt = parallel.FlatAdam.for_live_parameters(model, lambda: fwd_bwd(pool[0]), lr=1e-4)
     bucket = opt
+    graphed_head = fragnet_amd.graph_capture_head(model, PER_GPU_BATCH) if not args.eager_head else False
 
     def step(i):
         opt.zero_grad()
@@ -248,6 +250,7 @@ def main():
             "config": {"workload": "ESOL finetune batch=512 fp32 (BASELINE configs[1]): FragNetFineTune 4 layers x 4 heads, "
                                    "emb 128, FTHead3 128/1024/1024/512, drop 0.1; synthetic ESOL-shape molecules (synth.py)",
                        "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world, "parallelism": f"dp{world}",
+                       "head": "hipGraph-captured" if graphed_head else "eager",
                        "step": "plan+zero_grad+fwd+mse+bwd" + ("+allreduce(flat %.1f MB)" % (bucket.nbytes / 1e6) if world > 1 else "") + "+adam",
                        "atoms": int(pool[0]["x_atoms"].shape[0]), "bond_graph_edges": int(pool[0]["edge_index_bonds_graph"].shape[1])},
             "final_loss": round(final_loss, 6),

@@ -11,3 +11,37 @@ def prefer_rocblas_for_dense_heads() -> bool:
         return True
     except Exception:                                              # older torch: keep the default
         return False
+
+
+def graph_capture_head(model, batch_size: int, attr: str = "fthead") -> bool:
+    """Replaces ``model.<attr>`` (an MLP head with a static [batch_size, 256] input) by a HIP-graph-captured
+    callable (torch.cuda.make_graphed_callables): its ~45 small launches per step become two graph launches.
+    Call AFTER the optimiser has re-pointed the parameters (parallel.FlatAdam).  Eval mode and other batch sizes
+    keep running eagerly.  Returns False (and leaves the head untouched) if capture is not possible."""
+    import torch
+    head = getattr(model, attr)
+    dev = next(head.parameters()).device
+    if dev.type != "cuda":
+        return False
+    try:
+        was_training = head.training
+        head.train()
+        sample = torch.randn(batch_size, head_input_width(head), device=dev, requires_grad=True)
+        graphed = torch.cuda.make_graphed_callables(head, (sample,))
+        head.train(was_training)
+    except Exception as exc:      # pragma: no cover - depends on the runtime
+        import warnings
+        warnings.warn(f"head graph capture failed, running it eagerly: {exc}")
+        return False
+    # make_graphed_callables returns the same module with a patched forward: keep it in place, so state_dict keys,
+    # parameter identities and checkpoints are unchanged
+    setattr(model, attr, graphed)
+    return True
+
+
+def head_input_width(head) -> int:
+    import torch
+    for m in head.modules():
+        if isinstance(m, torch.nn.Linear):
+            return m.in_features
+    raise ValueError("head has no Linear layer")

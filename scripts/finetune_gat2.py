@@ -55,6 +55,7 @@ if __name__ == "__main__":
     trainer = train.TrainerFineTune(target_type=ft.target_type)
     probe = next(iter(train_loader))
     optimizer = train.make_optimizer(model, float(ft.lr), probe, lambda mdl, b: trainer._loss(mdl, b))
+    fragnet_amd.graph_capture_head(model, len(probe["y"]))      # training batches have a fixed size (drop_last)
     scheduler = None
     if ft.get("use_schedular"):
         class _Linear:          # LinearLR(start_factor=1.0, end_factor=0.5, total_iters=30), finetune_gat2.py:258-259
