@@ -32,7 +32,7 @@ class EdgeTerm(C.Structure):
 
 
 class ActEpilogue(C.Structure):
-    _fields_ = [("y", vp), ("p", f32), ("relu", i32), ("seed", u64), ("offset", u64)]
+    _fields_ = [("y", vp), ("p", f32), ("relu", i32), ("seed", u64), ("offset", u64), ("offset_dev", vp)]
 
 
 class GatPlan(C.Structure):
@@ -55,7 +55,7 @@ class LayerWeights(C.Structure):
 
 class Encoder(C.Structure):
     _fields_ = [("n_layers", i32), ("heads", i32), ("k_atom0", i32), ("k_bond0", i32), ("k_fbond0", i32), ("k_fattr", i32),
-                ("training", i32), ("pad_", i32), ("drop_p", f32), ("pad2_", f32), ("seed", u64), ("offset", u64),
+                ("training", i32), ("pad_", i32), ("drop_p", f32), ("pad2_", f32), ("seed", u64), ("offset", u64), ("offset_dev", vp),
                 ("N", i64), ("E", i64), ("F", i64), ("EF", i64),
                 ("bond", GatPlan), ("atom", GatPlan), ("fbond", GatPlan), ("frag", GatPlan), ("a2f", SegPlan),
                 ("x_atoms", vp), ("bond_nodes", vp), ("fbond_nodes", vp), ("cos_sorted", vp), ("fattr_sorted", vp),
@@ -93,8 +93,8 @@ SIGNATURES = {
     "fn_gather_rows_f32": [vp, vp, vp, i64, i64, vp],
     "fn_segment_softmax_f32": [vp, vp, vp, i32, vp, i64, i64, vp],
     "fn_segment_softmax_bwd_f32": [vp, vp, vp, vp, i32, vp, i64, i64, vp],
-    "fn_dropout_act_f32": [vp, vp, i64, f32, u64, u64, C.c_int, vp],
-    "fn_dropout_act_bwd_f32": [vp, vp, vp, i64, f32, u64, u64, C.c_int, vp],
+    "fn_dropout_act_f32": [vp, vp, i64, f32, u64, u64, vp, C.c_int, vp],
+    "fn_dropout_act_bwd_f32": [vp, vp, vp, i64, f32, u64, u64, vp, C.c_int, vp],
     "fn_adam_f32": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp],
     "fn_edge_concat_f32": [vp, vp, vp, vp, i64, vp],
 }

@@ -498,7 +498,7 @@ __global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h,
         if (ep.y) {          // fused act(dropout(.)): same Philox block index (element / 4) as k_dropout_act
             float4 r = acc;
             if (ep.p > 0.f) {
-                const uint4 rnd = philox4x32_10(ep.offset + (uint64_t)t * 32 + lane, ep.seed);
+                const uint4 rnd = philox4x32_10(ep.offset + (ep.offset_dev ? *ep.offset_dev : 0) + (uint64_t)t * 32 + lane, ep.seed);
                 const float ik = ep.p < 1.f ? 1.f / (1.f - ep.p) : 0.f;
                 r.x *= keep_scale(rnd.x, ep.p, ik); r.y *= keep_scale(rnd.y, ep.p, ik);
                 r.z *= keep_scale(rnd.z, ep.p, ik); r.w *= keep_scale(rnd.w, ep.p, ik);
@@ -1037,8 +1037,10 @@ __global__ void k_segment_softmax_bwd(const float* __restrict__ probs, const flo
 // =====================================================================================
 template <bool BWD>
 __global__ void k_dropout_act(const float* __restrict__ a, const float* __restrict__ y_saved, float* __restrict__ o,
-                              int64_t numel, float p, uint64_t seed, uint64_t offset, int relu) {
+                              int64_t numel, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                              int relu) {
     const int64_t n4 = (numel + 3) / 4;
+    if (offset_dev) offset += *offset_dev;
     const float inv_keep = p < 1.f ? 1.f / (1.f - p) : 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float m[4] = {1.f, 1.f, 1.f, 1.f};
@@ -1219,7 +1221,7 @@ __global__ __launch_bounds__(512) void k_linear128(const float* __restrict__ X, 
                 if (mk.y) {      // backward of act(dropout(.)) fused into the input-gradient GEMM: o *= mask * (y > 0)
                     const int64_t e4 = (r0 + rr) * 32 + 16 * wc + c4;            // Philox block = element / 4
                     if (mk.p > 0.f) {
-                        const uint4 rnd = philox4x32_10(mk.offset + (uint64_t)e4, mk.seed);
+                        const uint4 rnd = philox4x32_10(mk.offset + (mk.offset_dev ? *mk.offset_dev : 0) + (uint64_t)e4, mk.seed);
                         const float ik = mk.p < 1.f ? 1.f / (1.f - mk.p) : 0.f;
                         o.x *= keep_scale(rnd.x, mk.p, ik); o.y *= keep_scale(rnd.y, mk.p, ik);
                         o.z *= keep_scale(rnd.z, mk.p, ik); o.w *= keep_scale(rnd.w, mk.p, ik);
@@ -1499,6 +1501,15 @@ inline int wgrad_rows_per_block(int64_t M) {
 }
 }  // namespace
 
+namespace {
+__global__ void k_zero2_i32(int32_t* __restrict__ a, int64_t na, int32_t* __restrict__ b, int64_t nb) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < na) a[i] = 0;
+        else b[i - na] = 0;
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int fn_abi_version(void) { return FN_ABI_VERSION; }
@@ -1549,9 +1560,10 @@ int fn_plan_build(const fn_csr_task* tasks, int n_tasks, int32_t* rowptr_all, in
     int32_t* cursor = ws_i32;
     int32_t* tmp = ws_i32 + segs;          // unordered fill target (total_items)
     int32_t* status = ws_i32 + segs + items;
-    hipError_t e = hipMemsetAsync(rowptr_all, 0, (size_t)(segs + 1) * 4, st);
-    if (e == hipSuccess) e = hipMemsetAsync(ws_i32, 0, (size_t)(segs + items + 4) * 4, st);
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail((int)e, "fn_plan_build: memset failed"); }
+    // zeroing by kernel, not hipMemsetAsync: the call must be capturable in a hipGraph and replayable (memset nodes
+    // were observed to fault on the second replay on ROCm 7.2), and it is one launch for both regions
+    hipLaunchKernelGGL(k_zero2_i32, dim3(flat_grid(2 * segs + items + 5, kGridCap)), dim3(kBlock), 0, st, rowptr_all,
+                       segs + 1, ws_i32, segs + items + 4);
     if (items > 0) {
         const int g = flat_grid(items, kGridCap);
         hipLaunchKernelGGL(k_plan_hist, dim3(g), dim3(kBlock), 0, st, P, rowptr_all, status);
@@ -1589,11 +1601,11 @@ int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const
     if (!h || !s_dst || !s_src || !att || !plan || bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_fwd_f32: bad argument");
     if (!out && !(act && act->y)) return fail(FN_EINVAL, "fn_gat_fwd_f32: no output buffer");
     if (act && (act->p < 0.f || act->p > 1.f)) return fail(FN_EINVAL, "fn_gat_fwd_f32: dropout probability");
-    const fn_act_epilogue ep = act ? *act : fn_act_epilogue{nullptr, 0.f, 0, 0, 0};
+    const fn_act_epilogue ep = act ? *act : fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr};
     if (plan->m > 0 && !p_sorted) return fail(FN_EINVAL, "fn_gat_fwd_f32: null p_sorted");
     if (et->mode == 0 && plan->m > 0 && !et->s_sorted) return fail(FN_EINVAL, "fn_gat_fwd_f32: null s_sorted");
     if (plan->n == 0) return 0;
-    static const int fwd_cap = getenv("FN_FWD_CAP") ? atoi(getenv("FN_FWD_CAP")) : 8 * kGridCap;
+    constexpr int fwd_cap = 8 * kGridCap;
     FN_DISPATCH_H(heads, hipLaunchKernelGGL(k_gat_fwd<HH>, dim3(row_grid(plan->n, fwd_cap)), dim3(kBlock), 0, S(stream),
                                             h, s_dst, s_src, att, att_w, *et, *plan, neg_slope, out, p_sorted, probs_orig, ep));
     return launch_status("fn_gat_fwd_f32");
@@ -1698,7 +1710,7 @@ int fn_transpose_w_f32(const float* W, int K, float* Bt, fn_stream_t stream) {
 static int linear128_impl(const float* X, int K, const float* Bt, const float* bias, float* Y, int64_t M,
                           const fn_act_epilogue* act_bwd, NodeScalarEpi ns, fn_stream_t stream) {
     if (K < 1 || M < 0) return fail(FN_EINVAL, "fn_linear128_f32: bad argument");
-    const fn_act_epilogue mk = act_bwd ? *act_bwd : fn_act_epilogue{nullptr, 0.f, 0, 0, 0};
+    const fn_act_epilogue mk = act_bwd ? *act_bwd : fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr};
     if (M == 0) return 0;
     if (!X || !Bt || !Y || (((uintptr_t)X | (uintptr_t)Y) & 15)) return fail(FN_EINVAL, "fn_linear128_f32: null or misaligned buffer");
     int rc;
@@ -1725,9 +1737,9 @@ int64_t fn_linear128_wgrad_ws(int64_t M, int K) {
 int fn_linear128_wgrad_f32(const float* dY, const float* X, int K, int64_t M, float* ws, float* dW, float* db, fn_stream_t stream) {
     if (K < 1 || M < 0 || !dW || !db) return fail(FN_EINVAL, "fn_linear128_wgrad_f32: bad argument");
     if (M == 0) {
-        hipError_t e = hipMemsetAsync(dW, 0, (size_t)128 * K * 4, S(stream));
-        if (e == hipSuccess) e = hipMemsetAsync(db, 0, 128 * 4, S(stream));
-        return e == hipSuccess ? 0 : fail((int)e, "fn_linear128_wgrad_f32: memset failed");
+        hipLaunchKernelGGL(k_zero2_i32, dim3(flat_grid(128 * (K + 1), kGridCap)), dim3(kBlock), 0, S(stream),
+                           reinterpret_cast<int32_t*>(dW), (int64_t)128 * K, reinterpret_cast<int32_t*>(db), (int64_t)128);
+        return launch_status("fn_linear128_wgrad_f32");
     }
     if (!dY || !X || !ws || ((uintptr_t)dY & 15)) return fail(FN_EINVAL, "fn_linear128_wgrad_f32: null or misaligned buffer");
     const int rpb = wgrad_rows_per_block(M);
@@ -1794,24 +1806,24 @@ int fn_segment_softmax_bwd_f32(const float* probs, const float* g_probs, const i
     return launch_status("fn_segment_softmax_bwd_f32");
 }
 
-int fn_dropout_act_f32(const float* x, float* y, int64_t numel, float p, uint64_t seed, uint64_t offset, int relu,
-                       fn_stream_t stream) {
+int fn_dropout_act_f32(const float* x, float* y, int64_t numel, float p, uint64_t seed, uint64_t offset,
+                       const uint64_t* offset_dev, int relu, fn_stream_t stream) {
     if (numel < 0 || p < 0.f || p > 1.f) return fail(FN_EINVAL, "fn_dropout_act_f32: bad argument");
     if (numel == 0) return 0;
     if (!x || !y || (((uintptr_t)x | (uintptr_t)y) & 15)) return fail(FN_EINVAL, "fn_dropout_act_f32: null or misaligned buffer");
     hipLaunchKernelGGL(k_dropout_act<false>, dim3(flat_grid((numel + 3) / 4, kGridCap)), dim3(kBlock), 0, S(stream), x,
-                       (const float*)nullptr, y, numel, p, seed, offset, relu);
+                       (const float*)nullptr, y, numel, p, seed, offset, offset_dev, relu);
     return launch_status("fn_dropout_act_f32");
 }
 
 int fn_dropout_act_bwd_f32(const float* g_y, const float* y, float* g_x, int64_t numel, float p, uint64_t seed,
-                           uint64_t offset, int relu, fn_stream_t stream) {
+                           uint64_t offset, const uint64_t* offset_dev, int relu, fn_stream_t stream) {
     if (numel < 0 || p < 0.f || p > 1.f) return fail(FN_EINVAL, "fn_dropout_act_bwd_f32: bad argument");
     if (numel == 0) return 0;
     if (!g_y || !g_x || (relu && !y) || (((uintptr_t)g_y | (uintptr_t)g_x | (uintptr_t)y) & 15))
         return fail(FN_EINVAL, "fn_dropout_act_bwd_f32: null or misaligned buffer");
     hipLaunchKernelGGL(k_dropout_act<true>, dim3(flat_grid((numel + 3) / 4, kGridCap)), dim3(kBlock), 0, S(stream), g_y, y, g_x,
-                       numel, p, seed, offset, relu);
+                       numel, p, seed, offset, offset_dev, relu);
     return launch_status("fn_dropout_act_bwd_f32");
 }
 
@@ -1987,7 +1999,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
 
     const float* in_atoms = e->x_atoms;
     if (lay.in_atoms0) {
-        FN_TRY(fn_dropout_act_f32(e->x_atoms, lay.in_atoms0, e->N * e->k_atom0, p, e->seed, rng.in_atoms, 0, st));
+        FN_TRY(fn_dropout_act_f32(e->x_atoms, lay.in_atoms0, e->N * e->k_atom0, p, e->seed, rng.in_atoms, e->offset_dev, 0, st));
         in_atoms = lay.in_atoms0;
     }
     const float* in_bond = e->bond_nodes;
@@ -2029,8 +2041,8 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         float* y_bond = last ? out_bond : a.y_bond;
         float* y_fbond = last ? out_fbond : a.y_fbond;
         // act(dropout(.)) of the four layer outputs rides in the producing kernels' epilogues
-        const fn_act_epilogue ep_atoms{y_atoms, p, 1, e->seed, rng.y[l][0]}, ep_frags{y_frags, p, 1, e->seed, rng.y[l][1]};
-        const fn_act_epilogue ep_bond{y_bond, p, 1, e->seed, rng.y[l][2]}, ep_fbond{y_fbond, p, 1, e->seed, rng.y[l][3]};
+        const fn_act_epilogue ep_atoms{y_atoms, p, 1, e->seed, rng.y[l][0], e->offset_dev}, ep_frags{y_frags, p, 1, e->seed, rng.y[l][1], e->offset_dev};
+        const fn_act_epilogue ep_bond{y_bond, p, 1, e->seed, rng.y[l][2], e->offset_dev}, ep_fbond{y_fbond, p, 1, e->seed, rng.y[l][3], e->offset_dev};
         FN_TRY(fn_gat_fwd_f32(a.h_b, lay.s_dst, lay.s_src, w.a_b, 3 * d, &et_b, &e->bond, 0.2f, a.new_bond, a.p_bond, nullptr, &ep_bond, H, st));
 
         // L2 atom graph (+ self loops), edge term = <new_bond, a[:, d:d+128]>
@@ -2104,10 +2116,10 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         // (mask and ReLU gate fused into their epilogue), flagged by pre_* below.
         bool have_atoms = gy_atoms != nullptr || pre_atoms, have_frags = gy_frags != nullptr;
         bool have_bond = gy_bond != nullptr || pre_bond, have_fbond = gy_fbond != nullptr || pre_fbond;
-        if (gy_atoms) FN_TRY(fn_dropout_act_bwd_f32(gy_atoms, y_atoms, bw.g_pre_atoms, e->N * FN_D, p, e->seed, rng.y[l][0], 1, st));
-        if (gy_frags) FN_TRY(fn_dropout_act_bwd_f32(gy_frags, y_frags, bw.g_pre_frags, e->F * FN_D, p, e->seed, rng.y[l][1], 1, st));
-        if (gy_bond) FN_TRY(fn_dropout_act_bwd_f32(gy_bond, y_bond, bw.g_pre_bond, e->E * FN_D, p, e->seed, rng.y[l][2], 1, st));
-        if (gy_fbond) FN_TRY(fn_dropout_act_bwd_f32(gy_fbond, y_fbond, bw.g_pre_fbond, e->EF * FN_D, p, e->seed, rng.y[l][3], 1, st));
+        if (gy_atoms) FN_TRY(fn_dropout_act_bwd_f32(gy_atoms, y_atoms, bw.g_pre_atoms, e->N * FN_D, p, e->seed, rng.y[l][0], e->offset_dev, 1, st));
+        if (gy_frags) FN_TRY(fn_dropout_act_bwd_f32(gy_frags, y_frags, bw.g_pre_frags, e->F * FN_D, p, e->seed, rng.y[l][1], e->offset_dev, 1, st));
+        if (gy_bond) FN_TRY(fn_dropout_act_bwd_f32(gy_bond, y_bond, bw.g_pre_bond, e->E * FN_D, p, e->seed, rng.y[l][2], e->offset_dev, 1, st));
+        if (gy_fbond) FN_TRY(fn_dropout_act_bwd_f32(gy_fbond, y_fbond, bw.g_pre_fbond, e->EF * FN_D, p, e->seed, rng.y[l][3], e->offset_dev, 1, st));
         bool nxt_atoms = false, nxt_bond = false, nxt_fbond = false;     // what this layer hands to layer l-1
 
         // ---- L4b fragment graph (only where its output is consumed: the last layer, reference fact SURVEY §0.8)
@@ -2137,7 +2149,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, bw.part_e, n_e, &et_fb, w.f_a_b, 3 * d, 0, 2 * d, g.f_a_b, g.emb_fb_w, g.emb_fb_b, H, st));
             FN_TRY(fn_linear128_wgrad_f32(bw.g_h, in_fbond, kfb, e->EF, bw.wg_ws, g.proj_fb_w, g.proj_fb_b, st));
             if (l) {     // dL/d(pre-activation fbond output of layer l-1), gated by that layer's dropout mask and ReLU
-                const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_fbond), p, 1, e->seed, rng.y[l - 1][3]};
+                const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_fbond), p, 1, e->seed, rng.y[l - 1][3], e->offset_dev};
                 FN_TRY(fn_linear128_f32(bw.g_h, FN_D, w.proj_fb_w, nullptr, bw.g_pre_fbond, e->EF, &mk, st));
                 nxt_fbond = true;
             }
@@ -2167,7 +2179,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             }
             FN_TRY(fn_linear128_wgrad_f32(bw.g_h, in_atoms, ka, e->N, bw.wg_ws, g.proj_a_w, g.proj_a_b, st));
             if (l) {
-                const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_atoms), p, 1, e->seed, rng.y[l - 1][0]};
+                const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_atoms), p, 1, e->seed, rng.y[l - 1][0], e->offset_dev};
                 FN_TRY(fn_linear128_f32(bw.g_h, FN_D, w.proj_a_w, nullptr, bw.g_pre_atoms, e->N, &mk, st));
                 nxt_atoms = true;
             }
@@ -2181,7 +2193,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, bw.part_e, n_e, &et_b, w.a_b, 3 * d, 0, 2 * d, g.a_b, g.emb_b_w, g.emb_b_b, H, st));
             FN_TRY(fn_linear128_wgrad_f32(bw.g_h, in_bond, kb, e->E, bw.wg_ws, g.proj_b_w, g.proj_b_b, st));
             if (l) {
-                const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_bond), p, 1, e->seed, rng.y[l - 1][2]};
+                const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_bond), p, 1, e->seed, rng.y[l - 1][2], e->offset_dev};
                 FN_TRY(fn_linear128_f32(bw.g_h, FN_D, w.proj_b_w, nullptr, bw.g_pre_bond, e->E, &mk, st));
                 nxt_bond = true;
             }

@@ -37,13 +37,14 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 def _describe(plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, params: Sequence[torch.Tensor],
-              n_layers: int, heads: int, drop_p: float, training: bool, seed: int, offset: int) -> Encoder:
+              n_layers: int, heads: int, drop_p: float, training: bool, seed: int, offset: int, offset_dev=None) -> Encoder:
     e = Encoder()
     e.n_layers, e.heads = n_layers, heads
     e.k_atom0, e.k_bond0, e.k_fbond0 = x_atoms.shape[1], bond_nodes.shape[1], fbond_nodes.shape[1]
     e.k_fattr = fattr_sorted.shape[0]
     e.training, e.drop_p = int(training), float(drop_p)
     e.seed, e.offset = seed, offset
+    e.offset_dev = None if offset_dev is None else offset_dev.data_ptr()
     L = plan.levels
     e.N, e.E, e.F, e.EF = L["atom"].n, L["bond"].n, L["frag"].n, L["fbond"].n
     e.bond, e.atom, e.fbond, e.frag = L["bond"].c, L["atom"].c, L["fbond"].c, L["frag"].c
@@ -60,19 +61,19 @@ def _describe(plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fat
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, plan, n_layers, heads, drop_p, training,
-                seed, offset, *params):
+                seed, offset, offset_dev, *params):
         x_atoms, bond_nodes, fbond_nodes = _f32(x_atoms, "x_atoms"), _f32(bond_nodes, "node_features_bonds"), _f32(fbond_nodes, "node_features_fbonds")
         params = tuple(_f32(p, "parameter") for p in params)
         dev = x_atoms.device
         lib = _lib.load()
         e = _describe(plan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, params, n_layers, heads, drop_p,
-                      training, seed, offset)
+                      training, seed, offset, offset_dev)
         ws = torch.empty(lib.fn_encoder_ws_floats(C.byref(e)), dtype=torch.float32, device=dev)
         e.ws, e.ws_floats = ws.data_ptr(), ws.numel()
         outs = [torch.empty((n, FN_D), dtype=torch.float32, device=dev) for n in (e.N, e.F, e.E, e.EF)]
         _lib.check(lib.fn_encoder_forward(C.byref(e), *(o.data_ptr() for o in outs), _stream_ptr(dev)), "fn_encoder_forward")
         ctx.desc = e
-        ctx.keep = (plan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, ws)
+        ctx.keep = (plan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, ws, offset_dev)
         ctx.n_layers = n_layers
         ctx.save_for_backward(*params, *outs)
         ctx.set_materialize_grads(False)
@@ -103,7 +104,7 @@ class _EncoderFn(torch.autograd.Function):
             for k in range(NP):
                 live = any_grad and not (k == F_IDX and not (l == n_layers - 1 and have_frags))
                 out.append(grads[l * NP + k] if live else None)
-        return (None,) * 12 + tuple(out)
+        return (None,) * 13 + tuple(out)
 
 
 def encoder_forward(layers, plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, heads: int,
@@ -121,4 +122,4 @@ def encoder_forward(layers, plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, c
     else:
         seed, offset = 0, 0
     return _EncoderFn.apply(x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, plan, n_layers, heads, p_eff,
-                            bool(training), seed, offset, *params)
+                            bool(training), seed, offset, rng.dev if p_eff > 0.0 else None, *params)

@@ -357,6 +357,20 @@ class PhiloxStream:
         self.seed = None if seed is None else (int(seed) & 0xFFFFFFFFFFFFFFFF)
         self.rank = rank
         self.offset = 0
+        self.dev = None          # optional device-resident counter added to every offset when the kernels run
+
+    def use_device_counter(self, device):
+        """hipGraph mode: offsets handed out while a step is captured are baked into the graph, so the per-replay
+        part of the counter lives in device memory and ``advance_device`` (captured too) moves it on."""
+        if self.dev is None or self.dev.device != torch.device(device):
+            self.dev = torch.zeros(1, dtype=torch.int64, device=device)
+        return self.dev
+
+    def advance_device(self, blocks: int):
+        self.dev += int(blocks)
+
+    def dev_ptr(self):
+        return None if self.dev is None else self.dev.data_ptr()
 
     def take(self, numel: int):
         if self.seed is None:
@@ -368,25 +382,25 @@ class PhiloxStream:
 
 class _DropoutAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p: float, relu: bool, seed: int, offset: int):
+    def forward(ctx, x, p: float, relu: bool, seed: int, offset: int, dev):
         x = _f32c(x, "x")
         y = torch.empty_like(x)
-        _lib.call("fn_dropout_act_f32", x.data_ptr(), y.data_ptr(), x.numel(), float(p), seed, offset, int(relu),
+        _lib.call("fn_dropout_act_f32", x.data_ptr(), y.data_ptr(), x.numel(), float(p), seed, offset, _ptr(dev), int(relu),
                   _stream_ptr(x.device))
-        ctx.args = (float(p), bool(relu), seed, offset)
+        ctx.args = (float(p), bool(relu), seed, offset, dev)
         if relu:
             ctx.save_for_backward(y)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        p, relu, seed, offset = ctx.args
+        p, relu, seed, offset, dev = ctx.args
         y = ctx.saved_tensors[0] if relu else None
         g = _f32c(g, "g")
         gx = torch.empty_like(g)
-        _lib.call("fn_dropout_act_bwd_f32", g.data_ptr(), _ptr(y), gx.data_ptr(), g.numel(), p, seed, offset, int(relu),
-                  _stream_ptr(g.device))
-        return gx, None, None, None, None
+        _lib.call("fn_dropout_act_bwd_f32", g.data_ptr(), _ptr(y), gx.data_ptr(), g.numel(), p, seed, offset, _ptr(dev),
+                  int(relu), _stream_ptr(g.device))
+        return gx, None, None, None, None, None
 
 
 def dropout_act(x, p: float, training: bool, relu: bool, rng: PhiloxStream):
@@ -395,7 +409,7 @@ def dropout_act(x, p: float, training: bool, relu: bool, rng: PhiloxStream):
     if p_eff == 0.0 and not relu:
         return x
     seed, off = rng.take(x.numel()) if p_eff > 0.0 else (0, 0)
-    return _DropoutAct.apply(x, p_eff, relu, seed, off)
+    return _DropoutAct.apply(x, p_eff, relu, seed, off, rng.dev if p_eff > 0.0 else None)
 
 
 # ======================================================================================

@@ -143,6 +143,8 @@ typedef struct fn_act_epilogue {
     float p;                  /* dropout probability (0 = none)      */
     int32_t relu;
     uint64_t seed, offset;
+    const uint64_t* offset_dev; /* nullable: a device-resident counter ADDED to offset when the kernel runs, so that a
+                                 * captured hipGraph draws fresh masks on every replay (the owner advances it in-graph) */
 } fn_act_epilogue;
 
 /* p_sorted [H,m] (head-major): probabilities in destination-sorted order; the sign bit carries "z_e <= 0"
@@ -236,9 +238,9 @@ int fn_segment_softmax_bwd_f32(const float* probs, const float* g_probs, const i
  * Backward recomputes the mask from the same (seed, offset).
  * ------------------------------------------------------------------------------------------ */
 int fn_dropout_act_f32(const float* x, float* y, int64_t numel, float p, uint64_t seed, uint64_t offset,
-                       int relu, fn_stream_t stream);
+                       const uint64_t* offset_dev /*nullable, see fn_act_epilogue*/, int relu, fn_stream_t stream);
 int fn_dropout_act_bwd_f32(const float* g_y, const float* y, float* g_x, int64_t numel, float p, uint64_t seed,
-                           uint64_t offset, int relu, fn_stream_t stream);
+                           uint64_t offset, const uint64_t* offset_dev, int relu, fn_stream_t stream);
 
 /* torch.optim.Adam step (no amsgrad) on one flat fp32 tensor: finetune_gat2.py:257, pretrain_gat2.py:165.
  * `step` is the 1-based step count (bias corrections are computed on the host in double). */
@@ -282,6 +284,7 @@ typedef struct fn_encoder {
     int32_t training, pad_;
     float drop_p, pad2_;
     uint64_t seed, offset;                 /* Philox stream; fn_encoder_rng_blocks() offsets are consumed */
+    const uint64_t* offset_dev;            /* nullable device counter added to offset at run time (hipGraph replays) */
     int64_t N, E, F, EF;
     fn_gat_plan bond, atom, fbond, frag;
     fn_seg_plan a2f;

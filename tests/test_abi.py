@@ -50,7 +50,7 @@ def test_argument_errors_do_not_touch_the_gpu():
     lib = _lib.load()
     assert lib.fn_segment_sum_f32(None, 128, None, None, 0, None, 4, 128, 16, None) == -1
     assert lib.fn_row_dots_sorted_f32(None, None, 128, 0, 9, None, None, None) == -1
-    assert lib.fn_dropout_act_f32(None, None, 8, 1.5, 0, 0, 1, None) == -1
+    assert lib.fn_dropout_act_f32(None, None, 8, 1.5, 0, 0, None, 1, None) == -1
 
 
 def test_cpu_tensors_are_refused_not_silently_computed():
