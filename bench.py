@@ -10,6 +10,11 @@ A step = graph plan build + zero grads + forward + MSE loss + backward + (N>1: o
 gradient all-reduce over RCCL) + Adam step, on a batch the model has not seen in the previous step
 (a pool of pre-collated batches, seeds 1000+i).  Weak scaling: every rank owns 512 molecules per step.
 
+Default mode "graph": the batch is staged into fixed-capacity buffers (one kernel; the few % of padding are
+disconnected dummy rows, see fragnet_amd/graphstep.py) and plan + forward + loss + backward + gradient gather
+replay as ONE hipGraph; all-reduce and Adam follow on the stream.  `--eager` runs the same step launch by launch
+(hipGraph only around the prediction head).  Both count only the 512 real molecules per step.
+
 Besides the contract fields the JSON line carries
   roofline      for the dominant scatter kernel (bond-graph level, the largest of the four): algorithmic
                 bytes (SURVEY.md §8d closed form on this batch's n, m) / launch time, measured here with
@@ -176,7 +181,9 @@ def main():
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-collated batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--eager-head", action="store_true", help="do not HIP-graph-capture the prediction head")
+    ap.add_argument("--eager", action="store_true", help="launch-by-launch step instead of the whole-step hipGraph")
+    ap.add_argument("--margin", type=float, default=0.02, help="capacity head-room of the static shapes over the pool")
+    ap.add_argument("--eager-head", action="store_true", help="(--eager) do not HIP-graph-capture the prediction head")
     ap.add_argument("--kernels-only", action="store_true", help="only time the bond-level scatter kernels (dev loop)")
     ap.add_argument("--kbatch", type=int, default=PER_GPU_BATCH, help="molecules per batch for --kernels-only")
     args = ap.parse_args()
@@ -212,13 +219,22 @@ def main():
 
     opt = parallel.FlatAdam.for_live_parameters(model, lambda: fwd_bwd(pool[0]), lr=1e-4)
     bucket = opt
-    graphed_head = fragnet_amd.graph_capture_head(model, PER_GPU_BATCH) if not args.eager_head else False
+    gstep = None
+    if args.eager:
+        graphed_head = fragnet_amd.graph_capture_head(model, PER_GPU_BATCH) if not args.eager_head else False
 
-    def step(i):
-        opt.zero_grad()
-        loss = fwd_bwd(pool[i % len(pool)])
-        opt.step()                                   # one cat + (N>1: one all-reduce) + one fused Adam
-        return loss
+        def step(i):
+            opt.zero_grad()
+            loss = fwd_bwd(pool[i % len(pool)])
+            opt.step()                                   # one cat + (N>1: one all-reduce) + one fused Adam
+            return loss
+    else:
+        from fragnet_amd import graphstep
+        shapes = graphstep.StaticShapes.from_batches(pool, margin=args.margin, heads=MODEL_CFG["num_heads"])
+        gstep = graphstep.GraphedTrainStep(model, opt, shapes, pool[0], loss="regr")
+
+        def step(i):
+            return gstep(pool[i % len(pool)])            # stage (1 kernel) + graph replay + (all-reduce) + Adam
 
     for i in range(args.warmup):
         step(i)
@@ -250,7 +266,11 @@ def main():
             "config": {"workload": "ESOL finetune batch=512 fp32 (BASELINE configs[1]): FragNetFineTune 4 layers x 4 heads, "
                                    "emb 128, FTHead3 128/1024/1024/512, drop 0.1; synthetic ESOL-shape molecules (synth.py)",
                        "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world, "parallelism": f"dp{world}",
-                       "head": "hipGraph-captured" if graphed_head else "eager",
+                       "mode": "eager launches, head " + ("hipGraph-captured" if graphed_head else "eager") if args.eager else
+                               "whole-step hipGraph over static shapes (stage+plan+fwd+mse+bwd+grad gather in the graph)",
+                       "static_capacity": None if gstep is None else gstep.shapes.cap,
+                       "graph_replays": None if gstep is None else gstep.replays,
+                       "eager_fallbacks": None if gstep is None else gstep.fallbacks,
                        "step": "plan+zero_grad+fwd+mse+bwd" + ("+allreduce(flat %.1f MB)" % (bucket.nbytes / 1e6) if world > 1 else "") + "+adam",
                        "atoms": int(pool[0]["x_atoms"].shape[0]), "bond_graph_edges": int(pool[0]["edge_index_bonds_graph"].shape[1])},
             "final_loss": round(final_loss, 6),

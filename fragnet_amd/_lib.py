@@ -53,6 +53,15 @@ class LayerWeights(C.Structure):
     _fields_ = [(name, vp) for name in LAYER_FIELDS]
 
 
+class StageField(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("n_real", i64), ("cap", i64), ("width", i32), ("kind", i32),
+                ("pad_hi", i64), ("pad_mod", i64)]
+
+
+FN_MAX_STAGE_FIELDS = 24
+STAGE_ROWS, STAGE_IDS, STAGE_COLS, STAGE_MASK = 0, 1, 2, 3
+
+
 class Encoder(C.Structure):
     _fields_ = [("n_layers", i32), ("heads", i32), ("k_atom0", i32), ("k_bond0", i32), ("k_fbond0", i32), ("k_fattr", i32),
                 ("training", i32), ("pad_", i32), ("drop_p", f32), ("pad2_", f32), ("seed", u64), ("offset", u64), ("offset_dev", vp),
@@ -97,6 +106,7 @@ SIGNATURES = {
     "fn_dropout_act_bwd_f32": [vp, vp, vp, i64, f32, u64, u64, vp, C.c_int, vp],
     "fn_adam_f32": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp],
     "fn_edge_concat_f32": [vp, vp, vp, vp, i64, vp],
+    "fn_stage_padded": [C.POINTER(StageField), C.c_int, vp],
 }
 
 _lib = None

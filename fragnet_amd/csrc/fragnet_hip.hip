@@ -1502,6 +1502,31 @@ inline int wgrad_rows_per_block(int64_t M) {
 }  // namespace
 
 namespace {
+struct StageFields {
+    fn_stage_field f[FN_MAX_STAGE_FIELDS];
+    int n;
+};
+__global__ void k_stage_padded(StageFields F) {
+    const fn_stage_field& f = F.f[blockIdx.y];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f.kind == FN_STAGE_ROWS) {
+        const float* src = static_cast<const float*>(f.src);
+        float* dst = static_cast<float*>(f.dst);
+        const int64_t real = f.n_real * f.width, all = f.cap * f.width;
+        for (int64_t i = t0; i < all; i += stride) dst[i] = i < real ? src[i] : 0.f;
+    } else if (f.kind == FN_STAGE_MASK) {
+        float* dst = static_cast<float*>(f.dst);
+        for (int64_t i = t0; i < f.cap; i += stride) dst[i] = i < f.n_real ? 1.f : 0.f;
+    } else {
+        const int64_t* src = static_cast<const int64_t*>(f.src);
+        int64_t* dst = static_cast<int64_t*>(f.dst);
+        const int rows = f.kind == FN_STAGE_COLS ? 2 : 1;
+        for (int64_t i = t0; i < rows * f.cap; i += stride) {
+            const int64_t r = i / f.cap, c = i - r * f.cap;
+            dst[i] = c < f.n_real ? src[r * f.n_real + c] : f.pad_hi - c % f.pad_mod;
+        }
+    }
+}
 __global__ void k_zero2_i32(int32_t* __restrict__ a, int64_t na, int32_t* __restrict__ b, int64_t nb) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += (int64_t)gridDim.x * blockDim.x) {
         if (i < na) a[i] = 0;
@@ -1846,6 +1871,26 @@ int fn_edge_concat_f32(const float* x, const float* e_attr, const int64_t* edge_
     if (!x || !e_attr || !edge_index || !out) return fail(FN_EINVAL, "fn_edge_concat_f32: null buffer");
     hipLaunchKernelGGL(k_edge_concat, dim3(flat_grid(E * 96, kGridCap)), dim3(kBlock), 0, S(stream), x, e_attr, edge_index, out, E);
     return launch_status("fn_edge_concat_f32");
+}
+
+int fn_stage_padded(const fn_stage_field* fields, int n_fields, fn_stream_t stream) {
+    if (!fields || n_fields < 1 || n_fields > FN_MAX_STAGE_FIELDS) return fail(FN_EINVAL, "fn_stage_padded: bad field count");
+    StageFields F;
+    F.n = n_fields;
+    int64_t most = 0;
+    for (int i = 0; i < n_fields; ++i) {
+        const fn_stage_field& f = fields[i];
+        if (f.n_real < 0 || f.cap < f.n_real || f.width < 1 || f.kind < 0 || f.kind > FN_STAGE_MASK || (f.cap > 0 && !f.dst) ||
+            (f.n_real > 0 && f.kind != FN_STAGE_MASK && !f.src) ||
+            ((f.kind == FN_STAGE_IDS || f.kind == FN_STAGE_COLS) && f.cap > f.n_real && f.pad_mod < 1))
+            return fail(FN_EINVAL, "fn_stage_padded: bad field");
+        F.f[i] = f;
+        const int64_t elems = f.cap * (f.kind == FN_STAGE_ROWS ? f.width : f.kind == FN_STAGE_COLS ? 2 : 1);
+        most = elems > most ? elems : most;
+    }
+    if (most == 0) return 0;
+    hipLaunchKernelGGL(k_stage_padded, dim3(flat_grid(most, 256), n_fields), dim3(kBlock), 0, S(stream), F);
+    return launch_status("fn_stage_padded");
 }
 
 }  // extern "C"

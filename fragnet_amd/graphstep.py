@@ -1,0 +1,286 @@
+"""Static-shape training step replayed as ONE hipGraph.
+
+An eager step of the hot path is ~200 kernel launches plus the Python around them and is bound by the host
+(2.0 ms wall for 1.6 ms of GPU work at ESOL batch 512).  Kernel sizes, however, depend on the batch only through
+six counts (atoms, directed bonds, bond-graph edges, fragments, fragment edges, fragment-bond-graph edges), so a
+step over buffers of FIXED capacity can be captured once -- graph plan, encoder, pooling, head, loss, backward,
+gradient gather -- and replayed with one launch per step.  Every batch (the dict of the reference's
+``collate_fn``, dataset/data.py:931-948) is copied into the fixed buffers by one staging kernel
+(``fn_stage_padded``) which also fills the tails with PADDING:
+
+* padding rows carry zero features;
+* padding index values point at the last ``slack`` slots of the target index space (atoms, bond nodes,
+  fragments, fragment edges, molecules), which are guaranteed to be padding themselves, spread round-robin so
+  that no padding node collects a large in-degree.
+
+Padding therefore forms extra, disconnected "molecules" behind the real ones: real rows of every level see
+exactly the edges they had, the loss is weighted by a 1/0 molecule mask, and padding rows receive zero
+upstream gradient -- outputs, loss and parameter gradients of the real batch are unchanged
+(tests/test_graphstep.py checks this against the oracle on CPU and against the eager path on the GPU).
+Batches that do not fit the capacities fall back to the eager step, sharing optimiser and RNG state.
+
+The all-reduce and the Adam update stay outside the graph (one RCCL call + one kernel) so the N>1 path is the
+same collective as in the eager step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, Dict, Iterable, Optional
+
+import torch
+
+from . import _lib
+from .plan import PLAN_KEY
+
+# field -> (index space of the ragged axis, layout, index space its VALUES point into)
+FIELDS = {
+    "x_atoms": ("atom", "rows", None), "batch": ("atom", "ids", "mol"), "atom_to_frag_ids": ("atom", "ids", "frag"),
+    "edge_index": ("edge", "cols", "atom"), "edge_attr": ("edge", "rows", None), "node_features_bonds": ("edge", "rows", None),
+    "edge_index_bonds_graph": ("bedge", "cols", "edge"), "edge_attr_bonds": ("bedge", "rows", None),
+    "x_frags": ("frag", "rows", None), "frag_batch": ("frag", "ids", "mol"),
+    "frag_index": ("fedge", "cols", "frag"), "cnx_attr": ("fedge", "rows", None), "node_features_fbonds": ("fedge", "rows", None),
+    "edge_index_fbonds": ("fbedge", "cols", "fedge"), "edge_attr_fbonds": ("fbedge", "rows", None),
+    "y": ("mol", "rows", None),
+}
+COUNT_FIELD = {"atom": "x_atoms", "edge": "node_features_bonds", "bedge": "edge_attr_bonds", "frag": "x_frags",
+               "fedge": "node_features_fbonds", "fbedge": "edge_attr_fbonds", "mol": "y"}
+MASK_KEY = "mol_weight"           # float32 [mol cap]: 1 for real molecules, 0 for padding
+
+
+def _gat_limit(heads: int) -> int:
+    """Padding in-degree that stays on the kernels' one-pass path (in-degree <= 2 * 32/heads, self loop included)."""
+    return max(2, min(12, (2 * (32 // heads) * 3) // 4))
+
+
+def _pairs(heads: int):
+    g = _gat_limit(heads)
+    # node space -> [(item space whose values point into it, max padding items per padding node)]
+    return [("edge", [("bedge", g)]), ("fedge", [("fbedge", g)]), ("atom", [("edge", g)]),
+            ("frag", [("fedge", g), ("atom", 32)]), ("mol", [("atom", 64), ("frag", 64)])]
+
+
+def batch_counts(batch: Dict[str, torch.Tensor]) -> Dict[str, int]:
+    return {sp: int(batch[f].shape[0]) for sp, f in COUNT_FIELD.items()}
+
+
+def _up(x: int, q: int = 64) -> int:
+    return (x + q - 1) // q * q
+
+
+class StaticShapes:
+    """Capacities per index space + the number of trailing slots of each node space reserved for padding."""
+
+    def __init__(self, cap: Dict[str, int], slack: Dict[str, int], heads: int = 4):
+        self.cap, self.slack, self.heads = dict(cap), dict(slack), heads
+
+    @classmethod
+    def from_counts(cls, counts: Iterable[Dict[str, int]], margin: float = 0.03, heads: int = 4) -> "StaticShapes":
+        counts = list(counts)
+        mx = {sp: max(c[sp] for c in counts) for sp in COUNT_FIELD}
+        mn = {sp: min(c[sp] for c in counts) for sp in COUNT_FIELD}
+        lower = {sp: int(mn[sp] * (1.0 - margin)) for sp in COUNT_FIELD}
+        cap, slack = {}, {}
+        for sp in ("bedge", "fbedge"):
+            cap[sp] = _up(int(math.ceil(mx[sp] * (1.0 + margin))))
+        for node, sources in _pairs(heads):
+            need = max(-(-(cap[item] - lower[item]) // lim) for item, lim in sources)
+            slack[node] = max(8, need)
+            grow = 0.0 if node == "mol" else margin
+            cap[node] = _up(int(math.ceil(mx[node] * (1.0 + grow))) + slack[node], 8)
+        return cls(cap, slack, heads)
+
+    @classmethod
+    def from_batches(cls, batches, margin: float = 0.03, heads: int = 4) -> "StaticShapes":
+        return cls.from_counts([batch_counts(b) for b in batches], margin, heads)
+
+    def fits(self, counts: Dict[str, int]) -> bool:
+        for sp, n in counts.items():
+            if n > self.cap[sp] - self.slack.get(sp, 0):
+                return False
+        for node, sources in _pairs(self.heads):
+            for item, lim in sources:
+                if self.cap[item] - counts[item] > lim * self.slack[node]:
+                    return False
+        return True
+
+    def pad_rule(self, target: str):
+        """(pad_hi, pad_mod): padding position i of a field pointing into ``target`` holds pad_hi - i % pad_mod."""
+        return self.cap[target] - 1, self.slack[target]
+
+    def __repr__(self):
+        return f"StaticShapes(cap={self.cap}, slack={self.slack})"
+
+
+def pad_batch(batch: Dict[str, torch.Tensor], shapes: StaticShapes) -> Dict[str, torch.Tensor]:
+    """Reference implementation of the staging kernel with torch ops (any device): the padded batch dict."""
+    counts = batch_counts(batch)
+    if not shapes.fits(counts):
+        raise ValueError(f"batch {counts} does not fit {shapes}")
+    out = {}
+    for name, (space, layout, target) in FIELDS.items():
+        if name not in batch:
+            continue
+        src, cap, n = batch[name], shapes.cap[space], counts[space]
+        if layout == "rows":
+            dst = src.new_zeros((cap,) + tuple(src.shape[1:]))
+            dst[:n] = src
+        else:
+            hi, mod = shapes.pad_rule(target)
+            pad = hi - torch.arange(cap, device=src.device, dtype=torch.long) % mod
+            if layout == "ids":
+                dst = pad.clone()
+                dst[:n] = src
+            else:
+                dst = pad.repeat(2, 1)
+                dst[:, :n] = src
+        out[name] = dst
+    w = torch.zeros(shapes.cap["mol"], dtype=torch.float32, device=batch["y"].device)
+    w[: counts["mol"]] = 1.0
+    out[MASK_KEY] = w
+    return out
+
+
+def masked_regr_loss(out: torch.Tensor, y: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """MSELoss()(out.view(-1), y) of train/utils.py:341 restricted to the molecules with weight 1."""
+    d = out.reshape(w.shape[0], -1) - y.reshape(w.shape[0], -1)
+    return (d * d * w[:, None]).sum() / (w.sum() * d.shape[1])
+
+
+def masked_bce_loss(out: torch.Tensor, y: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """compute_bce_loss (train/utils.py:297-304): targets <= -0.5 are missing labels; padding molecules too."""
+    y = y.reshape(out.shape)
+    valid = (y > -0.5) & (w[:, None] > 0)
+    mat = torch.nn.functional.binary_cross_entropy_with_logits(out, y.clamp(min=0.0), reduction="none")
+    return torch.where(valid, mat, torch.zeros_like(mat)).sum() / valid.sum()
+
+
+class StaticBatch:
+    """Fixed-capacity device buffers for one batch + the single-launch staging call."""
+
+    def __init__(self, shapes: StaticShapes, example: Dict[str, torch.Tensor]):
+        dev = example["x_atoms"].device
+        if dev.type != "cuda":
+            raise _lib.FragnetHipError("StaticBatch stages batches on the GPU (fn_stage_padded); there is no CPU path")
+        self.shapes, self.device = shapes, dev
+        self.t: Dict[str, torch.Tensor] = {}
+        self._desc = []
+        for name, (space, layout, target) in FIELDS.items():
+            if name not in example:
+                continue
+            src, cap = example[name], shapes.cap[space]
+            if layout == "rows":
+                if src.dtype != torch.float32:
+                    raise TypeError(f"{name}: expected float32 rows, got {src.dtype}")
+                self.t[name] = torch.zeros((cap,) + tuple(src.shape[1:]), dtype=torch.float32, device=dev)
+                width = int(src[0].numel()) if src.dim() > 1 else 1
+                self._desc.append((name, space, _lib.STAGE_ROWS, max(width, 1), 0, 1))
+            else:
+                if src.dtype != torch.int64:
+                    raise TypeError(f"{name}: expected int64 indices, got {src.dtype}")
+                hi, mod = shapes.pad_rule(target)
+                self.t[name] = torch.zeros((cap,) if layout == "ids" else (2, cap), dtype=torch.int64, device=dev)
+                self._desc.append((name, space, _lib.STAGE_IDS if layout == "ids" else _lib.STAGE_COLS, 1, hi, mod))
+        self.t[MASK_KEY] = torch.zeros(shapes.cap["mol"], dtype=torch.float32, device=dev)
+        self._fields = (_lib.StageField * _lib.FN_MAX_STAGE_FIELDS)()
+        for i, (name, space, kind, width, hi, mod) in enumerate(self._desc):
+            f = self._fields[i]
+            f.dst, f.cap, f.width, f.kind, f.pad_hi, f.pad_mod = self.t[name].data_ptr(), shapes.cap[space], width, kind, hi, mod
+        m = self._fields[len(self._desc)]
+        m.dst, m.cap, m.width, m.kind, m.pad_hi, m.pad_mod = self.t[MASK_KEY].data_ptr(), shapes.cap["mol"], 1, _lib.STAGE_MASK, 0, 1
+        self.n_fields = len(self._desc) + 1
+        self.counts: Optional[Dict[str, int]] = None
+
+    def load(self, batch: Dict[str, torch.Tensor]) -> bool:
+        """Stage ``batch`` (GPU tensors); False when it does not fit the capacities (nothing is written then)."""
+        counts = batch_counts(batch)
+        if not self.shapes.fits(counts):
+            return False
+        keep = []
+        for i, (name, space, kind, width, hi, mod) in enumerate(self._desc):
+            src = batch[name]
+            if not src.is_cuda:
+                raise _lib.FragnetHipError(f"{name} must live on the GPU to be staged (got {src.device})")
+            if not src.is_contiguous():
+                src = src.contiguous()
+                keep.append(src)
+            f = self._fields[i]
+            f.src, f.n_real = src.data_ptr(), counts[space]
+        m = self._fields[self.n_fields - 1]
+        m.src, m.n_real = None, counts["mol"]
+        _lib.call("fn_stage_padded", self._fields, self.n_fields, torch.cuda.current_stream(self.device).cuda_stream)
+        self.counts = counts
+        return True
+
+
+class GraphedTrainStep:
+    """zero_grad + forward + loss + backward + gradient gather as one hipGraph; all-reduce + Adam after it.
+
+    ``model``: FragNetFineTune (fragnet_amd.model) in train mode; ``opt``: parallel.FlatAdam over its live
+    parameters; ``loss``: "regr" (MSE, train/utils.py:341) or "clsf" (masked BCE, train/utils.py:297).
+    """
+
+    def __init__(self, model, opt, shapes: StaticShapes, example: Dict[str, torch.Tensor], loss: str = "regr",
+                 group=None, warmup: int = 3):
+        self.model, self.opt, self.shapes, self.group = model, opt, shapes, group
+        self.loss_kind = loss
+        self._masked = {"regr": masked_regr_loss, "clsf": masked_bce_loss}[loss]
+        self.static = StaticBatch(shapes, example)
+        self.device = self.static.device
+        self.rng = model.pretrain.rng
+        self.rng.use_device_counter(self.device)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.loss: Optional[torch.Tensor] = None
+        self.replays = self.fallbacks = 0
+        self._capture(example, warmup)
+
+    # -- pieces
+    def _fwd_bwd_static(self):
+        sb = self.static.t
+        sb.pop(PLAN_KEY, None)                      # every step builds its own graph plan (inside the graph)
+        loss = self._masked(self.model(sb), sb["y"], sb[MASK_KEY])
+        loss.backward()
+        self.opt.gather_grads()
+        return loss
+
+    def _capture(self, example, warmup: int):
+        if not self.model.training:
+            raise RuntimeError("GraphedTrainStep captures a TRAINING step: call model.train() first")
+        if not self.static.load(example):
+            raise ValueError(f"the example batch {batch_counts(example)} does not fit {self.shapes}")
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.opt.zero_grad()
+                self._fwd_bwd_static()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self.opt.zero_grad()
+        graph = torch.cuda.CUDAGraph()
+        off0 = self.rng.offset
+        with torch.cuda.graph(graph):
+            loss = self._fwd_bwd_static()
+            consumed = self.rng.offset - off0
+            if consumed:
+                self.rng.advance_device(consumed)   # fresh dropout masks on every replay
+        self.graph, self.loss = graph, loss.detach()
+
+    def _eager(self, batch):
+        self.opt.zero_grad()
+        out = self.model(batch)
+        w = torch.ones(batch["y"].shape[0], dtype=torch.float32, device=out.device)
+        loss = self._masked(out, batch["y"], w)
+        loss.backward()
+        self.opt.step(self.group)
+        return loss.detach()
+
+    def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """One optimiser step on ``batch``.  Returns the loss (a tensor that the next call overwrites)."""
+        if not self.static.load(batch):
+            self.fallbacks += 1
+            return self._eager(batch)
+        self.graph.replay()
+        self.opt.apply_gathered(self.group)
+        self.replays += 1
+        return self.loss

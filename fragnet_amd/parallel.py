@@ -182,6 +182,11 @@ class FlatAdam:
     def step(self, group=None):
         """gather -> all-reduce (if distributed) -> Adam."""
         self.gather_grads()
+        self.apply_gathered(group)
+
+    def apply_gathered(self, group=None):
+        """all-reduce (if distributed) -> Adam on gradients that are already in the flat buffer (the captured
+        step of graphstep.GraphedTrainStep gathers them inside its hipGraph)."""
         self.all_reduce(group)
         self.steps += 1
         if self.opt is not None:

@@ -252,6 +252,27 @@ int fn_edge_concat_f32(const float* x /*[N,128]*/, const float* e_attr /*[E,128]
                        float* out /*[E,384]*/, int64_t E, fn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Static-shape staging for hipGraph replay.  A training step captured in a hipGraph has fixed tensor shapes, so
+ * every batch (the dict of dataset/data.py:931-948) is copied into fixed-capacity buffers and the tail of each
+ * buffer is filled with PADDING that is itself a valid, disconnected piece of graph: zero feature rows, and index
+ * values pointing at the last `pad_mod` slots of the target index space (pad value at position i =
+ * pad_hi - i % pad_mod), so padding only ever talks to padding and in-degrees stay small.  One launch, all fields.
+ * ------------------------------------------------------------------------------------------ */
+#define FN_MAX_STAGE_FIELDS 24
+#define FN_STAGE_ROWS 0 /* float32 [cap,width]  <- [n_real,width], zero rows after                         */
+#define FN_STAGE_IDS 1  /* int64   [cap]        <- [n_real], pad ids after                                 */
+#define FN_STAGE_COLS 2 /* int64   [2,cap]      <- [2,n_real] (edge_index layout), pad ids in both rows    */
+#define FN_STAGE_MASK 3 /* float32 [cap]        =  1 for i < n_real, 0 after (loss weights); src unused    */
+typedef struct fn_stage_field {
+    const void* src;
+    void* dst;
+    int64_t n_real, cap;
+    int32_t width, kind;
+    int64_t pad_hi, pad_mod;
+} fn_stage_field;
+int fn_stage_padded(const fn_stage_field* fields, int n_fields, fn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Encoder engine: the reference's FragNet.forward (gat2.py:381-442: L x FragNetLayerA + act(dropout(.))) and
  * its backward pass as one call each.  The host side only walks the layers and enqueues kernels on `stream`;
  * nothing is allocated, nothing synchronises.  `ws` keeps the activations the backward pass reads.

@@ -1,0 +1,171 @@
+"""Static-shape hipGraph step (fragnet_amd/graphstep.py).
+
+CPU: capacities, padding structure, and -- against the ORACLE -- that the padding is semantically neutral
+(real molecules' predictions, the loss and every parameter gradient are unchanged).
+GPU: the staging kernel is bit-identical to the torch reference ``pad_batch``; a captured step reproduces the
+eager step; dropout masks move between replays; batches beyond the capacities fall back to the eager step."""
+import copy
+
+import pytest
+import torch
+
+from fragnet_amd import data, graphstep, synth
+
+CFG = dict(n_classes=1, atom_features=167, frag_features=167, edge_features=17, num_layer=2, num_heads=4,
+           drop_ratio=0.0, h1=64, h2=64, h3=64, h4=64, act="relu", emb_dim=128, fthead="FTHead3")
+
+
+def _batches(n, B, seed=50):
+    return [data.collate_fn(synth.synth_molecules(B, seed=seed + i, profile="esol")) for i in range(n)]
+
+
+def test_capacities_and_padding_structure():
+    batches = _batches(4, 24)
+    shapes = graphstep.StaticShapes.from_batches(batches, margin=0.05)
+    lim = graphstep._gat_limit(4)
+    for b in batches:
+        counts = graphstep.batch_counts(b)
+        assert shapes.fits(counts)
+        pb = graphstep.pad_batch(b, shapes)
+        for name, (space, layout, target) in graphstep.FIELDS.items():
+            n, cap = counts[space], shapes.cap[space]
+            t = pb[name]
+            assert (t.shape[1] if layout == "cols" else t.shape[0]) == cap
+            real = t[:, :n] if layout == "cols" else t[:n]
+            assert torch.equal(real, b[name])                            # real data untouched, in place
+            tail = t[:, n:] if layout == "cols" else t[n:]
+            if target is None:
+                assert float(tail.abs().sum()) == 0.0
+            else:                                                         # padding only points at reserved padding slots
+                assert int(tail.min()) >= shapes.cap[target] - shapes.slack[target]
+                assert int(tail.max()) <= shapes.cap[target] - 1
+                assert counts[target] <= shapes.cap[target] - shapes.slack[target]
+        assert torch.equal(pb["edge_index"][0, counts["edge"]:], pb["edge_index"][1, counts["edge"]:])
+        # padding in-degrees stay on the kernels' one-pass path
+        for key, tgt in (("edge_index_bonds_graph", "edge"), ("edge_index", "atom"), ("frag_index", "frag"),
+                         ("edge_index_fbonds", "fedge")):
+            pad_cols = pb[key][:, counts[graphstep.FIELDS[key][0]]:]
+            if pad_cols.numel():
+                assert int(torch.bincount(pad_cols[0]).max()) <= lim
+        assert float(pb[graphstep.MASK_KEY].sum()) == counts["mol"]
+    big = _batches(1, 40, seed=99)[0]
+    assert not shapes.fits(graphstep.batch_counts(big))
+    with pytest.raises(ValueError):
+        graphstep.pad_batch(big, shapes)
+
+
+def test_padding_is_neutral_for_the_oracle():
+    from oracle import fragnet_ref as ref
+    batches = _batches(3, 12, seed=7)
+    shapes = graphstep.StaticShapes.from_batches(batches, margin=0.05)
+    torch.manual_seed(3)
+    model = ref.FragNetFineTune(**CFG)
+    model.eval()
+    b = batches[1]
+    pb = graphstep.pad_batch(b, shapes)
+    B = b["y"].shape[0]
+    out = model(b)
+    loss = ref.finetune_regr_loss(out, b["y"])
+    grads = torch.autograd.grad(loss, [p for p in model.parameters() if p.requires_grad], allow_unused=True)
+    out_p = model(pb)
+    assert out_p.shape[0] == shapes.cap["mol"]
+    torch.testing.assert_close(out_p[:B], out, atol=1e-6, rtol=1e-6)
+    loss_p = graphstep.masked_regr_loss(out_p, pb["y"], pb[graphstep.MASK_KEY])
+    torch.testing.assert_close(loss_p, loss, atol=1e-6, rtol=1e-6)
+    grads_p = torch.autograd.grad(loss_p, [p for p in model.parameters() if p.requires_grad], allow_unused=True)
+    for g, gp in zip(grads, grads_p):
+        assert (g is None) == (gp is None)
+        if g is not None:
+            torch.testing.assert_close(gp, g, atol=2e-6, rtol=1e-5)
+
+
+def test_masked_bce_matches_reference_formula():
+    from fragnet_amd import train
+    torch.manual_seed(0)
+    out, y = torch.randn(6, 3), torch.randint(-1, 2, (6, 3)).float()
+    w = torch.tensor([1.0, 1, 1, 1, 0, 0])
+    torch.testing.assert_close(graphstep.masked_bce_loss(out, y, w), train.compute_bce_loss(out[:4], y[:4]))
+
+
+# --------------------------------------------------------------------------------------------- GPU
+gpu = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+@gpu
+def test_stage_kernel_matches_pad_batch():
+    dev = _dev()
+    batches = [data.batch_to(b, dev) for b in _batches(3, 32)]
+    shapes = graphstep.StaticShapes.from_batches(batches, margin=0.05)
+    sb = graphstep.StaticBatch(shapes, batches[0])
+    for b in (batches[2], batches[0], batches[1]):      # later, smaller batches must overwrite earlier tails
+        assert sb.load(b)
+        ref = graphstep.pad_batch(b, shapes)
+        for k, v in ref.items():
+            assert torch.equal(sb.t[k], v), k
+    big = data.batch_to(_batches(1, 64, seed=5)[0], dev)
+    assert not sb.load(big)
+
+
+def _make(dev, drop=0.0, lr=1e-3):
+    from fragnet_amd import parallel
+    from fragnet_amd.model import FragNetFineTune
+    torch.manual_seed(11)
+    cfg = dict(CFG, drop_ratio=drop)
+    model = FragNetFineTune(**cfg).to(dev)
+    model.train()
+    return model, parallel, lr
+
+
+@gpu
+def test_graph_step_matches_eager_step():
+    dev = _dev()
+    batches = [data.batch_to(b, dev) for b in _batches(4, 48, seed=21)]
+    shapes = graphstep.StaticShapes.from_batches(batches, margin=0.05)
+    model_a, parallel, lr = _make(dev)
+    model_b = copy.deepcopy(model_a)
+
+    def probe(model):
+        def run():
+            torch.nn.functional.mse_loss(model(dict(batches[0])).view(-1), batches[0]["y"]).backward()
+        return run
+    opt_a = parallel.FlatAdam.for_live_parameters(model_a, probe(model_a), lr=lr)
+    opt_b = parallel.FlatAdam.for_live_parameters(model_b, probe(model_b), lr=lr)
+    step_b = graphstep.GraphedTrainStep(model_b, opt_b, shapes, dict(batches[0]), loss="regr")
+    torch.testing.assert_close(opt_b.flat, opt_a.flat, atol=0, rtol=0)       # capture itself must not move the weights
+    for i in range(6):
+        b = batches[i % 4]
+        opt_a.zero_grad()
+        loss_a = torch.nn.functional.mse_loss(model_a(dict(b)).view(-1), b["y"])
+        loss_a.backward()
+        opt_a.step()
+        loss_b = step_b(dict(b)).clone()
+        torch.testing.assert_close(loss_b, loss_a.detach(), atol=1e-5, rtol=1e-4)
+    assert step_b.replays == 6 and step_b.fallbacks == 0
+    torch.testing.assert_close(opt_b.flat, opt_a.flat, atol=2e-5, rtol=1e-3)
+    # a batch beyond the capacities takes the eager path and still updates the same optimiser state
+    big = data.batch_to(_batches(1, 96, seed=77)[0], dev)
+    before = opt_b.flat.detach().clone()
+    step_b(dict(big))
+    assert step_b.fallbacks == 1 and not torch.equal(before, opt_b.flat)
+    step_b(dict(batches[1]))
+    assert step_b.replays == 7
+
+
+@gpu
+def test_graph_step_draws_fresh_dropout_masks():
+    dev = _dev()
+    batches = [data.batch_to(b, dev) for b in _batches(2, 48, seed=31)]
+    shapes = graphstep.StaticShapes.from_batches(batches, margin=0.05)
+    model, parallel, _ = _make(dev, drop=0.2, lr=0.0)
+    opt = parallel.FlatAdam.for_live_parameters(
+        model, lambda: torch.nn.functional.mse_loss(model(dict(batches[0])).view(-1), batches[0]["y"]).backward(), lr=0.0)
+    step = graphstep.GraphedTrainStep(model, opt, shapes, dict(batches[0]))
+    losses = [float(step(dict(batches[0]))) for _ in range(4)]      # lr = 0: only the masks differ between replays
+    assert len(set(losses)) == 4, losses
+    assert int(model.pretrain.rng.dev) > 0
