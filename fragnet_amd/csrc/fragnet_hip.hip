@@ -377,116 +377,190 @@ __global__ __launch_bounds__(kBlock) void k_node_scalars(const float* __restrict
     }
 }
 
-// The vector memory pipe serves one wave instruction per ~16 cycles whatever its width, and these kernels are
-// bound by it (TA busy ~60 %, rocprofv3 r01b).  So every per-edge scalar is fetched ONCE by the lane that owns the
-// edge -- lane j of a head group owns the consecutive in-edges 2j and 2j+1, one 8-byte load per array -- and handed
-// to the other lanes through LDS-crossbar broadcasts (__shfl), never through repeated uniform global loads.
-// Row gathers are issued four at a time and only for edges that exist.
-template <int H>
+// What bounds these kernels at molecule-batch sizes is neither HBM nor L2 bandwidth but the CHAIN of dependent
+// global round trips a row needs (row extent -> edge ids/terms -> source rows + source scalars -> store), ~1.2 us
+// each when ~100 rows per CU is all the work there is (ablation in DESIGN.md: gathering the same rows from an LDS
+// window instead of L2 changed nothing; an empty skeleton with two round trips already costs 9.5 us).  So:
+//  * every per-edge scalar is fetched ONCE by the lane that owns the edge -- lane j of a head group owns the
+//    consecutive in-edges 2j and 2j+1, one 8-byte load per array -- and handed round through LDS-crossbar
+//    broadcasts (__shfl), never through repeated uniform global loads (TA: one wave instruction per ~16 cycles);
+//  * up to eight source rows are in flight per half-wave before the softmax needs anything;
+//  * a half-wave owns R CONSECUTIVE rows and software-pipelines them: while row i's gathers fly, the edge data of
+//    row i+1 and the extent of row i+2 are already being fetched, so a row costs one round trip, not four.
+struct FwdExtent { int beg, deg; float sd; };                 // deg < 0: no row
+struct FwdEdges { int src0, src1; float z0, z1; };            // the lane's two in-edges: source ids, edge terms
+struct FwdRaw {                                               // the same, as loaded (folded one iteration later)
+    int pos;
+    i32x2u sp;
+    f32x2u e[FN_MAX_EDGE_K];
+};
+template <int NE> struct FwdRawT {                            // sized to the loads a kernel instance makes
+    int pos;
+    i32x2u sp;
+    f32x2u e[NE];
+};
+__device__ __forceinline__ float4 ld4_off(const float* base, uint32_t byte_off) {      // scalar base + 32-bit offset
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float ld1_off(const float* base, uint32_t byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// The hot loop is STRAIGHT-LINE: every load is unconditional (addresses clamped into the arrays, results masked
+// afterwards).  A load inside a divergent branch whose value is used inside that branch makes the compiler wait
+// for vmcnt(0) right there -- which serialised the row gathers, the two source-scalar gathers and the prefetches
+// into separate round trips in the previous version of this kernel.
+// KL: 0 = the edge term is a stored per-edge scalar (mode 0); 1 / FN_MAX_EDGE_K = folded Linear(K -> d) of a raw
+// attribute with K == 1 / K <= FN_MAX_EDGE_K (attribute columns beyond K are re-loads of column K-1 with weight 0,
+// so that the number of loads is a compile-time constant and none of them sits in a branch).
+template <int H, int KL>
 __global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h, const float* __restrict__ s_dst,
                                                     const float* __restrict__ s_src, const float* __restrict__ att,
                                                     int att_w, fn_edge_term et, fn_gat_plan pl, float slope,
                                                     float* __restrict__ out, float* __restrict__ p_sorted,
-                                                    float* __restrict__ probs_orig, fn_act_epilogue ep) {
+                                                    float* __restrict__ probs_orig, fn_act_epilogue ep, int rows_per_hw) {
     constexpr int LPH = 32 / H;
+    constexpr int NE = KL ? KL : 1;                       // 8-byte edge loads per lane and row
     __shared__ float sWf[8][kWfLd];
     fold_edge_embed(et, att, att_w, H, sWf);
     const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH;
-    const int64_t m = pl.m;
-    int64_t g0, g1;
-    block_groups(pl.n, kRows, g0, g1);
-    for (int64_t gi = g0; gi < g1; ++gi) {
-        const int64_t t = gi * kRows + (threadIdx.x >> 5);
-        if (t >= pl.n) continue;
-        const i32x2u rp = ldp(pl.rowptr_d + t);
-        const int beg = rp.x - pl.pos_base_d, deg = rp.y - rp.x;
-        const float sd = s_dst[t * H + head];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (deg <= 2 * LPH) {
-            const int pos0 = beg + 2 * j;
-            const bool has0 = 2 * j < deg, has1 = 2 * j + 1 < deg;
-            int src0 = 0, src1 = 0;
-            float z0 = 0.f, z1 = 0.f;
-            if (has0 && pos0 + 1 < m) {                   // paired loads even when only edge 2j exists (the second
-                const i32x2u sp = ldp(pl.src_d + pos0);   // value then belongs to the next node and is ignored):
-                src0 = sp.x; src1 = sp.y;                 // one code path = one instruction per array
-                if (et.mode == 0) {
-                    const f32x2u e2 = ldp(et.s_sorted + (size_t)head * m + pos0);
-                    z0 = e2.x; z1 = e2.y;
-                } else {
-                    z0 = z1 = sWf[head][et.K];
-                    for (int k = 0; k < et.K; ++k) {
-                        const f32x2u x2 = ldp(et.x_sorted + (size_t)k * m + pos0);
-                        z0 = fmaf(x2.x, sWf[head][k], z0);
-                        z1 = fmaf(x2.y, sWf[head][k], z1);
-                    }
-                }
-            } else if (has0) {                            // very last edge of the level
-                src0 = pl.src_d[pos0];
-                z0 = edge_term_at<H>(pos0, head, m, et, sWf);
-            }
-            if (!has1) src1 = src0;
-            // the first four source rows depend only on the source ids: issue their gathers now, so that they fly
-            // together with the s_src gathers instead of after the softmax (one round trip less per node)
-            const int slast = deg ? __shfl(((deg - 1) & 1) ? src1 : src0, (deg - 1) >> 1, LPH) : 0;
-            float4 r0[4];
+    const int m = (int)pl.m, n = (int)pl.n;
+    const int K = KL ? et.K : 0;
+    float wf[NE];                                         // this head's folded edge-embedding weights
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int sk = __shfl((i & 1) ? src1 : src0, i >> 1, LPH);
-                if (i >= deg) sk = slast;
-                r0[i] = deg ? ld4(h + (size_t)sk * FN_D + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < NE; ++k) wf[k] = (KL && k < K) ? sWf[head][k] : 0.f;
+    const float wbias = KL ? sWf[head][K] : 0.f;
+    const int tb = (xcd_block(blockIdx.x, gridDim.x) * kRows + (int)(threadIdx.x >> 5)) * rows_per_hw;
+    const int te = tb + rows_per_hw < n ? tb + rows_per_hw : n;
+    const bool pairs = m >= 2;                            // paired edge loads need two edges in the level
+    const float* e_sorted = KL ? nullptr : et.s_sorted + (size_t)head * m;
+
+    auto load_extent = [&](int t) {
+        const int tc = t < n ? t : n - 1;
+        const i32x2u rp = ldp(pl.rowptr_d + tc);
+        FwdExtent x;
+        x.beg = rp.x - pl.pos_base_d;
+        x.deg = t < te ? rp.y - rp.x : -1;
+        x.sd = s_dst[(uint32_t)tc * H + head];
+        return x;
+    };
+    auto issue_edges = [&](const FwdExtent& x, FwdRawT<NE>& r) {
+        int pos = x.beg + 2 * j;
+        pos = pos > m - 2 ? m - 2 : pos;
+        pos = pos < 0 ? 0 : pos;
+        r.pos = pos;
+        if (!pairs) { r.sp.x = r.sp.y = 0;  return; }
+        r.sp = ldp(pl.src_d + pos);
+        if (KL == 0) r.e[0] = ldp(e_sorted + pos);
+        else {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) r.e[k] = ldp(et.x_sorted + (size_t)(k < K ? k : K - 1) * m + pos);
+        }
+    };
+    auto fold_edges = [&](const FwdExtent& x, const FwdRawT<NE>& r) {
+        FwdEdges e;
+        float za, zb;
+        if (KL == 0) { za = r.e[0].x;  zb = r.e[0].y; }
+        else {
+            za = zb = wbias;
+#pragma unroll
+            for (int k = 0; k < NE; ++k) { za = fmaf(r.e[k].x, wf[k], za);  zb = fmaf(r.e[k].y, wf[k], zb); }
+        }
+        const bool shifted = x.beg + 2 * j != r.pos;      // only the very last edge of the level: its pair starts one early
+        e.src0 = shifted ? r.sp.y : r.sp.x;  e.z0 = shifted ? zb : za;
+        e.src1 = r.sp.y;  e.z1 = zb;
+        return e;
+    };
+
+    const uint64_t rng_base = ep.offset + ((ep.y && ep.p > 0.f && ep.offset_dev) ? *ep.offset_dev : 0);
+    FwdRawT<NE> raw;
+    FwdExtent cur = load_extent(tb);
+    issue_edges(cur, raw);
+    FwdExtent nxt = load_extent(tb + 1);
+    FwdEdges ed = fold_edges(cur, raw);
+    // drain the prologue's loads here: otherwise the compiler, unable to tell the first iteration from the others,
+    // puts a vmcnt(0) at the loop head, where it also waits for the previous iteration's STORES
+    asm volatile("" ::"v"(nxt.sd), "v"(nxt.beg), "v"(nxt.deg), "v"(ed.src0), "v"(ed.src1), "v"(ed.z0), "v"(ed.z1));
+    for (int t = tb; t < tb + rows_per_hw; ++t) {         // uniform trip count: both half-waves of a wave stay in step
+        const int beg = cur.beg, deg = cur.deg;
+        const bool fast = pairs && deg >= 0 && deg <= 2 * LPH;
+        const bool has0 = fast && 2 * j < deg, has1 = fast && 2 * j + 1 < deg;
+        const int src0 = ed.src0, src1 = has1 ? ed.src1 : ed.src0;
+        // one round trip: next row's edge data, the row after's extent, this row's source rows and source scalars
+        issue_edges(nxt, raw);
+        const FwdExtent nn = load_extent(t + 2);
+        const bool wide = __any(fast && deg > 4);
+        float4 r0[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sk = __shfl((i & 1) ? src1 : src0, i >> 1, LPH);
+            r0[i] = ld4_off(h, (uint32_t)sk * (FN_D * 4) + lane * 16);
+        }
+        if (wide) {
+#pragma unroll
+            for (int i = 4; i < 8; ++i) {
+                const int sk = __shfl((i & 1) ? src1 : src0, i >> 1, LPH);
+                r0[i] = ld4_off(h, (uint32_t)sk * (FN_D * 4) + lane * 16);
             }
-            if (has0) z0 += sd + s_src[(size_t)src0 * H + head];
-            if (has1) z1 += sd + s_src[(size_t)src1 * H + head];
-            const float l0 = has0 ? (z0 > 0.f ? z0 : slope * z0) : -INFINITY;
-            const float l1 = has1 ? (z1 > 0.f ? z1 : slope * z1) : -INFINITY;
-            const float mx = head_max<LPH>(fmaxf(l0, l1));
-            const float e0 = has0 ? expf(l0 - mx) : 0.f;
-            const float e1 = has1 ? expf(l1 - mx) : 0.f;
-            const float den = head_sum<LPH>(e0 + e1);
-            const float p0 = has0 ? e0 / den : 0.f;
-            const float p1 = has1 ? e1 / den : 0.f;
+        }
+        const float ss0 = ld1_off(s_src, ((uint32_t)src0 * H + head) * 4);
+        const float ss1 = ld1_off(s_src, ((uint32_t)src1 * H + head) * 4);
+
+        const float z0 = ed.z0 + cur.sd + ss0, z1 = ed.z1 + cur.sd + ss1;
+        const float l0 = has0 ? fmaxf(z0, slope * z0) : -INFINITY;       // LeakyReLU, 0 < slope < 1
+        const float l1 = has1 ? fmaxf(z1, slope * z1) : -INFINITY;
+        const float mx = head_max<LPH>(fmaxf(l0, l1));
+        const float e0 = has0 ? __expf(l0 - mx) : 0.f;
+        const float e1 = has1 ? __expf(l1 - mx) : 0.f;
+        const float inv = __builtin_amdgcn_rcpf(head_sum<LPH>(e0 + e1));
+        const float p0 = has0 ? e0 * inv : 0.f;
+        const float p1 = has1 ? e1 * inv : 0.f;
+        // everything issued above has arrived by now (loads return in order): fold the next row's edge data BEFORE
+        // this row's stores, so that nothing at the top of the next iteration has to wait behind those stores
+        const FwdEdges ed_n = fold_edges(nxt, raw);
+        const float sd_cur = cur.sd;
+        cur = nxt;  nxt = nn;  ed = ed_n;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fma4(acc, __shfl((i & 1) ? p1 : p0, i >> 1, LPH), r0[i]);
+        if (wide) {
+#pragma unroll
+            for (int i = 4; i < 8; ++i) fma4(acc, __shfl((i & 1) ? p1 : p0, i >> 1, LPH), r0[i]);
+        }
+        if (fast) {
+            const int pos0 = beg + 2 * j;
             float* pdst = p_sorted + (size_t)head * m + pos0;
-            if (has1) stp(pdst, l0 > 0.f ? p0 : -p0, l1 > 0.f ? p1 : -p1);
-            else if (has0) pdst[0] = l0 > 0.f ? p0 : -p0;
+            if (has1) stp(pdst, z0 > 0.f ? p0 : -p0, z1 > 0.f ? p1 : -p1);
+            else if (has0) pdst[0] = z0 > 0.f ? p0 : -p0;
             if (probs_orig) {
                 if (has0) probs_orig[(size_t)pl.eid_d[pos0] * H + head] = p0;
                 if (has1) probs_orig[(size_t)pl.eid_d[pos0 + 1] * H + head] = p1;
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float pk = __shfl((i & 1) ? p1 : p0, i >> 1, LPH);
-                fma4(acc, i < deg ? pk : 0.f, r0[i]);
-            }
-            for (int k0 = 4; k0 < deg; k0 += 4) {
-                float4 r[4];
-                float pk[4];
+            for (int k0 = 8; k0 < deg; k0 += 4) {         // in-degree 9 .. 2*LPH
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int k = k0 + i;
-                    int sk = __shfl((i & 1) ? src1 : src0, k >> 1, LPH);
-                    pk[i] = __shfl((i & 1) ? p1 : p0, k >> 1, LPH);
-                    if (k >= deg) { sk = slast; pk[i] = 0.f; }
-                    r[i] = ld4(h + (size_t)sk * FN_D + lane * 4);
+                    const int sk = __shfl((i & 1) ? src1 : src0, k >> 1, LPH);
+                    const float pk = __shfl((i & 1) ? p1 : p0, k >> 1, LPH);
+                    fma4(acc, pk, ld4_off(h, (uint32_t)sk * (FN_D * 4) + lane * 16));
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fma4(acc, pk[i], r[i]);
             }
-        } else {
-            // rare high in-degree node: every lane walks the edge list (three passes)
+        } else if (deg >= 0) {
+            // rare high in-degree node (or a level with a single edge): every lane walks the edge list (three passes)
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
             auto logit = [&](int pos, int& sk) {
                 sk = pl.src_d[pos];
-                const float z = sd + s_src[(size_t)sk * H + head] + edge_term_at<H>(pos, head, m, et, sWf);
+                const float z = sd_cur + s_src[(size_t)sk * H + head] + edge_term_at<H>(pos, head, m, et, sWf);
                 return z > 0.f ? z : slope * z;
             };
             int sk = 0;
-            float mx = -INFINITY;
-            for (int i = 0; i < deg; ++i) mx = fmaxf(mx, logit(beg + i, sk));
+            float mxs = -INFINITY;
+            for (int i = 0; i < deg; ++i) mxs = fmaxf(mxs, logit(beg + i, sk));
             float den = 0.f;
-            for (int i = 0; i < deg; ++i) den += expf(logit(beg + i, sk) - mx);
+            for (int i = 0; i < deg; ++i) den += expf(logit(beg + i, sk) - mxs);
             for (int i = 0; i < deg; ++i) {
                 const float l = logit(beg + i, sk);
-                const float p = expf(l - mx) / den;
+                const float p = expf(l - mxs) / den;
                 if (j == 0) {
                     p_sorted[(size_t)head * m + beg + i] = l > 0.f ? p : -p;
                     if (probs_orig) probs_orig[(size_t)pl.eid_d[beg + i] * H + head] = p;
@@ -494,17 +568,19 @@ __global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h,
                 fma4(acc, p, ld4(h + (size_t)sk * FN_D + lane * 4));
             }
         }
-        if (out) st4(out + t * FN_D + lane * 4, acc);
-        if (ep.y) {          // fused act(dropout(.)): same Philox block index (element / 4) as k_dropout_act
-            float4 r = acc;
-            if (ep.p > 0.f) {
-                const uint4 rnd = philox4x32_10(ep.offset + (ep.offset_dev ? *ep.offset_dev : 0) + (uint64_t)t * 32 + lane, ep.seed);
-                const float ik = ep.p < 1.f ? 1.f / (1.f - ep.p) : 0.f;
-                r.x *= keep_scale(rnd.x, ep.p, ik); r.y *= keep_scale(rnd.y, ep.p, ik);
-                r.z *= keep_scale(rnd.z, ep.p, ik); r.w *= keep_scale(rnd.w, ep.p, ik);
+        if (deg >= 0) {
+            if (out) st4(out + (size_t)t * FN_D + lane * 4, acc);
+            if (ep.y) {          // fused act(dropout(.)): same Philox block index (element / 4) as k_dropout_act
+                float4 r = acc;
+                if (ep.p > 0.f) {
+                    const uint4 rnd = philox4x32_10(rng_base + (uint64_t)t * 32 + lane, ep.seed);
+                    const float ik = ep.p < 1.f ? 1.f / (1.f - ep.p) : 0.f;
+                    r.x *= keep_scale(rnd.x, ep.p, ik); r.y *= keep_scale(rnd.y, ep.p, ik);
+                    r.z *= keep_scale(rnd.z, ep.p, ik); r.w *= keep_scale(rnd.w, ep.p, ik);
+                }
+                if (ep.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+                st4(ep.y + (size_t)t * FN_D + lane * 4, r);
             }
-            if (ep.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
-            st4(ep.y + t * FN_D + lane * 4, r);
         }
     }
 }
@@ -1141,6 +1217,7 @@ __global__ __launch_bounds__(512) void k_linear128(const float* __restrict__ X, 
                                                    const float* __restrict__ bias, float* __restrict__ Y, int64_t M,
                                                    fn_act_epilogue mk, NodeScalarEpi ns) {
     extern __shared__ __attribute__((aligned(16))) float sBt[];        // [4*KQ][kBtLd] then 8 x [16][kLinOutLd]
+    const uint64_t mk_base = mk.offset + ((mk.y && mk.p > 0.f && mk.offset_dev) ? *mk.offset_dev : 0);   // read once, not per tile
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
     const int wr = w & 3, wc = w >> 2;
     float* sOut = sBt + 4 * KQ * kBtLd + w * 16 * kLinOutLd;
@@ -1221,7 +1298,7 @@ __global__ __launch_bounds__(512) void k_linear128(const float* __restrict__ X, 
                 if (mk.y) {      // backward of act(dropout(.)) fused into the input-gradient GEMM: o *= mask * (y > 0)
                     const int64_t e4 = (r0 + rr) * 32 + 16 * wc + c4;            // Philox block = element / 4
                     if (mk.p > 0.f) {
-                        const uint4 rnd = philox4x32_10(mk.offset + (mk.offset_dev ? *mk.offset_dev : 0) + (uint64_t)e4, mk.seed);
+                        const uint4 rnd = philox4x32_10(mk_base + (uint64_t)e4, mk.seed);
                         const float ik = mk.p < 1.f ? 1.f / (1.f - mk.p) : 0.f;
                         o.x *= keep_scale(rnd.x, mk.p, ik); o.y *= keep_scale(rnd.y, mk.p, ik);
                         o.z *= keep_scale(rnd.z, mk.p, ik); o.w *= keep_scale(rnd.w, mk.p, ik);
@@ -1464,6 +1541,8 @@ bool bad_edge_term(const fn_edge_term* et) {
 // C-ABI
 // =====================================================================================
 namespace {
+int g_tune[FN_TUNE_COUNT] = {1792, 0};      // FN_TUNE_FWD_BLOCKS, FN_TUNE_DEBUG
+#define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -1538,6 +1617,13 @@ __global__ void k_zero2_i32(int32_t* __restrict__ a, int64_t na, int32_t* __rest
 extern "C" {
 
 int fn_abi_version(void) { return FN_ABI_VERSION; }
+
+int fn_set_tuning(int key, int value) {
+    if (key < 0 || key >= FN_TUNE_COUNT) return fail(FN_EINVAL, "fn_set_tuning: unknown key");
+    if (key == FN_TUNE_FWD_BLOCKS && value < 1) return fail(FN_EINVAL, "fn_set_tuning: block count must be positive");
+    g_tune[key] = value;
+    return 0;
+}
 const char* fn_last_error(void) { return tl_err; }
 
 int fn_plan_layout(fn_csr_task* tasks, int n_tasks, int64_t* total_items, int64_t* total_segs) {
@@ -1630,9 +1716,22 @@ int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const
     if (plan->m > 0 && !p_sorted) return fail(FN_EINVAL, "fn_gat_fwd_f32: null p_sorted");
     if (et->mode == 0 && plan->m > 0 && !et->s_sorted) return fail(FN_EINVAL, "fn_gat_fwd_f32: null s_sorted");
     if (plan->n == 0) return 0;
-    constexpr int fwd_cap = 8 * kGridCap;
-    FN_DISPATCH_H(heads, hipLaunchKernelGGL(k_gat_fwd<HH>, dim3(row_grid(plan->n, fwd_cap)), dim3(kBlock), 0, S(stream),
-                                            h, s_dst, s_src, att, att_w, *et, *plan, neg_slope, out, p_sorted, probs_orig, ep));
+    if (!(neg_slope >= 0.f && neg_slope <= 1.f)) return fail(FN_EUNSUPPORTED, "fn_gat_fwd_f32: LeakyReLU slope must be in [0, 1]");
+    if (plan->n > (1 << 23) || plan->m * heads > (1 << 29))
+        return fail(FN_EUNSUPPORTED, "fn_gat_fwd_f32: level too large for 32-bit byte offsets (n <= 2^23 rows, m*heads <= 2^29)");
+    // persistent half-waves: as many as fit on the chip at once, each pipelining R consecutive rows
+    const int64_t groups = (plan->n + kRows - 1) / kRows;
+    const int64_t resident = (int64_t)g_tune[FN_TUNE_FWD_BLOCKS];
+    const int R = (int)((groups + resident - 1) / resident);
+    const int64_t grid = (plan->n + (int64_t)kRows * R - 1) / ((int64_t)kRows * R);
+#define FN_FWD_LAUNCH(KL) hipLaunchKernelGGL((k_gat_fwd<HH, KL>), dim3((unsigned)grid), dim3(kBlock), 0, S(stream), h, s_dst, \
+                                             s_src, att, att_w, *et, *plan, neg_slope, out, p_sorted, probs_orig, ep, R)
+    FN_DISPATCH_H(heads, {
+        if (et->mode == 0) FN_FWD_LAUNCH(0);
+        else if (et->K == 1) FN_FWD_LAUNCH(1);
+        else FN_FWD_LAUNCH(FN_MAX_EDGE_K);
+    });
+#undef FN_FWD_LAUNCH
     return launch_status("fn_gat_fwd_f32");
 }
 
@@ -2020,8 +2119,6 @@ int enc_check(const fn_encoder* e) {
         return fail(FN_EINVAL, "fn_encoder: null input");
     return 0;
 }
-
-#define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 
 }  // namespace
 

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Probe: do two independent kernel chains captured on two streams of one hipGraph overlap on the GPU?
+Chain A = bond-level k_gat_fwd x R, chain B = k_linear128 (atom rows) + atom-sized k_gat_fwd x R."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from fragnet_amd import _lib  # noqa: E402
+from fragnet_amd.model import FragNetFineTune  # noqa: E402
+from fragnet_amd.plan import GraphPlan  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    batch = bench.make_pool(1, 0, dev)[0]
+    model = FragNetFineTune(**bench.MODEL_CFG).to(dev)
+    plan = GraphPlan.from_batch(batch)
+    layer = model.pretrain.layers[1]
+    H = 4
+    f32 = dict(dtype=torch.float32, device=dev)
+
+    def level(name, att, att_w, et):
+        lv = plan.levels[name]
+        n, m = lv.n, lv.m
+        h = torch.randn(n, 128, **f32)
+        s_dst, s_src = torch.randn(n, H, **f32), torch.randn(n, H, **f32)
+        out, p = torch.empty(n, 128, **f32), torch.empty(m, H, **f32)
+
+        def run(st):
+            _lib.call("fn_gat_fwd_f32", h.data_ptr(), s_dst.data_ptr(), s_src.data_ptr(), att.data_ptr(), att_w, C.byref(et),
+                      C.byref(lv.c), 0.2, out.data_ptr(), p.data_ptr(), None, None, H, st)
+        return run, (h, s_dst, s_src, out, p)
+
+    att_b = layer.a_b.detach().contiguous()
+    embW, embb = layer.edge_attr_bond_embed.weight.detach().contiguous(), layer.edge_attr_bond_embed.bias.detach().contiguous()
+    x = plan.sorted_attr("bond", batch["edge_attr_bonds"])
+    et_b = _lib.EdgeTerm(2, 1, 32, 32, None, x.data_ptr(), embW.data_ptr(), embb.data_ptr())
+    run_b, keep_b = level("bond", att_b, 96, et_b)
+    att_a = layer.a.detach().contiguous()
+    s_sorted = torch.randn(H, plan.levels["atom"].m, **f32)
+    et_a = _lib.EdgeTerm(0, 0, 0, 0, s_sorted.data_ptr(), None, None, None)
+    run_a, keep_a = level("atom", att_a, 192, et_a)
+    N = plan.levels["atom"].n
+    X, Bt, bias, Y = torch.randn(N, 128, **f32), torch.randn(128, 128, **f32), torch.randn(128, **f32), torch.empty(N, 128, **f32)
+
+    def gemm(st):
+        _lib.call("fn_linear128_f32", X.data_ptr(), 128, Bt.data_ptr(), bias.data_ptr(), Y.data_ptr(), N, None, st)
+
+    R = 8
+
+    def chain_a(st):
+        for _ in range(R):
+            run_b(st)
+
+    def chain_b(st):
+        for _ in range(R):
+            gemm(st)
+            run_a(st)
+
+    def timed(graph, iters=30):
+        for _ in range(3):
+            graph.replay()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(iters):
+            graph.replay()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1000.0 / iters
+
+    cur = torch.cuda.current_stream()
+    chain_a(cur.cuda_stream); chain_b(cur.cuda_stream)
+    torch.cuda.synchronize()
+    res = {}
+    for name, fa, fb in (("A only", chain_a, None), ("B only", None, chain_b), ("A then B, one stream", chain_a, chain_b)):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            st = torch.cuda.current_stream().cuda_stream
+            if fa:
+                fa(st)
+            if fb:
+                fb(st)
+        res[name] = timed(g)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.graph(g):
+        main_s = torch.cuda.current_stream()
+        side.wait_stream(main_s)
+        with torch.cuda.stream(side):
+            chain_b(side.cuda_stream)
+        chain_a(main_s.cuda_stream)
+        main_s.wait_stream(side)
+    res["A || B, two streams"] = timed(g)
+    for k, v in res.items():
+        print(f"{k:26s} {v:8.1f} us")
+
+
+if __name__ == "__main__":
+    main()
