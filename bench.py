@@ -200,6 +200,9 @@ def main():
     if args.fwd_win is not None:
         from fragnet_amd import _lib
         _lib.call("fn_set_tuning", 0, args.fwd_win)
+    if os.environ.get("FN_STREAMS"):
+        from fragnet_amd import _lib
+        _lib.call("fn_set_tuning", 2, int(os.environ["FN_STREAMS"]))
     if os.environ.get("FN_DEBUG_MASK"):
         from fragnet_amd import _lib
         _lib.call("fn_set_tuning", 1, int(os.environ["FN_DEBUG_MASK"]))

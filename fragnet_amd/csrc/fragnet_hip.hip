@@ -1198,6 +1198,7 @@ __global__ void k_edge_concat(const float* __restrict__ x, const float* __restri
 // =====================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kBtLd = 144;     // LDS leading dimension of the [K][128] operand: 144 % 32 == 16
+constexpr int kLinLd = 132;    // k_linear128's own: 4 rows apart = 16 banks apart, so the four k-quarters of a wave do not collide
 
 // A block = 8 waves = 64 rows x 128 columns: wave w owns rows 16*(w&3).. and columns 64*(w>>2).. (4 accumulator
 // tiles), so two waves share every SIMD and one wave's LDS reads hide under the other's MFMAs.  Bt is staged in
@@ -1212,15 +1213,18 @@ struct NodeScalarEpi {             // optional fused epilogue: s_dst/s_src[row, 
     float* s_src;
     int att_w, dst_off, src_off, heads;     // heads in {2, 4, 8}: a head's columns must lie inside one wave's 64
 };
-template <int KQ>
+// VEC (K == 4*KQ, KQ % 4 == 0): lane (i, kq) owns the k's {16 s + 4 kq + c}: one wave-instruction then reads 64
+// contiguous bytes of each of its 16 rows (a blocked split, k = kq*KQ + .., made every lane touch its own 128-byte
+// line and re-fetched each line eight times through a thrashing L1).  The B rows in LDS are indexed to match.
+template <int KQ, bool VEC>
 __global__ __launch_bounds__(512) void k_linear128(const float* __restrict__ X, int K, const float* __restrict__ Bt,
                                                    const float* __restrict__ bias, float* __restrict__ Y, int64_t M,
                                                    fn_act_epilogue mk, NodeScalarEpi ns) {
-    extern __shared__ __attribute__((aligned(16))) float sBt[];        // [4*KQ][kBtLd] then 8 x [16][kLinOutLd]
+    extern __shared__ __attribute__((aligned(16))) float sBt[];        // [4*KQ][kLinLd] then 8 x [16][kLinOutLd]
     const uint64_t mk_base = mk.offset + ((mk.y && mk.p > 0.f && mk.offset_dev) ? *mk.offset_dev : 0);   // read once, not per tile
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
     const int wr = w & 3, wc = w >> 2;
-    float* sOut = sBt + 4 * KQ * kBtLd + w * 16 * kLinOutLd;
+    float* sOut = sBt + 4 * KQ * kLinLd + w * 16 * kLinOutLd;
     {   // stage Bt [4*KQ][128] -> LDS with 16-byte loads, all loads of a thread in flight before the first LDS store
         constexpr int N4 = 4 * KQ * 32;                 // float4 count
         constexpr int PER = (N4 + 511) / 512;
@@ -1233,20 +1237,19 @@ __global__ __launch_bounds__(512) void k_linear128(const float* __restrict__ X, 
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const int idx = tid + q * 512, k = idx >> 5, n4 = idx & 31;
-            if (idx < N4) st4(sBt + k * kBtLd + n4 * 4, v[q]);
+            if (idx < N4) st4(sBt + k * kLinLd + n4 * 4, v[q]);
         }
     }
     const int64_t tiles = (M + 63) / 64;
-    const bool vec = (K == 4 * KQ) && (KQ % 4 == 0);
 
     auto load_rows = [&](int64_t tile, float (&xa)[KQ]) {
         int64_t row = tile * 64 + wr * 16 + i;
         row = row < M ? row : M - 1;
-        const float* src = X + row * K + kq * KQ;
-        if (vec) {
+        const float* src = X + row * K + (VEC ? 4 * kq : kq * KQ);
+        if (VEC) {
 #pragma unroll
             for (int s = 0; s < KQ / 4; ++s) {
-                const float4 v = ld4(src + s * 4);
+                const float4 v = ld4(src + s * 16);
                 xa[4 * s + 0] = v.x; xa[4 * s + 1] = v.y; xa[4 * s + 2] = v.z; xa[4 * s + 3] = v.w;
             }
         } else {
@@ -1259,7 +1262,8 @@ __global__ __launch_bounds__(512) void k_linear128(const float* __restrict__ X, 
     int64_t tile = blockIdx.x;
     if (tile < tiles) load_rows(tile, cur);
     __syncthreads();
-    const float* bbase = sBt + (kq * KQ) * kBtLd + 64 * wc + i;
+    const float* bbase = sBt + (VEC ? 4 * kq : kq * KQ) * kLinLd + 64 * wc + i;
+    auto brow = [](int s) { return VEC ? 16 * (s >> 2) + (s & 3) : s; };      // LDS row of MFMA step s, relative to bbase
     for (; tile < tiles; tile += gridDim.x) {
         const int64_t ntile = tile + gridDim.x;
         if (ntile < tiles) load_rows(ntile, nxt);
@@ -1268,12 +1272,12 @@ __global__ __launch_bounds__(512) void k_linear128(const float* __restrict__ X, 
         for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         float b0[4], b1[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) b0[t] = bbase[16 * t];
+        for (int t = 0; t < 4; ++t) b0[t] = bbase[brow(0) * kLinLd + 16 * t];
 #pragma unroll
         for (int s = 0; s < KQ; ++s) {                       // B operands of step s+1 are read while step s multiplies
             if (s + 1 < KQ) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) b1[t] = bbase[(s + 1) * kBtLd + 16 * t];
+                for (int t = 0; t < 4; ++t) b1[t] = bbase[brow(s + 1) * kLinLd + 16 * t];
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[s], b0[t], acc[t], 0, 0, 0);
@@ -1541,7 +1545,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 // C-ABI
 // =====================================================================================
 namespace {
-int g_tune[FN_TUNE_COUNT] = {1792, 0};      // FN_TUNE_FWD_BLOCKS, FN_TUNE_DEBUG
+int g_tune[FN_TUNE_COUNT] = {1024, 0, 0};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_DEBUG, FN_TUNE_STREAMS
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -1552,11 +1556,16 @@ template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
 template <int KQ>
 int launch_linear128(const float* X, int K, const float* Bt, const float* bias, float* Y, int64_t M, fn_act_epilogue mk,
                      NodeScalarEpi ns, hipStream_t st) {
-    const size_t lds = ((size_t)4 * KQ * kBtLd + 8 * 16 * kLinOutLd) * sizeof(float);
-    if (int rc = allow_lds(k_linear128<KQ>, lds)) return rc;
+    const size_t lds = ((size_t)4 * KQ * kLinLd + 8 * 16 * kLinOutLd) * sizeof(float);
     const int64_t tiles = (M + 63) / 64;
     const int grid = (int)(tiles < 256 ? tiles : 256);       // one block per CU: MFMA-bound, X prefetched a tile ahead
-    hipLaunchKernelGGL(k_linear128<KQ>, dim3(grid), dim3(512), lds, st, X, K, Bt, bias, Y, M, mk, ns);
+    if (KQ % 4 == 0 && K == 4 * KQ) {
+        if (int rc = allow_lds(k_linear128<KQ, (KQ % 4 == 0)>, lds)) return rc;
+        hipLaunchKernelGGL((k_linear128<KQ, (KQ % 4 == 0)>), dim3(grid), dim3(512), lds, st, X, K, Bt, bias, Y, M, mk, ns);
+    } else {
+        if (int rc = allow_lds(k_linear128<KQ, false>, lds)) return rc;
+        hipLaunchKernelGGL((k_linear128<KQ, false>), dim3(grid), dim3(512), lds, st, X, K, Bt, bias, Y, M, mk, ns);
+    }
     return 0;
 }
 template <int CTW, int NH>
@@ -2021,7 +2030,7 @@ struct EncLayout {
     LayerActs L[FN_MAX_LAYERS];
     float* in_atoms0;        // dropout(x_atoms) when training with p > 0, else null (use x_atoms)
     // forward scratch
-    float *atoms_new, *frags_new, *s_sorted, *s_dst, *s_src, *bt;
+    float *atoms_new, *frags_new, *s_sorted, *s_dst, *s_src, *s_dst_fb, *s_src_fb, *bt;
     int64_t total;
 };
 
@@ -2050,14 +2059,23 @@ EncLayout enc_layout(const fn_encoder* e, float* ws) {
     const int64_t nmax = max4(e->E, e->N, e->EF, e->F);
     o.s_dst = b.take(nmax * H);
     o.s_src = b.take(nmax * H);
+    o.s_dst_fb = b.take(e->EF * H);
+    o.s_src_fb = b.take(e->EF * H);
     o.bt = b.take((int64_t)3 * e->n_layers * 192 * FN_D);
     o.total = b.used;
     return o;
 }
 
+// Backward scratch.  Nothing is reused across levels or layers: the kernels that only produce parameter gradients
+// (finalize, weight-gradient GEMMs, column sums) run on an auxiliary stream behind the main dependency chain, so a
+// buffer they read must not be rewritten by the next level.  ~60 MB per layer at ESOL batch 512.
+struct LevelScratch {
+    float *g_h, *dz, *pz, *g_s_dst, *part_a, *part_e, *part_rd, *wg_ws;
+};
 struct BwdLayout {
-    float *g_pre_atoms, *g_pre_frags, *g_pre_bond, *g_pre_fbond;   // grads w.r.t. pre-activation layer outputs
-    float *g_h, *g_frags, *dz, *pz, *g_s_dst, *part_a, *part_e, *part_rd, *wg_ws;
+    float *g_pre_atoms, *g_pre_frags, *g_pre_bond, *g_pre_fbond;   // grads w.r.t. pre-activation layer outputs (the chain)
+    float* g_frags;
+    LevelScratch bond[FN_MAX_LAYERS], atom[FN_MAX_LAYERS], fbond[FN_MAX_LAYERS], frag;
     int64_t total;
 };
 
@@ -2065,20 +2083,25 @@ BwdLayout bwd_layout(const fn_encoder* e, float* ws) {
     BwdLayout o{};
     Bump b(ws);
     const int H = e->heads;
-    const int64_t nmax = max4(e->E, e->N, e->EF, e->F), mmax = max4(e->bond.m, e->atom.m, e->fbond.m, e->frag.m);
     o.g_pre_atoms = b.take(e->N * FN_D);  o.g_pre_frags = b.take(e->F * FN_D);
     o.g_pre_bond = b.take(e->E * FN_D);   o.g_pre_fbond = b.take(e->EF * FN_D);
-    o.g_h = b.take(nmax * FN_D);          o.g_frags = b.take(e->F * FN_D);
-    o.dz = b.take(mmax * H);              o.g_s_dst = b.take(nmax * H);
-    o.pz = b.take(2 * mmax * H);
-    o.part_a = b.take((int64_t)FN_MAX_PART * 2 * FN_D);
-    o.part_e = b.take((int64_t)FN_MAX_PART * H * (FN_MAX_EDGE_K + 1));
-    o.part_rd = b.take((int64_t)FN_MAX_PART * H * FN_D);
-    int64_t wg = 0;
-    const int ks[3] = {e->k_bond0 > FN_D ? e->k_bond0 : FN_D, e->k_atom0 > FN_D ? e->k_atom0 : FN_D, e->k_fbond0 > FN_D ? e->k_fbond0 : FN_D};
-    const int64_t ms[3] = {e->E, e->N, e->EF};
-    for (int i = 0; i < 3; ++i) wg = std::max(wg, fn_linear128_wgrad_ws(ms[i], ks[i]));
-    o.wg_ws = b.take(wg);
+    o.g_frags = b.take(e->F * FN_D);
+    auto level = [&](LevelScratch& s, int64_t n, int64_t m, int k0, bool edge_params, bool row_dots, bool proj) {
+        s.g_h = b.take(n * FN_D);
+        s.dz = row_dots ? b.take(m * H) : nullptr;
+        s.pz = b.take(2 * m * H);
+        s.g_s_dst = b.take(n * H);
+        s.part_a = b.take((int64_t)FN_MAX_PART * 2 * FN_D);
+        s.part_e = edge_params ? b.take((int64_t)FN_MAX_PART * H * (FN_MAX_EDGE_K + 1)) : nullptr;
+        s.part_rd = row_dots ? b.take((int64_t)FN_MAX_PART * H * FN_D) : nullptr;
+        s.wg_ws = proj ? b.take(fn_linear128_wgrad_ws(n, k0 > FN_D ? k0 : FN_D)) : nullptr;
+    };
+    for (int l = 0; l < e->n_layers; ++l) {
+        level(o.bond[l], e->E, e->bond.m, e->k_bond0, true, false, true);
+        level(o.atom[l], e->N, e->atom.m, e->k_atom0, false, true, true);
+        level(o.fbond[l], e->EF, e->fbond.m, e->k_fbond0, true, false, true);
+    }
+    level(o.frag, e->F, e->frag.m, 0, false, true, false);
     o.total = b.used;
     return o;
 }
@@ -2103,6 +2126,40 @@ RngPlan rng_plan(const fn_encoder* e) {
     }
     r.total = off - e->offset;
     return r;
+}
+
+// Auxiliary streams.  The main dependency chain of a step is ~100 kernels of 5-20 us, each waiting for its
+// predecessor; everything that nobody downstream waits for -- parameter-gradient reductions and weight-gradient
+// GEMMs ("leaf" work) and the whole fragment-bond chain, which only meets the others at the last fragment level --
+// can be forked onto two side streams with event dependencies and joined before the call returns.  Works the same
+// launched eagerly or while the caller's stream is being captured into a hipGraph (the forks become graph branches).
+// OFF by default (FN_TUNE_STREAMS): measured on MI355X / ROCm 7.2 the forked hipGraph replays SLOWER than the linear
+// one (1.84 vs 1.69 ms per step, ~14 cross-branch dependencies), and two big kernel chains side by side gain only
+// 11 % over running them back to back (tools/concurrency_probe.py); launched eagerly it is worth ~5 %.
+struct AuxStreams {
+    hipStream_t s[2] = {nullptr, nullptr};       // 0: leaf work, 1: fragment-bond chain
+    hipEvent_t ev[64];
+    int cursor = 0;
+    bool ready = false;
+};
+AuxStreams g_aux;
+int aux_init() {
+    if (g_aux.ready) return 0;
+    for (auto& st : g_aux.s)
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return fail(FN_EINVAL, "auxiliary stream creation failed"); }
+    for (auto& ev : g_aux.ev)
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return fail(FN_EINVAL, "event creation failed"); }
+    g_aux.ready = true;
+    return 0;
+}
+// everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on
+int order_after(hipStream_t from, hipStream_t to) {
+    if (from == to) return 0;
+    hipEvent_t ev = g_aux.ev[g_aux.cursor++ & 63];
+    hipError_t e = hipEventRecord(ev, from);
+    if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail((int)e, "stream dependency (event record / wait) failed"); }
+    return 0;
 }
 
 int enc_check(const fn_encoder* e) {
@@ -2138,6 +2195,9 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
     const int H = e->heads, d = FN_D / H;
     const float p = e->training ? e->drop_p : 0.f;
     const int wide = 2 * d + FN_D;             // width of a / f
+    const bool multi = g_tune[FN_TUNE_STREAMS] != 0;
+    if (multi) FN_TRY(aux_init());
+    fn_stream_t st_fb = multi ? (fn_stream_t)g_aux.s[1] : st;       // the fragment-bond chain's stream
 
     const float* in_atoms = e->x_atoms;
     if (lay.in_atoms0) {
@@ -2159,6 +2219,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         hipLaunchKernelGGL(k_transpose_many, dim3(6, 4, 3 * e->n_layers), dim3(256), 0, S(st), tm, lay.bt);
         FN_TRY(launch_status("fn_encoder_forward: transpose"));
     }
+    FN_TRY(order_after(S(st), S(st_fb)));      // fork: the fragment-bond levels of ALL layers depend on nothing else
 
     for (int l = 0; l < e->n_layers; ++l) {
         const fn_layer_weights& w = e->w[l];
@@ -2171,12 +2232,12 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         // L1 bond graph
         const bool fuse_ns = H >= 2;         // a head's columns fit one wave's 64-column half for H >= 2
         auto project = [&](const float* x, int k, const float* bt, const float* bias, float* hout, int64_t rows,
-                           const float* att, int att_w, int src_off) -> int {
-            if (fuse_ns) return linear128_impl(x, k, bt, bias, hout, rows, nullptr, NodeScalarEpi{att, lay.s_dst, lay.s_src, att_w, 0, src_off, H}, st);
-            FN_TRY(fn_linear128_f32(x, k, bt, bias, hout, rows, nullptr, st));
-            return fn_node_scalars_f32(hout, att, att_w, 0, src_off, lay.s_dst, lay.s_src, rows, H, st);
+                           const float* att, int att_w, int src_off, float* sdst, float* ssrc, fn_stream_t sq) -> int {
+            if (fuse_ns) return linear128_impl(x, k, bt, bias, hout, rows, nullptr, NodeScalarEpi{att, sdst, ssrc, att_w, 0, src_off, H}, sq);
+            FN_TRY(fn_linear128_f32(x, k, bt, bias, hout, rows, nullptr, sq));
+            return fn_node_scalars_f32(hout, att, att_w, 0, src_off, sdst, ssrc, rows, H, sq);
         };
-        FN_TRY(project(in_bond, kb, bt_b, w.proj_b_b, a.h_b, e->E, w.a_b, 3 * d, 2 * d));
+        FN_TRY(project(in_bond, kb, bt_b, w.proj_b_b, a.h_b, e->E, w.a_b, 3 * d, 2 * d, lay.s_dst, lay.s_src, st));
         fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
         float* y_atoms = last ? out_atoms : a.y_atoms;
         float* y_frags = last ? out_frags : a.y_frags;
@@ -2188,7 +2249,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         FN_TRY(fn_gat_fwd_f32(a.h_b, lay.s_dst, lay.s_src, w.a_b, 3 * d, &et_b, &e->bond, 0.2f, a.new_bond, a.p_bond, nullptr, &ep_bond, H, st));
 
         // L2 atom graph (+ self loops), edge term = <new_bond, a[:, d:d+128]>
-        FN_TRY(project(in_atoms, ka, bt_a, w.proj_a_b, a.h_a, e->N, w.a, wide, d + FN_D));
+        FN_TRY(project(in_atoms, ka, bt_a, w.proj_a_b, a.h_a, e->N, w.a, wide, d + FN_D, lay.s_dst, lay.s_src, st));
         FN_TRY(fn_row_dots_sorted_f32(a.new_bond, w.a, wide, d, H, &e->atom, lay.s_sorted, st));
         fn_edge_term et_a{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
         FN_TRY(fn_gat_fwd_f32(a.h_a, lay.s_dst, lay.s_src, w.a, wide, &et_a, &e->atom, 0.2f, lay.atoms_new, a.p_atom, nullptr, &ep_atoms, H, st));
@@ -2196,15 +2257,16 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         // L3 atom -> fragment sum
         FN_TRY(fn_segment_sum_f32(lay.atoms_new, FN_D, e->a2f.rowptr, e->a2f.perm, e->a2f.pos_base, a.frags, e->F, FN_D, e->N, st));
 
-        // L4a fragment-bond graph
-        FN_TRY(project(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, w.f_a_b, 3 * d, 2 * d));
+        // L4a fragment-bond graph (own stream: its inputs are the previous layer's fragment-bond outputs only)
+        FN_TRY(project(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, w.f_a_b, 3 * d, 2 * d, lay.s_dst_fb, lay.s_src_fb, st_fb));
         fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
-        FN_TRY(fn_gat_fwd_f32(a.h_fb, lay.s_dst, lay.s_src, w.f_a_b, 3 * d, &et_fb, &e->fbond, 0.2f, a.new_fbond, a.p_fbond, nullptr, &ep_fbond, H, st));
+        FN_TRY(fn_gat_fwd_f32(a.h_fb, lay.s_dst_fb, lay.s_src_fb, w.f_a_b, 3 * d, &et_fb, &e->fbond, 0.2f, a.new_fbond, a.p_fbond, nullptr, &ep_fbond, H, st_fb));
 
         // L4b fragment graph on the raw fragment sums.  Only the last layer's result is ever read: the next layer
         // overwrites x_frags with its own atom->fragment sum before first use (gat2.py:234), so inner
         // layers skip this level entirely (the reference computes it and throws it away).
         if (last) {
+            FN_TRY(order_after(S(st_fb), S(st)));            // join: the fragment graph's edge term reads new_fbond
             FN_TRY(fn_row_dots_sorted_f32(a.new_fbond, w.f, wide, d, H, &e->frag, lay.s_sorted, st));
             FN_TRY(fn_node_scalars_f32(a.frags, w.f, wide, 0, d + FN_D, lay.s_dst, lay.s_src, e->F, H, st));
             fn_edge_term et_f{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
@@ -2230,6 +2292,13 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
     const float p = e->training ? e->drop_p : 0.f;
     const int wide = 2 * d + FN_D;
     hipStream_t hs = S(st);
+    const bool multi = g_tune[FN_TUNE_STREAMS] != 0;
+    if (multi) FN_TRY(aux_init());
+    // leaf: kernels nobody downstream waits for (parameter-gradient reductions, weight-gradient GEMMs);
+    // fb: the fragment-bond chain, which after the last layer's fragment level never meets the others again
+    fn_stream_t st_leaf = multi ? (fn_stream_t)g_aux.s[0] : st;
+    fn_stream_t st_fb = multi ? (fn_stream_t)g_aux.s[1] : st;
+    bool fb_forked = false, leaf_forked = false;
 
     // gradients w.r.t. the current layer's post-activation outputs (null = zero)
     bool pre_atoms = false, pre_bond = false, pre_fbond = false;   // g_pre_* already hold layer l's pre-activation grads
@@ -2251,7 +2320,8 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         const float* in_bond = l ? lay.L[l - 1].y_bond : e->bond_nodes;
         const float* in_fbond = l ? lay.L[l - 1].y_fbond : e->fbond_nodes;
         const int ka = l ? FN_D : e->k_atom0, kb = l ? FN_D : e->k_bond0, kfb = l ? FN_D : e->k_fbond0;
-        int n_a = 0, n_e = 0, n_rd = 0;
+        const LevelScratch &sb = bw.bond[l], &sa = bw.atom[l], &sfb = bw.fbond[l], &sf = bw.frag;
+        int n_a = 0, n_e = 0;
 
         // ---- through act(dropout(.)): gradients of the pre-activation tensors.  For the last layer they come from
         // the caller's output gradients; for inner layers the input-gradient GEMMs of layer l+1 already wrote them
@@ -2268,33 +2338,36 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         bool have_g_frags_h = false;
         if (have_frags) {
             fn_edge_term et_f{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_frags, a.frags, a.p_frag, &et_f, &e->frag, 0.2f, nullptr, bw.dz, bw.pz, bw.g_s_dst, nullptr, &n_e, H, st));
-            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_frags, a.frags, bw.pz, bw.g_s_dst, w.f, wide, 0, d + FN_D, &e->frag, bw.g_frags, bw.part_a, &n_a, H, st));
-            FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, nullptr, 0, &et_f, w.f, wide, 0, d + FN_D, g.f, nullptr, nullptr, H, st));
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_frags, a.frags, a.p_frag, &et_f, &e->frag, 0.2f, nullptr, sf.dz, sf.pz, sf.g_s_dst, nullptr, &n_e, H, st));
+            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_frags, a.frags, sf.pz, sf.g_s_dst, w.f, wide, 0, d + FN_D, &e->frag, bw.g_frags, sf.part_a, &n_a, H, st));
             // edge term <new_fbond, f[:, d:d+128]>: dL/dnew_fbond accumulates into g_pre_fbond, dL/df mid block
+            int gr = 0;
             if (e->frag.m_real > 0) {
-                const int gr = row_grid(e->frag.m_real, 512);
-                hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(gr), dim3(kBlock), 0, hs, bw.dz, a.new_fbond, w.f, wide, d, H, e->frag,
-                                   bw.g_pre_fbond, bw.part_rd, have_fbond ? (const float*)bw.g_pre_fbond : (const float*)nullptr, 1);
+                gr = row_grid(e->frag.m_real, 512);
+                hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(gr), dim3(kBlock), 0, hs, sf.dz, a.new_fbond, w.f, wide, d, H, e->frag,
+                                   bw.g_pre_fbond, sf.part_rd, have_fbond ? (const float*)bw.g_pre_fbond : (const float*)nullptr, 1);
                 FN_TRY(launch_status("fn_encoder_backward: row_dots(frag)"));
-                FN_TRY(fn_colsum_f32(bw.part_rd, gr, H * FN_D, g.f, wide, d, st));
                 have_fbond = true;
             }
+            FN_TRY(order_after(hs, S(st_leaf)));  leaf_forked = true;
+            FN_TRY(fn_gat_bwd_finalize_f32(sf.part_a, n_a, nullptr, 0, &et_f, w.f, wide, 0, d + FN_D, g.f, nullptr, nullptr, H, st_leaf));
+            if (gr) FN_TRY(fn_colsum_f32(sf.part_rd, gr, H * FN_D, g.f, wide, d, st_leaf));
             have_g_frags_h = true;
         }
 
-        // ---- L4a fragment-bond graph
+        // ---- L4a fragment-bond graph, on its own stream from here to layer 0
         if (have_fbond) {
+            if (!fb_forked) { FN_TRY(order_after(hs, S(st_fb)));  fb_forked = true; }
             fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_fbond, a.h_fb, a.p_fbond, &et_fb, &e->fbond, 0.2f, nullptr, nullptr, bw.pz, bw.g_s_dst, bw.part_e, &n_e, H, st));
-            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_fbond, a.h_fb, bw.pz, bw.g_s_dst, w.f_a_b, 3 * d, 0, 2 * d, &e->fbond, bw.g_h, bw.part_a, &n_a, H, st));
-            FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, bw.part_e, n_e, &et_fb, w.f_a_b, 3 * d, 0, 2 * d, g.f_a_b, g.emb_fb_w, g.emb_fb_b, H, st));
-            FN_TRY(fn_linear128_wgrad_f32(bw.g_h, in_fbond, kfb, e->EF, bw.wg_ws, g.proj_fb_w, g.proj_fb_b, st));
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_fbond, a.h_fb, a.p_fbond, &et_fb, &e->fbond, 0.2f, nullptr, nullptr, sfb.pz, sfb.g_s_dst, sfb.part_e, &n_e, H, st_fb));
+            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_fbond, a.h_fb, sfb.pz, sfb.g_s_dst, w.f_a_b, 3 * d, 0, 2 * d, &e->fbond, sfb.g_h, sfb.part_a, &n_a, H, st_fb));
             if (l) {     // dL/d(pre-activation fbond output of layer l-1), gated by that layer's dropout mask and ReLU
                 const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_fbond), p, 1, e->seed, rng.y[l - 1][3], e->offset_dev};
-                FN_TRY(fn_linear128_f32(bw.g_h, FN_D, w.proj_fb_w, nullptr, bw.g_pre_fbond, e->EF, &mk, st));
+                FN_TRY(fn_linear128_f32(sfb.g_h, FN_D, w.proj_fb_w, nullptr, bw.g_pre_fbond, e->EF, &mk, st_fb));
                 nxt_fbond = true;
             }
+            FN_TRY(fn_gat_bwd_finalize_f32(sfb.part_a, n_a, sfb.part_e, n_e, &et_fb, w.f_a_b, 3 * d, 0, 2 * d, g.f_a_b, g.emb_fb_w, g.emb_fb_b, H, st_fb));
+            FN_TRY(fn_linear128_wgrad_f32(sfb.g_h, in_fbond, kfb, e->EF, sfb.wg_ws, g.proj_fb_w, g.proj_fb_b, st_fb));
         }
 
         // ---- L3 atom -> fragment sum: dL/datoms_new += dL/dfrags[a2f]
@@ -2308,21 +2381,23 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         // ---- L2 atom graph
         if (have_atoms) {
             fn_edge_term et_a{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_atoms, a.h_a, a.p_atom, &et_a, &e->atom, 0.2f, nullptr, bw.dz, bw.pz, bw.g_s_dst, nullptr, &n_e, H, st));
-            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_atoms, a.h_a, bw.pz, bw.g_s_dst, w.a, wide, 0, d + FN_D, &e->atom, bw.g_h, bw.part_a, &n_a, H, st));
-            FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, nullptr, 0, &et_a, w.a, wide, 0, d + FN_D, g.a, nullptr, nullptr, H, st));
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_atoms, a.h_a, a.p_atom, &et_a, &e->atom, 0.2f, nullptr, sa.dz, sa.pz, sa.g_s_dst, nullptr, &n_e, H, st));
+            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_atoms, a.h_a, sa.pz, sa.g_s_dst, w.a, wide, 0, d + FN_D, &e->atom, sa.g_h, sa.part_a, &n_a, H, st));
+            int gr = 0;
             if (e->atom.m_real > 0) {
-                const int gr = row_grid(e->atom.m_real, 512);
-                hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(gr), dim3(kBlock), 0, hs, bw.dz, a.new_bond, w.a, wide, d, H, e->atom,
-                                   bw.g_pre_bond, bw.part_rd, have_bond ? (const float*)bw.g_pre_bond : (const float*)nullptr, 1);
+                gr = row_grid(e->atom.m_real, 512);
+                hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(gr), dim3(kBlock), 0, hs, sa.dz, a.new_bond, w.a, wide, d, H, e->atom,
+                                   bw.g_pre_bond, sa.part_rd, have_bond ? (const float*)bw.g_pre_bond : (const float*)nullptr, 1);
                 FN_TRY(launch_status("fn_encoder_backward: row_dots(atom)"));
-                FN_TRY(fn_colsum_f32(bw.part_rd, gr, H * FN_D, g.a, wide, d, st));
                 have_bond = true;
             }
-            FN_TRY(fn_linear128_wgrad_f32(bw.g_h, in_atoms, ka, e->N, bw.wg_ws, g.proj_a_w, g.proj_a_b, st));
+            FN_TRY(order_after(hs, S(st_leaf)));  leaf_forked = true;
+            FN_TRY(fn_gat_bwd_finalize_f32(sa.part_a, n_a, nullptr, 0, &et_a, w.a, wide, 0, d + FN_D, g.a, nullptr, nullptr, H, st_leaf));
+            if (gr) FN_TRY(fn_colsum_f32(sa.part_rd, gr, H * FN_D, g.a, wide, d, st_leaf));
+            FN_TRY(fn_linear128_wgrad_f32(sa.g_h, in_atoms, ka, e->N, sa.wg_ws, g.proj_a_w, g.proj_a_b, st_leaf));
             if (l) {
                 const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_atoms), p, 1, e->seed, rng.y[l - 1][0], e->offset_dev};
-                FN_TRY(fn_linear128_f32(bw.g_h, FN_D, w.proj_a_w, nullptr, bw.g_pre_atoms, e->N, &mk, st));
+                FN_TRY(fn_linear128_f32(sa.g_h, FN_D, w.proj_a_w, nullptr, bw.g_pre_atoms, e->N, &mk, st));
                 nxt_atoms = true;
             }
         }
@@ -2330,21 +2405,24 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         // ---- L1 bond graph
         if (have_bond) {
             fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_bond, a.h_b, a.p_bond, &et_b, &e->bond, 0.2f, nullptr, nullptr, bw.pz, bw.g_s_dst, bw.part_e, &n_e, H, st));
-            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_bond, a.h_b, bw.pz, bw.g_s_dst, w.a_b, 3 * d, 0, 2 * d, &e->bond, bw.g_h, bw.part_a, &n_a, H, st));
-            FN_TRY(fn_gat_bwd_finalize_f32(bw.part_a, n_a, bw.part_e, n_e, &et_b, w.a_b, 3 * d, 0, 2 * d, g.a_b, g.emb_b_w, g.emb_b_b, H, st));
-            FN_TRY(fn_linear128_wgrad_f32(bw.g_h, in_bond, kb, e->E, bw.wg_ws, g.proj_b_w, g.proj_b_b, st));
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_bond, a.h_b, a.p_bond, &et_b, &e->bond, 0.2f, nullptr, nullptr, sb.pz, sb.g_s_dst, sb.part_e, &n_e, H, st));
+            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_bond, a.h_b, sb.pz, sb.g_s_dst, w.a_b, 3 * d, 0, 2 * d, &e->bond, sb.g_h, sb.part_a, &n_a, H, st));
+            FN_TRY(order_after(hs, S(st_leaf)));  leaf_forked = true;
+            FN_TRY(fn_gat_bwd_finalize_f32(sb.part_a, n_a, sb.part_e, n_e, &et_b, w.a_b, 3 * d, 0, 2 * d, g.a_b, g.emb_b_w, g.emb_b_b, H, st_leaf));
+            FN_TRY(fn_linear128_wgrad_f32(sb.g_h, in_bond, kb, e->E, sb.wg_ws, g.proj_b_w, g.proj_b_b, st_leaf));
             if (l) {
                 const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_bond), p, 1, e->seed, rng.y[l - 1][2], e->offset_dev};
-                FN_TRY(fn_linear128_f32(bw.g_h, FN_D, w.proj_b_w, nullptr, bw.g_pre_bond, e->E, &mk, st));
+                FN_TRY(fn_linear128_f32(sb.g_h, FN_D, w.proj_b_w, nullptr, bw.g_pre_bond, e->E, &mk, st));
                 nxt_bond = true;
             }
         }
-        (void)n_rd;
         pre_atoms = nxt_atoms;  pre_bond = nxt_bond;  pre_fbond = nxt_fbond;
         gy_atoms = gy_bond = gy_fbond = nullptr;
         gy_frags = nullptr;        // a layer's x_frags input is dead in the reference (overwritten at gat2.py:234)
     }
+    // join: the caller's stream continues only after both side streams have drained
+    if (leaf_forked) FN_TRY(order_after(S(st_leaf), hs));
+    if (fb_forked) FN_TRY(order_after(S(st_fb), hs));
     return 0;
 }
 

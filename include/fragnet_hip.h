@@ -43,11 +43,13 @@ typedef void* fn_stream_t;    /* hipStream_t */
 int fn_abi_version(void);
 
 /* Process-wide tuning knobs (defaults are the measured best for MI355X; the bench uses them for A/B runs).
- * FN_TUNE_FWD_BLOCKS: workgroups of the forward kernel that are resident at once (default 1792 = 256 CUs x 7); a
+ * FN_TUNE_FWD_BLOCKS: workgroups of the forward kernel that are resident at once (default 1024 = 256 CUs x 4); a
  *   level with more row groups than that gives every half-wave several consecutive rows to software-pipeline. */
 #define FN_TUNE_FWD_BLOCKS 0
 #define FN_TUNE_DEBUG 1        /* development only: bit mask that disables parts of kernels (results become wrong) */
-#define FN_TUNE_COUNT 2
+#define FN_TUNE_STREAMS 2      /* 1: the encoder forks parameter-gradient work and the fragment-bond chain onto side streams;
+                                * 0 (default): one stream -- forked hipGraph replays measured slower on ROCm 7.2 */
+#define FN_TUNE_COUNT 3
 int fn_set_tuning(int key, int value);
 const char* fn_last_error(void);
 
