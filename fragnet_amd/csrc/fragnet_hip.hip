@@ -808,17 +808,19 @@ __device__ __forceinline__ float block_sum_1024(float v, float* s16) {
 
 // blocks 0..255: one column each of the column-major [256][FN_MAX_PART] a_dst/a_src partials; block 256 (mode 2
 // only): the [n_e, H*(K+1)] edge-embedding partials and the chain rule through the folded weights.
-__global__ __launch_bounds__(1024) void k_gat_finalize(const float* __restrict__ part_a, int n_a,
-                                                       const float* __restrict__ part_e, int n_e, fn_edge_term et,
-                                                       const float* __restrict__ att, int att_w, int dst_off,
-                                                       int src_off, float* __restrict__ g_att,
-                                                       float* __restrict__ g_embW, float* __restrict__ g_embb, int H) {
-    __shared__ float s16[16];
-    __shared__ float redE[8][128];
-    __shared__ float sE[128];
+// (body shared by k_gat_finalize and the deferred task-table kernel k_reduce_tasks; vb = virtual block index,
+// sm = 1200 floats of shared memory)
+__device__ __forceinline__ void gat_finalize_body(int vb, float* sm, const float* __restrict__ part_a, int n_a,
+                                                  const float* __restrict__ part_e, int n_e, const fn_edge_term& et,
+                                                  const float* __restrict__ att, int att_w, int dst_off, int src_off,
+                                                  float* __restrict__ g_att, float* __restrict__ g_embW,
+                                                  float* __restrict__ g_embb, int H) {
+    float* s16 = sm;
+    float(*redE)[128] = reinterpret_cast<float(*)[128]>(sm + 16);
+    float* sE = sm + 16 + 1024;
     const int tid = threadIdx.x;
-    if (blockIdx.x < 2 * FN_D) {
-        const int col = blockIdx.x;
+    if (vb < 2 * FN_D) {
+        const int col = vb;
         float mine = 0.f;
         for (int r = tid; r < n_a; r += 1024) mine += part_a[(size_t)col * FN_MAX_PART + r];
         const float v = block_sum_1024(mine, s16);
@@ -866,6 +868,15 @@ __global__ __launch_bounds__(1024) void k_gat_finalize(const float* __restrict__
         for (int hh = 0; hh < H; ++hh) a = fmaf(sE[hh * (K + 1) + K], att[hh * att_w + et.mid_off + tid], a);
         g_embb[tid] = a;
     }
+}
+
+__global__ __launch_bounds__(1024) void k_gat_finalize(const float* __restrict__ part_a, int n_a,
+                                                       const float* __restrict__ part_e, int n_e, fn_edge_term et,
+                                                       const float* __restrict__ att, int att_w, int dst_off,
+                                                       int src_off, float* __restrict__ g_att,
+                                                       float* __restrict__ g_embW, float* __restrict__ g_embb, int H) {
+    __shared__ float sm[1200];
+    gat_finalize_body(blockIdx.x, sm, part_a, n_a, part_e, n_e, et, att, att_w, dst_off, src_off, g_att, g_embW, g_embb, H);
 }
 
 template <int H>
@@ -978,14 +989,18 @@ __global__ void k_sort_edge_attr(const float* __restrict__ x, int K, fn_gat_plan
 }
 
 // one block per column of the column-major partials [cols][FN_MAX_PART]
-__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ part, int n_rows, int cols,
-                                                  float* __restrict__ out, int ld, int off) {
-    __shared__ float s16[16];
-    const int col = blockIdx.x;
+__device__ __forceinline__ void colsum_body(int vb, float* s16, const float* __restrict__ part, int n_rows,
+                                            float* __restrict__ out, int ld, int off) {
+    const int col = vb;
     float mine = 0.f;
     for (int r = threadIdx.x; r < n_rows; r += 1024) mine += part[(size_t)col * FN_MAX_PART + r];
     const float v = block_sum_1024(mine, s16);
     if (threadIdx.x == 0) out[(col / FN_D) * ld + off + (col % FN_D)] = v;
+}
+__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ part, int n_rows, int cols,
+                                                  float* __restrict__ out, int ld, int off) {
+    __shared__ float s16[16];
+    colsum_body(blockIdx.x, s16, part, n_rows, out, ld, off);
 }
 
 // =====================================================================================
@@ -1475,13 +1490,13 @@ __global__ __launch_bounds__(256 * NH) void k_linear128_wgrad(const float* __res
 
 // sums the native-layout partials over blocks and scatters them to dW [128][K] / db [128]
 template <int CTW, int NH>
-__global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__ part, int n_rows, int K,
-                                                       float* __restrict__ dW, float* __restrict__ db) {
+__device__ __forceinline__ void wgrad_reduce_body(int vb, float* sm, const float* __restrict__ part, int n_rows, int K,
+                                                  float* __restrict__ dW, float* __restrict__ db) {
     constexpr int XW = 16 * CTW * NH;
     constexpr int PW = 128 * XW + 128;
-    __shared__ float red[32][33];
+    float(*red)[33] = reinterpret_cast<float(*)[33]>(sm);
     const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int col = blockIdx.x * 32 + c;
+    const int col = vb * 32 + c;
     float acc = 0.f;
     if (col < PW)
         for (int r = rg; r < n_rows; r += 32) acc += part[(size_t)r * PW + col];
@@ -1499,6 +1514,53 @@ __global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__
             const int o = 32 * (w & 3) + 16 * u + 4 * (lane >> 4) + r;
             const int xc = 16 * (CTW * (w >> 2) + cc) + (lane & 15);
             if (xc < K) dW[(size_t)o * K + xc] = v;
+        }
+    }
+}
+
+template <int CTW, int NH>
+__global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__ part, int n_rows, int K,
+                                                       float* __restrict__ dW, float* __restrict__ db) {
+    __shared__ float sm[32 * 33];
+    wgrad_reduce_body<CTW, NH>(blockIdx.x, sm, part, n_rows, K, dW, db);
+}
+
+// ---- deferred reductions.  The backward pass leaves every per-block partial (attention-vector and edge-embedding
+// partials of each level, the edge-term column sums, the weight-gradient partials) in its own buffer and records a
+// task; ONE launch then runs them all (a dependent kernel costs >= 4.6 us of launch-to-launch latency on this
+// machine however small it is, and there were 27 of these per step).
+enum { RT_FINALIZE = 0, RT_COLSUM = 1, RT_WGRAD = 2 };
+struct ReduceTask {
+    int kind, first, nblk, H;
+    const float *p0, *p1;
+    int n0, n1;
+    fn_edge_term et;
+    const float* att;
+    int att_w, dst_off, src_off, K;
+    float *o0, *o1, *o2;
+    int ld, off, cls, pad_;
+};
+constexpr int kMaxReduceTasks = 24;
+struct ReduceTasks {
+    ReduceTask t[kMaxReduceTasks];
+    int n;
+};
+__global__ __launch_bounds__(1024) void k_reduce_tasks(ReduceTasks T) {
+    __shared__ float sm[1200];
+    int ti = 0;
+    while (ti + 1 < T.n && (int)blockIdx.x >= T.t[ti + 1].first) ++ti;
+    const ReduceTask& t = T.t[ti];
+    const int vb = (int)blockIdx.x - t.first;
+    if (t.kind == RT_FINALIZE) {
+        gat_finalize_body(vb, sm, t.p0, t.n0, t.p1, t.n1, t.et, t.att, t.att_w, t.dst_off, t.src_off, t.o0, t.o1, t.o2, t.H);
+    } else if (t.kind == RT_COLSUM) {
+        colsum_body(vb, sm, t.p0, t.n0, t.o0, t.ld, t.off);
+    } else {
+        switch (t.cls) {
+            case 0: wgrad_reduce_body<1, 1>(vb, sm, t.p0, t.n0, t.K, t.o0, t.o1); break;
+            case 1: wgrad_reduce_body<1, 2>(vb, sm, t.p0, t.n0, t.K, t.o0, t.o1); break;
+            case 2: wgrad_reduce_body<4, 2>(vb, sm, t.p0, t.n0, t.K, t.o0, t.o1); break;
+            default: wgrad_reduce_body<6, 2>(vb, sm, t.p0, t.n0, t.K, t.o0, t.o1); break;
         }
     }
 }
@@ -1575,7 +1637,7 @@ int launch_wgrad(const float* dY, const float* X, int K, int64_t M, int rpb, int
     const size_t lds = (size_t)2 * kWgChunk * (kBtLd + XLD) * sizeof(float);
     if (int rc = allow_lds(k_linear128_wgrad<CTW, NH>, lds)) return rc;
     hipLaunchKernelGGL((k_linear128_wgrad<CTW, NH>), dim3(grid), dim3(256 * NH), lds, st, dY, X, K, M, rpb, part);
-    hipLaunchKernelGGL((k_wgrad_reduce<CTW, NH>), dim3((PW + 31) / 32), dim3(1024), 0, st, part, grid, K, dW, db);
+    if (dW) hipLaunchKernelGGL((k_wgrad_reduce<CTW, NH>), dim3((PW + 31) / 32), dim3(1024), 0, st, part, grid, K, dW, db);
     return 0;
 }
 inline int64_t wgrad_part_width(int K) {
@@ -2162,6 +2224,61 @@ int order_after(hipStream_t from, hipStream_t to) {
     return 0;
 }
 
+// weight-gradient partials only (the reduction is deferred); *grid = partial rows written, *cls = kernel class
+int wgrad_partials(const float* dY, const float* X, int K, int64_t M, float* ws, hipStream_t st, int* grid, int* cls) {
+    const int rpb = wgrad_rows_per_block(M);
+    *grid = (int)((M + rpb - 1) / rpb);
+    if (K <= 16) { *cls = 0;  return launch_wgrad<1, 1>(dY, X, K, M, rpb, *grid, ws, nullptr, nullptr, st); }
+    if (K <= 32) { *cls = 1;  return launch_wgrad<1, 2>(dY, X, K, M, rpb, *grid, ws, nullptr, nullptr, st); }
+    if (K <= 128) { *cls = 2;  return launch_wgrad<4, 2>(dY, X, K, M, rpb, *grid, ws, nullptr, nullptr, st); }
+    if (K <= 192) { *cls = 3;  return launch_wgrad<6, 2>(dY, X, K, M, rpb, *grid, ws, nullptr, nullptr, st); }
+    return fail(FN_EUNSUPPORTED, "weight gradient: K > 192");
+}
+
+struct ReduceQueue {
+    ReduceTasks T{};
+    int blocks = 0;
+    hipStream_t st = nullptr;
+    int flush() {
+        if (T.n == 0) return 0;
+        hipLaunchKernelGGL(k_reduce_tasks, dim3(blocks), dim3(1024), 0, st, T);
+        T.n = 0;  blocks = 0;
+        return launch_status("deferred reductions");
+    }
+    int push(ReduceTask t, int nblk) {
+        if (T.n == kMaxReduceTasks) { if (int rc = flush()) return rc; }
+        t.first = blocks;  t.nblk = nblk;
+        T.t[T.n++] = t;
+        blocks += nblk;
+        return 0;
+    }
+    int finalize(const float* part_a, int n_a, const float* part_e, int n_e, const fn_edge_term& et, const float* att, int att_w,
+                 int dst_off, int src_off, float* g_att, float* g_embW, float* g_embb, int H) {
+        ReduceTask t{};
+        t.kind = RT_FINALIZE;  t.H = H;  t.p0 = part_a;  t.n0 = n_a;  t.p1 = part_e;  t.n1 = n_e;  t.et = et;
+        t.att = att;  t.att_w = att_w;  t.dst_off = dst_off;  t.src_off = src_off;  t.o0 = g_att;  t.o1 = g_embW;  t.o2 = g_embb;
+        return push(t, 2 * FN_D + (et.mode == 2 ? 1 : 0));
+    }
+    int colsum(const float* part, int n_rows, int cols, float* out, int ld, int off) {
+        ReduceTask t{};
+        t.kind = RT_COLSUM;  t.p0 = part;  t.n0 = n_rows;  t.o0 = out;  t.ld = ld;  t.off = off;
+        return push(t, cols);
+    }
+    // dW [128,K], db [128] of a projection: partial kernel now (on `launch_on`), reduction with the rest
+    int wgrad(const float* dY, const float* X, int K, int64_t M, float* ws, float* dW, float* db, hipStream_t launch_on) {
+        if (M == 0) {
+            hipLaunchKernelGGL(k_zero2_i32, dim3(flat_grid(128 * (K + 1), kGridCap)), dim3(kBlock), 0, launch_on,
+                               reinterpret_cast<int32_t*>(dW), (int64_t)128 * K, reinterpret_cast<int32_t*>(db), (int64_t)128);
+            return launch_status("weight gradient (empty)");
+        }
+        ReduceTask t{};
+        int grid = 0;
+        if (int rc = wgrad_partials(dY, X, K, M, ws, launch_on, &grid, &t.cls)) return rc;
+        t.kind = RT_WGRAD;  t.p0 = ws;  t.n0 = grid;  t.K = K;  t.o0 = dW;  t.o1 = db;
+        return push(t, (int)((wgrad_part_width(K) + 31) / 32));
+    }
+};
+
 int enc_check(const fn_encoder* e) {
     if (!e) return fail(FN_EINVAL, "fn_encoder: null descriptor");
     if (e->n_layers < 1 || e->n_layers > FN_MAX_LAYERS) return fail(FN_EINVAL, "fn_encoder: n_layers out of range");
@@ -2299,6 +2416,8 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
     fn_stream_t st_leaf = multi ? (fn_stream_t)g_aux.s[0] : st;
     fn_stream_t st_fb = multi ? (fn_stream_t)g_aux.s[1] : st;
     bool fb_forked = false, leaf_forked = false;
+    ReduceQueue rq;
+    rq.st = hs;                      // all parameter-gradient reductions run as one launch at the very end
 
     // gradients w.r.t. the current layer's post-activation outputs (null = zero)
     bool pre_atoms = false, pre_bond = false, pre_fbond = false;   // g_pre_* already hold layer l's pre-activation grads
@@ -2349,9 +2468,8 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
                 FN_TRY(launch_status("fn_encoder_backward: row_dots(frag)"));
                 have_fbond = true;
             }
-            FN_TRY(order_after(hs, S(st_leaf)));  leaf_forked = true;
-            FN_TRY(fn_gat_bwd_finalize_f32(sf.part_a, n_a, nullptr, 0, &et_f, w.f, wide, 0, d + FN_D, g.f, nullptr, nullptr, H, st_leaf));
-            if (gr) FN_TRY(fn_colsum_f32(sf.part_rd, gr, H * FN_D, g.f, wide, d, st_leaf));
+            FN_TRY(rq.finalize(sf.part_a, n_a, nullptr, 0, et_f, w.f, wide, 0, d + FN_D, g.f, nullptr, nullptr, H));
+            if (gr) FN_TRY(rq.colsum(sf.part_rd, gr, H * FN_D, g.f, wide, d));
             have_g_frags_h = true;
         }
 
@@ -2366,8 +2484,8 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
                 FN_TRY(fn_linear128_f32(sfb.g_h, FN_D, w.proj_fb_w, nullptr, bw.g_pre_fbond, e->EF, &mk, st_fb));
                 nxt_fbond = true;
             }
-            FN_TRY(fn_gat_bwd_finalize_f32(sfb.part_a, n_a, sfb.part_e, n_e, &et_fb, w.f_a_b, 3 * d, 0, 2 * d, g.f_a_b, g.emb_fb_w, g.emb_fb_b, H, st_fb));
-            FN_TRY(fn_linear128_wgrad_f32(sfb.g_h, in_fbond, kfb, e->EF, sfb.wg_ws, g.proj_fb_w, g.proj_fb_b, st_fb));
+            FN_TRY(rq.finalize(sfb.part_a, n_a, sfb.part_e, n_e, et_fb, w.f_a_b, 3 * d, 0, 2 * d, g.f_a_b, g.emb_fb_w, g.emb_fb_b, H));
+            FN_TRY(rq.wgrad(sfb.g_h, in_fbond, kfb, e->EF, sfb.wg_ws, g.proj_fb_w, g.proj_fb_b, S(st_fb)));
         }
 
         // ---- L3 atom -> fragment sum: dL/datoms_new += dL/dfrags[a2f]
@@ -2391,10 +2509,10 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
                 FN_TRY(launch_status("fn_encoder_backward: row_dots(atom)"));
                 have_bond = true;
             }
-            FN_TRY(order_after(hs, S(st_leaf)));  leaf_forked = true;
-            FN_TRY(fn_gat_bwd_finalize_f32(sa.part_a, n_a, nullptr, 0, &et_a, w.a, wide, 0, d + FN_D, g.a, nullptr, nullptr, H, st_leaf));
-            if (gr) FN_TRY(fn_colsum_f32(sa.part_rd, gr, H * FN_D, g.a, wide, d, st_leaf));
-            FN_TRY(fn_linear128_wgrad_f32(sa.g_h, in_atoms, ka, e->N, sa.wg_ws, g.proj_a_w, g.proj_a_b, st_leaf));
+            FN_TRY(rq.finalize(sa.part_a, n_a, nullptr, 0, et_a, w.a, wide, 0, d + FN_D, g.a, nullptr, nullptr, H));
+            if (gr) FN_TRY(rq.colsum(sa.part_rd, gr, H * FN_D, g.a, wide, d));
+            if (multi) { FN_TRY(order_after(hs, S(st_leaf)));  leaf_forked = true; }
+            FN_TRY(rq.wgrad(sa.g_h, in_atoms, ka, e->N, sa.wg_ws, g.proj_a_w, g.proj_a_b, S(st_leaf)));
             if (l) {
                 const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_atoms), p, 1, e->seed, rng.y[l - 1][0], e->offset_dev};
                 FN_TRY(fn_linear128_f32(sa.g_h, FN_D, w.proj_a_w, nullptr, bw.g_pre_atoms, e->N, &mk, st));
@@ -2407,9 +2525,9 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
             FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_bond, a.h_b, a.p_bond, &et_b, &e->bond, 0.2f, nullptr, nullptr, sb.pz, sb.g_s_dst, sb.part_e, &n_e, H, st));
             FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_bond, a.h_b, sb.pz, sb.g_s_dst, w.a_b, 3 * d, 0, 2 * d, &e->bond, sb.g_h, sb.part_a, &n_a, H, st));
-            FN_TRY(order_after(hs, S(st_leaf)));  leaf_forked = true;
-            FN_TRY(fn_gat_bwd_finalize_f32(sb.part_a, n_a, sb.part_e, n_e, &et_b, w.a_b, 3 * d, 0, 2 * d, g.a_b, g.emb_b_w, g.emb_b_b, H, st_leaf));
-            FN_TRY(fn_linear128_wgrad_f32(sb.g_h, in_bond, kb, e->E, sb.wg_ws, g.proj_b_w, g.proj_b_b, st_leaf));
+            FN_TRY(rq.finalize(sb.part_a, n_a, sb.part_e, n_e, et_b, w.a_b, 3 * d, 0, 2 * d, g.a_b, g.emb_b_w, g.emb_b_b, H));
+            if (multi) { FN_TRY(order_after(hs, S(st_leaf)));  leaf_forked = true; }
+            FN_TRY(rq.wgrad(sb.g_h, in_bond, kb, e->E, sb.wg_ws, g.proj_b_w, g.proj_b_b, S(st_leaf)));
             if (l) {
                 const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_bond), p, 1, e->seed, rng.y[l - 1][2], e->offset_dev};
                 FN_TRY(fn_linear128_f32(sb.g_h, FN_D, w.proj_b_w, nullptr, bw.g_pre_bond, e->E, &mk, st));
@@ -2423,7 +2541,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
     // join: the caller's stream continues only after both side streams have drained
     if (leaf_forked) FN_TRY(order_after(S(st_leaf), hs));
     if (fb_forked) FN_TRY(order_after(S(st_fb), hs));
-    return 0;
+    return rq.flush();
 }
 
 }  // extern "C"
