@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""HBM-side bytes per launch of the scatter kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o p -- python3 bench.py --kernels-only
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o p -- python3 bench.py --kernels-only
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/pmc_per_launch.json
+
+Units and the gfx950 correction follow MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are in KiB;
+FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is doubled; WRITE_SIZE is exact.  Separate passes because
+the two counters do not fit one TCC pass."""
+import collections
+import csv
+import json
+import sys
+
+KERNELS = ("k_gat_fwd", "k_gat_bwd_dst", "k_gat_bwd_src")
+
+
+def per_kernel(path, counter):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f"{path}/p_counter_collection.csv")):
+        if r["Counter_Name"] != counter:
+            continue
+        for k in KERNELS:
+            if k + "<" in r["Kernel_Name"] or k + "I" in r["Kernel_Name"]:
+                agg[k].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in KERNELS:
+        if k in fetch and k in write:
+            f, w = fetch[k] * 1024 * 2, write[k] * 1024
+            out[k] = {"hbm_bytes_per_launch": int(f + w), "fetch_bytes_corrected_x2": int(f), "write_bytes": int(w),
+                      "raw_FETCH_SIZE_KiB": round(fetch[k], 1), "raw_WRITE_SIZE_KiB": round(write[k], 1)}
+    out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --kernels-only` (bond-graph level, "
+                    "B=512 ESOL shape), averaged over the launches of each kernel; FETCH_SIZE doubled per MI355X_MICROARCH.md "
+                    "section HBM; tools/pmc_traffic.py")
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
