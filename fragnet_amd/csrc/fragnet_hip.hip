@@ -430,8 +430,11 @@ __global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h,
 #pragma unroll
     for (int k = 0; k < NE; ++k) wf[k] = (KL && k < K) ? sWf[head][k] : 0.f;
     const float wbias = KL ? sWf[head][K] : 0.f;
-    const int tb = (xcd_block(blockIdx.x, gridDim.x) * kRows + (int)(threadIdx.x >> 5)) * rows_per_hw;
-    const int te = tb + rows_per_hw < n ? tb + rows_per_hw : n;
+    // a block owns kRows * R consecutive rows; its half-waves take them INTERLEAVED (row = base + i * kRows + hw), so
+    // that at any moment the block works on kRows neighbouring rows whose source rows overlap (L1 reuse across waves)
+    const int blk0 = xcd_block(blockIdx.x, gridDim.x) * kRows * rows_per_hw;
+    const int tb = blk0 + (int)(threadIdx.x >> 5);
+    const int te = blk0 + kRows * rows_per_hw < n ? blk0 + kRows * rows_per_hw : n;
     const bool pairs = m >= 2;                            // paired edge loads need two edges in the level
     const float* e_sorted = KL ? nullptr : et.s_sorted + (size_t)head * m;
 
@@ -476,19 +479,19 @@ __global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h,
     FwdRawT<NE> raw;
     FwdExtent cur = load_extent(tb);
     issue_edges(cur, raw);
-    FwdExtent nxt = load_extent(tb + 1);
+    FwdExtent nxt = load_extent(tb + kRows);
     FwdEdges ed = fold_edges(cur, raw);
     // drain the prologue's loads here: otherwise the compiler, unable to tell the first iteration from the others,
     // puts a vmcnt(0) at the loop head, where it also waits for the previous iteration's STORES
     asm volatile("" ::"v"(nxt.sd), "v"(nxt.beg), "v"(nxt.deg), "v"(ed.src0), "v"(ed.src1), "v"(ed.z0), "v"(ed.z1));
-    for (int t = tb; t < tb + rows_per_hw; ++t) {         // uniform trip count: both half-waves of a wave stay in step
+    for (int t = tb; t < tb + kRows * rows_per_hw; t += kRows) {     // uniform trip count: both half-waves of a wave stay in step
         const int beg = cur.beg, deg = cur.deg;
         const bool fast = pairs && deg >= 0 && deg <= 2 * LPH;
         const bool has0 = fast && 2 * j < deg, has1 = fast && 2 * j + 1 < deg;
         const int src0 = ed.src0, src1 = has1 ? ed.src1 : ed.src0;
         // one round trip: next row's edge data, the row after's extent, this row's source rows and source scalars
         issue_edges(nxt, raw);
-        const FwdExtent nn = load_extent(t + 2);
+        const FwdExtent nn = load_extent(t + 2 * kRows);
         const bool wide = __any(fast && deg > 4);
         float4 r0[8];
 #pragma unroll
@@ -586,129 +589,196 @@ __global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h,
 }
 
 // Backward kernels use RB rows (half-waves) per block.
-template <int H, int RB>
+// Destination pass: dz[e] = p[e] * (<g_out[dst], h[src]> - sum_e' p[e'] <g_out[dst], h[src']>) * LeakyReLU', per head.
+// Same shape as the forward kernel: persistent half-waves over R consecutive rows, straight-line body with clamped
+// unconditional loads, the next row's edge data fetched while this row's source rows fly.
+template <int NE> struct BwdRaw {
+    int pos;
+    i32x2u sp, sq, eq;        // source ids, positions in source order, original edge ids
+    f32x2u pp;                // signed probabilities
+    f32x2u x[NE];             // raw edge attributes (mode 2)
+};
+
+template <int H, int KL, int RB>
 __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(const float* __restrict__ g_out, const float* __restrict__ h,
                                                          const float* __restrict__ p_sorted, fn_edge_term et,
                                                          fn_gat_plan pl, float slope, float* __restrict__ dz_sorted,
                                                          float* __restrict__ g_s_orig, float* __restrict__ pz_src,
-                                                         float* __restrict__ g_s_dst, float* __restrict__ part_e) {
+                                                         float* __restrict__ g_s_dst, float* __restrict__ part_e,
+                                                         int rows_per_hw) {
     constexpr int LPH = 32 / H;
+    constexpr int NE = KL ? KL : 1;
     __shared__ float sP[RB][8][kWfLd];
     const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH, hw = threadIdx.x >> 5;
-    const int64_t m = pl.m;
-    float pw[kWfLd];
+    const int m = (int)pl.m, n = (int)pl.n;
+    const int K = KL ? et.K : 0;
+    const bool pairs = m >= 2;
+    const bool want_orig = KL == 0 && g_s_orig != nullptr;
+    float pw[NE + 1];
 #pragma unroll
-    for (int k = 0; k < kWfLd; ++k) pw[k] = 0.f;
+    for (int k = 0; k <= NE; ++k) pw[k] = 0.f;
+    const float* p_head = p_sorted + (size_t)head * m;
+    float* pz_head = pz_src + (size_t)head * m * 2;
+    const int blk0 = xcd_block(blockIdx.x, gridDim.x) * RB * rows_per_hw;      // rows interleaved over the half-waves
+    const int tb = blk0 + hw;
+    const int te = blk0 + RB * rows_per_hw < n ? blk0 + RB * rows_per_hw : n;
 
-    // (|p|, dz) of every edge goes to its slot in SOURCE order ([H][m][2]), so the source pass streams them;
-    // dz in destination order is only kept where it is a gradient itself (mode 0: dL/ds_sorted)
-    auto emit = [&](int pos, float dz, float pabs) {
-        stp(pz_src + ((size_t)head * m + pl.spos_d[pos]) * 2, pabs, dz);
-        if (et.mode == 0) {
-            if (dz_sorted) dz_sorted[(size_t)head * m + pos] = dz;
-            if (g_s_orig) { const int eid = pl.eid_d[pos]; if (eid < pl.m_real) g_s_orig[(size_t)eid * H + head] = dz; }
+    auto load_extent = [&](int t, int& beg, int& deg) {
+        const int tc = t < n ? t : n - 1;
+        const i32x2u rp = ldp(pl.rowptr_d + tc);
+        beg = rp.x - pl.pos_base_d;
+        deg = t < te ? rp.y - rp.x : -1;
+    };
+    auto issue_edges = [&](int beg, BwdRaw<NE>& r) {
+        int pos = beg + 2 * j;
+        pos = pos > m - 2 ? m - 2 : pos;
+        pos = pos < 0 ? 0 : pos;
+        r.pos = pos;
+        if (!pairs) { r.sp.x = r.sp.y = 0;  r.sq.x = r.sq.y = 0;  r.eq.x = r.eq.y = 0;  r.pp.x = r.pp.y = 0.f;  return; }
+        r.sp = ldp(pl.src_d + pos);
+        r.pp = ldp(p_head + pos);
+        r.sq = ldp(pl.spos_d + pos);
+        if (want_orig) r.eq = ldp(pl.eid_d + pos);
+        if (KL) {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) r.x[k] = ldp(et.x_sorted + (size_t)(k < K ? k : K - 1) * m + pos);
         }
     };
-    auto edge_partials = [&](int pos, float dz) {
-        pw[FN_MAX_EDGE_K] += dz;
-#pragma unroll
-        for (int k = 0; k < FN_MAX_EDGE_K; ++k)
-            if (k < et.K) pw[k] = fmaf(dz, et.x_sorted[(size_t)k * m + pos], pw[k]);
-    };
 
-    for (int64_t t = (int64_t)xcd_block(blockIdx.x, gridDim.x) * RB + hw; t < pl.n; t += (int64_t)gridDim.x * RB) {
-        const i32x2u rp = ldp(pl.rowptr_d + t);
-        const int beg = rp.x - pl.pos_base_d, deg = rp.y - rp.x;
-        const float4 g = ld4(g_out + t * FN_D + lane * 4);
-        if (deg <= 2 * LPH) {
-            const int pos0 = beg + 2 * j;
-            const bool has0 = 2 * j < deg, has1 = 2 * j + 1 < deg;
-            int src0 = 0, src1 = 0;
-            float ps0 = 0.f, ps1 = 0.f;
-            if (has0 && pos0 + 1 < m) {
-                const i32x2u sp = ldp(pl.src_d + pos0);
-                const f32x2u pp = ldp(p_sorted + (size_t)head * m + pos0);
-                src0 = sp.x; src1 = sp.y; ps0 = pp.x; ps1 = has1 ? pp.y : 0.f;
-            } else if (has0) {
-                src0 = pl.src_d[pos0];
-                ps0 = p_sorted[(size_t)head * m + pos0];
+    int beg, deg, beg_n, deg_n;
+    BwdRaw<NE> raw, cur;
+    load_extent(tb, beg, deg);
+    issue_edges(beg, raw);
+    load_extent(tb + RB, beg_n, deg_n);
+    cur = raw;
+    asm volatile("" ::"v"(beg_n), "v"(deg_n), "v"(cur.sp.x), "v"(cur.sp.y), "v"(cur.pp.x), "v"(cur.pp.y), "v"(cur.sq.x), "v"(cur.sq.y));
+    for (int t = tb; t < tb + RB * rows_per_hw; t += RB) {
+        const bool fast = pairs && deg >= 0 && deg <= 2 * LPH;
+        const bool has0 = fast && 2 * j < deg, has1 = fast && 2 * j + 1 < deg;
+        const bool shifted = beg + 2 * j != cur.pos;              // only the very last edge of the level
+        const int src0 = shifted ? cur.sp.y : cur.sp.x, src1 = has1 ? cur.sp.y : src0;
+        const float ps0 = has0 ? (shifted ? cur.pp.y : cur.pp.x) : 0.f, ps1 = has1 ? cur.pp.y : 0.f;
+        const int sq0 = shifted ? cur.sq.y : cur.sq.x, sq1 = cur.sq.y;
+        const int eq0 = shifted ? cur.eq.y : cur.eq.x, eq1 = cur.eq.y;
+        // one round trip: next row's edge data, the row after's extent, this row's gradient row and source rows
+        issue_edges(beg_n, raw);
+        int beg_nn, deg_nn;
+        load_extent(t + 2 * RB, beg_nn, deg_nn);
+        const int tc = t < n ? t : n - 1;
+        const float4 g = ld4_off(g_out, (uint32_t)tc * (FN_D * 4) + lane * 16);
+        const bool wide = __any(fast && deg > 4);
+        float4 r0[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sk = __shfl((i & 1) ? src1 : src0, i >> 1, LPH);
+            r0[i] = ld4_off(h, (uint32_t)sk * (FN_D * 4) + lane * 16);
+        }
+        if (wide) {
+#pragma unroll
+            for (int i = 4; i < 8; ++i) {
+                const int sk = __shfl((i & 1) ? src1 : src0, i >> 1, LPH);
+                r0[i] = ld4_off(h, (uint32_t)sk * (FN_D * 4) + lane * 16);
             }
-            if (!has1) src1 = src0;
-            float dp0 = 0.f, dp1 = 0.f;
-            const int slast = deg ? __shfl(((deg - 1) & 1) ? src1 : src0, (deg - 1) >> 1, LPH) : 0;
-            for (int k0 = 0; k0 < deg; k0 += 4) {
-                float4 r[4];
+        }
+        float dp0 = 0.f, dp1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dsum = head_sum<LPH>(dot4(g, r0[i]));
+            if ((i >> 1) == j) { if (i & 1) dp1 = dsum; else dp0 = dsum; }
+        }
+        if (wide) {
+#pragma unroll
+            for (int i = 4; i < 8; ++i) {
+                const float dsum = head_sum<LPH>(dot4(g, r0[i]));
+                if ((i >> 1) == j) { if (i & 1) dp1 = dsum; else dp0 = dsum; }
+            }
+        }
+        if (fast) {
+            for (int k0 = 8; k0 < deg; k0 += 4) {                 // in-degree 9 .. 2*LPH
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int k = k0 + i;
-                    int sk = __shfl((i & 1) ? src1 : src0, k >> 1, LPH);
-                    if (k >= deg) sk = slast;
-                    r[i] = ld4(h + (size_t)sk * FN_D + lane * 4);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float d = head_sum<LPH>(dot4(g, r[i]));
-                    const int k = k0 + i;
-                    if ((k >> 1) == j && k < deg) { if (i & 1) dp1 = d; else dp0 = d; }
+                    const int sk = __shfl((i & 1) ? src1 : src0, k >> 1, LPH);
+                    const float dsum = head_sum<LPH>(dot4(g, ld4_off(h, (uint32_t)sk * (FN_D * 4) + lane * 16)));
+                    if ((k >> 1) == j) { if (i & 1) dp1 = dsum; else dp0 = dsum; }
                 }
             }
-            const float p0 = fabsf(ps0), p1 = fabsf(ps1);
-            const float c = head_sum<LPH>(p0 * dp0 + p1 * dp1);
-            const float dz0 = p0 * (dp0 - c) * ((__float_as_uint(ps0) >> 31) ? slope : 1.f);
-            const float dz1 = p1 * (dp1 - c) * ((__float_as_uint(ps1) >> 31) ? slope : 1.f);
-            if (has1) {
-                const i32x2u sq = ldp(pl.spos_d + pos0);
-                stp(pz_src + ((size_t)head * m + sq.x) * 2, p0, dz0);
-                stp(pz_src + ((size_t)head * m + sq.y) * 2, p1, dz1);
-                if (et.mode == 0) {
-                    if (dz_sorted) stp(dz_sorted + (size_t)head * m + pos0, dz0, dz1);
-                    if (g_s_orig) {                         // gradient of the edge term in ORIGINAL edge order, [m_real][H]
-                        const i32x2u eq = ldp(pl.eid_d + pos0);
-                        if (eq.x < pl.m_real) g_s_orig[(size_t)eq.x * H + head] = dz0;
-                        if (eq.y < pl.m_real) g_s_orig[(size_t)eq.y * H + head] = dz1;
-                    }
-                } else { edge_partials(pos0, dz0); edge_partials(pos0 + 1, dz1); }
-            } else if (has0) {
-                emit(pos0, dz0, p0);
-                if (et.mode == 2) edge_partials(pos0, dz0);
+        }
+        const float p0 = fabsf(ps0), p1 = fabsf(ps1);
+        const float c = head_sum<LPH>(p0 * dp0 + p1 * dp1);
+        const float dz0 = p0 * (dp0 - c) * ((__float_as_uint(ps0) >> 31) ? slope : 1.f);
+        const float dz1 = p1 * (dp1 - c) * ((__float_as_uint(ps1) >> 31) ? slope : 1.f);
+        // the raw data of this row is consumed: take over the next row's before the stores (see k_gat_fwd)
+        float xa[NE], xb[NE];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) { xa[k] = shifted ? cur.x[k].y : cur.x[k].x;  xb[k] = cur.x[k].y; }
+        const int pos0 = beg + 2 * j, t_cur_deg = deg, t_cur_beg = beg;
+        cur = raw;
+        beg = beg_n;  deg = deg_n;  beg_n = beg_nn;  deg_n = deg_nn;
+        if (fast) {
+            if (has0) stp(pz_head + (size_t)sq0 * 2, p0, dz0);
+            if (has1) stp(pz_head + (size_t)sq1 * 2, p1, dz1);
+            if (KL == 0) {
+                if (dz_sorted) {
+                    if (has1) stp(dz_sorted + (size_t)head * m + pos0, dz0, dz1);
+                    else if (has0) dz_sorted[(size_t)head * m + pos0] = dz0;
+                }
+                if (want_orig) {                                  // gradient of the edge term in ORIGINAL edge order, [m_real][H]
+                    if (has0 && eq0 < pl.m_real) g_s_orig[(size_t)eq0 * H + head] = dz0;
+                    if (has1 && eq1 < pl.m_real) g_s_orig[(size_t)eq1 * H + head] = dz1;
+                }
+            } else {
+                pw[NE] += dz0 + dz1;                              // dz is 0 where the lane has no edge
+#pragma unroll
+                for (int k = 0; k < NE; ++k) pw[k] = fmaf(dz0, xa[k], fmaf(dz1, xb[k], pw[k]));
             }
             const float gs = head_sum<LPH>(dz0 + dz1);
-            if (j == 0) g_s_dst[t * H + head] = gs;
-        } else {
-            float c = 0.f;
-            for (int k = 0; k < deg; ++k) {
-                const int sk = pl.src_d[beg + k];
-                const float d = head_sum<LPH>(dot4(g, ld4(h + (size_t)sk * FN_D + lane * 4)));
-                c = fmaf(fabsf(p_sorted[(size_t)head * m + beg + k]), d, c);
+            if (j == 0) g_s_dst[(size_t)t * H + head] = gs;
+        } else if (t_cur_deg >= 0) {
+            // rare high in-degree node (or a level with a single edge): every lane walks the edge list
+            const int bg = t_cur_beg, dg = t_cur_deg;
+            float cs = 0.f;
+            for (int k = 0; k < dg; ++k) {
+                const int sk = pl.src_d[bg + k];
+                const float dsum = head_sum<LPH>(dot4(g, ld4(h + (size_t)sk * FN_D + lane * 4)));
+                cs = fmaf(fabsf(p_head[bg + k]), dsum, cs);
             }
             float gs = 0.f;
-            for (int k = 0; k < deg; ++k) {
-                const int sk = pl.src_d[beg + k];
-                const float d = head_sum<LPH>(dot4(g, ld4(h + (size_t)sk * FN_D + lane * 4)));
-                const float ps = p_sorted[(size_t)head * m + beg + k];
-                const float dz = fabsf(ps) * (d - c) * ((__float_as_uint(ps) >> 31) ? slope : 1.f);
+            for (int k = 0; k < dg; ++k) {
+                const int sk = pl.src_d[bg + k];
+                const float dsum = head_sum<LPH>(dot4(g, ld4(h + (size_t)sk * FN_D + lane * 4)));
+                const float ps = p_head[bg + k];
+                const float dz = fabsf(ps) * (dsum - cs) * ((__float_as_uint(ps) >> 31) ? slope : 1.f);
                 if (j == 0) {
-                    emit(beg + k, dz, fabsf(ps));
-                    if (et.mode == 2) edge_partials(beg + k, dz);
+                    stp(pz_head + (size_t)pl.spos_d[bg + k] * 2, fabsf(ps), dz);
+                    if (KL == 0) {
+                        if (dz_sorted) dz_sorted[(size_t)head * m + bg + k] = dz;
+                        if (g_s_orig) { const int eid = pl.eid_d[bg + k]; if (eid < pl.m_real) g_s_orig[(size_t)eid * H + head] = dz; }
+                    } else {
+                        pw[NE] += dz;
+#pragma unroll
+                        for (int kk = 0; kk < NE; ++kk)
+                            if (kk < K) pw[kk] = fmaf(dz, et.x_sorted[(size_t)kk * m + bg + k], pw[kk]);
+                    }
                 }
                 gs += dz;
             }
-            if (j == 0) g_s_dst[t * H + head] = gs;
+            if (j == 0) g_s_dst[(size_t)t * H + head] = gs;
         }
     }
 
-    if (et.mode == 2) {
-        // deterministic block partial of sum_e dz[e,h] * (x[e,0..K), 1)
+    if (KL) {
+        // deterministic block partial of sum_e dz[e,h] * (x[e,0..K), 1); columns k >= K carry weight-0 duplicates
 #pragma unroll
-        for (int k = 0; k < kWfLd; ++k) {
+        for (int k = 0; k <= NE; ++k) {
             const float v = head_sum<LPH>(pw[k]);
-            if (j == 0) sP[hw][head][k] = v;
+            if (j == 0) sP[hw][head][k == NE ? FN_MAX_EDGE_K : k] = v;
         }
         __syncthreads();
-        const int ne = H * (et.K + 1);
+        const int ne = H * (K + 1);
         for (int i = threadIdx.x; i < ne; i += blockDim.x) {
-            const int hh = i / (et.K + 1), k = i % (et.K + 1);
-            const int kk = (k == et.K) ? FN_MAX_EDGE_K : k;
+            const int hh = i / (K + 1), k = i % (K + 1);
+            const int kk = (k == K) ? FN_MAX_EDGE_K : k;
             float a = 0.f;
 #pragma unroll
             for (int w = 0; w < RB; ++w) a += sP[w][hh][kk];
@@ -717,71 +787,127 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(const float* __restrict
     }
 }
 
+// Source pass: g_h[s] = sum over out-edges p * g_out[dst] + g_s_dst[s] * a_dst + (sum dz) * a_src, and the block
+// partials of dL/da_dst, dL/da_src.  Its stores are whole rows, so it pipelines like the forward kernel: persistent
+// half-waves over R consecutive source rows, straight-line body, next row's (dst ids, p, dz) in flight during the
+// gathers of this one.
+struct SrcRaw {
+    int pos;
+    i32x2u tp;
+    f32x4u v;               // p0, dz0, p1, dz1
+};
+
 template <int H, int RB>
 __global__ __launch_bounds__(RB * 32) void k_gat_bwd_src(const float* __restrict__ g_out, const float* __restrict__ h,
                                                          const float* __restrict__ pz_src,
                                                          const float* __restrict__ g_s_dst, const float* __restrict__ att,
                                                          int att_w, int dst_off, int src_off, fn_gat_plan pl,
-                                                         float* __restrict__ g_h, float* __restrict__ part_a) {
+                                                         float* __restrict__ g_h, float* __restrict__ part_a,
+                                                         int rows_per_hw) {
     constexpr int LPH = 32 / H;
     __shared__ float sA[RB][2 * FN_D];
     const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH, hw = threadIdx.x >> 5;
-    const int64_t m = pl.m;
+    const int m = (int)pl.m, n = (int)pl.n;
+    const bool pairs = m >= 2;
     const float4 ad = ld4(att + head * att_w + dst_off + j * 4);
     const float4 as = ld4(att + head * att_w + src_off + j * 4);
+    const float* pz_head = pz_src + (size_t)head * m * 2;
     float4 qd = make_float4(0.f, 0.f, 0.f, 0.f), qs = qd;
-    for (int64_t s = (int64_t)xcd_block(blockIdx.x, gridDim.x) * RB + hw; s < pl.n; s += (int64_t)gridDim.x * RB) {
-        const i32x2u rp = ldp(pl.rowptr_s + s);
-        const int beg = rp.x - pl.pos_base_s, deg = rp.y - rp.x;
-        const float gsd = g_s_dst[s * H + head];
-        const float4 hr = ld4(h + s * FN_D + lane * 4);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        float gss = 0.f;
-        if (deg <= 2 * LPH) {
-            const int pos0 = beg + 2 * j;
-            const bool has0 = 2 * j < deg, has1 = 2 * j + 1 < deg;
-            int t0 = 0, t1 = 0;
-            float p0 = 0.f, p1 = 0.f, z0 = 0.f, z1 = 0.f;
-            const float* pzp = pz_src + ((size_t)head * m + pos0) * 2;
-            if (has0 && pos0 + 1 < m) {
-                const i32x2u tp = ldp(pl.dst_s + pos0);
-                const f32x4u v = *reinterpret_cast<const f32x4u*>(pzp);
-                t0 = tp.x; t1 = has1 ? tp.y : tp.x; p0 = v.x; z0 = v.y;
-                if (has1) { p1 = v.z; z1 = v.w; }
-            } else if (has0) {
-                t0 = t1 = pl.dst_s[pos0];
-                const f32x2u v = ldp(pzp);
-                p0 = v.x; z0 = v.y;
+    const int blk0 = xcd_block(blockIdx.x, gridDim.x) * RB * rows_per_hw;      // rows interleaved over the half-waves
+    const int sb = blk0 + hw;
+    const int se = blk0 + RB * rows_per_hw < n ? blk0 + RB * rows_per_hw : n;
+
+    auto load_extent = [&](int s, int& beg, int& deg, float& gsd) {
+        const int sc = s < n ? s : n - 1;
+        const i32x2u rp = ldp(pl.rowptr_s + sc);
+        beg = rp.x - pl.pos_base_s;
+        deg = s < se ? rp.y - rp.x : -1;
+        gsd = g_s_dst[(uint32_t)sc * H + head];
+    };
+    auto issue_edges = [&](int beg, SrcRaw& r) {
+        int pos = beg + 2 * j;
+        pos = pos > m - 2 ? m - 2 : pos;
+        pos = pos < 0 ? 0 : pos;
+        r.pos = pos;
+        if (!pairs) { r.tp.x = r.tp.y = 0;  r.v.x = r.v.y = r.v.z = r.v.w = 0.f;  return; }
+        r.tp = ldp(pl.dst_s + pos);
+        r.v = *reinterpret_cast<const f32x4u*>(pz_head + (size_t)pos * 2);
+    };
+
+    int beg, deg, beg_n, deg_n;
+    float gsd, gsd_n;
+    SrcRaw raw, cur;
+    load_extent(sb, beg, deg, gsd);
+    issue_edges(beg, raw);
+    load_extent(sb + RB, beg_n, deg_n, gsd_n);
+    cur = raw;
+    asm volatile("" ::"v"(beg_n), "v"(deg_n), "v"(gsd_n), "v"(cur.tp.x), "v"(cur.tp.y), "v"(cur.v.x), "v"(cur.v.y), "v"(cur.v.z), "v"(cur.v.w));
+    for (int s = sb; s < sb + RB * rows_per_hw; s += RB) {
+        const bool fast = pairs && deg >= 0 && deg <= 2 * LPH;
+        const bool has0 = fast && 2 * j < deg, has1 = fast && 2 * j + 1 < deg;
+        const bool shifted = beg + 2 * j != cur.pos;              // only the very last edge of the level
+        const int t0 = shifted ? cur.tp.y : cur.tp.x, t1 = has1 ? cur.tp.y : t0;
+        const float p0 = has0 ? (shifted ? cur.v.z : cur.v.x) : 0.f, z0 = has0 ? (shifted ? cur.v.w : cur.v.y) : 0.f;
+        const float p1 = has1 ? cur.v.z : 0.f, z1 = has1 ? cur.v.w : 0.f;
+        issue_edges(beg_n, raw);
+        int beg_nn, deg_nn;
+        float gsd_nn;
+        load_extent(s + 2 * RB, beg_nn, deg_nn, gsd_nn);
+        const int sc = s < n ? s : n - 1;
+        const float4 hr = ld4_off(h, (uint32_t)sc * (FN_D * 4) + lane * 16);
+        const bool wide = __any(fast && deg > 4);
+        float4 r0[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tk = __shfl((i & 1) ? t1 : t0, i >> 1, LPH);
+            r0[i] = ld4_off(g_out, (uint32_t)tk * (FN_D * 4) + lane * 16);
+        }
+        if (wide) {
+#pragma unroll
+            for (int i = 4; i < 8; ++i) {
+                const int tk = __shfl((i & 1) ? t1 : t0, i >> 1, LPH);
+                r0[i] = ld4_off(g_out, (uint32_t)tk * (FN_D * 4) + lane * 16);
             }
-            gss = head_sum<LPH>(z0 + z1);
-            for (int k0 = 0; k0 < deg; k0 += 4) {
-                float4 r[4];
-                float pk[4];
+        }
+        float gss = head_sum<LPH>(z0 + z1);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fma4(acc, __shfl((i & 1) ? p1 : p0, i >> 1, LPH), r0[i]);
+        if (wide) {
+#pragma unroll
+            for (int i = 4; i < 8; ++i) fma4(acc, __shfl((i & 1) ? p1 : p0, i >> 1, LPH), r0[i]);
+        }
+        const int cur_beg = beg, cur_deg = deg;
+        const float cur_gsd = gsd;
+        cur = raw;
+        beg = beg_n;  deg = deg_n;  gsd = gsd_n;  beg_n = beg_nn;  deg_n = deg_nn;  gsd_n = gsd_nn;
+        if (fast) {
+            for (int k0 = 8; k0 < cur_deg; k0 += 4) {             // out-degree 9 .. 2*LPH
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int k = k0 + i;
                     const int tk = __shfl((i & 1) ? t1 : t0, k >> 1, LPH);
-                    pk[i] = __shfl((i & 1) ? p1 : p0, k >> 1, LPH);
-                    r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (k < deg) r[i] = ld4(g_out + (size_t)tk * FN_D + lane * 4);
-                    else pk[i] = 0.f;
+                    const float pk = __shfl((i & 1) ? p1 : p0, k >> 1, LPH);
+                    fma4(acc, pk, ld4_off(g_out, (uint32_t)tk * (FN_D * 4) + lane * 16));
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fma4(acc, pk[i], r[i]);
             }
-        } else {
-            for (int i = 0; i < deg; ++i) {
-                const int t = pl.dst_s[beg + i];
-                const f32x2u v = ldp(pz_src + ((size_t)head * m + beg + i) * 2);
+        } else if (cur_deg >= 0) {
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            gss = 0.f;
+            for (int i = 0; i < cur_deg; ++i) {
+                const int t = pl.dst_s[cur_beg + i];
+                const f32x2u v = ldp(pz_head + (size_t)(cur_beg + i) * 2);
                 fma4(acc, v.x, ld4(g_out + (size_t)t * FN_D + lane * 4));
                 gss += v.y;
             }
         }
-        fma4(acc, gsd, ad);
-        fma4(acc, gss, as);
-        st4(g_h + s * FN_D + lane * 4, acc);
-        fma4(qd, gsd, hr);
-        fma4(qs, gss, hr);
+        if (cur_deg >= 0) {
+            fma4(acc, cur_gsd, ad);
+            fma4(acc, gss, as);
+            st4(g_h + (size_t)s * FN_D + lane * 4, acc);
+            fma4(qd, cur_gsd, hr);
+            fma4(qs, gss, hr);
+        }
     }
     st4(&sA[hw][lane * 4], qd);
     st4(&sA[hw][FN_D + lane * 4], qs);
@@ -1607,7 +1733,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 // C-ABI
 // =====================================================================================
 namespace {
-int g_tune[FN_TUNE_COUNT] = {1024, 0, 0};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_DEBUG, FN_TUNE_STREAMS
+int g_tune[FN_TUNE_COUNT] = {1792, 0, 0};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_DEBUG, FN_TUNE_STREAMS
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -1816,10 +1942,25 @@ int fn_gat_bwd_dst_f32(const float* g_out, const float* h, const float* p_sorted
     if (et->mode == 2 && !part_e) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: null part_e");
     *n_part_e = 0;
     if (plan->n == 0) return 0;
-    const int g = bwd_grid(plan->n);
+    if (plan->n > (1 << 23) || plan->m * heads > (1 << 29))
+        return fail(FN_EUNSUPPORTED, "fn_gat_bwd_dst_f32: level too large for 32-bit byte offsets (n <= 2^23 rows, m*heads <= 2^29)");
+    // R consecutive rows per half-wave; one edge-parameter partial row per block, hence at most FN_MAX_PART blocks.
+    // Unlike the forward kernel this one wants R SMALL: its (p, dz) stores are scattered 8-byte writes into source
+    // order, vmcnt counts loads and stores in one in-order queue, so every extra row per wave waits behind the
+    // previous row's slow stores (B=2048: R=4 56 us, R=8 84 us; B=512: 16 us at any R)
+    const int64_t groups = (plan->n + kBwdRows - 1) / kBwdRows;
+    const int64_t resident = FN_MAX_PART;
+    const int R = (int)((groups + resident - 1) / resident);
+    const int g = (int)((plan->n + (int64_t)kBwdRows * R - 1) / ((int64_t)kBwdRows * R));
     *n_part_e = (et->mode == 2) ? g : 0;
-    FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_dst<HH, kBwdRows>), dim3(g), dim3(kBwdRows * 32), 0, S(stream), g_out, h,
-                                            p_sorted, *et, *plan, neg_slope, dz_sorted, g_s_orig, pz_src, g_s_dst, part_e));
+#define FN_BWD_LAUNCH(KL) hipLaunchKernelGGL((k_gat_bwd_dst<HH, KL, kBwdRows>), dim3(g), dim3(kBwdRows * 32), 0, S(stream), g_out, \
+                                             h, p_sorted, *et, *plan, neg_slope, dz_sorted, g_s_orig, pz_src, g_s_dst, part_e, R)
+    FN_DISPATCH_H(heads, {
+        if (et->mode == 0) FN_BWD_LAUNCH(0);
+        else if (et->K == 1) FN_BWD_LAUNCH(1);
+        else FN_BWD_LAUNCH(FN_MAX_EDGE_K);
+    });
+#undef FN_BWD_LAUNCH
     return launch_status("fn_gat_bwd_dst_f32");
 }
 
@@ -1831,12 +1972,18 @@ int fn_gat_bwd_src_f32(const float* g_out, const float* h, const float* pz_src,
     if ((att_w | dst_off | src_off) & 3) return fail(FN_EINVAL, "fn_gat_bwd_src_f32: att blocks must be 16-byte aligned");
     *n_part_a = 0;
     if (plan->n == 0) return 0;
-    // every block writes 256 partial sums: keep the block count (= scattered partial writes, finalize work) moderate
-    int g = bwd_grid(plan->n);
-    if (g > 1024) g = 1024;
+    if (plan->n > (1 << 23) || plan->m * heads > (1 << 28))
+        return fail(FN_EUNSUPPORTED, "fn_gat_bwd_src_f32: level too large for 32-bit byte offsets (n <= 2^23 rows, m*heads <= 2^28)");
+    // every block writes 256 partial sums column-major (scattered): at most 1024 blocks, each half-wave pipelining
+    // R consecutive source rows
+    const int64_t groups = (plan->n + kBwdRows - 1) / kBwdRows;
+    int64_t resident = (int64_t)g_tune[FN_TUNE_FWD_BLOCKS];
+    if (resident > 1024) resident = 1024;
+    const int R = (int)((groups + resident - 1) / resident);
+    const int g = (int)((plan->n + (int64_t)kBwdRows * R - 1) / ((int64_t)kBwdRows * R));
     *n_part_a = g;
     FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src<HH, kBwdRows>), dim3(g), dim3(kBwdRows * 32), 0, S(stream), g_out, h, pz_src,
-                                            g_s_dst, att, att_w, dst_off, src_off, *plan, g_h, part_a));
+                                            g_s_dst, att, att_w, dst_off, src_off, *plan, g_h, part_a, R));
     return launch_status("fn_gat_bwd_src_f32");
 }
 

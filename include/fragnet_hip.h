@@ -43,7 +43,7 @@ typedef void* fn_stream_t;    /* hipStream_t */
 int fn_abi_version(void);
 
 /* Process-wide tuning knobs (defaults are the measured best for MI355X; the bench uses them for A/B runs).
- * FN_TUNE_FWD_BLOCKS: workgroups of the forward kernel that are resident at once (default 1024 = 256 CUs x 4); a
+ * FN_TUNE_FWD_BLOCKS: workgroups of the forward kernel that are resident at once (default 1792 = 256 CUs x 7); a
  *   level with more row groups than that gives every half-wave several consecutive rows to software-pipeline. */
 #define FN_TUNE_FWD_BLOCKS 0
 #define FN_TUNE_DEBUG 1        /* development only: bit mask that disables parts of kernels (results become wrong) */
