@@ -23,6 +23,8 @@ def graph_capture_head(model, batch_size: int, attr: str = "fthead") -> bool:
     dev = next(head.parameters()).device
     if dev.type != "cuda":
         return False
+    if getattr(head, "rng", None) is not None:
+        head.rng = None      # torch's own dropout is graph-safe; the fused Philox epilogue would replay one fixed mask here
     try:
         was_training = head.training
         head.train()

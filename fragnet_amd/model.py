@@ -218,9 +218,15 @@ class FTHead1(nn.Sequential):
 class _PredictorStack(nn.Sequential):
     """act(dropout(linear(x))) between layers, plain last layer -- gat2.py:631-637, 719-725, 745-751."""
 
+    rng = None       # the encoder's Philox stream when the owning model attaches it (FragNetFineTune does)
+
     def _run(self, enc):
+        fused = self.rng is not None and isinstance(self.activation, nn.ReLU) and enc.is_cuda
         for lin in self.predictor[:-1]:
-            enc = self.activation(self.dropout(lin(enc)))
+            if fused:    # relu(dropout(.)) as one kernel each way instead of two (same op as between encoder layers)
+                enc = ops.dropout_act(lin(enc), self.dropout.p, self.training, True, self.rng)
+            else:
+                enc = self.activation(self.dropout(lin(enc)))
         return self.predictor[-1](enc)
 
 
@@ -302,6 +308,9 @@ class FragNetFineTune(nn.Module):
                                   drop_ratio=drop_ratio, act=act)
         elif fthead == "FTHead4":
             self.fthead = FTHead4(n_classes=n_classes, h1=h1, drop_ratio=drop_ratio, act=act)
+
+        if isinstance(self.fthead, _PredictorStack):
+            self.fthead.rng = self.pretrain.rng
 
     def forward(self, batch):
         x_atoms, x_frags, _, _ = self.pretrain(batch)
