@@ -108,6 +108,9 @@ SIGNATURES = {
     "fn_adam_f32": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp],
     "fn_edge_concat_f32": [vp, vp, vp, vp, i64, vp],
     "fn_stage_padded": [C.POINTER(StageField), C.c_int, vp],
+    "fn_pool_cat_f32": [vp, vp, C.POINTER(SegPlan), C.POINTER(SegPlan), vp, vp],
+    "fn_pool_cat_bwd_f32": [vp, vp, vp, vp, vp, i64, i64, vp],
+    "fn_masked_mse_f32": [vp, vp, vp, i64, C.c_int, vp, vp, vp],
 }
 
 _lib = None

@@ -1180,6 +1180,65 @@ __global__ __launch_bounds__(kBlock) void k_segment_sum128_wide(const float* __r
     }
 }
 
+// pooled = cat(sum of a molecule's atom rows, sum of its fragment rows): [B, 256] in one launch (gat2.py:820-823).
+// grid (B, 2): y = 0 atoms -> columns 0..127, y = 1 fragments -> columns 128..255; one block per molecule and half.
+__global__ __launch_bounds__(kBlock) void k_pool_cat(const float* __restrict__ x_atoms, const float* __restrict__ x_frags,
+                                                     fn_seg_plan sa, fn_seg_plan sf, float* __restrict__ out) {
+    __shared__ float sS[kRows][FN_D];
+    const fn_seg_plan& sp = blockIdx.y ? sf : sa;
+    const float* src = blockIdx.y ? x_frags : x_atoms;
+    const int lane = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    const int64_t s = blockIdx.x;
+    const int beg = sp.rowptr[s] - sp.pos_base, deg = sp.rowptr[s + 1] - sp.rowptr[s];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = hw; i < deg; i += kRows) {
+        const float4 v = ld4(src + (size_t)sp.perm[beg + i] * FN_D + lane * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    st4(&sS[hw][lane * 4], acc);
+    __syncthreads();
+    if (threadIdx.x < FN_D) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < kRows; ++w) v += sS[w][threadIdx.x];
+        out[s * 2 * FN_D + blockIdx.y * FN_D + threadIdx.x] = v;
+    }
+}
+// its backward: g_atoms[i,:] = g[batch[i], 0:128], g_frags[f,:] = g[frag_batch[f], 128:256]
+__global__ void k_pool_cat_bwd(const float* __restrict__ g, const int64_t* __restrict__ batch, const int64_t* __restrict__ frag_batch,
+                               float* __restrict__ g_atoms, float* __restrict__ g_frags, int64_t N, int64_t F) {
+    const int64_t total = (N + F) * 32;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i >> 5;
+        const int c4 = (int)(i & 31);
+        if (r < N) st4(g_atoms + r * FN_D + c4 * 4, ld4(g + batch[r] * 2 * FN_D + c4 * 4));
+        else st4(g_frags + (r - N) * FN_D + c4 * 4, ld4(g + frag_batch[r - N] * 2 * FN_D + FN_D + c4 * 4));
+    }
+}
+
+// loss = sum_i w[i] * sum_t (out[i,t] - y[i,t])^2 / (sum_i w[i] * T) and its gradient w.r.t. out, one block
+// (MSELoss of train/utils.py:341 restricted to the rows with weight 1; B*T is a few hundred to a few thousand)
+__global__ __launch_bounds__(1024) void k_masked_mse(const float* __restrict__ out, const float* __restrict__ y,
+                                                     const float* __restrict__ w, int64_t B, int T, float* __restrict__ loss,
+                                                     float* __restrict__ g_out) {
+    __shared__ float s16[16];
+    __shared__ float sW;
+    float sq = 0.f, ws = 0.f;
+    for (int64_t i = threadIdx.x; i < B * T; i += 1024) {
+        const float d = out[i] - y[i], wi = w[i / T];
+        sq = fmaf(wi * d, d, sq);
+    }
+    for (int64_t i = threadIdx.x; i < B; i += 1024) ws += w[i];
+    const float S = block_sum_1024(sq, s16);
+    __syncthreads();
+    const float W = block_sum_1024(ws, s16);
+    const float denom = W * (float)T;
+    if (threadIdx.x == 0) { loss[0] = S / denom;  sW = denom; }
+    __syncthreads();
+    const float scale = 2.f / sW;
+    for (int64_t i = threadIdx.x; i < B * T; i += 1024) g_out[i] = scale * w[i / T] * (out[i] - y[i]);
+}
+
 __global__ void k_segment_sum_any(const float* __restrict__ src, int64_t src_ld, const int32_t* __restrict__ rowptr,
                                   const int32_t* __restrict__ perm, int32_t pos_base, float* __restrict__ out,
                                   int64_t n_seg, int64_t width) {
@@ -2188,6 +2247,34 @@ int fn_edge_concat_f32(const float* x, const float* e_attr, const int64_t* edge_
     if (!x || !e_attr || !edge_index || !out) return fail(FN_EINVAL, "fn_edge_concat_f32: null buffer");
     hipLaunchKernelGGL(k_edge_concat, dim3(flat_grid(E * 96, kGridCap)), dim3(kBlock), 0, S(stream), x, e_attr, edge_index, out, E);
     return launch_status("fn_edge_concat_f32");
+}
+
+int fn_pool_cat_f32(const float* x_atoms, const float* x_frags, const fn_seg_plan* mol_atoms, const fn_seg_plan* mol_frags,
+                    float* out, fn_stream_t stream) {
+    if (!mol_atoms || !mol_frags || !out || mol_atoms->n_seg != mol_frags->n_seg) return fail(FN_EINVAL, "fn_pool_cat_f32: bad argument");
+    if (mol_atoms->n_seg == 0) return 0;
+    if ((mol_atoms->n_items > 0 && !x_atoms) || (mol_frags->n_items > 0 && !x_frags) || !mol_atoms->rowptr || !mol_frags->rowptr)
+        return fail(FN_EINVAL, "fn_pool_cat_f32: null buffer");
+    hipLaunchKernelGGL(k_pool_cat, dim3((unsigned)mol_atoms->n_seg, 2), dim3(kBlock), 0, S(stream), x_atoms, x_frags, *mol_atoms,
+                       *mol_frags, out);
+    return launch_status("fn_pool_cat_f32");
+}
+
+int fn_pool_cat_bwd_f32(const float* g, const int64_t* batch, const int64_t* frag_batch, float* g_atoms, float* g_frags,
+                        int64_t N, int64_t F, fn_stream_t stream) {
+    if (N < 0 || F < 0) return fail(FN_EINVAL, "fn_pool_cat_bwd_f32: bad argument");
+    if (N + F == 0) return 0;
+    if (!g || (N && (!batch || !g_atoms)) || (F && (!frag_batch || !g_frags))) return fail(FN_EINVAL, "fn_pool_cat_bwd_f32: null buffer");
+    hipLaunchKernelGGL(k_pool_cat_bwd, dim3(flat_grid((N + F) * 32, kGridCap)), dim3(kBlock), 0, S(stream), g, batch, frag_batch,
+                       g_atoms, g_frags, N, F);
+    return launch_status("fn_pool_cat_bwd_f32");
+}
+
+int fn_masked_mse_f32(const float* out, const float* y, const float* w, int64_t B, int T, float* loss, float* g_out,
+                      fn_stream_t stream) {
+    if (!out || !y || !w || !loss || !g_out || B < 1 || T < 1) return fail(FN_EINVAL, "fn_masked_mse_f32: bad argument");
+    hipLaunchKernelGGL(k_masked_mse, dim3(1), dim3(1024), 0, S(stream), out, y, w, B, T, loss, g_out);
+    return launch_status("fn_masked_mse_f32");
 }
 
 int fn_stage_padded(const fn_stage_field* fields, int n_fields, fn_stream_t stream) {

@@ -286,10 +286,7 @@ class FTHead2(_PredictorStack):
 
 def pooled(x_atoms, x_frags, batch):
     """cat(sum of atoms per molecule, sum of fragments per molecule) -- gat2.py:820-823."""
-    plan = plan_for(batch)
-    atoms = ops.segment_sum(x_atoms, plan.segs["mol_atoms"], plan)
-    frags = ops.segment_sum(x_frags, plan.segs["mol_frags"], plan)
-    return torch.cat((atoms, frags), 1)
+    return ops.pool_cat(x_atoms, x_frags, plan_for(batch))
 
 
 class FragNetFineTune(nn.Module):

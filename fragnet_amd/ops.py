@@ -259,6 +259,71 @@ def segment_sum(src, seg: Segments, plan=None):
     return _SegmentSum.apply(src, seg, plan)
 
 
+def _seg_struct(seg: Segments):
+    return _lib.SegPlan(seg.rowptr.data_ptr(), seg.perm.data_ptr(), seg.index.data_ptr(), seg.n_seg, seg.n_items, seg.pos_base, 0)
+
+
+class _PoolCat(torch.autograd.Function):
+    """cat(scatter_add(x_atoms, batch), scatter_add(x_frags, frag_batch), dim=1) -> [B, 256] (gat2.py:820-823): one
+    launch forward, one launch backward (two segment sums + cat, and two strided copies + two gathers, otherwise)."""
+
+    @staticmethod
+    def forward(ctx, x_atoms, x_frags, plan):
+        x_atoms, x_frags = _f32c(x_atoms, "x_atoms"), _f32c(x_frags, "x_frags")
+        sa, sf = plan.segs["mol_atoms"], plan.segs["mol_frags"]
+        if x_atoms.shape[0] != sa.n_items or x_frags.shape[0] != sf.n_items or x_atoms.shape[1] != FN_D or x_frags.shape[1] != FN_D:
+            raise ValueError("pool_cat: feature tables do not match the batch / frag_batch index")
+        out = torch.empty((sa.n_seg, 2 * FN_D), dtype=torch.float32, device=x_atoms.device)
+        a, f = _seg_struct(sa), _seg_struct(sf)
+        _lib.call("fn_pool_cat_f32", x_atoms.data_ptr(), x_frags.data_ptr(), C.byref(a), C.byref(f), out.data_ptr(),
+                  _stream_ptr(x_atoms.device))
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        sa, sf = plan.segs["mol_atoms"], plan.segs["mol_frags"]
+        g = _f32c(g, "g")
+        g_atoms = torch.empty((sa.n_items, FN_D), dtype=torch.float32, device=g.device)
+        g_frags = torch.empty((sf.n_items, FN_D), dtype=torch.float32, device=g.device)
+        _lib.call("fn_pool_cat_bwd_f32", g.data_ptr(), sa.index.data_ptr(), sf.index.data_ptr(), g_atoms.data_ptr(),
+                  g_frags.data_ptr(), sa.n_items, sf.n_items, _stream_ptr(g.device))
+        return g_atoms, g_frags, None
+
+
+def pool_cat(x_atoms, x_frags, plan):
+    return _PoolCat.apply(x_atoms, x_frags, plan)
+
+
+class _MaskedMSE(torch.autograd.Function):
+    """sum_i w_i |out_i - y_i|^2 / (sum_i w_i * T): loss and d loss / d out from one single-block kernel."""
+
+    @staticmethod
+    def forward(ctx, out, y, w):
+        B = w.shape[0]
+        out2, y2 = _f32c(out, "out").reshape(B, -1), _f32c(y, "y").reshape(B, -1)
+        if out2.shape != y2.shape:
+            raise ValueError(f"masked_mse: prediction {tuple(out.shape)} vs target {tuple(y.shape)}")
+        w = _f32c(w, "w")
+        loss = torch.empty((), dtype=torch.float32, device=out.device)
+        g = torch.empty_like(out2)
+        _lib.call("fn_masked_mse_f32", out2.data_ptr(), y2.data_ptr(), w.data_ptr(), B, out2.shape[1], loss.data_ptr(),
+                  g.data_ptr(), _stream_ptr(out.device))
+        ctx.save_for_backward(g)
+        ctx.shape = out.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (g,) = ctx.saved_tensors
+        return (g * g_loss).reshape(ctx.shape), None, None
+
+
+def masked_mse(out, y, w):
+    return _MaskedMSE.apply(out, y, w)
+
+
 class _GatherRows(torch.autograd.Function):
     """index_select(table, 0, index) with a segment-sum backward (needs the CSR of ``index``)."""
 

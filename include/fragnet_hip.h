@@ -262,6 +262,19 @@ int fn_edge_concat_f32(const float* x /*[N,128]*/, const float* e_attr /*[E,128]
                        float* out /*[E,384]*/, int64_t E, fn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Readout and loss.  pooled = cat(scatter_add(x_atoms, batch), scatter_add(x_frags, frag_batch)) (gat2.py:820-823)
+ * as one launch into a [B,256] buffer, its backward as one launch; the molecule-weighted MSE (MSELoss of
+ * train/utils.py:341 over the rows with weight 1) with its gradient in one single-block launch.
+ * ------------------------------------------------------------------------------------------ */
+struct fn_seg_plan;
+int fn_pool_cat_f32(const float* x_atoms /*[N,128]*/, const float* x_frags /*[F,128]*/, const struct fn_seg_plan* mol_atoms,
+                    const struct fn_seg_plan* mol_frags, float* out /*[B,256]*/, fn_stream_t stream);
+int fn_pool_cat_bwd_f32(const float* g /*[B,256]*/, const int64_t* batch /*[N]*/, const int64_t* frag_batch /*[F]*/,
+                        float* g_atoms /*[N,128]*/, float* g_frags /*[F,128]*/, int64_t N, int64_t F, fn_stream_t stream);
+int fn_masked_mse_f32(const float* out /*[B,T]*/, const float* y /*[B,T]*/, const float* w /*[B]*/, int64_t B, int T,
+                      float* loss /*[1]*/, float* g_out /*[B,T] = dloss/dout*/, fn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Static-shape staging for hipGraph replay.  A training step captured in a hipGraph has fixed tensor shapes, so
  * every batch (the dict of dataset/data.py:931-948) is copied into fixed-capacity buffers and the tail of each
  * buffer is filled with PADDING that is itself a valid, disconnected piece of graph: zero feature rows, and index

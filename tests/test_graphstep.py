@@ -169,3 +169,34 @@ def test_graph_step_draws_fresh_dropout_masks():
     losses = [float(step(dict(batches[0]))) for _ in range(4)]      # lr = 0: only the masks differ between replays
     assert len(set(losses)) == 4, losses
     assert int(model.pretrain.rng.dev) > 0
+
+
+@gpu
+def test_pool_cat_and_masked_mse_match_torch():
+    from fragnet_amd import ops
+    from fragnet_amd.plan import plan_for
+    dev = _dev()
+    b = data.batch_to(_batches(1, 40, seed=3)[0], dev)
+    plan = plan_for(b)
+    N, F, B = b["x_atoms"].shape[0], b["x_frags"].shape[0], b["y"].shape[0]
+    g = torch.Generator().manual_seed(0)
+    xa = torch.randn(N, 128, generator=g).to(dev).requires_grad_()
+    xf = torch.randn(F, 128, generator=g).to(dev).requires_grad_()
+    up = torch.randn(B, 256, generator=g).to(dev)
+    out = ops.pool_cat(xa, xf, plan)
+    ref = torch.cat((torch.zeros(B, 128, device=dev).index_add_(0, b["batch"], xa.detach()),
+                     torch.zeros(B, 128, device=dev).index_add_(0, b["frag_batch"], xf.detach())), 1)
+    torch.testing.assert_close(out, ref, atol=1e-5, rtol=1e-5)
+    out.backward(up)
+    assert torch.equal(xa.grad, up[b["batch"], :128]) and torch.equal(xf.grad, up[b["frag_batch"], 128:])
+    for T in (1, 3):
+        o = torch.randn(B, T, generator=g).to(dev).requires_grad_()
+        y = torch.randn(B, T, generator=g).to(dev)
+        w = (torch.rand(B, generator=g) > 0.3).float().to(dev)
+        loss = ops.masked_mse(o, y, w)
+        (3.0 * loss).backward()
+        o2 = o.detach().clone().requires_grad_()
+        ref_loss = (((o2 - y) ** 2) * w[:, None]).sum() / (w.sum() * T)
+        (3.0 * ref_loss).backward()
+        torch.testing.assert_close(loss, ref_loss.detach(), atol=1e-6, rtol=1e-5)
+        torch.testing.assert_close(o.grad, o2.grad, atol=1e-7, rtol=1e-5)
