@@ -1730,22 +1730,82 @@ struct ReduceTasks {
     ReduceTask t[kMaxReduceTasks];
     int n;
 };
+// "fat" bodies for the task-table kernel: a block reduces 8 columns of a column-major [cols][FN_MAX_PART] partial
+// array (128 threads per column, contiguous reads), or a 256-column strip of the row-major weight-gradient partials
+// (64 float4 columns x 16 row groups: 1 KiB contiguous per wave and row) -- ~1.5 k blocks per backward pass instead
+// of ~10 k one-column blocks.
+__device__ __forceinline__ float colmajor_sum_128(const float* __restrict__ col, int n_rows, float* sW) {
+    const int lane = threadIdx.x & 127;
+    float v = 0.f;
+    for (int r = lane; r < n_rows; r += 128) v += col[r];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) sW[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const int c = threadIdx.x >> 7;
+    return sW[2 * c] + sW[2 * c + 1];
+}
+template <int CTW, int NH>
+__device__ __forceinline__ void wgrad_reduce_strip(int vb, float* sm, const float* __restrict__ part, int n_rows, int K,
+                                                   float* __restrict__ dW, float* __restrict__ db) {
+    constexpr int XW = 16 * CTW * NH;
+    constexpr int PW = 128 * XW + 128;
+    const int c4 = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col0 = vb * 256 + c4 * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col0 < PW)
+        for (int r = rg; r < n_rows; r += 16) {
+            const float4 v = ld4(part + (size_t)r * PW + col0);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    st4(sm + rg * 256 + c4 * 4, acc);
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int col = vb * 256 + threadIdx.x;
+        if (col < PW) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) v += sm[g * 256 + threadIdx.x];
+            if (col >= 128 * XW) {
+                db[col - 128 * XW] = v;
+            } else {
+                const int r = col & 3, lane = (col >> 2) & 63, tile = col >> 8;        // tile = (w*2+u)*CTW + cc
+                const int cc = tile % CTW, wu = tile / CTW, u = wu & 1, w = wu >> 1;
+                const int o = 32 * (w & 3) + 16 * u + 4 * (lane >> 4) + r;
+                const int xc = 16 * (CTW * (w >> 2) + cc) + (lane & 15);
+                if (xc < K) dW[(size_t)o * K + xc] = v;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_reduce_tasks(ReduceTasks T) {
-    __shared__ float sm[1200];
+    __shared__ float sm[16 * 256];
     int ti = 0;
     while (ti + 1 < T.n && (int)blockIdx.x >= T.t[ti + 1].first) ++ti;
     const ReduceTask& t = T.t[ti];
     const int vb = (int)blockIdx.x - t.first;
     if (t.kind == RT_FINALIZE) {
-        gat_finalize_body(vb, sm, t.p0, t.n0, t.p1, t.n1, t.et, t.att, t.att_w, t.dst_off, t.src_off, t.o0, t.o1, t.o2, t.H);
+        if (vb < 2 * FN_D / 8) {
+            const int col = vb * 8 + (threadIdx.x >> 7);
+            const float v = colmajor_sum_128(t.p0 + (size_t)col * FN_MAX_PART, t.n0, sm);
+            if ((threadIdx.x & 127) == 0) {
+                const int DH = FN_D / t.H, cc = col & 127, part = col >> 7;
+                t.o0[(cc / DH) * t.att_w + (part ? t.src_off : t.dst_off) + (cc % DH)] = v;
+            }
+        } else {
+            gat_finalize_body(2 * FN_D, sm, t.p0, t.n0, t.p1, t.n1, t.et, t.att, t.att_w, t.dst_off, t.src_off, t.o0, t.o1, t.o2, t.H);
+        }
     } else if (t.kind == RT_COLSUM) {
-        colsum_body(vb, sm, t.p0, t.n0, t.o0, t.ld, t.off);
+        const int col = vb * 8 + (threadIdx.x >> 7);
+        const float v = colmajor_sum_128(t.p0 + (size_t)col * FN_MAX_PART, t.n0, sm);
+        if ((threadIdx.x & 127) == 0) t.o0[(col / FN_D) * t.ld + t.off + (col % FN_D)] = v;
     } else {
         switch (t.cls) {
-            case 0: wgrad_reduce_body<1, 1>(vb, sm, t.p0, t.n0, t.K, t.o0, t.o1); break;
-            case 1: wgrad_reduce_body<1, 2>(vb, sm, t.p0, t.n0, t.K, t.o0, t.o1); break;
-            case 2: wgrad_reduce_body<4, 2>(vb, sm, t.p0, t.n0, t.K, t.o0, t.o1); break;
-            default: wgrad_reduce_body<6, 2>(vb, sm, t.p0, t.n0, t.K, t.o0, t.o1); break;
+            case 0: wgrad_reduce_strip<1, 1>(vb, sm, t.p0, t.n0, t.K, t.o0, t.o1); break;
+            case 1: wgrad_reduce_strip<1, 2>(vb, sm, t.p0, t.n0, t.K, t.o0, t.o1); break;
+            case 2: wgrad_reduce_strip<4, 2>(vb, sm, t.p0, t.n0, t.K, t.o0, t.o1); break;
+            default: wgrad_reduce_strip<6, 2>(vb, sm, t.p0, t.n0, t.K, t.o0, t.o1); break;
         }
     }
 }
@@ -2491,12 +2551,13 @@ struct ReduceQueue {
         ReduceTask t{};
         t.kind = RT_FINALIZE;  t.H = H;  t.p0 = part_a;  t.n0 = n_a;  t.p1 = part_e;  t.n1 = n_e;  t.et = et;
         t.att = att;  t.att_w = att_w;  t.dst_off = dst_off;  t.src_off = src_off;  t.o0 = g_att;  t.o1 = g_embW;  t.o2 = g_embb;
-        return push(t, 2 * FN_D + (et.mode == 2 ? 1 : 0));
+        return push(t, 2 * FN_D / 8 + (et.mode == 2 ? 1 : 0));
     }
     int colsum(const float* part, int n_rows, int cols, float* out, int ld, int off) {
         ReduceTask t{};
         t.kind = RT_COLSUM;  t.p0 = part;  t.n0 = n_rows;  t.o0 = out;  t.ld = ld;  t.off = off;
-        return push(t, cols);
+        if (cols % 8) return fail(FN_EINVAL, "deferred column sum: column count must be a multiple of 8");
+        return push(t, cols / 8);
     }
     // dW [128,K], db [128] of a projection: partial kernel now (on `launch_on`), reduction with the rest
     int wgrad(const float* dY, const float* X, int K, int64_t M, float* ws, float* dW, float* db, hipStream_t launch_on) {
@@ -2509,7 +2570,7 @@ struct ReduceQueue {
         int grid = 0;
         if (int rc = wgrad_partials(dY, X, K, M, ws, launch_on, &grid, &t.cls)) return rc;
         t.kind = RT_WGRAD;  t.p0 = ws;  t.n0 = grid;  t.K = K;  t.o0 = dW;  t.o1 = db;
-        return push(t, (int)((wgrad_part_width(K) + 31) / 32));
+        return push(t, (int)((wgrad_part_width(K) + 255) / 256));
     }
 };
 
