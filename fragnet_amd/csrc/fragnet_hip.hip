@@ -1417,10 +1417,10 @@ struct NodeScalarEpi {             // optional fused epilogue: s_dst/s_src[row, 
 // contiguous bytes of each of its 16 rows (a blocked split, k = kq*KQ + .., made every lane touch its own 128-byte
 // line and re-fetched each line eight times through a thrashing L1).  The B rows in LDS are indexed to match.
 template <int KQ, bool VEC>
-__global__ __launch_bounds__(512) void k_linear128(const float* __restrict__ X, int K, const float* __restrict__ Bt,
-                                                   const float* __restrict__ bias, float* __restrict__ Y, int64_t M,
-                                                   fn_act_epilogue mk, NodeScalarEpi ns) {
-    extern __shared__ __attribute__((aligned(16))) float sBt[];        // [4*KQ][kLinLd] then 8 x [16][kLinOutLd]
+__device__ __forceinline__ void linear128_body(float* sBt, const float* __restrict__ X, int K, const float* __restrict__ Bt,
+                                               const float* __restrict__ bias, float* __restrict__ Y, int64_t M,
+                                               const fn_act_epilogue& mk, const NodeScalarEpi& ns, int bid, int nblk) {
+    // sBt: [4*KQ][kLinLd] then 8 x [16][kLinOutLd]; block bid of the nblk blocks that share this GEMM
     const uint64_t mk_base = mk.offset + ((mk.y && mk.p > 0.f && mk.offset_dev) ? *mk.offset_dev : 0);   // read once, not per tile
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
     const int wr = w & 3, wc = w >> 2;
@@ -1459,13 +1459,13 @@ __global__ __launch_bounds__(512) void k_linear128(const float* __restrict__ X, 
     };
 
     float cur[KQ], nxt[KQ];
-    int64_t tile = blockIdx.x;
+    int64_t tile = bid;
     if (tile < tiles) load_rows(tile, cur);
     __syncthreads();
     const float* bbase = sBt + (VEC ? 4 * kq : kq * KQ) * kLinLd + 64 * wc + i;
     auto brow = [](int s) { return VEC ? 16 * (s >> 2) + (s & 3) : s; };      // LDS row of MFMA step s, relative to bbase
-    for (; tile < tiles; tile += gridDim.x) {
-        const int64_t ntile = tile + gridDim.x;
+    for (; tile < tiles; tile += nblk) {
+        const int64_t ntile = tile + nblk;
         if (ntile < tiles) load_rows(ntile, nxt);
         f32x4 acc[4];
 #pragma unroll
@@ -1541,6 +1541,37 @@ __global__ __launch_bounds__(512) void k_linear128(const float* __restrict__ X, 
 #pragma unroll
         for (int s = 0; s < KQ; ++s) cur[s] = nxt[s];
     }
+}
+
+template <int KQ, bool VEC>
+__global__ __launch_bounds__(512) void k_linear128(const float* __restrict__ X, int K, const float* __restrict__ Bt,
+                                                   const float* __restrict__ bias, float* __restrict__ Y, int64_t M,
+                                                   fn_act_epilogue mk, NodeScalarEpi ns) {
+    extern __shared__ __attribute__((aligned(16))) float sBt[];
+    linear128_body<KQ, VEC>(sBt, X, K, Bt, bias, Y, M, mk, ns, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// up to three independent [M_i,K]·[K,128] products in one launch: the three projections of a layer (forward) or
+// their three input-gradient products (backward) depend only on the previous layer, never on each other
+struct LinTask {
+    const float *X, *Bt, *bias;
+    float* Y;
+    int64_t M;
+    fn_act_epilogue mk;
+    NodeScalarEpi ns;
+    int first, nblk;
+};
+struct LinTasks {
+    LinTask t[3];
+    int n, K;
+};
+template <int KQ, bool VEC>
+__global__ __launch_bounds__(512) void k_linear128_multi(LinTasks T) {
+    extern __shared__ __attribute__((aligned(16))) float sBt[];
+    int ti = 0;
+    while (ti + 1 < T.n && (int)blockIdx.x >= T.t[ti + 1].first) ++ti;
+    const LinTask& t = T.t[ti];
+    linear128_body<KQ, VEC>(sBt, t.X, T.K, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, (int)blockIdx.x - t.first, t.nblk);
 }
 
 // Bt[k][n] = W[n][k]  (W is nn.Linear.weight [128, K])
@@ -1875,6 +1906,28 @@ int launch_linear128(const float* X, int K, const float* Bt, const float* bias, 
     }
     return 0;
 }
+// grouped launch for K == 128 (every projection beyond layer 0 and every input-gradient product)
+int launch_linear128_group(LinTasks& T, hipStream_t st) {
+    constexpr int KQ = 32;
+    const size_t lds = ((size_t)4 * KQ * kLinLd + 8 * 16 * kLinOutLd) * sizeof(float);
+    int blocks = 0, live = 0;
+    for (int i = 0; i < T.n; ++i) {
+        if (T.t[i].M <= 0) continue;
+        const int64_t tiles = (T.t[i].M + 63) / 64;
+        LinTask t = T.t[i];
+        t.first = blocks;
+        t.nblk = (int)(tiles < 256 ? tiles : 256);
+        blocks += t.nblk;
+        T.t[live++] = t;
+    }
+    T.n = live;
+    T.K = 128;
+    if (!live) return 0;
+    if (int rc = allow_lds(k_linear128_multi<KQ, true>, lds)) return rc;
+    hipLaunchKernelGGL((k_linear128_multi<KQ, true>), dim3(blocks), dim3(512), lds, st, T);
+    return launch_status("grouped projection GEMM");
+}
+
 template <int CTW, int NH>
 int launch_wgrad(const float* dY, const float* X, int K, int64_t M, int rpb, int grid, float* part, float* dW, float* db,
                  hipStream_t st) {
@@ -2386,7 +2439,7 @@ struct EncLayout {
     LayerActs L[FN_MAX_LAYERS];
     float* in_atoms0;        // dropout(x_atoms) when training with p > 0, else null (use x_atoms)
     // forward scratch
-    float *atoms_new, *frags_new, *s_sorted, *s_dst, *s_src, *s_dst_fb, *s_src_fb, *bt;
+    float *atoms_new, *frags_new, *s_sorted, *s_dst, *s_src, *s_dst_a, *s_src_a, *s_dst_fb, *s_src_fb, *bt;
     int64_t total;
 };
 
@@ -2415,6 +2468,8 @@ EncLayout enc_layout(const fn_encoder* e, float* ws) {
     const int64_t nmax = max4(e->E, e->N, e->EF, e->F);
     o.s_dst = b.take(nmax * H);
     o.s_src = b.take(nmax * H);
+    o.s_dst_a = b.take(e->N * H);
+    o.s_src_a = b.take(e->N * H);
     o.s_dst_fb = b.take(e->EF * H);
     o.s_src_fb = b.take(e->EF * H);
     o.bt = b.take((int64_t)3 * e->n_layers * 192 * FN_D);
@@ -2649,7 +2704,21 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
             FN_TRY(fn_linear128_f32(x, k, bt, bias, hout, rows, nullptr, sq));
             return fn_node_scalars_f32(hout, att, att_w, 0, src_off, sdst, ssrc, rows, H, sq);
         };
-        FN_TRY(project(in_bond, kb, bt_b, w.proj_b_b, a.h_b, e->E, w.a_b, 3 * d, 2 * d, lay.s_dst, lay.s_src, st));
+        // layers >= 1: the three projections (K = 128) depend only on the previous layer -> one grouped launch
+        const bool grouped = l > 0 && fuse_ns && !multi;
+        if (grouped) {
+            LinTasks T{};
+            T.n = 3;
+            T.t[0] = LinTask{in_bond, bt_b, w.proj_b_b, a.h_b, e->E, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
+                             NodeScalarEpi{w.a_b, lay.s_dst, lay.s_src, 3 * d, 0, 2 * d, H}, 0, 0};
+            T.t[1] = LinTask{in_atoms, bt_a, w.proj_a_b, a.h_a, e->N, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
+                             NodeScalarEpi{w.a, lay.s_dst_a, lay.s_src_a, wide, 0, d + FN_D, H}, 0, 0};
+            T.t[2] = LinTask{in_fbond, bt_fb, w.proj_fb_b, a.h_fb, e->EF, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
+                             NodeScalarEpi{w.f_a_b, lay.s_dst_fb, lay.s_src_fb, 3 * d, 0, 2 * d, H}, 0, 0};
+            FN_TRY(launch_linear128_group(T, S(st)));
+        } else {
+            FN_TRY(project(in_bond, kb, bt_b, w.proj_b_b, a.h_b, e->E, w.a_b, 3 * d, 2 * d, lay.s_dst, lay.s_src, st));
+        }
         fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
         float* y_atoms = last ? out_atoms : a.y_atoms;
         float* y_frags = last ? out_frags : a.y_frags;
@@ -2661,16 +2730,16 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         FN_TRY(fn_gat_fwd_f32(a.h_b, lay.s_dst, lay.s_src, w.a_b, 3 * d, &et_b, &e->bond, 0.2f, a.new_bond, a.p_bond, nullptr, &ep_bond, H, st));
 
         // L2 atom graph (+ self loops), edge term = <new_bond, a[:, d:d+128]>
-        FN_TRY(project(in_atoms, ka, bt_a, w.proj_a_b, a.h_a, e->N, w.a, wide, d + FN_D, lay.s_dst, lay.s_src, st));
+        if (!grouped) FN_TRY(project(in_atoms, ka, bt_a, w.proj_a_b, a.h_a, e->N, w.a, wide, d + FN_D, lay.s_dst_a, lay.s_src_a, st));
         FN_TRY(fn_row_dots_sorted_f32(a.new_bond, w.a, wide, d, H, &e->atom, lay.s_sorted, st));
         fn_edge_term et_a{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
-        FN_TRY(fn_gat_fwd_f32(a.h_a, lay.s_dst, lay.s_src, w.a, wide, &et_a, &e->atom, 0.2f, lay.atoms_new, a.p_atom, nullptr, &ep_atoms, H, st));
+        FN_TRY(fn_gat_fwd_f32(a.h_a, lay.s_dst_a, lay.s_src_a, w.a, wide, &et_a, &e->atom, 0.2f, lay.atoms_new, a.p_atom, nullptr, &ep_atoms, H, st));
 
         // L3 atom -> fragment sum
         FN_TRY(fn_segment_sum_f32(lay.atoms_new, FN_D, e->a2f.rowptr, e->a2f.perm, e->a2f.pos_base, a.frags, e->F, FN_D, e->N, st));
 
         // L4a fragment-bond graph (own stream: its inputs are the previous layer's fragment-bond outputs only)
-        FN_TRY(project(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, w.f_a_b, 3 * d, 2 * d, lay.s_dst_fb, lay.s_src_fb, st_fb));
+        if (!grouped) FN_TRY(project(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, w.f_a_b, 3 * d, 2 * d, lay.s_dst_fb, lay.s_src_fb, st_fb));
         fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
         FN_TRY(fn_gat_fwd_f32(a.h_fb, lay.s_dst_fb, lay.s_src_fb, w.f_a_b, 3 * d, &et_fb, &e->fbond, 0.2f, a.new_fbond, a.p_fbond, nullptr, &ep_fbond, H, st_fb));
 
@@ -2736,6 +2805,13 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         const int ka = l ? FN_D : e->k_atom0, kb = l ? FN_D : e->k_bond0, kfb = l ? FN_D : e->k_fbond0;
         const LevelScratch &sb = bw.bond[l], &sa = bw.atom[l], &sfb = bw.fbond[l], &sf = bw.frag;
         int n_a = 0, n_e = 0;
+        // the three input-gradient products of a layer feed layer l-1 only: one grouped launch at the end of the layer
+        LinTasks dxT{};
+        auto input_grad = [&](const float* gh, const float* W, float* gy, int64_t rows, const fn_act_epilogue& mk, fn_stream_t sq) -> int {
+            if (multi) return fn_linear128_f32(gh, FN_D, W, nullptr, gy, rows, &mk, sq);
+            dxT.t[dxT.n++] = LinTask{gh, W, nullptr, gy, rows, mk, NodeScalarEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0}, 0, 0};
+            return 0;
+        };
 
         // ---- through act(dropout(.)): gradients of the pre-activation tensors.  For the last layer they come from
         // the caller's output gradients; for inner layers the input-gradient GEMMs of layer l+1 already wrote them
@@ -2776,7 +2852,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_fbond, a.h_fb, sfb.pz, sfb.g_s_dst, w.f_a_b, 3 * d, 0, 2 * d, &e->fbond, sfb.g_h, sfb.part_a, &n_a, H, st_fb));
             if (l) {     // dL/d(pre-activation fbond output of layer l-1), gated by that layer's dropout mask and ReLU
                 const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_fbond), p, 1, e->seed, rng.y[l - 1][3], e->offset_dev};
-                FN_TRY(fn_linear128_f32(sfb.g_h, FN_D, w.proj_fb_w, nullptr, bw.g_pre_fbond, e->EF, &mk, st_fb));
+                FN_TRY(input_grad(sfb.g_h, w.proj_fb_w, bw.g_pre_fbond, e->EF, mk, st_fb));
                 nxt_fbond = true;
             }
             FN_TRY(rq.finalize(sfb.part_a, n_a, sfb.part_e, n_e, et_fb, w.f_a_b, 3 * d, 0, 2 * d, g.f_a_b, g.emb_fb_w, g.emb_fb_b, H));
@@ -2810,7 +2886,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             FN_TRY(rq.wgrad(sa.g_h, in_atoms, ka, e->N, sa.wg_ws, g.proj_a_w, g.proj_a_b, S(st_leaf)));
             if (l) {
                 const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_atoms), p, 1, e->seed, rng.y[l - 1][0], e->offset_dev};
-                FN_TRY(fn_linear128_f32(sa.g_h, FN_D, w.proj_a_w, nullptr, bw.g_pre_atoms, e->N, &mk, st));
+                FN_TRY(input_grad(sa.g_h, w.proj_a_w, bw.g_pre_atoms, e->N, mk, st));
                 nxt_atoms = true;
             }
         }
@@ -2825,10 +2901,11 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             FN_TRY(rq.wgrad(sb.g_h, in_bond, kb, e->E, sb.wg_ws, g.proj_b_w, g.proj_b_b, S(st_leaf)));
             if (l) {
                 const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_bond), p, 1, e->seed, rng.y[l - 1][2], e->offset_dev};
-                FN_TRY(fn_linear128_f32(sb.g_h, FN_D, w.proj_b_w, nullptr, bw.g_pre_bond, e->E, &mk, st));
+                FN_TRY(input_grad(sb.g_h, w.proj_b_w, bw.g_pre_bond, e->E, mk, st));
                 nxt_bond = true;
             }
         }
+        if (dxT.n) FN_TRY(launch_linear128_group(dxT, hs));
         pre_atoms = nxt_atoms;  pre_bond = nxt_bond;  pre_fbond = nxt_fbond;
         gy_atoms = gy_bond = gy_fbond = nullptr;
         gy_frags = nullptr;        // a layer's x_frags input is dead in the reference (overwritten at gat2.py:234)
