@@ -1607,18 +1607,16 @@ __global__ void k_transpose_many(TransposeMany tm, float* __restrict__ bt_base) 
 // put two waves on every SIMD.  part [grid][128*K + 128]: dW partial followed by the db partial.
 constexpr int kWgChunk = 32;
 template <int CTW, int NH>
-__global__ __launch_bounds__(256 * NH) void k_linear128_wgrad(const float* __restrict__ dY, const float* __restrict__ X,
-                                                              int K, int64_t M, int rows_per_block,
-                                                              float* __restrict__ part) {
+__device__ __forceinline__ void wgrad_body(float* smem, const float* __restrict__ dY, const float* __restrict__ X, int K,
+                                           int64_t M, int rows_per_block, float* __restrict__ part, int bid) {
     constexpr int NT = 256 * NH;
     constexpr int XW = 16 * CTW * NH;            // padded X width held in LDS
     constexpr int XLD = XW + 16;                 // XW is a multiple of 32 for every instantiation but <1,1>
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sY = smem;                                   // [2][32][144]
     float* sX = smem + 2 * kWgChunk * kBtLd;            // [2][32][XLD]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
     const int wo = w & 3, wc = w >> 2;
-    const int64_t m_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t m_begin = (int64_t)bid * rows_per_block;
     const int64_t m_end = m_begin + rows_per_block < M ? m_begin + rows_per_block : M;
     const int n_chunks = (int)((m_end - m_begin + kWgChunk - 1) / kWgChunk);
 
@@ -1686,7 +1684,7 @@ __global__ __launch_bounds__(256 * NH) void k_linear128_wgrad(const float* __res
     // partials are written in the accumulators' native layout: one coalesced 16-byte store per lane and tile;
     // k_wgrad_reduce maps them back to dW[o][col] while summing over blocks
     constexpr int PW = 128 * XW + 128;
-    float* pw = part + (size_t)blockIdx.x * PW;
+    float* pw = part + (size_t)bid * PW;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -1702,6 +1700,35 @@ __global__ __launch_bounds__(256 * NH) void k_linear128_wgrad(const float* __res
             if (kq == 0) pw[(size_t)128 * XW + 32 * wo + 16 * u + i] = v;
         }
     }
+}
+
+template <int CTW, int NH>
+__global__ __launch_bounds__(256 * NH) void k_linear128_wgrad(const float* __restrict__ dY, const float* __restrict__ X,
+                                                              int K, int64_t M, int rows_per_block,
+                                                              float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    wgrad_body<CTW, NH>(smem, dY, X, K, M, rows_per_block, part, (int)blockIdx.x);
+}
+
+// all weight-gradient partial products of a backward pass that share K (every projection beyond layer 0): one launch
+struct WgradTask {
+    const float *dY, *X;
+    float* part;
+    int64_t M;
+    int rpb, first;
+};
+constexpr int kMaxWgradTasks = 3 * FN_MAX_LAYERS;
+struct WgradTasks {
+    WgradTask t[kMaxWgradTasks];
+    int n, K;
+};
+template <int CTW, int NH>
+__global__ __launch_bounds__(256 * NH) void k_linear128_wgrad_multi(WgradTasks T) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int ti = 0;
+    while (ti + 1 < T.n && (int)blockIdx.x >= T.t[ti + 1].first) ++ti;
+    const WgradTask& t = T.t[ti];
+    wgrad_body<CTW, NH>(smem, t.dY, t.X, T.K, t.M, t.rpb, t.part, (int)blockIdx.x - t.first);
 }
 
 // sums the native-layout partials over blocks and scatters them to dW [128][K] / db [128]
@@ -2586,9 +2613,12 @@ int wgrad_partials(const float* dY, const float* X, int K, int64_t M, float* ws,
 
 struct ReduceQueue {
     ReduceTasks T{};
-    int blocks = 0;
+    WgradTasks W{};
+    int blocks = 0, wblocks = 0;
+    bool defer_wgrad = false;
     hipStream_t st = nullptr;
     int flush() {
+        if (int rc = flush_wgrad()) return rc;
         if (T.n == 0) return 0;
         hipLaunchKernelGGL(k_reduce_tasks, dim3(blocks), dim3(1024), 0, st, T);
         T.n = 0;  blocks = 0;
@@ -2623,9 +2653,25 @@ struct ReduceQueue {
         }
         ReduceTask t{};
         int grid = 0;
-        if (int rc = wgrad_partials(dY, X, K, M, ws, launch_on, &grid, &t.cls)) return rc;
+        if (K == FN_D && defer_wgrad && W.n < kMaxWgradTasks) {   // partial product joins the grouped launch in flush()
+            const int rpb = wgrad_rows_per_block(M);
+            grid = (int)((M + rpb - 1) / rpb);
+            W.t[W.n++] = WgradTask{dY, X, ws, M, rpb, wblocks};
+            wblocks += grid;
+            t.cls = 2;
+        } else if (int rc = wgrad_partials(dY, X, K, M, ws, launch_on, &grid, &t.cls)) return rc;
         t.kind = RT_WGRAD;  t.p0 = ws;  t.n0 = grid;  t.K = K;  t.o0 = dW;  t.o1 = db;
         return push(t, (int)((wgrad_part_width(K) + 255) / 256));
+    }
+    int flush_wgrad() {
+        if (W.n == 0) return 0;
+        constexpr int XW = 16 * 4 * 2, XLD = XW + 16;
+        const size_t lds = (size_t)2 * kWgChunk * (kBtLd + XLD) * sizeof(float);
+        if (int rc = allow_lds(k_linear128_wgrad_multi<4, 2>, lds)) return rc;
+        W.K = FN_D;
+        hipLaunchKernelGGL((k_linear128_wgrad_multi<4, 2>), dim3(wblocks), dim3(512), lds, st, W);
+        W.n = 0;  wblocks = 0;
+        return launch_status("grouped weight-gradient partials");
     }
 };
 
@@ -2782,6 +2828,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
     bool fb_forked = false, leaf_forked = false;
     ReduceQueue rq;
     rq.st = hs;                      // all parameter-gradient reductions run as one launch at the very end
+    rq.defer_wgrad = !multi;         // ... and so do the K = 128 weight-gradient partial products
 
     // gradients w.r.t. the current layer's post-activation outputs (null = zero)
     bool pre_atoms = false, pre_bond = false, pre_fbond = false;   // g_pre_* already hold layer l's pre-activation grads
