@@ -413,15 +413,32 @@ __device__ __forceinline__ float ld1_off(const float* base, uint32_t byte_off) {
 // KL: 0 = the edge term is a stored per-edge scalar (mode 0); 1 / FN_MAX_EDGE_K = folded Linear(K -> d) of a raw
 // attribute with K == 1 / K <= FN_MAX_EDGE_K (attribute columns beyond K are re-loads of column K-1 with weight 0,
 // so that the number of loads is a compile-time constant and none of them sits in a branch).
+struct GatFwdArgs {
+    const float *h, *s_dst, *s_src, *att;
+    int att_w;
+    fn_edge_term et;
+    fn_gat_plan pl;
+    float slope;
+    float *out, *p_sorted, *probs_orig;
+    fn_act_epilogue ep;
+    int rows_per_hw, nblk;
+};
 template <int H, int KL>
-__global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h, const float* __restrict__ s_dst,
-                                                    const float* __restrict__ s_src, const float* __restrict__ att,
-                                                    int att_w, fn_edge_term et, fn_gat_plan pl, float slope,
-                                                    float* __restrict__ out, float* __restrict__ p_sorted,
-                                                    float* __restrict__ probs_orig, fn_act_epilogue ep, int rows_per_hw) {
+__device__ __forceinline__ void gat_fwd_body(const GatFwdArgs& A, float (*sWf)[kWfLd], int bid, int nblk) {
+    const float* __restrict__ h = A.h;
+    const float* __restrict__ s_dst = A.s_dst;
+    const float* __restrict__ s_src = A.s_src;
+    const float* __restrict__ att = A.att;
+    const int att_w = A.att_w, rows_per_hw = A.rows_per_hw;
+    const fn_edge_term& et = A.et;
+    const fn_gat_plan& pl = A.pl;
+    const float slope = A.slope;
+    float* __restrict__ out = A.out;
+    float* __restrict__ p_sorted = A.p_sorted;
+    float* __restrict__ probs_orig = A.probs_orig;
+    const fn_act_epilogue& ep = A.ep;
     constexpr int LPH = 32 / H;
     constexpr int NE = KL ? KL : 1;                       // 8-byte edge loads per lane and row
-    __shared__ float sWf[8][kWfLd];
     fold_edge_embed(et, att, att_w, H, sWf);
     const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH;
     const int m = (int)pl.m, n = (int)pl.n;
@@ -432,7 +449,7 @@ __global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h,
     const float wbias = KL ? sWf[head][K] : 0.f;
     // a block owns kRows * R consecutive rows; its half-waves take them INTERLEAVED (row = base + i * kRows + hw), so
     // that at any moment the block works on kRows neighbouring rows whose source rows overlap (L1 reuse across waves)
-    const int blk0 = xcd_block(blockIdx.x, gridDim.x) * kRows * rows_per_hw;
+    const int blk0 = xcd_block(bid, nblk) * kRows * rows_per_hw;
     const int tb = blk0 + (int)(threadIdx.x >> 5);
     const int te = blk0 + kRows * rows_per_hw < n ? blk0 + kRows * rows_per_hw : n;
     const bool pairs = m >= 2;                            // paired edge loads need two edges in the level
@@ -588,6 +605,19 @@ __global__ __launch_bounds__(kBlock) void k_gat_fwd(const float* __restrict__ h,
     }
 }
 
+template <int H, int KL>
+__global__ __launch_bounds__(kBlock) void k_gat_fwd(GatFwdArgs A) {
+    __shared__ float sWf[8][kWfLd];
+    gat_fwd_body<H, KL>(A, sWf, (int)blockIdx.x, (int)gridDim.x);
+}
+// two independent levels in one launch (bond graph + fragment-bond graph: neither reads the other's output)
+template <int H, int KLA, int KLB>
+__global__ __launch_bounds__(kBlock) void k_gat_fwd_pair(GatFwdArgs A, GatFwdArgs B) {
+    __shared__ float sWf[8][kWfLd];
+    if ((int)blockIdx.x < A.nblk) gat_fwd_body<H, KLA>(A, sWf, (int)blockIdx.x, A.nblk);
+    else gat_fwd_body<H, KLB>(B, sWf, (int)blockIdx.x - A.nblk, B.nblk);
+}
+
 // Backward kernels use RB rows (half-waves) per block.
 // Destination pass: dz[e] = p[e] * (<g_out[dst], h[src]> - sum_e' p[e'] <g_out[dst], h[src']>) * LeakyReLU', per head.
 // Same shape as the forward kernel: persistent half-waves over R consecutive rows, straight-line body with clamped
@@ -599,16 +629,30 @@ template <int NE> struct BwdRaw {
     f32x2u x[NE];             // raw edge attributes (mode 2)
 };
 
+struct GatBwdDstArgs {
+    const float *g_out, *h, *p_sorted;
+    fn_edge_term et;
+    fn_gat_plan pl;
+    float slope;
+    float *dz_sorted, *g_s_orig, *pz_src, *g_s_dst, *part_e;
+    int rows_per_hw, nblk;
+};
 template <int H, int KL, int RB>
-__global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(const float* __restrict__ g_out, const float* __restrict__ h,
-                                                         const float* __restrict__ p_sorted, fn_edge_term et,
-                                                         fn_gat_plan pl, float slope, float* __restrict__ dz_sorted,
-                                                         float* __restrict__ g_s_orig, float* __restrict__ pz_src,
-                                                         float* __restrict__ g_s_dst, float* __restrict__ part_e,
-                                                         int rows_per_hw) {
+__device__ __forceinline__ void gat_bwd_dst_body(const GatBwdDstArgs& A, float (*sP)[8][kWfLd], int bid, int nblk) {
+    const float* __restrict__ g_out = A.g_out;
+    const float* __restrict__ h = A.h;
+    const float* __restrict__ p_sorted = A.p_sorted;
+    const fn_edge_term& et = A.et;
+    const fn_gat_plan& pl = A.pl;
+    const float slope = A.slope;
+    float* __restrict__ dz_sorted = A.dz_sorted;
+    float* __restrict__ g_s_orig = A.g_s_orig;
+    float* __restrict__ pz_src = A.pz_src;
+    float* __restrict__ g_s_dst = A.g_s_dst;
+    float* __restrict__ part_e = A.part_e;
+    const int rows_per_hw = A.rows_per_hw;
     constexpr int LPH = 32 / H;
     constexpr int NE = KL ? KL : 1;
-    __shared__ float sP[RB][8][kWfLd];
     const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH, hw = threadIdx.x >> 5;
     const int m = (int)pl.m, n = (int)pl.n;
     const int K = KL ? et.K : 0;
@@ -619,7 +663,7 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(const float* __restrict
     for (int k = 0; k <= NE; ++k) pw[k] = 0.f;
     const float* p_head = p_sorted + (size_t)head * m;
     float* pz_head = pz_src + (size_t)head * m * 2;
-    const int blk0 = xcd_block(blockIdx.x, gridDim.x) * RB * rows_per_hw;      // rows interleaved over the half-waves
+    const int blk0 = xcd_block(bid, nblk) * RB * rows_per_hw;      // rows interleaved over the half-waves
     const int tb = blk0 + hw;
     const int te = blk0 + RB * rows_per_hw < n ? blk0 + RB * rows_per_hw : n;
 
@@ -782,7 +826,7 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(const float* __restrict
             float a = 0.f;
 #pragma unroll
             for (int w = 0; w < RB; ++w) a += sP[w][hh][kk];
-            part_e[(size_t)blockIdx.x * ne + i] = a;
+            part_e[(size_t)bid * ne + i] = a;
         }
     }
 }
@@ -797,15 +841,37 @@ struct SrcRaw {
     f32x4u v;               // p0, dz0, p1, dz1
 };
 
+template <int H, int KL, int RB>
+__global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(GatBwdDstArgs A) {
+    __shared__ float sP[RB][8][kWfLd];
+    gat_bwd_dst_body<H, KL, RB>(A, sP, (int)blockIdx.x, (int)gridDim.x);
+}
+template <int H, int KLA, int KLB, int RB>
+__global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst_pair(GatBwdDstArgs A, GatBwdDstArgs B) {
+    __shared__ float sP[RB][8][kWfLd];
+    if ((int)blockIdx.x < A.nblk) gat_bwd_dst_body<H, KLA, RB>(A, sP, (int)blockIdx.x, A.nblk);
+    else gat_bwd_dst_body<H, KLB, RB>(B, sP, (int)blockIdx.x - A.nblk, B.nblk);
+}
+
+struct GatBwdSrcArgs {
+    const float *g_out, *h, *pz_src, *g_s_dst, *att;
+    int att_w, dst_off, src_off;
+    fn_gat_plan pl;
+    float *g_h, *part_a;
+    int rows_per_hw, nblk;
+};
 template <int H, int RB>
-__global__ __launch_bounds__(RB * 32) void k_gat_bwd_src(const float* __restrict__ g_out, const float* __restrict__ h,
-                                                         const float* __restrict__ pz_src,
-                                                         const float* __restrict__ g_s_dst, const float* __restrict__ att,
-                                                         int att_w, int dst_off, int src_off, fn_gat_plan pl,
-                                                         float* __restrict__ g_h, float* __restrict__ part_a,
-                                                         int rows_per_hw) {
+__device__ __forceinline__ void gat_bwd_src_body(const GatBwdSrcArgs& A, float (*sA)[2 * FN_D], int bid, int nblk) {
+    const float* __restrict__ g_out = A.g_out;
+    const float* __restrict__ h = A.h;
+    const float* __restrict__ pz_src = A.pz_src;
+    const float* __restrict__ g_s_dst = A.g_s_dst;
+    const float* __restrict__ att = A.att;
+    const int att_w = A.att_w, dst_off = A.dst_off, src_off = A.src_off, rows_per_hw = A.rows_per_hw;
+    const fn_gat_plan& pl = A.pl;
+    float* __restrict__ g_h = A.g_h;
+    float* __restrict__ part_a = A.part_a;
     constexpr int LPH = 32 / H;
-    __shared__ float sA[RB][2 * FN_D];
     const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH, hw = threadIdx.x >> 5;
     const int m = (int)pl.m, n = (int)pl.n;
     const bool pairs = m >= 2;
@@ -813,7 +879,7 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_src(const float* __restrict
     const float4 as = ld4(att + head * att_w + src_off + j * 4);
     const float* pz_head = pz_src + (size_t)head * m * 2;
     float4 qd = make_float4(0.f, 0.f, 0.f, 0.f), qs = qd;
-    const int blk0 = xcd_block(blockIdx.x, gridDim.x) * RB * rows_per_hw;      // rows interleaved over the half-waves
+    const int blk0 = xcd_block(bid, nblk) * RB * rows_per_hw;      // rows interleaved over the half-waves
     const int sb = blk0 + hw;
     const int se = blk0 + RB * rows_per_hw < n ? blk0 + RB * rows_per_hw : n;
 
@@ -916,8 +982,20 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_src(const float* __restrict
         float a = 0.f;
 #pragma unroll
         for (int w = 0; w < RB; ++w) a += sA[w][c];
-        part_a[(size_t)c * FN_MAX_PART + blockIdx.x] = a;          // column-major: finalize reads a column contiguously
+        part_a[(size_t)c * FN_MAX_PART + bid] = a;          // column-major: finalize reads a column contiguously
     }
+}
+
+template <int H, int RB>
+__global__ __launch_bounds__(RB * 32) void k_gat_bwd_src(GatBwdSrcArgs A) {
+    __shared__ float sA[RB][2 * FN_D];
+    gat_bwd_src_body<H, RB>(A, sA, (int)blockIdx.x, (int)gridDim.x);
+}
+template <int H, int RB>
+__global__ __launch_bounds__(RB * 32) void k_gat_bwd_src_pair(GatBwdSrcArgs A, GatBwdSrcArgs B) {
+    __shared__ float sA[RB][2 * FN_D];
+    if ((int)blockIdx.x < A.nblk) gat_bwd_src_body<H, RB>(A, sA, (int)blockIdx.x, A.nblk);
+    else gat_bwd_src_body<H, RB>(B, sA, (int)blockIdx.x - A.nblk, B.nblk);
 }
 
 // sum of up to 1024 values, one per thread (deterministic: wave butterflies, then 16 wave sums in order)
@@ -2102,88 +2180,164 @@ int fn_node_scalars_f32(const float* h, const float* att, int att_w, int dst_off
     return launch_status("fn_node_scalars_f32");
 }
 
-int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const float* att, int att_w,
-                   const fn_edge_term* et, const fn_gat_plan* plan, float neg_slope, float* out, float* p_sorted,
-                   float* probs_orig, const fn_act_epilogue* act, int heads, fn_stream_t stream) {
+// ---- argument validation + launch geometry of the three attention kernels (shared by the single-level C-ABI
+// entry points and the engine's two-level launches); nblk == 0 means "nothing to do"
+static int edge_class(const fn_edge_term* et) { return et->mode == 0 ? 0 : (et->K == 1 ? 1 : FN_MAX_EDGE_K); }
+
+static int prep_gat_fwd(const float* h, const float* s_dst, const float* s_src, const float* att, int att_w,
+                        const fn_edge_term* et, const fn_gat_plan* plan, float neg_slope, float* out, float* p_sorted,
+                        float* probs_orig, const fn_act_epilogue* act, int heads, GatFwdArgs* A) {
     if (!h || !s_dst || !s_src || !att || !plan || bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_fwd_f32: bad argument");
     if (!out && !(act && act->y)) return fail(FN_EINVAL, "fn_gat_fwd_f32: no output buffer");
     if (act && (act->p < 0.f || act->p > 1.f)) return fail(FN_EINVAL, "fn_gat_fwd_f32: dropout probability");
-    const fn_act_epilogue ep = act ? *act : fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr};
     if (plan->m > 0 && !p_sorted) return fail(FN_EINVAL, "fn_gat_fwd_f32: null p_sorted");
     if (et->mode == 0 && plan->m > 0 && !et->s_sorted) return fail(FN_EINVAL, "fn_gat_fwd_f32: null s_sorted");
+    if (heads != 1 && heads != 2 && heads != 4 && heads != 8) return fail(FN_EUNSUPPORTED, "heads must be 1, 2, 4 or 8 (128 = heads * head_dim)");
+    *A = GatFwdArgs{h, s_dst, s_src, att, att_w, *et, *plan, neg_slope, out, p_sorted, probs_orig,
+                    act ? *act : fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr}, 1, 0};
     if (plan->n == 0) return 0;
     if (!(neg_slope >= 0.f && neg_slope <= 1.f)) return fail(FN_EUNSUPPORTED, "fn_gat_fwd_f32: LeakyReLU slope must be in [0, 1]");
     if (plan->n > (1 << 23) || plan->m * heads > (1 << 29))
         return fail(FN_EUNSUPPORTED, "fn_gat_fwd_f32: level too large for 32-bit byte offsets (n <= 2^23 rows, m*heads <= 2^29)");
-    // persistent half-waves: as many as fit on the chip at once, each pipelining R consecutive rows
+    // persistent half-waves: as many as fit on the chip at once, each pipelining R rows
     const int64_t groups = (plan->n + kRows - 1) / kRows;
     const int64_t resident = (int64_t)g_tune[FN_TUNE_FWD_BLOCKS];
-    const int R = (int)((groups + resident - 1) / resident);
-    const int64_t grid = (plan->n + (int64_t)kRows * R - 1) / ((int64_t)kRows * R);
-#define FN_FWD_LAUNCH(KL) hipLaunchKernelGGL((k_gat_fwd<HH, KL>), dim3((unsigned)grid), dim3(kBlock), 0, S(stream), h, s_dst, \
-                                             s_src, att, att_w, *et, *plan, neg_slope, out, p_sorted, probs_orig, ep, R)
-    FN_DISPATCH_H(heads, {
-        if (et->mode == 0) FN_FWD_LAUNCH(0);
-        else if (et->K == 1) FN_FWD_LAUNCH(1);
-        else FN_FWD_LAUNCH(FN_MAX_EDGE_K);
-    });
-#undef FN_FWD_LAUNCH
-    return launch_status("fn_gat_fwd_f32");
+    A->rows_per_hw = (int)((groups + resident - 1) / resident);
+    A->nblk = (int)((plan->n + (int64_t)kRows * A->rows_per_hw - 1) / ((int64_t)kRows * A->rows_per_hw));
+    return 0;
 }
 
-int fn_gat_bwd_dst_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et,
-                       const fn_gat_plan* plan, float neg_slope, float* dz_sorted, float* g_s_orig, float* pz_src,
-                       float* g_s_dst, float* part_e, int* n_part_e, int heads, fn_stream_t stream) {
+static int launch_gat_fwd(const GatFwdArgs& A, int heads, hipStream_t st) {
+    if (A.nblk == 0) return 0;
+    const int kl = edge_class(&A.et);
+    FN_DISPATCH_H(heads, {
+        if (kl == 0) hipLaunchKernelGGL((k_gat_fwd<HH, 0>), dim3(A.nblk), dim3(kBlock), 0, st, A);
+        else if (kl == 1) hipLaunchKernelGGL((k_gat_fwd<HH, 1>), dim3(A.nblk), dim3(kBlock), 0, st, A);
+        else hipLaunchKernelGGL((k_gat_fwd<HH, FN_MAX_EDGE_K>), dim3(A.nblk), dim3(kBlock), 0, st, A);
+    });
+    return launch_status("fn_gat_fwd_f32");
+}
+// two levels, one launch, when their edge classes are (1, FN_MAX_EDGE_K) or (1, 1); two launches otherwise
+static int launch_gat_fwd_pair(const GatFwdArgs& A, const GatFwdArgs& B, int heads, hipStream_t st) {
+    const int ka = edge_class(&A.et), kb = edge_class(&B.et);
+    if (A.nblk == 0 || B.nblk == 0 || ka != 1 || (kb != 1 && kb != FN_MAX_EDGE_K)) {
+        if (int rc = launch_gat_fwd(A, heads, st)) return rc;
+        return launch_gat_fwd(B, heads, st);
+    }
+    FN_DISPATCH_H(heads, {
+        if (kb == 1) hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, 1>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);
+        else hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, FN_MAX_EDGE_K>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);
+    });
+    return launch_status("attention forward (two levels)");
+}
+
+int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const float* att, int att_w,
+                   const fn_edge_term* et, const fn_gat_plan* plan, float neg_slope, float* out, float* p_sorted,
+                   float* probs_orig, const fn_act_epilogue* act, int heads, fn_stream_t stream) {
+    GatFwdArgs A;
+    if (int rc = prep_gat_fwd(h, s_dst, s_src, att, att_w, et, plan, neg_slope, out, p_sorted, probs_orig, act, heads, &A)) return rc;
+    return launch_gat_fwd(A, heads, S(stream));
+}
+
+static int prep_gat_bwd_dst(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et,
+                            const fn_gat_plan* plan, float neg_slope, float* dz_sorted, float* g_s_orig, float* pz_src,
+                            float* g_s_dst, float* part_e, int* n_part_e, int heads, GatBwdDstArgs* A) {
     if (!g_out || !h || !plan || !g_s_dst || !n_part_e || !et) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: bad argument");
     if (et->mode != 0 && bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: bad edge term");
     if (plan->m > 0 && (!p_sorted || !pz_src || !plan->spos_d || (et->mode == 0 && !dz_sorted && !g_s_orig)))
         return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: null edge buffer");
     if (et->mode == 2 && !part_e) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: null part_e");
+    if (heads != 1 && heads != 2 && heads != 4 && heads != 8) return fail(FN_EUNSUPPORTED, "heads must be 1, 2, 4 or 8 (128 = heads * head_dim)");
     *n_part_e = 0;
+    *A = GatBwdDstArgs{g_out, h, p_sorted, *et, *plan, neg_slope, dz_sorted, g_s_orig, pz_src, g_s_dst, part_e, 1, 0};
     if (plan->n == 0) return 0;
     if (plan->n > (1 << 23) || plan->m * heads > (1 << 29))
         return fail(FN_EUNSUPPORTED, "fn_gat_bwd_dst_f32: level too large for 32-bit byte offsets (n <= 2^23 rows, m*heads <= 2^29)");
-    // R consecutive rows per half-wave; one edge-parameter partial row per block, hence at most FN_MAX_PART blocks.
+    // R rows per half-wave; one edge-parameter partial row per block, hence at most FN_MAX_PART blocks.
     // Unlike the forward kernel this one wants R SMALL: its (p, dz) stores are scattered 8-byte writes into source
     // order, vmcnt counts loads and stores in one in-order queue, so every extra row per wave waits behind the
     // previous row's slow stores (B=2048: R=4 56 us, R=8 84 us; B=512: 16 us at any R)
     const int64_t groups = (plan->n + kBwdRows - 1) / kBwdRows;
     const int64_t resident = FN_MAX_PART;
-    const int R = (int)((groups + resident - 1) / resident);
-    const int g = (int)((plan->n + (int64_t)kBwdRows * R - 1) / ((int64_t)kBwdRows * R));
-    *n_part_e = (et->mode == 2) ? g : 0;
-#define FN_BWD_LAUNCH(KL) hipLaunchKernelGGL((k_gat_bwd_dst<HH, KL, kBwdRows>), dim3(g), dim3(kBwdRows * 32), 0, S(stream), g_out, \
-                                             h, p_sorted, *et, *plan, neg_slope, dz_sorted, g_s_orig, pz_src, g_s_dst, part_e, R)
+    A->rows_per_hw = (int)((groups + resident - 1) / resident);
+    A->nblk = (int)((plan->n + (int64_t)kBwdRows * A->rows_per_hw - 1) / ((int64_t)kBwdRows * A->rows_per_hw));
+    *n_part_e = (et->mode == 2) ? A->nblk : 0;
+    return 0;
+}
+
+static int launch_gat_bwd_dst(const GatBwdDstArgs& A, int heads, hipStream_t st) {
+    if (A.nblk == 0) return 0;
+    const int kl = edge_class(&A.et);
     FN_DISPATCH_H(heads, {
-        if (et->mode == 0) FN_BWD_LAUNCH(0);
-        else if (et->K == 1) FN_BWD_LAUNCH(1);
-        else FN_BWD_LAUNCH(FN_MAX_EDGE_K);
+        if (kl == 0) hipLaunchKernelGGL((k_gat_bwd_dst<HH, 0, kBwdRows>), dim3(A.nblk), dim3(kBwdRows * 32), 0, st, A);
+        else if (kl == 1) hipLaunchKernelGGL((k_gat_bwd_dst<HH, 1, kBwdRows>), dim3(A.nblk), dim3(kBwdRows * 32), 0, st, A);
+        else hipLaunchKernelGGL((k_gat_bwd_dst<HH, FN_MAX_EDGE_K, kBwdRows>), dim3(A.nblk), dim3(kBwdRows * 32), 0, st, A);
     });
-#undef FN_BWD_LAUNCH
     return launch_status("fn_gat_bwd_dst_f32");
+}
+static int launch_gat_bwd_dst_pair(const GatBwdDstArgs& A, const GatBwdDstArgs& B, int heads, hipStream_t st) {
+    const int ka = edge_class(&A.et), kb = edge_class(&B.et);
+    if (A.nblk == 0 || B.nblk == 0 || ka != 1 || (kb != 1 && kb != FN_MAX_EDGE_K)) {
+        if (int rc = launch_gat_bwd_dst(A, heads, st)) return rc;
+        return launch_gat_bwd_dst(B, heads, st);
+    }
+    FN_DISPATCH_H(heads, {
+        if (kb == 1) hipLaunchKernelGGL((k_gat_bwd_dst_pair<HH, 1, 1, kBwdRows>), dim3(A.nblk + B.nblk), dim3(kBwdRows * 32), 0, st, A, B);
+        else hipLaunchKernelGGL((k_gat_bwd_dst_pair<HH, 1, FN_MAX_EDGE_K, kBwdRows>), dim3(A.nblk + B.nblk), dim3(kBwdRows * 32), 0, st, A, B);
+    });
+    return launch_status("attention backward, destination pass (two levels)");
+}
+
+int fn_gat_bwd_dst_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et,
+                       const fn_gat_plan* plan, float neg_slope, float* dz_sorted, float* g_s_orig, float* pz_src,
+                       float* g_s_dst, float* part_e, int* n_part_e, int heads, fn_stream_t stream) {
+    GatBwdDstArgs A;
+    if (int rc = prep_gat_bwd_dst(g_out, h, p_sorted, et, plan, neg_slope, dz_sorted, g_s_orig, pz_src, g_s_dst, part_e, n_part_e, heads, &A)) return rc;
+    return launch_gat_bwd_dst(A, heads, S(stream));
+}
+
+static int prep_gat_bwd_src(const float* g_out, const float* h, const float* pz_src, const float* g_s_dst, const float* att,
+                            int att_w, int dst_off, int src_off, const fn_gat_plan* plan, float* g_h, float* part_a,
+                            int* n_part_a, int heads, GatBwdSrcArgs* A) {
+    if (!g_out || !h || !g_s_dst || !att || !plan || !g_h || !part_a || !n_part_a) return fail(FN_EINVAL, "fn_gat_bwd_src_f32: bad argument");
+    if (plan->m > 0 && !pz_src) return fail(FN_EINVAL, "fn_gat_bwd_src_f32: null edge buffer");
+    if ((att_w | dst_off | src_off) & 3) return fail(FN_EINVAL, "fn_gat_bwd_src_f32: att blocks must be 16-byte aligned");
+    if (heads != 1 && heads != 2 && heads != 4 && heads != 8) return fail(FN_EUNSUPPORTED, "heads must be 1, 2, 4 or 8 (128 = heads * head_dim)");
+    *n_part_a = 0;
+    *A = GatBwdSrcArgs{g_out, h, pz_src, g_s_dst, att, att_w, dst_off, src_off, *plan, g_h, part_a, 1, 0};
+    if (plan->n == 0) return 0;
+    if (plan->n > (1 << 23) || plan->m * heads > (1 << 28))
+        return fail(FN_EUNSUPPORTED, "fn_gat_bwd_src_f32: level too large for 32-bit byte offsets (n <= 2^23 rows, m*heads <= 2^28)");
+    // every block writes 256 partial sums column-major (scattered): at most 1024 blocks, each half-wave pipelining R rows
+    const int64_t groups = (plan->n + kBwdRows - 1) / kBwdRows;
+    int64_t resident = (int64_t)g_tune[FN_TUNE_FWD_BLOCKS];
+    if (resident > 1024) resident = 1024;
+    A->rows_per_hw = (int)((groups + resident - 1) / resident);
+    A->nblk = (int)((plan->n + (int64_t)kBwdRows * A->rows_per_hw - 1) / ((int64_t)kBwdRows * A->rows_per_hw));
+    *n_part_a = A->nblk;
+    return 0;
+}
+
+static int launch_gat_bwd_src(const GatBwdSrcArgs& A, int heads, hipStream_t st) {
+    if (A.nblk == 0) return 0;
+    FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src<HH, kBwdRows>), dim3(A.nblk), dim3(kBwdRows * 32), 0, st, A));
+    return launch_status("fn_gat_bwd_src_f32");
+}
+static int launch_gat_bwd_src_pair(const GatBwdSrcArgs& A, const GatBwdSrcArgs& B, int heads, hipStream_t st) {
+    if (A.nblk == 0 || B.nblk == 0) {
+        if (int rc = launch_gat_bwd_src(A, heads, st)) return rc;
+        return launch_gat_bwd_src(B, heads, st);
+    }
+    FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src_pair<HH, kBwdRows>), dim3(A.nblk + B.nblk), dim3(kBwdRows * 32), 0, st, A, B));
+    return launch_status("attention backward, source pass (two levels)");
 }
 
 int fn_gat_bwd_src_f32(const float* g_out, const float* h, const float* pz_src,
                        const float* g_s_dst, const float* att, int att_w, int dst_off, int src_off,
                        const fn_gat_plan* plan, float* g_h, float* part_a, int* n_part_a, int heads, fn_stream_t stream) {
-    if (!g_out || !h || !g_s_dst || !att || !plan || !g_h || !part_a || !n_part_a) return fail(FN_EINVAL, "fn_gat_bwd_src_f32: bad argument");
-    if (plan->m > 0 && !pz_src) return fail(FN_EINVAL, "fn_gat_bwd_src_f32: null edge buffer");
-    if ((att_w | dst_off | src_off) & 3) return fail(FN_EINVAL, "fn_gat_bwd_src_f32: att blocks must be 16-byte aligned");
-    *n_part_a = 0;
-    if (plan->n == 0) return 0;
-    if (plan->n > (1 << 23) || plan->m * heads > (1 << 28))
-        return fail(FN_EUNSUPPORTED, "fn_gat_bwd_src_f32: level too large for 32-bit byte offsets (n <= 2^23 rows, m*heads <= 2^28)");
-    // every block writes 256 partial sums column-major (scattered): at most 1024 blocks, each half-wave pipelining
-    // R consecutive source rows
-    const int64_t groups = (plan->n + kBwdRows - 1) / kBwdRows;
-    int64_t resident = (int64_t)g_tune[FN_TUNE_FWD_BLOCKS];
-    if (resident > 1024) resident = 1024;
-    const int R = (int)((groups + resident - 1) / resident);
-    const int g = (int)((plan->n + (int64_t)kBwdRows * R - 1) / ((int64_t)kBwdRows * R));
-    *n_part_a = g;
-    FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src<HH, kBwdRows>), dim3(g), dim3(kBwdRows * 32), 0, S(stream), g_out, h, pz_src,
-                                            g_s_dst, att, att_w, dst_off, src_off, *plan, g_h, part_a, R));
-    return launch_status("fn_gat_bwd_src_f32");
+    GatBwdSrcArgs A;
+    if (int rc = prep_gat_bwd_src(g_out, h, pz_src, g_s_dst, att, att_w, dst_off, src_off, plan, g_h, part_a, n_part_a, heads, &A)) return rc;
+    return launch_gat_bwd_src(A, heads, S(stream));
 }
 
 int fn_gat_bwd_finalize_f32(const float* part_a, int n_part_a, const float* part_e, int n_part_e, const fn_edge_term* et,
@@ -2764,8 +2918,10 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
             FN_TRY(launch_linear128_group(T, S(st)));
         } else {
             FN_TRY(project(in_bond, kb, bt_b, w.proj_b_b, a.h_b, e->E, w.a_b, 3 * d, 2 * d, lay.s_dst, lay.s_src, st));
+            FN_TRY(project(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, w.f_a_b, 3 * d, 2 * d, lay.s_dst_fb, lay.s_src_fb, st_fb));
         }
         fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
+        fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
         float* y_atoms = last ? out_atoms : a.y_atoms;
         float* y_frags = last ? out_frags : a.y_frags;
         float* y_bond = last ? out_bond : a.y_bond;
@@ -2773,7 +2929,16 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         // act(dropout(.)) of the four layer outputs rides in the producing kernels' epilogues
         const fn_act_epilogue ep_atoms{y_atoms, p, 1, e->seed, rng.y[l][0], e->offset_dev}, ep_frags{y_frags, p, 1, e->seed, rng.y[l][1], e->offset_dev};
         const fn_act_epilogue ep_bond{y_bond, p, 1, e->seed, rng.y[l][2], e->offset_dev}, ep_fbond{y_fbond, p, 1, e->seed, rng.y[l][3], e->offset_dev};
-        FN_TRY(fn_gat_fwd_f32(a.h_b, lay.s_dst, lay.s_src, w.a_b, 3 * d, &et_b, &e->bond, 0.2f, a.new_bond, a.p_bond, nullptr, &ep_bond, H, st));
+        // L1 bond graph and L4a fragment-bond graph: neither reads the other's output -> one launch for both
+        GatFwdArgs gb, gfb;
+        FN_TRY(prep_gat_fwd(a.h_b, lay.s_dst, lay.s_src, w.a_b, 3 * d, &et_b, &e->bond, 0.2f, a.new_bond, a.p_bond, nullptr, &ep_bond, H, &gb));
+        FN_TRY(prep_gat_fwd(a.h_fb, lay.s_dst_fb, lay.s_src_fb, w.f_a_b, 3 * d, &et_fb, &e->fbond, 0.2f, a.new_fbond, a.p_fbond, nullptr, &ep_fbond, H, &gfb));
+        if (multi) {
+            FN_TRY(launch_gat_fwd(gb, H, S(st)));
+            FN_TRY(launch_gat_fwd(gfb, H, S(st_fb)));
+        } else {
+            FN_TRY(launch_gat_fwd_pair(gb, gfb, H, S(st)));
+        }
 
         // L2 atom graph (+ self loops), edge term = <new_bond, a[:, d:d+128]>
         if (!grouped) FN_TRY(project(in_atoms, ka, bt_a, w.proj_a_b, a.h_a, e->N, w.a, wide, d + FN_D, lay.s_dst_a, lay.s_src_a, st));
@@ -2783,11 +2948,6 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
 
         // L3 atom -> fragment sum
         FN_TRY(fn_segment_sum_f32(lay.atoms_new, FN_D, e->a2f.rowptr, e->a2f.perm, e->a2f.pos_base, a.frags, e->F, FN_D, e->N, st));
-
-        // L4a fragment-bond graph (own stream: its inputs are the previous layer's fragment-bond outputs only)
-        if (!grouped) FN_TRY(project(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, w.f_a_b, 3 * d, 2 * d, lay.s_dst_fb, lay.s_src_fb, st_fb));
-        fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
-        FN_TRY(fn_gat_fwd_f32(a.h_fb, lay.s_dst_fb, lay.s_src_fb, w.f_a_b, 3 * d, &et_fb, &e->fbond, 0.2f, a.new_fbond, a.p_fbond, nullptr, &ep_fbond, H, st_fb));
 
         // L4b fragment graph on the raw fragment sums.  Only the last layer's result is ever read: the next layer
         // overwrites x_frags with its own atom->fragment sum before first use (gat2.py:234), so inner
@@ -2891,21 +3051,6 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             have_g_frags_h = true;
         }
 
-        // ---- L4a fragment-bond graph, on its own stream from here to layer 0
-        if (have_fbond) {
-            if (!fb_forked) { FN_TRY(order_after(hs, S(st_fb)));  fb_forked = true; }
-            fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_fbond, a.h_fb, a.p_fbond, &et_fb, &e->fbond, 0.2f, nullptr, nullptr, sfb.pz, sfb.g_s_dst, sfb.part_e, &n_e, H, st_fb));
-            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_fbond, a.h_fb, sfb.pz, sfb.g_s_dst, w.f_a_b, 3 * d, 0, 2 * d, &e->fbond, sfb.g_h, sfb.part_a, &n_a, H, st_fb));
-            if (l) {     // dL/d(pre-activation fbond output of layer l-1), gated by that layer's dropout mask and ReLU
-                const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_fbond), p, 1, e->seed, rng.y[l - 1][3], e->offset_dev};
-                FN_TRY(input_grad(sfb.g_h, w.proj_fb_w, bw.g_pre_fbond, e->EF, mk, st_fb));
-                nxt_fbond = true;
-            }
-            FN_TRY(rq.finalize(sfb.part_a, n_a, sfb.part_e, n_e, et_fb, w.f_a_b, 3 * d, 0, 2 * d, g.f_a_b, g.emb_fb_w, g.emb_fb_b, H));
-            FN_TRY(rq.wgrad(sfb.g_h, in_fbond, kfb, e->EF, sfb.wg_ws, g.proj_fb_w, g.proj_fb_b, S(st_fb)));
-        }
-
         // ---- L3 atom -> fragment sum: dL/datoms_new += dL/dfrags[a2f]
         if (have_g_frags_h) {
             hipLaunchKernelGGL(k_gather_rows4, dim3(flat_grid(e->N * 32, kGridCap)), dim3(kBlock), 0, hs, bw.g_frags, e->a2f.index,
@@ -2938,18 +3083,50 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             }
         }
 
-        // ---- L1 bond graph
-        if (have_bond) {
+        // ---- L1 bond graph and L4a fragment-bond graph: independent of each other, so their destination passes
+        // share one launch and so do their source passes (with side streams on: one launch each on their own stream)
+        if (have_bond || have_fbond) {
             fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_bond, a.h_b, a.p_bond, &et_b, &e->bond, 0.2f, nullptr, nullptr, sb.pz, sb.g_s_dst, sb.part_e, &n_e, H, st));
-            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_bond, a.h_b, sb.pz, sb.g_s_dst, w.a_b, 3 * d, 0, 2 * d, &e->bond, sb.g_h, sb.part_a, &n_a, H, st));
-            FN_TRY(rq.finalize(sb.part_a, n_a, sb.part_e, n_e, et_b, w.a_b, 3 * d, 0, 2 * d, g.a_b, g.emb_b_w, g.emb_b_b, H));
-            if (multi) { FN_TRY(order_after(hs, S(st_leaf)));  leaf_forked = true; }
-            FN_TRY(rq.wgrad(sb.g_h, in_bond, kb, e->E, sb.wg_ws, g.proj_b_w, g.proj_b_b, S(st_leaf)));
-            if (l) {
-                const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_bond), p, 1, e->seed, rng.y[l - 1][2], e->offset_dev};
-                FN_TRY(input_grad(sb.g_h, w.proj_b_w, bw.g_pre_bond, e->E, mk, st));
-                nxt_bond = true;
+            fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
+            GatBwdDstArgs db{}, dfb{};
+            GatBwdSrcArgs sbA{}, sfbA{};
+            int n_a_b = 0, n_e_b = 0, n_a_fb = 0, n_e_fb = 0;
+            if (have_bond) {
+                FN_TRY(prep_gat_bwd_dst(bw.g_pre_bond, a.h_b, a.p_bond, &et_b, &e->bond, 0.2f, nullptr, nullptr, sb.pz, sb.g_s_dst, sb.part_e, &n_e_b, H, &db));
+                FN_TRY(prep_gat_bwd_src(bw.g_pre_bond, a.h_b, sb.pz, sb.g_s_dst, w.a_b, 3 * d, 0, 2 * d, &e->bond, sb.g_h, sb.part_a, &n_a_b, H, &sbA));
+            }
+            if (have_fbond) {
+                FN_TRY(prep_gat_bwd_dst(bw.g_pre_fbond, a.h_fb, a.p_fbond, &et_fb, &e->fbond, 0.2f, nullptr, nullptr, sfb.pz, sfb.g_s_dst, sfb.part_e, &n_e_fb, H, &dfb));
+                FN_TRY(prep_gat_bwd_src(bw.g_pre_fbond, a.h_fb, sfb.pz, sfb.g_s_dst, w.f_a_b, 3 * d, 0, 2 * d, &e->fbond, sfb.g_h, sfb.part_a, &n_a_fb, H, &sfbA));
+            }
+            if (multi) {
+                if (have_fbond && !fb_forked) { FN_TRY(order_after(hs, S(st_fb)));  fb_forked = true; }
+                FN_TRY(launch_gat_bwd_dst(db, H, hs));
+                FN_TRY(launch_gat_bwd_src(sbA, H, hs));
+                FN_TRY(launch_gat_bwd_dst(dfb, H, S(st_fb)));
+                FN_TRY(launch_gat_bwd_src(sfbA, H, S(st_fb)));
+            } else {
+                FN_TRY(launch_gat_bwd_dst_pair(db, dfb, H, hs));
+                FN_TRY(launch_gat_bwd_src_pair(sbA, sfbA, H, hs));
+            }
+            if (have_fbond) {
+                if (l) {     // dL/d(pre-activation fbond output of layer l-1), gated by that layer's dropout mask and ReLU
+                    const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_fbond), p, 1, e->seed, rng.y[l - 1][3], e->offset_dev};
+                    FN_TRY(input_grad(sfb.g_h, w.proj_fb_w, bw.g_pre_fbond, e->EF, mk, st_fb));
+                    nxt_fbond = true;
+                }
+                FN_TRY(rq.finalize(sfb.part_a, n_a_fb, sfb.part_e, n_e_fb, et_fb, w.f_a_b, 3 * d, 0, 2 * d, g.f_a_b, g.emb_fb_w, g.emb_fb_b, H));
+                FN_TRY(rq.wgrad(sfb.g_h, in_fbond, kfb, e->EF, sfb.wg_ws, g.proj_fb_w, g.proj_fb_b, S(st_fb)));
+            }
+            if (have_bond) {
+                FN_TRY(rq.finalize(sb.part_a, n_a_b, sb.part_e, n_e_b, et_b, w.a_b, 3 * d, 0, 2 * d, g.a_b, g.emb_b_w, g.emb_b_b, H));
+                if (multi) { FN_TRY(order_after(hs, S(st_leaf)));  leaf_forked = true; }
+                FN_TRY(rq.wgrad(sb.g_h, in_bond, kb, e->E, sb.wg_ws, g.proj_b_w, g.proj_b_b, S(st_leaf)));
+                if (l) {
+                    const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_bond), p, 1, e->seed, rng.y[l - 1][2], e->offset_dev};
+                    FN_TRY(input_grad(sb.g_h, w.proj_b_w, bw.g_pre_bond, e->E, mk, st));
+                    nxt_bond = true;
+                }
             }
         }
         if (dxT.n) FN_TRY(launch_linear128_group(dxT, hs));
