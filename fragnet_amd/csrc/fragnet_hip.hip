@@ -1498,26 +1498,14 @@ template <int KQ, bool VEC>
 __device__ __forceinline__ void linear128_body(float* sBt, const float* __restrict__ X, int K, const float* __restrict__ Bt,
                                                const float* __restrict__ bias, float* __restrict__ Y, int64_t M,
                                                const fn_act_epilogue& mk, const NodeScalarEpi& ns, int bid, int nblk) {
-    // sBt: [4*KQ][kLinLd] then 8 x [16][kLinOutLd]; block bid of the nblk blocks that share this GEMM
+    // sBt: [4*KQ][kLinLd] operand tile; once a tile's products are done the SAME LDS holds the 8 result tiles
+    // [16][kLinOutLd] (the footprint decides how many blocks share a CU: 67 KB -> two, and with two the staging and
+    // epilogue of one block run under the MFMA chain of the other; with operand + result regions side by side it
+    // was one block per CU and the MFMA pipe sat idle 80 % of the time, PMC).  Block bid of nblk blocks of this GEMM.
     const uint64_t mk_base = mk.offset + ((mk.y && mk.p > 0.f && mk.offset_dev) ? *mk.offset_dev : 0);   // read once, not per tile
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
     const int wr = w & 3, wc = w >> 2;
-    float* sOut = sBt + 4 * KQ * kLinLd + w * 16 * kLinOutLd;
-    {   // stage Bt [4*KQ][128] -> LDS with 16-byte loads, all loads of a thread in flight before the first LDS store
-        constexpr int N4 = 4 * KQ * 32;                 // float4 count
-        constexpr int PER = (N4 + 511) / 512;
-        float4 v[PER];
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int idx = tid + q * 512, k = idx >> 5, n4 = idx & 31;
-            v[q] = (idx < N4 && k < K) ? ld4(Bt + (size_t)k * 128 + n4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int idx = tid + q * 512, k = idx >> 5, n4 = idx & 31;
-            if (idx < N4) st4(sBt + k * kLinLd + n4 * 4, v[q]);
-        }
-    }
+    float* sOut = sBt + w * 16 * kLinOutLd;
     const int64_t tiles = (M + 63) / 64;
 
     auto load_rows = [&](int64_t tile, float (&xa)[KQ]) {
@@ -1536,15 +1524,27 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
         }
     };
 
-    float cur[KQ], nxt[KQ];
-    int64_t tile = bid;
-    if (tile < tiles) load_rows(tile, cur);
-    __syncthreads();
+    float cur[KQ];
     const float* bbase = sBt + (VEC ? 4 * kq : kq * KQ) * kLinLd + 64 * wc + i;
     auto brow = [](int s) { return VEC ? 16 * (s >> 2) + (s & 3) : s; };      // LDS row of MFMA step s, relative to bbase
-    for (; tile < tiles; tile += nblk) {
-        const int64_t ntile = tile + nblk;
-        if (ntile < tiles) load_rows(ntile, nxt);
+    for (int64_t tile = bid; tile < tiles; tile += nblk) {
+        {   // stage Bt [4*KQ][128] -> LDS with 16-byte loads; the A rows of this tile are requested in the same round trip
+            constexpr int N4 = 4 * KQ * 32;                 // float4 count
+            constexpr int PER = (N4 + 511) / 512;
+            float4 v[PER];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int idx = tid + q * 512, k = idx >> 5, n4 = idx & 31;
+                v[q] = (idx < N4 && k < K) ? ld4(Bt + (size_t)k * 128 + n4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            load_rows(tile, cur);
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int idx = tid + q * 512, k = idx >> 5, n4 = idx & 31;
+                if (idx < N4) st4(sBt + k * kLinLd + n4 * 4, v[q]);
+            }
+        }
+        __syncthreads();
         f32x4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1562,6 +1562,7 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
 #pragma unroll
             for (int t = 0; t < 4; ++t) b0[t] = b1[t];
         }
+        __syncthreads();                                     // every wave is done with the operand tile: reuse its LDS
         // wave-private transpose through LDS: acc[t][r] is (row kq*4+r, col 16t+i) of the 16 x 64 tile
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -1615,9 +1616,7 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
                 ns.s_src[(r0 + rr) * ns.heads + head] = ps;
             }
         }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int s = 0; s < KQ; ++s) cur[s] = nxt[s];
+        __syncthreads();                                     // result tiles consumed before the next operand tile lands
     }
 }
 
@@ -1999,9 +1998,9 @@ template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
 template <int KQ>
 int launch_linear128(const float* X, int K, const float* Bt, const float* bias, float* Y, int64_t M, fn_act_epilogue mk,
                      NodeScalarEpi ns, hipStream_t st) {
-    const size_t lds = ((size_t)4 * KQ * kLinLd + 8 * 16 * kLinOutLd) * sizeof(float);
+    const size_t lds = (size_t)std::max(4 * KQ * kLinLd, 8 * 16 * kLinOutLd) * sizeof(float);
     const int64_t tiles = (M + 63) / 64;
-    const int grid = (int)(tiles < 256 ? tiles : 256);       // one block per CU: MFMA-bound, X prefetched a tile ahead
+    const int grid = (int)(tiles < 8192 ? tiles : 8192);     // one 64-row tile per block, two blocks per CU
     if (KQ % 4 == 0 && K == 4 * KQ) {
         if (int rc = allow_lds(k_linear128<KQ, (KQ % 4 == 0)>, lds)) return rc;
         hipLaunchKernelGGL((k_linear128<KQ, (KQ % 4 == 0)>), dim3(grid), dim3(512), lds, st, X, K, Bt, bias, Y, M, mk, ns);
@@ -2014,14 +2013,14 @@ int launch_linear128(const float* X, int K, const float* Bt, const float* bias, 
 // grouped launch for K == 128 (every projection beyond layer 0 and every input-gradient product)
 int launch_linear128_group(LinTasks& T, hipStream_t st) {
     constexpr int KQ = 32;
-    const size_t lds = ((size_t)4 * KQ * kLinLd + 8 * 16 * kLinOutLd) * sizeof(float);
+    const size_t lds = (size_t)std::max(4 * KQ * kLinLd, 8 * 16 * kLinOutLd) * sizeof(float);
     int blocks = 0, live = 0;
     for (int i = 0; i < T.n; ++i) {
         if (T.t[i].M <= 0) continue;
         const int64_t tiles = (T.t[i].M + 63) / 64;
         LinTask t = T.t[i];
         t.first = blocks;
-        t.nblk = (int)(tiles < 256 ? tiles : 256);
+        t.nblk = (int)(tiles < 8192 ? tiles : 8192);
         blocks += t.nblk;
         T.t[live++] = t;
     }
