@@ -1476,7 +1476,7 @@ __global__ void k_edge_concat(const float* __restrict__ x, const float* __restri
 // =====================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kBtLd = 144;     // LDS leading dimension of the [K][128] operand: 144 % 32 == 16
-constexpr int kLinLd = 132;    // k_linear128's own: 4 rows apart = 16 banks apart, so the four k-quarters of a wave do not collide
+constexpr int kLinLd = 68;     // k_linear128's operand tile [K][64 columns]: 4 rows apart = 16 banks apart, so the four k-quarters of a wave do not collide
 
 // A block = 8 waves = 64 rows x 128 columns: wave w owns rows 16*(w&3).. and columns 64*(w>>2).. (4 accumulator
 // tiles), so two waves share every SIMD and one wave's LDS reads hide under the other's MFMAs.  Bt is staged in
@@ -1503,9 +1503,12 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
     // epilogue of one block run under the MFMA chain of the other; with operand + result regions side by side it
     // was one block per CU and the MFMA pipe sat idle 80 % of the time, PMC).  Block bid of nblk blocks of this GEMM.
     const uint64_t mk_base = mk.offset + ((mk.y && mk.p > 0.f && mk.offset_dev) ? *mk.offset_dev : 0);   // read once, not per tile
+    // A block is 4 waves = 64 rows x 64 COLUMNS (column half wc = bid & 1): half the operand tile (35 KB -> four
+    // blocks per CU), one wave per SIMD and block, and twice the blocks for the small levels.
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
-    const int wr = w & 3, wc = w >> 2;
+    const int wr = w, wc = bid & 1;
     float* sOut = sBt + w * 16 * kLinOutLd;
+    float* sAtt = sBt + (4 * KQ * kLinLd > 4 * 16 * kLinOutLd ? 4 * KQ * kLinLd : 4 * 16 * kLinOutLd);   // [3][64]: a_dst, a_src, bias of this column half
     const int64_t tiles = (M + 63) / 64;
 
     auto load_rows = [&](int64_t tile, float (&xa)[KQ]) {
@@ -1525,25 +1528,35 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
     };
 
     float cur[KQ];
-    const float* bbase = sBt + (VEC ? 4 * kq : kq * KQ) * kLinLd + 64 * wc + i;
+    const float* bbase = sBt + (VEC ? 4 * kq : kq * KQ) * kLinLd + i;
     auto brow = [](int s) { return VEC ? 16 * (s >> 2) + (s & 3) : s; };      // LDS row of MFMA step s, relative to bbase
-    for (int64_t tile = bid; tile < tiles; tile += nblk) {
-        {   // stage Bt [4*KQ][128] -> LDS with 16-byte loads; the A rows of this tile are requested in the same round trip
-            constexpr int N4 = 4 * KQ * 32;                 // float4 count
-            constexpr int PER = (N4 + 511) / 512;
+    for (int64_t tile = bid >> 1; tile < tiles; tile += nblk >> 1) {
+        {   // stage Bt [4*KQ][this half's 64 columns] -> LDS with 16-byte loads; the A rows ride in the same round trip
+            constexpr int N4 = 4 * KQ * 16;                 // float4 count
+            constexpr int PER = (N4 + 255) / 256;
             float4 v[PER];
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
-                const int idx = tid + q * 512, k = idx >> 5, n4 = idx & 31;
-                v[q] = (idx < N4 && k < K) ? ld4(Bt + (size_t)k * 128 + n4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int idx = tid + q * 256, k = idx >> 4, n4 = idx & 15;
+                v[q] = (idx < N4 && k < K) ? ld4(Bt + (size_t)k * 128 + 64 * wc + n4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             load_rows(tile, cur);
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
-                const int idx = tid + q * 512, k = idx >> 5, n4 = idx & 31;
+                const int idx = tid + q * 256, k = idx >> 4, n4 = idx & 15;
                 if (idx < N4) st4(sBt + k * kLinLd + n4 * 4, v[q]);
             }
         }
+        // everything the epilogue reads from global memory is requested NOW, so that it arrives under the MFMA
+        // chain instead of after it: bias, this lane's attention-vector columns, the ReLU gate rows
+        const int64_t r0 = tile * 64 + wr * 16;
+        const int ns_q = lane & 3, ns_d = ns.att ? FN_D / ns.heads : FN_D;
+        const int ns_head = (64 * wc + 16 * ns_q) / ns_d;
+        if (ns.att && tid < 32) {        // this column half's attention-vector entries -> LDS behind the operand tile
+            const int c = (tid & 15) * 4, col = 64 * wc + c, hd = col / ns_d, within = col % ns_d;
+            st4(sAtt + (tid >> 4) * 64 + c, ld4(ns.att + hd * ns.att_w + ((tid >> 4) ? ns.src_off : ns.dst_off) + within));
+        }
+        if (tid >= 64 && tid < 128) sAtt[128 + tid - 64] = bias ? bias[64 * wc + tid - 64] : 0.f;   // and its bias
         __syncthreads();
         f32x4 acc[4];
 #pragma unroll
@@ -1566,13 +1579,11 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
         // wave-private transpose through LDS: acc[t][r] is (row kq*4+r, col 16t+i) of the 16 x 64 tile
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const float bv = bias ? bias[64 * wc + 16 * t + i] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sOut[(kq * 4 + r) * kLinOutLd + 16 * t + i] = acc[t][r] + bv;
+            for (int r = 0; r < 4; ++r) sOut[(kq * 4 + r) * kLinOutLd + 16 * t + i] = acc[t][r] + sAtt[128 + 16 * t + i];
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the wave's own LDS writes have landed
         __builtin_amdgcn_wave_barrier();
-        const int64_t r0 = tile * 64 + wr * 16;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                        // 16 rows x 16 float4 = 256 pieces, 4 per lane
             const int idx = lane + q * 64, rr = idx >> 4, c4 = idx & 15;
@@ -1596,17 +1607,13 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
             }
         }
         if (ns.att) {        // node scalars of the finished rows straight from the LDS tile (lane = row rr, 16-column quarter q)
-            const int rr = lane >> 2, q = lane & 3, d = FN_D / ns.heads;
-            const int col0 = 64 * wc + 16 * q, head = col0 / d, within = col0 % d;
-            const float* ad = ns.att + head * ns.att_w + ns.dst_off + within;
-            const float* as = ns.att + head * ns.att_w + ns.src_off + within;
+            const int rr = lane >> 2, q = ns_q, d = ns_d, head = ns_head;
             float pd = 0.f, ps = 0.f;
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
                 const float4 yv = *reinterpret_cast<const float4*>(sOut + rr * kLinOutLd + 16 * q + c4 * 4);
-                const float4 a4 = ld4(ad + c4 * 4), b4 = ld4(as + c4 * 4);
-                pd += dot4(yv, a4);
-                ps += dot4(yv, b4);
+                pd += dot4(yv, *reinterpret_cast<const float4*>(sAtt + 16 * q + c4 * 4));
+                ps += dot4(yv, *reinterpret_cast<const float4*>(sAtt + 64 + 16 * q + c4 * 4));
             }
             if (d >= 32) { pd += dpp_mov<kDppXor1>(pd); ps += dpp_mov<kDppXor1>(ps); }
             if (d >= 64) { pd += dpp_mov<kDppXor2>(pd); ps += dpp_mov<kDppXor2>(ps); }
@@ -1621,7 +1628,7 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
 }
 
 template <int KQ, bool VEC>
-__global__ __launch_bounds__(512) void k_linear128(const float* __restrict__ X, int K, const float* __restrict__ Bt,
+__global__ __launch_bounds__(256) void k_linear128(const float* __restrict__ X, int K, const float* __restrict__ Bt,
                                                    const float* __restrict__ bias, float* __restrict__ Y, int64_t M,
                                                    fn_act_epilogue mk, NodeScalarEpi ns) {
     extern __shared__ __attribute__((aligned(16))) float sBt[];
@@ -1643,7 +1650,7 @@ struct LinTasks {
     int n, K;
 };
 template <int KQ, bool VEC>
-__global__ __launch_bounds__(512) void k_linear128_multi(LinTasks T) {
+__global__ __launch_bounds__(256) void k_linear128_multi(LinTasks T) {
     extern __shared__ __attribute__((aligned(16))) float sBt[];
     int ti = 0;
     while (ti + 1 < T.n && (int)blockIdx.x >= T.t[ti + 1].first) ++ti;
@@ -1998,29 +2005,29 @@ template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
 template <int KQ>
 int launch_linear128(const float* X, int K, const float* Bt, const float* bias, float* Y, int64_t M, fn_act_epilogue mk,
                      NodeScalarEpi ns, hipStream_t st) {
-    const size_t lds = (size_t)std::max(4 * KQ * kLinLd, 8 * 16 * kLinOutLd) * sizeof(float);
+    const size_t lds = (size_t)(std::max(4 * KQ * kLinLd, 4 * 16 * kLinOutLd) + 192) * sizeof(float);
     const int64_t tiles = (M + 63) / 64;
-    const int grid = (int)(tiles < 8192 ? tiles : 8192);     // one 64-row tile per block, two blocks per CU
+    const int grid = 2 * (int)(tiles < 8192 ? tiles : 8192); // one 64 x 64 output tile per block, four blocks per CU
     if (KQ % 4 == 0 && K == 4 * KQ) {
         if (int rc = allow_lds(k_linear128<KQ, (KQ % 4 == 0)>, lds)) return rc;
-        hipLaunchKernelGGL((k_linear128<KQ, (KQ % 4 == 0)>), dim3(grid), dim3(512), lds, st, X, K, Bt, bias, Y, M, mk, ns);
+        hipLaunchKernelGGL((k_linear128<KQ, (KQ % 4 == 0)>), dim3(grid), dim3(256), lds, st, X, K, Bt, bias, Y, M, mk, ns);
     } else {
         if (int rc = allow_lds(k_linear128<KQ, false>, lds)) return rc;
-        hipLaunchKernelGGL((k_linear128<KQ, false>), dim3(grid), dim3(512), lds, st, X, K, Bt, bias, Y, M, mk, ns);
+        hipLaunchKernelGGL((k_linear128<KQ, false>), dim3(grid), dim3(256), lds, st, X, K, Bt, bias, Y, M, mk, ns);
     }
     return 0;
 }
 // grouped launch for K == 128 (every projection beyond layer 0 and every input-gradient product)
 int launch_linear128_group(LinTasks& T, hipStream_t st) {
     constexpr int KQ = 32;
-    const size_t lds = (size_t)std::max(4 * KQ * kLinLd, 8 * 16 * kLinOutLd) * sizeof(float);
+    const size_t lds = (size_t)(std::max(4 * KQ * kLinLd, 4 * 16 * kLinOutLd) + 192) * sizeof(float);
     int blocks = 0, live = 0;
     for (int i = 0; i < T.n; ++i) {
         if (T.t[i].M <= 0) continue;
         const int64_t tiles = (T.t[i].M + 63) / 64;
         LinTask t = T.t[i];
         t.first = blocks;
-        t.nblk = (int)(tiles < 8192 ? tiles : 8192);
+        t.nblk = 2 * (int)(tiles < 8192 ? tiles : 8192);
         blocks += t.nblk;
         T.t[live++] = t;
     }
@@ -2028,7 +2035,7 @@ int launch_linear128_group(LinTasks& T, hipStream_t st) {
     T.K = 128;
     if (!live) return 0;
     if (int rc = allow_lds(k_linear128_multi<KQ, true>, lds)) return rc;
-    hipLaunchKernelGGL((k_linear128_multi<KQ, true>), dim3(blocks), dim3(512), lds, st, T);
+    hipLaunchKernelGGL((k_linear128_multi<KQ, true>), dim3(blocks), dim3(256), lds, st, T);
     return launch_status("grouped projection GEMM");
 }
 
