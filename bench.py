@@ -186,7 +186,7 @@ def main():
     ap.add_argument("--eager-head", action="store_true", help="(--eager) do not HIP-graph-capture the prediction head")
     ap.add_argument("--kernels-only", action="store_true", help="only time the bond-level scatter kernels (dev loop)")
     ap.add_argument("--kbatch", type=int, default=PER_GPU_BATCH, help="molecules per batch for --kernels-only")
-    ap.add_argument("--fwd-win", type=int, default=None, help="A/B: resident workgroups of the forward kernel (FN_TUNE_FWD_BLOCKS)")
+    ap.add_argument("--scatter-blocks", type=int, default=None, help="A/B: resident workgroups of the scatter kernels (FN_TUNE_FWD_BLOCKS)")
     args = ap.parse_args()
 
     import fragnet_amd
@@ -197,15 +197,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    if args.fwd_win is not None:
+    if args.scatter_blocks is not None:
         from fragnet_amd import _lib
-        _lib.call("fn_set_tuning", 0, args.fwd_win)
+        _lib.call("fn_set_tuning", 0, args.scatter_blocks)
     if os.environ.get("FN_STREAMS"):
         from fragnet_amd import _lib
         _lib.call("fn_set_tuning", 2, int(os.environ["FN_STREAMS"]))
-    if os.environ.get("FN_DEBUG_MASK"):
-        from fragnet_amd import _lib
-        _lib.call("fn_set_tuning", 1, int(os.environ["FN_DEBUG_MASK"]))
     rank, local_rank, world = parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")

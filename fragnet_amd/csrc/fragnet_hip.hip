@@ -1994,7 +1994,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 // C-ABI
 // =====================================================================================
 namespace {
-int g_tune[FN_TUNE_COUNT] = {1792, 0, 0};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_DEBUG, FN_TUNE_STREAMS
+int g_tune[FN_TUNE_COUNT] = {1792, 0, 0};   // FN_TUNE_FWD_BLOCKS, (reserved), FN_TUNE_STREAMS
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;

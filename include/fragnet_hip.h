@@ -43,10 +43,10 @@ typedef void* fn_stream_t;    /* hipStream_t */
 int fn_abi_version(void);
 
 /* Process-wide tuning knobs (defaults are the measured best for MI355X; the bench uses them for A/B runs).
- * FN_TUNE_FWD_BLOCKS: workgroups of the forward kernel that are resident at once (default 1792 = 256 CUs x 7); a
+ * FN_TUNE_FWD_BLOCKS: workgroups of the attention kernels that are resident at once (default 1792 = 256 CUs x 7); a
  *   level with more row groups than that gives every half-wave several consecutive rows to software-pipeline. */
 #define FN_TUNE_FWD_BLOCKS 0
-#define FN_TUNE_DEBUG 1        /* development only: bit mask that disables parts of kernels (results become wrong) */
+#define FN_TUNE_RESERVED 1     /* unused */
 #define FN_TUNE_STREAMS 2      /* 1: the encoder forks parameter-gradient work and the fragment-bond chain onto side streams;
                                 * 0 (default): one stream -- forked hipGraph replays measured slower on ROCm 7.2 */
 #define FN_TUNE_COUNT 3
@@ -162,11 +162,11 @@ typedef struct fn_act_epilogue {
  * order, unsigned -- the reference's attn_probs. */
 int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const float* att, int att_w,
                    const fn_edge_term* et, const fn_gat_plan* plan, float neg_slope,
-                   float* out /*[n,128], nullable when act->y is given*/, float* p_sorted /*[m,H]*/,
+                   float* out /*[n,128], nullable when act->y is given*/, float* p_sorted /*[H,m]*/,
                    float* probs_orig /*nullable*/, const fn_act_epilogue* act /*nullable*/, int heads, fn_stream_t stream);
 
-/* Backward, destination pass.  Writes, per edge, (|p|, dz) into pz_src [m,H,2] at the edge's slot in SOURCE
- * order (so the source pass streams them), dz_sorted [m,H] in mode 0 (= dL/ds_sorted, the gradient of the edge
+/* Backward, destination pass.  Writes, per edge, (|p|, dz) into pz_src [H,m,2] at the edge's slot in SOURCE
+ * order (so the source pass streams them), dz_sorted [H,m] in mode 0 (= dL/ds_sorted, the gradient of the edge
  * term), g_s_dst [n,H]; mode 2 writes per-block partial sums part_e [grid, H*(K+1)].
  * Returns the grid size used through *n_part_e. */
 int fn_gat_bwd_dst_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et,
@@ -196,16 +196,16 @@ int fn_gat_bwd_finalize_f32(const float* part_a, int n_part_a, const float* part
 int fn_attn_by_src_f32(const float* p_sorted, const fn_gat_plan* plan, float* attn /*[n,H]*/, int heads,
                        fn_stream_t stream);
 
-/* s_sorted[pos, j] = <feat[eid(pos), 0:128], A[j*lda + off : +128]>, j < J <= 8, 0 at loop positions: the
+/* s_sorted[j, pos] = <feat[eid(pos), 0:128], A[j*lda + off : +128]>, j < J <= 8, 0 at loop positions: the
  * full-width edge term of the atom and fragment graphs (edge block of `a` / `f`, gat2.py:203-208, 293-300),
  * written directly in destination-sorted order. */
 int fn_row_dots_sorted_f32(const float* feat /*[m_real,128]*/, const float* A, int lda, int off, int J,
-                           const fn_gat_plan* plan, float* s_sorted /*[m,J]*/, fn_stream_t stream);
+                           const fn_gat_plan* plan, float* s_sorted /*[J,m] head-major*/, fn_stream_t stream);
 /* g_feat[e,:] = sum_j g_s_sorted[j, inv_d[e]] A[j]; part: column-major partial sums of g_A[j,:] */
 int fn_row_dots_sorted_bwd_f32(const float* g_s_sorted, const float* feat, const float* A, int lda, int off, int J,
                                const fn_gat_plan* plan, float* g_feat, float* part, int* n_part, fn_stream_t stream);
-/* x_sorted[pos,:] = x[eid(pos),:] (0 at loop positions): once per batch for the raw edge attributes */
-int fn_sort_edge_attr_f32(const float* x /*[m_real,K]*/, int K, const fn_gat_plan* plan, float* x_sorted /*[m,K]*/,
+/* x_sorted[:,pos] = x[eid(pos),:] (0 at loop positions): once per batch for the raw edge attributes */
+int fn_sort_edge_attr_f32(const float* x /*[m_real,K]*/, int K, const fn_gat_plan* plan, float* x_sorted /*[K,m]*/,
                           fn_stream_t stream);
 /* out[(c / 128) * ld + off + c % 128] = sum_{r < n_rows} part[c * FN_MAX_PART + r], c < cols (partials are column-major) */
 int fn_colsum_f32(const float* part, int n_rows, int cols, float* out, int ld, int off, fn_stream_t stream);
