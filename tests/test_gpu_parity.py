@@ -485,3 +485,74 @@ def test_b512_gradients_match_oracle_b64():
             continue
         scale = max(1.0, float(p1.grad.abs().max()))
         torch.testing.assert_close(p2.grad.cpu(), p1.grad, atol=ATOL * scale, rtol=2e-3, msg=lambda s: f"{n1}: {s}")
+
+
+# ----------------------------------------------------------------- full size, the other BASELINE configs (3, 4, 5)
+def test_tox21_b1024_matches_oracle_on_a_slice_and_masked_bce_is_reproducible():
+    """BASELINE config 3: Tox21-shape, 12 tasks, FTHead4, batch 1024.  First 32 molecules == oracle on those 32;
+    the masked BCE training step is bitwise reproducible."""
+    from fragnet_amd import data, synth, train
+    from fragnet_amd.model import FragNetFineTune
+    from oracle import fragnet_ref as ref
+    cfg = dict(n_classes=12, num_layer=4, drop_ratio=0.0, h1=128, act="relu", fthead="FTHead4")
+    mols = synth.synth_molecules(1024, seed=2000, profile="tox21")
+    batch = data.collate_fn(mols)
+    assert batch["y"].shape == (1024, 12)
+    torch.manual_seed(0)
+    model = FragNetFineTune(**cfg).to(DEV)
+    b = _to_dev(batch)
+    with torch.no_grad():
+        full = model.eval()(b).cpu()
+    torch.manual_seed(0)
+    gold = ref.FragNetFineTune(**cfg).eval()
+    with torch.no_grad():
+        want = gold(data.collate_fn(mols[:32]))
+    torch.testing.assert_close(full[:32], want, atol=ATOL, rtol=1e-4)
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        m = FragNetFineTune(**cfg).to(DEV).train()
+        bb = _to_dev(batch)
+        loss = train.compute_bce_loss(m(bb), bb["y"])
+        loss.backward()
+        runs.append((loss.item(), m.pretrain.layers[2].a.grad.clone()))
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+
+
+def test_pretrain_b512_heads_match_oracle_on_a_slice():
+    """BASELINE config 4 (per-rank shape): the four pretrain outputs of the first 48 molecules of a B=512 batch equal
+    the oracle's on those molecules alone (atoms / directed bonds of a molecule prefix are a prefix of the batch's)."""
+    from fragnet_amd import data, synth
+    from fragnet_amd.model import FragNetPreTrain
+    from oracle import fragnet_ref as ref
+    mols = synth.synth_molecules(512, seed=3000, profile="esol", pretrain_targets=True)
+    torch.manual_seed(0)
+    model = FragNetPreTrain(num_layer=4, drop_ratio=0.0, edge_features=17).to(DEV).eval()
+    torch.manual_seed(0)
+    gold = ref.FragNetPreTrain(num_layer=4, drop_ratio=0.0, edge_features=17).eval()
+    small = data.collate_fn_pt(mols[:48])
+    with torch.no_grad():
+        got = [t.cpu() for t in model(_to_dev(data.collate_fn_pt(mols)))]
+        want = gold(small)
+    n_e, n_a = small["edge_attr"].shape[0], small["x_atoms"].shape[0]
+    for g, w, n in zip(got, want, (n_e, n_a, n_e, 48)):
+        torch.testing.assert_close(g[:n], w, atol=ATOL, rtol=1e-4)
+
+
+def test_synth40_b2048_forward_is_permutation_equivariant_and_matches_oracle_slice():
+    """BASELINE config 5 (forward-only sweep shape): 40-atom / 12-fragment molecules, 2048 per batch."""
+    from fragnet_amd import data, synth
+    from oracle import fragnet_ref as ref
+    mols = synth.synth_molecules(2048, seed=4000, profile="synth40")
+    model = _esol_model().eval()
+    with torch.no_grad():
+        full = model(_to_dev(data.collate_fn(mols))).cpu()
+        perm = torch.randperm(2048, generator=torch.Generator().manual_seed(5)).tolist()
+        shuffled = model(_to_dev(data.collate_fn([mols[i] for i in perm]))).cpu()
+    torch.testing.assert_close(shuffled, full[perm], atol=5e-5, rtol=1e-4)
+    torch.manual_seed(0)
+    gold = ref.FragNetFineTune(n_classes=1, num_layer=4, drop_ratio=0.0, h1=128, h2=1024, h3=1024, h4=512, act="relu",
+                               fthead="FTHead3").eval()
+    with torch.no_grad():
+        want = gold(data.collate_fn(mols[:24]))
+    torch.testing.assert_close(full[:24], want, atol=ATOL, rtol=1e-4)
