@@ -173,6 +173,46 @@ def kernel_roofline(batch, model, iters=50):
     return res
 
 
+def forward_sweep(rank, world, dev, args):
+    """Forward-only (eval mode) molecules/s on synthetic 40-atom / 12-fragment molecules: every
+    rank runs its own shard, no collective at all.  Plan build + forward per step, batches resident in HBM."""
+    from fragnet_amd import data, synth
+    from fragnet_amd.model import FragNetFineTune
+    from fragnet_amd.plan import PLAN_KEY
+    torch.manual_seed(0)
+    model = FragNetFineTune(**MODEL_CFG).to(dev).eval()
+    for B in (512, 2048, 8192):
+        pool = [data.batch_to(data.collate_fn(synth.synth_molecules(B, seed=5000 + 31 * rank + i, profile="synth40")), dev)
+                for i in range(2)]
+        with torch.no_grad():
+            for i in range(3):
+                pool[i % 2].pop(PLAN_KEY, None)
+                model(pool[i % 2])
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                pool[i % 2].pop(PLAN_KEY, None)
+                model(pool[i % 2])
+            torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+        if rank == 0:
+            sec = float(el.item())
+            print(json.dumps({"metric": "molecules/sec forward only (eval), synthetic 40-atom/12-fragment molecules",
+                              "value": round(B * world * args.steps / sec, 1), "unit": "molecules/s", "n_gpus": world,
+                              "per_gpu_batch": B, "steps": args.steps, "ms_per_step": round(sec / args.steps * 1e3, 3),
+                              "atoms": int(pool[0]["x_atoms"].shape[0]),
+                              "bond_graph_edges": int(pool[0]["edge_index_bonds_graph"].shape[1]), "dtype": "f32",
+                              "data": "synthetic", "scaling": "weak"}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,6 +226,8 @@ def main():
     ap.add_argument("--eager-head", action="store_true", help="(--eager) do not HIP-graph-capture the prediction head")
     ap.add_argument("--kernels-only", action="store_true", help="only time the bond-level scatter kernels (dev loop)")
     ap.add_argument("--kbatch", type=int, default=PER_GPU_BATCH, help="molecules per batch for --kernels-only")
+    ap.add_argument("--forward-sweep", action="store_true",
+                    help="extra (BASELINE configs[4]): forward-only eval throughput on 40-atom/12-fragment molecules, one line per batch size")
     ap.add_argument("--scatter-blocks", type=int, default=None, help="A/B: resident workgroups of the scatter kernels (FN_TUNE_FWD_BLOCKS)")
     args = ap.parse_args()
 
@@ -209,6 +251,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    if args.forward_sweep:
+        forward_sweep(rank, world, dev, args)
+        return
     pool = make_pool(1, rank, dev, args.kbatch) if args.kernels_only else make_pool(args.pool, rank, dev)
     torch.manual_seed(0)
     model = FragNetFineTune(**MODEL_CFG).to(dev)
