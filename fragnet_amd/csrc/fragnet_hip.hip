@@ -40,6 +40,7 @@ inline hipStream_t S(fn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 constexpr int kBlock = 256;
 constexpr int kRows = 8;          // rows (half-waves) per block
 constexpr int kGridCap = 2048;    // memory-bound kernels: ~8 blocks per CU, grid-stride the rest
+constexpr int kRowDotsBwdBlocks = 512;    // blocks of k_row_dots_sorted_bwd (each writes one J*128-wide partial row)
 constexpr int kBwdRows = 8;       // rows (half-waves) per block in the attention backward kernels
 
 inline int bwd_grid(int64_t rows) {
@@ -2381,7 +2382,7 @@ int fn_row_dots_sorted_bwd_f32(const float* g_s_sorted, const float* feat, const
         return fail(FN_EINVAL, "fn_row_dots_sorted_bwd_f32: bad argument");
     if (plan->m_real > 0 && (!g_s_sorted || !feat || !g_feat || !plan->inv_d))
         return fail(FN_EINVAL, "fn_row_dots_sorted_bwd_f32: null buffer");
-    const int g = row_grid(plan->m_real, 512);
+    const int g = row_grid(plan->m_real, kRowDotsBwdBlocks);
     *n_part = g;
     hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(g), dim3(kBlock), 0, S(stream), g_s_sorted, feat, A, lda, off, J, *plan,
                        g_feat, part, (const float*)nullptr, 0);
@@ -3046,7 +3047,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             // edge term <new_fbond, f[:, d:d+128]>: dL/dnew_fbond accumulates into g_pre_fbond, dL/df mid block
             int gr = 0;
             if (e->frag.m_real > 0) {
-                gr = row_grid(e->frag.m_real, 512);
+                gr = row_grid(e->frag.m_real, kRowDotsBwdBlocks);
                 hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(gr), dim3(kBlock), 0, hs, sf.dz, a.new_fbond, w.f, wide, d, H, e->frag,
                                    bw.g_pre_fbond, sf.part_rd, have_fbond ? (const float*)bw.g_pre_fbond : (const float*)nullptr, 1);
                 FN_TRY(launch_status("fn_encoder_backward: row_dots(frag)"));
@@ -3072,7 +3073,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_atoms, a.h_a, sa.pz, sa.g_s_dst, w.a, wide, 0, d + FN_D, &e->atom, sa.g_h, sa.part_a, &n_a, H, st));
             int gr = 0;
             if (e->atom.m_real > 0) {
-                gr = row_grid(e->atom.m_real, 512);
+                gr = row_grid(e->atom.m_real, kRowDotsBwdBlocks);
                 hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(gr), dim3(kBlock), 0, hs, sa.dz, a.new_bond, w.a, wide, d, H, e->atom,
                                    bw.g_pre_bond, sa.part_rd, have_bond ? (const float*)bw.g_pre_bond : (const float*)nullptr, 1);
                 FN_TRY(launch_status("fn_encoder_backward: row_dots(atom)"));
