@@ -1477,7 +1477,8 @@ __global__ void k_edge_concat(const float* __restrict__ x, const float* __restri
 // =====================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kBtLd = 144;     // LDS leading dimension of the [K][128] operand: 144 % 32 == 16
-constexpr int kLinLd = 68;     // k_linear128's operand tile [K][64 columns]: 4 rows apart = 16 banks apart, so the four k-quarters of a wave do not collide
+constexpr int kLinLd = 64;     // k_linear128's operand tile [K][64 columns], unpadded: a lane reads 4 consecutive columns (ds_read_b128) and the
+                               // 16-lane groups of that instruction then cover all 64 banks exactly once (rows 4 apart share the bank alignment)
 
 // A block = 8 waves = 64 rows x 128 columns: wave w owns rows 16*(w&3).. and columns 64*(w>>2).. (4 accumulator
 // tiles), so two waves share every SIMD and one wave's LDS reads hide under the other's MFMAs.  Bt is staged in
@@ -1529,7 +1530,8 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
     };
 
     float cur[KQ];
-    const float* bbase = sBt + (VEC ? 4 * kq : kq * KQ) * kLinLd + i;
+    // MFMA tile t of a wave covers the columns {4 i + t}: one 16-byte LDS read per step feeds all four tiles
+    const float* bbase = sBt + (VEC ? 4 * kq : kq * KQ) * kLinLd + 4 * i;
     auto brow = [](int s) { return VEC ? 16 * (s >> 2) + (s & 3) : s; };      // LDS row of MFMA step s, relative to bbase
     for (int64_t tile = bid >> 1; tile < tiles; tile += nblk >> 1) {
         {   // stage Bt [4*KQ][this half's 64 columns] -> LDS with 16-byte loads; the A rows ride in the same round trip
@@ -1562,26 +1564,40 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
         f32x4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        float b0[4], b1[4];
+        // B operands are read four steps (16 MFMAs) ahead, in two register groups
+        constexpr int NG = (KQ + 3) / 4;
+        float4 bg[2][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) b0[t] = bbase[brow(0) * kLinLd + 16 * t];
+        for (int q = 0; q < 4; ++q) bg[0][q] = q < KQ ? *reinterpret_cast<const float4*>(bbase + brow(q) * kLinLd) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int s = 0; s < KQ; ++s) {                       // B operands of step s+1 are read while step s multiplies
-            if (s + 1 < KQ) {
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) b1[t] = bbase[brow(s + 1) * kLinLd + 16 * t];
+                for (int q = 0; q < 4; ++q) {
+                    const int sn = 4 * (g + 1) + q;
+                    if (sn < KQ) bg[(g + 1) & 1][q] = *reinterpret_cast<const float4*>(bbase + brow(sn) * kLinLd);
+                }
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[s], b0[t], acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) b0[t] = b1[t];
+            for (int q = 0; q < 4; ++q) {
+                const int sc = 4 * g + q;
+                if (sc < KQ) {
+                    const float4 b = bg[g & 1][q];
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[sc], b.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[sc], b.y, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[sc], b.z, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[sc], b.w, acc[3], 0, 0, 0);
+                }
+            }
         }
         __syncthreads();                                     // every wave is done with the operand tile: reuse its LDS
-        // wave-private transpose through LDS: acc[t][r] is (row kq*4+r, col 16t+i) of the 16 x 64 tile
+        // wave-private transpose through LDS: acc[t][r] is (row kq*4+r, col 4i+t) of the 16 x 64 tile
+        {
+            const float4 bv = *reinterpret_cast<const float4*>(sAtt + 128 + 4 * i);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sOut[(kq * 4 + r) * kLinOutLd + 16 * t + i] = acc[t][r] + sAtt[128 + 16 * t + i];
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<float4*>(sOut + (kq * 4 + r) * kLinOutLd + 4 * i) =
+                    make_float4(acc[0][r] + bv.x, acc[1][r] + bv.y, acc[2][r] + bv.z, acc[3][r] + bv.w);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the wave's own LDS writes have landed
         __builtin_amdgcn_wave_barrier();
