@@ -1149,6 +1149,30 @@ __global__ __launch_bounds__(kBlock) void k_row_dots_sorted_bwd(const float* __r
     // destination-sorted head-major order [J][m] through the inverse permutation (autograd path)
     int64_t g0, g1;
     block_groups(pl.m_real, kRows, g0, g1);
+    if (g_is_orig && J == 4) {
+        // engine path: 4 heads, gradient in original edge order.  Four rows per trip, every load issued before the
+        // first use (a single-row loop is one dependent round trip per row: 15 us for 28 k rows)
+        for (int64_t gi = g0; gi < g1; gi += 4) {
+            float4 v[4], ad[4], gs[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int64_t e = (gi + u) * kRows + hw;
+                e = (gi + u < g1 && e < pl.m_real) ? e : pl.m_real - 1;
+                v[u] = ld4(feat + e * FN_D + lane * 4);
+                gs[u] = ld4(g_s_sorted + e * 4);
+                ad[u] = addend ? ld4(addend + e * FN_D + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t e = (gi + u) * kRows + hw;
+                if (gi + u >= g1 || e >= pl.m_real) continue;
+                float4 acc = ad[u];
+                fma4(acc, gs[u].x, a[0]);  fma4(acc, gs[u].y, a[1]);  fma4(acc, gs[u].z, a[2]);  fma4(acc, gs[u].w, a[3]);
+                fma4(q[0], gs[u].x, v[u]);  fma4(q[1], gs[u].y, v[u]);  fma4(q[2], gs[u].z, v[u]);  fma4(q[3], gs[u].w, v[u]);
+                st4(g_feat + e * FN_D + lane * 4, acc);
+            }
+        }
+    } else
     for (int64_t gi = g0; gi < g1; ++gi) {
         const int64_t e = gi * kRows + hw;
         if (e >= pl.m_real) continue;
