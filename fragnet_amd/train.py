@@ -168,12 +168,17 @@ class TrainerFineTune:
             return self.loss_fn(out.view(-1), batch["y"])
         return self.loss_fn(out, batch["y"].view(out.shape))
 
-    def train(self, model, loader, optimizer, scheduler=None, device=None, val_loader=None):
-        """``optimizer``: torch.optim.Optimizer or parallel.FlatAdam."""
+    def train(self, model, loader, optimizer, scheduler=None, device=None, val_loader=None, graph_step=None):
+        """``optimizer``: torch.optim.Optimizer or parallel.FlatAdam.  ``graph_step``: a graphstep.GraphedTrainStep over
+        the same model and optimiser -- every batch then costs one staging kernel, one hipGraph replay and the Adam
+        kernel (batches beyond its capacities take the eager step inside it)."""
         model.train()
         total = 0.0
         losses = []
         for batch in loader:
+            if graph_step is not None:
+                losses.append(graph_step(batch).clone())
+                continue
             optimizer.zero_grad()
             loss = self._loss(model, batch)
             loss.backward()

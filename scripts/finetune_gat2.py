@@ -55,7 +55,17 @@ if __name__ == "__main__":
     trainer = train.TrainerFineTune(target_type=ft.target_type)
     probe = next(iter(train_loader))
     optimizer = train.make_optimizer(model, float(ft.lr), probe, lambda mdl, b: trainer._loss(mdl, b))
-    fragnet_amd.graph_capture_head(model, len(probe["y"]))      # training batches have a fixed size (drop_last)
+    # whole-step hipGraph over static shapes (fragnet_amd/graphstep.py); `finetune.graph_step: false` in the YAML keeps
+    # the launch-by-launch step (then only the prediction head is graph-captured)
+    graph_step = None
+    if ft.get("graph_step", True) and ft.target_type in ("regr", "clsf"):
+        from fragnet_amd import graphstep
+        sample = [probe] + [b for _, b in zip(range(7), iter(train_loader))]
+        shapes = graphstep.StaticShapes.from_batches(sample, margin=0.05, heads=m.num_heads)
+        model.train()
+        graph_step = graphstep.GraphedTrainStep(model, optimizer, shapes, probe, loss=ft.target_type)
+    else:
+        fragnet_amd.graph_capture_head(model, len(probe["y"]))      # training batches have a fixed size (drop_last)
     scheduler = None
     if ft.get("use_schedular"):
         class _Linear:          # LinearLR(start_factor=1.0, end_factor=0.5, total_iters=30), finetune_gat2.py:258-259
@@ -67,10 +77,10 @@ if __name__ == "__main__":
     stopper = train.EarlyStopping(patience=ft.es_patience, verbose=rank == 0, chkpoint_name=ft.chkpoint_name)
     log = open(os.path.join(exp_dir, "log.jsonl"), "a") if rank == 0 else None
     for epoch in range(ft.n_epochs):
-        train_loss = trainer.train(model=model, loader=train_loader, optimizer=optimizer, scheduler=scheduler)
+        train_loss = trainer.train(model=model, loader=train_loader, optimizer=optimizer, scheduler=scheduler, graph_step=graph_step)
         val_loss, _, _ = trainer.test(model=model, loader=val_loader)
         if rank == 0:
-            print("epoch: ", epoch, train_loss, val_loss)
+            print("epoch: ", epoch, train_loss, val_loss, "" if graph_step is None else f"(graph replays {graph_step.replays}, eager fallbacks {graph_step.fallbacks})")
             log.write(json.dumps({"epoch": epoch, "Loss/train": train_loss, "Loss/val": val_loss}) + "\n")
             log.flush()
         score = -val_loss if ft.target_type == "clsf" else val_loss      # AUC: higher is better
