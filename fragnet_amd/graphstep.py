@@ -42,10 +42,14 @@ FIELDS = {
     "frag_index": ("fedge", "cols", "frag"), "cnx_attr": ("fedge", "rows", None), "node_features_fbonds": ("fedge", "rows", None),
     "edge_index_fbonds": ("fbedge", "cols", "fedge"), "edge_attr_fbonds": ("fbedge", "rows", None),
     "y": ("mol", "rows", None),
+    # pretrain targets (collate_fn_pt, dataset/data.py:1028-1030)
+    "bnd_lngth": ("edge", "rows", None), "bnd_angl": ("atom", "rows", None), "dh_angl": ("edge", "rows", None),
 }
 COUNT_FIELD = {"atom": "x_atoms", "edge": "node_features_bonds", "bedge": "edge_attr_bonds", "frag": "x_frags",
                "fedge": "node_features_fbonds", "fbedge": "edge_attr_fbonds", "mol": "y"}
 MASK_KEY = "mol_weight"           # float32 [mol cap]: 1 for real molecules, 0 for padding
+MASKS = {"mol": MASK_KEY, "atom": "atom_weight", "edge": "edge_weight"}     # 1/0 weights of the mean losses
+SCALE_KEY = "loss_scales"         # float32 [2]: (per-edge, per-atom) rank weights of the pretrain loss, 1 on one GPU
 
 
 def _gat_limit(heads: int) -> int:
@@ -135,9 +139,10 @@ def pad_batch(batch: Dict[str, torch.Tensor], shapes: StaticShapes) -> Dict[str,
                 dst = pad.repeat(2, 1)
                 dst[:, :n] = src
         out[name] = dst
-    w = torch.zeros(shapes.cap["mol"], dtype=torch.float32, device=batch["y"].device)
-    w[: counts["mol"]] = 1.0
-    out[MASK_KEY] = w
+    for space, key in MASKS.items():
+        w = torch.zeros(shapes.cap[space], dtype=torch.float32, device=batch["y"].device)
+        w[: counts[space]] = 1.0
+        out[key] = w
     return out
 
 
@@ -156,6 +161,18 @@ def masked_bce_loss(out: torch.Tensor, y: torch.Tensor, w: torch.Tensor) -> torc
     valid = (y > -0.5) & (w[:, None] > 0)
     mat = torch.nn.functional.binary_cross_entropy_with_logits(out, y.clamp(min=0.0), reduction="none")
     return torch.where(valid, mat, torch.zeros_like(mat)).sum() / valid.sum()
+
+
+def masked_pretrain_loss(outputs, sb: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """The reference's pretrain loss (pretrain_utils.py:9-31: 2*MSE(dihedral) + MSE(angle) + MSE(energy); the
+    bond-length term is overwritten there before use) over a padded batch, with the rank weights of
+    parallel.weighted_loss_scale applied to the per-edge and per-atom means."""
+    from . import ops
+    _, ba, da, graph_rep = outputs
+    sc = sb[SCALE_KEY]
+    l_dh = ops.masked_mse(da, sb["dh_angl"], sb[MASKS["edge"]]) * sc[0]
+    return l_dh + ops.masked_mse(ba, sb["bnd_angl"], sb[MASKS["atom"]]) * sc[1] + l_dh \
+        + ops.masked_mse(graph_rep, sb["y"], sb[MASK_KEY])
 
 
 class StaticBatch:
@@ -184,14 +201,20 @@ class StaticBatch:
                 hi, mod = shapes.pad_rule(target)
                 self.t[name] = torch.zeros((cap,) if layout == "ids" else (2, cap), dtype=torch.int64, device=dev)
                 self._desc.append((name, space, _lib.STAGE_IDS if layout == "ids" else _lib.STAGE_COLS, 1, hi, mod))
-        self.t[MASK_KEY] = torch.zeros(shapes.cap["mol"], dtype=torch.float32, device=dev)
+        for space, key in MASKS.items():
+            self.t[key] = torch.zeros(shapes.cap[space], dtype=torch.float32, device=dev)
+        self.t[SCALE_KEY] = torch.ones(2, dtype=torch.float32, device=dev)
         self._fields = (_lib.StageField * _lib.FN_MAX_STAGE_FIELDS)()
         for i, (name, space, kind, width, hi, mod) in enumerate(self._desc):
             f = self._fields[i]
             f.dst, f.cap, f.width, f.kind, f.pad_hi, f.pad_mod = self.t[name].data_ptr(), shapes.cap[space], width, kind, hi, mod
-        m = self._fields[len(self._desc)]
-        m.dst, m.cap, m.width, m.kind, m.pad_hi, m.pad_mod = self.t[MASK_KEY].data_ptr(), shapes.cap["mol"], 1, _lib.STAGE_MASK, 0, 1
-        self.n_fields = len(self._desc) + 1
+        self._mask_spaces = list(MASKS)
+        for q, space in enumerate(self._mask_spaces):
+            m = self._fields[len(self._desc) + q]
+            m.dst, m.cap, m.width, m.kind, m.pad_hi, m.pad_mod = self.t[MASKS[space]].data_ptr(), shapes.cap[space], 1, _lib.STAGE_MASK, 0, 1
+        self.n_fields = len(self._desc) + len(self._mask_spaces)
+        if self.n_fields > _lib.FN_MAX_STAGE_FIELDS:
+            raise ValueError("too many batch fields for one staging launch")
         self.counts: Optional[Dict[str, int]] = None
 
     def load(self, batch: Dict[str, torch.Tensor]) -> bool:
@@ -209,8 +232,9 @@ class StaticBatch:
                 keep.append(src)
             f = self._fields[i]
             f.src, f.n_real = src.data_ptr(), counts[space]
-        m = self._fields[self.n_fields - 1]
-        m.src, m.n_real = None, counts["mol"]
+        for q, space in enumerate(self._mask_spaces):
+            m = self._fields[len(self._desc) + q]
+            m.src, m.n_real = None, counts[space]
         _lib.call("fn_stage_padded", self._fields, self.n_fields, torch.cuda.current_stream(self.device).cuda_stream)
         self.counts = counts
         return True
@@ -219,17 +243,22 @@ class StaticBatch:
 class GraphedTrainStep:
     """zero_grad + forward + loss + backward + gradient gather as one hipGraph; all-reduce + Adam after it.
 
-    ``model``: FragNetFineTune (fragnet_amd.model) in train mode; ``opt``: parallel.FlatAdam over its live
-    parameters; ``loss``: "regr" (MSE, train/utils.py:341) or "clsf" (masked BCE, train/utils.py:297).
+    ``model``: FragNetFineTune / FragNetPreTrain (fragnet_amd.model) in train mode; ``opt``: parallel.FlatAdam over its
+    live parameters; ``loss``: "regr" (MSE, train/utils.py:341), "clsf" (masked BCE, train/utils.py:297) or "pretrain"
+    (pretrain_utils.py:9-31 on the collate_fn_pt batch).
     """
 
     def __init__(self, model, opt, shapes: StaticShapes, example: Dict[str, torch.Tensor], loss: str = "regr",
                  group=None, warmup: int = 3):
         self.model, self.opt, self.shapes, self.group = model, opt, shapes, group
         self.loss_kind = loss
-        self._masked = {"regr": masked_regr_loss, "clsf": masked_bce_loss}[loss]
+        if loss not in ("regr", "clsf", "pretrain"):
+            raise ValueError(f"unknown loss kind {loss!r}")
+        self._masked = {"regr": masked_regr_loss, "clsf": masked_bce_loss, "pretrain": None}[loss]
         self.static = StaticBatch(shapes, example)
         self.device = self.static.device
+        if loss == "pretrain" and "dh_angl" not in example:
+            raise ValueError("pretrain step needs the collate_fn_pt batch (bnd_lngth, bnd_angl, dh_angl)")
         self.rng = model.pretrain.rng
         self.rng.use_device_counter(self.device)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
@@ -241,7 +270,10 @@ class GraphedTrainStep:
     def _fwd_bwd_static(self):
         sb = self.static.t
         sb.pop(PLAN_KEY, None)                      # every step builds its own graph plan (inside the graph)
-        loss = self._masked(self.model(sb), sb["y"], sb[MASK_KEY])
+        if self.loss_kind == "pretrain":
+            loss = masked_pretrain_loss(self.model(sb), sb)
+        else:
+            loss = self._masked(self.model(sb), sb["y"], sb[MASK_KEY])
         loss.backward()
         self.opt.gather_grads()
         return loss
@@ -269,11 +301,26 @@ class GraphedTrainStep:
                 self.rng.advance_device(consumed)   # fresh dropout masks on every replay
         self.graph, self.loss = graph, loss.detach()
 
+    def _rank_scales(self, batch) -> Optional[torch.Tensor]:
+        """(per-edge, per-atom) loss weights local_count * world / global_count as a device tensor (no host sync)."""
+        import torch.distributed as dist
+        if self.loss_kind != "pretrain" or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return None
+        local = torch.tensor([float(batch["dh_angl"].shape[0]), float(batch["bnd_angl"].shape[0])], device=self.device)
+        total = local.clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+        return (local * dist.get_world_size(self.group) / total).to(torch.float32)
+
     def _eager(self, batch):
         self.opt.zero_grad()
-        out = self.model(batch)
-        w = torch.ones(batch["y"].shape[0], dtype=torch.float32, device=out.device)
-        loss = self._masked(out, batch["y"], w)
+        if self.loss_kind == "pretrain":
+            from .train import pretrain_loss
+            sc = self._rank_scales(batch)
+            loss = pretrain_loss(self.model(batch), batch, (1.0, 1.0) if sc is None else (sc[0], sc[1]))
+        else:
+            out = self.model(batch)
+            w = torch.ones(batch["y"].shape[0], dtype=torch.float32, device=out.device)
+            loss = self._masked(out, batch["y"], w)
         loss.backward()
         self.opt.step(self.group)
         return loss.detach()
@@ -283,6 +330,9 @@ class GraphedTrainStep:
         if not self.static.load(batch):
             self.fallbacks += 1
             return self._eager(batch)
+        sc = self._rank_scales(batch)
+        if sc is not None:
+            self.static.t[SCALE_KEY].copy_(sc)
         self.graph.replay()
         self.opt.apply_gathered(self.group)
         self.replays += 1

@@ -221,10 +221,13 @@ class PretrainTrainer:
     def __init__(self, loss_fn=None):
         self.loss_fn = loss_fn
 
-    def train(self, model, loader, optimizer, device=None):
+    def train(self, model, loader, optimizer, device=None, graph_step=None):
         model.train()
         losses = []
         for batch in loader:
+            if graph_step is not None:          # graphstep.GraphedTrainStep(..., loss="pretrain")
+                losses.append(graph_step(batch).clone())
+                continue
             optimizer.zero_grad()
             scales = (1.0, 1.0)
             if parallel.dist.is_available() and parallel.dist.is_initialized() and parallel.dist.get_world_size() > 1:

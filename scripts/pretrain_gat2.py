@@ -45,11 +45,18 @@ if __name__ == "__main__":
     trainer = train.PretrainTrainer()
     probe = next(iter(train_loader))
     optimizer = train.make_optimizer(model, float(pt.lr), probe, lambda mdl, b: train.pretrain_loss(mdl(b), b))
+    graph_step = None
+    if pt.get("graph_step", True):      # whole-step hipGraph over static shapes; `pretrain.graph_step: false` = eager step
+        from fragnet_amd import graphstep
+        sample = [probe] + [b for _, b in zip(range(7), iter(train_loader))]
+        shapes = graphstep.StaticShapes.from_batches(sample, margin=0.05, heads=pt.num_heads)
+        model.train()
+        graph_step = graphstep.GraphedTrainStep(model, optimizer, shapes, probe, loss="pretrain")
     stopper = train.EarlyStopping(patience=pt.es_patience, verbose=rank == 0, chkpoint_name=pt.chkpoint_name)
     every = int(pt.get("valdiate_every", 5))          # sic: the reference's key
     log = open(os.path.join(exp_dir, "log.jsonl"), "a") if rank == 0 else None
     for epoch in range(pt.n_epochs):
-        train_loss = trainer.train(model, train_loader, optimizer)
+        train_loss = trainer.train(model, train_loader, optimizer, graph_step=graph_step)
         rec = {"epoch": epoch, "Loss/train": train_loss}
         if epoch % every == 0:
             val_loss = trainer.validate(val_loader, model)

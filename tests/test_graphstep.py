@@ -28,6 +28,8 @@ def test_capacities_and_padding_structure():
         assert shapes.fits(counts)
         pb = graphstep.pad_batch(b, shapes)
         for name, (space, layout, target) in graphstep.FIELDS.items():
+            if name not in b:            # pretrain targets are only in collate_fn_pt batches
+                continue
             n, cap = counts[space], shapes.cap[space]
             t = pb[name]
             assert (t.shape[1] if layout == "cols" else t.shape[0]) == cap
@@ -47,7 +49,8 @@ def test_capacities_and_padding_structure():
             pad_cols = pb[key][:, counts[graphstep.FIELDS[key][0]]:]
             if pad_cols.numel():
                 assert int(torch.bincount(pad_cols[0]).max()) <= lim
-        assert float(pb[graphstep.MASK_KEY].sum()) == counts["mol"]
+        for space, key in graphstep.MASKS.items():
+            assert float(pb[key].sum()) == counts[space] and float(pb[key][: counts[space]].min()) == 1.0
     big = _batches(1, 40, seed=99)[0]
     assert not shapes.fits(graphstep.batch_counts(big))
     with pytest.raises(ValueError):
@@ -200,3 +203,33 @@ def test_pool_cat_and_masked_mse_match_torch():
         (3.0 * ref_loss).backward()
         torch.testing.assert_close(loss, ref_loss.detach(), atol=1e-6, rtol=1e-5)
         torch.testing.assert_close(o.grad, o2.grad, atol=1e-7, rtol=1e-5)
+
+
+@gpu
+def test_pretrain_graph_step_matches_eager_step():
+    """loss="pretrain": per-edge / per-atom / per-molecule masked means over the padded collate_fn_pt batch."""
+    from fragnet_amd import parallel, train
+    from fragnet_amd.model import FragNetPreTrain
+    dev = _dev()
+    batches = [data.batch_to(data.collate_fn_pt(synth.synth_molecules(40, seed=60 + i, profile="esol", pretrain_targets=True)), dev)
+               for i in range(3)]
+    shapes = graphstep.StaticShapes.from_batches(batches, margin=0.05)
+    torch.manual_seed(5)
+    model_a = FragNetPreTrain(num_layer=2, drop_ratio=0.0, edge_features=17).to(dev).train()
+    model_b = copy.deepcopy(model_a)
+
+    def probe(model):
+        return lambda: train.pretrain_loss(model(dict(batches[0])), batches[0]).backward()
+    opt_a = parallel.FlatAdam.for_live_parameters(model_a, probe(model_a), lr=1e-3)
+    opt_b = parallel.FlatAdam.for_live_parameters(model_b, probe(model_b), lr=1e-3)
+    step_b = graphstep.GraphedTrainStep(model_b, opt_b, shapes, dict(batches[0]), loss="pretrain")
+    for i in range(5):
+        b = batches[i % 3]
+        opt_a.zero_grad()
+        loss_a = train.pretrain_loss(model_a(dict(b)), b)
+        loss_a.backward()
+        opt_a.step()
+        loss_b = step_b(dict(b)).clone()
+        torch.testing.assert_close(loss_b, loss_a.detach(), atol=1e-5, rtol=1e-4)
+    assert step_b.replays == 5 and step_b.fallbacks == 0
+    torch.testing.assert_close(opt_b.flat, opt_a.flat, atol=2e-5, rtol=1e-3)
