@@ -97,6 +97,8 @@ class FragNetLayerA(nn.Module):
         self.frag_bond_mask = frag_bond_mask
         self.atom_mask_individual = atom_mask_individual
 
+    lite = False      # set by FragNet(variant="gat2_lite")
+
     def forward(self, x_atoms, edge_index, edge_attr, frag_index, x_frags, atom_to_frag_ids,
                 node_feautures_bond_graph, edge_index_bonds_graph, edge_attr_bond_graph,
                 node_feautures_fbond_graph, edge_index_fbond_graph, edge_attr_fbond_graph):
@@ -136,6 +138,11 @@ class FragNetLayerA(nn.Module):
 
         # L3 atom -> fragment sum (gat2.py:234)
         frags = ops.segment_sum(atoms_new, plan.segs["a2f"], plan)
+        if self.lite:            # model_version gat2_lite (gat2_lite.py:65-150): levels L1-L3 only
+            if want:
+                return (atoms_new, frags, new_bond, None, ops.attn_by_src(p_atom, L["atom"], H), None,
+                        ops.attn_by_src(p_bond, L["bond"], H), None)
+            return atoms_new, frags, new_bond, None
 
         # L4a fragment-bond graph (gat2.py:239-272)
         r = ops.gat_level(F.linear(fbond_nodes, self.projection_fb.weight, self.projection_fb.bias), self.f_a_b,
@@ -161,8 +168,11 @@ class FragNetLayerA(nn.Module):
 
 class FragNet(nn.Module):
     def __init__(self, num_layer, drop_ratio=0.2, emb_dim=128, atom_features=167, frag_features=167,
-                 edge_features=17, fedge_in=6, fbond_edge_in=6, num_heads=4):
+                 edge_features=17, fedge_in=6, fbond_edge_in=6, num_heads=4, variant="gat2"):
         super().__init__()
+        if variant not in ("gat2", "gat2_lite"):
+            raise ValueError(f"model_version {variant!r}: gat2 and gat2_lite are on the accelerated path")
+        self.variant = variant      # gat2_lite = fragnet/model/gat/gat2_lite.py: same parameters, levels L1-L3 only
         self.num_layer = num_layer
         self.dropout = nn.Dropout(p=drop_ratio)
         self.act = nn.ReLU()
@@ -180,7 +190,10 @@ class FragNet(nn.Module):
     def forward(self, batch):
         plan = plan_for(batch)
         p, train = self.dropout.p, self.training
-        if self.use_engine and not any(l.return_attentions or l.bond_mask is not None or l.frag_bond_mask is not None
+        lite = self.variant == "gat2_lite"
+        for layer in self.layers:
+            layer.lite = lite
+        if self.use_engine and not lite and not any(l.return_attentions or l.bond_mask is not None or l.frag_bond_mask is not None
                                        or l.atom_mask_individual is not None for l in self.layers):
             # whole encoder in two C calls (fragnet_amd/engine.py); masks / attention outputs use the per-level path
             return engine.encoder_forward(self.layers, plan, batch["x_atoms"], batch["node_features_bonds"],
@@ -198,8 +211,9 @@ class FragNet(nn.Module):
             x_atoms = ops.dropout_act(x_atoms, p, train, True, self.rng)
             x_frags = ops.dropout_act(x_frags, p, train, True, self.rng)
             bond_nodes = ops.dropout_act(bond_nodes, p, train, True, self.rng)
-            fbond_nodes = ops.dropout_act(fbond_nodes, p, train, True, self.rng)
-        return x_atoms, x_frags, bond_nodes, fbond_nodes
+            if not lite:
+                fbond_nodes = ops.dropout_act(fbond_nodes, p, train, True, self.rng)
+        return x_atoms, x_frags, bond_nodes, (None if lite else fbond_nodes)
 
 
 # ------------------------------------------------------------------------------------ heads
@@ -292,10 +306,11 @@ def pooled(x_atoms, x_frags, batch):
 class FragNetFineTune(nn.Module):
     def __init__(self, n_classes=1, atom_features=167, frag_features=167, edge_features=17, num_layer=4,
                  num_heads=4, drop_ratio=0.15, h1=256, h2=256, h3=256, h4=256, act="celu", emb_dim=128,
-                 fthead="FTHead3"):
+                 fthead="FTHead3", variant="gat2"):
         super().__init__()
         self.pretrain = FragNet(num_layer=num_layer, drop_ratio=drop_ratio, num_heads=num_heads, emb_dim=emb_dim,
-                                atom_features=atom_features, frag_features=frag_features, edge_features=edge_features)
+                                atom_features=atom_features, frag_features=frag_features, edge_features=edge_features,
+                                variant=variant)
         if fthead == "FTHead1":
             self.fthead = FTHead1(n_classes=n_classes)
         elif fthead == "FTHead2":
@@ -312,6 +327,15 @@ class FragNetFineTune(nn.Module):
     def forward(self, batch):
         x_atoms, x_frags, _, _ = self.pretrain(batch)
         return self.fthead(pooled(x_atoms, x_frags, batch))
+
+
+class FragNetFineTuneLite(FragNetFineTune):
+    """fragnet.model.gat.gat2_lite.FragNetFineTune (finetune_gat2.py:141-146, model_version "gat2_lite"): the same
+    parameters and state-dict keys as gat2, each layer stops after the atom -> fragment sum."""
+
+    def __init__(self, *args, **kw):
+        kw["variant"] = "gat2_lite"
+        super().__init__(*args, **kw)
 
 
 class PretrainTask(nn.Module):

@@ -95,6 +95,8 @@ class FragNetLayerA(nn.Module):
         self.frag_bond_mask = frag_bond_mask
         self.atom_mask_individual = atom_mask_individual
 
+    lite = False
+
     def forward(self, x_atoms, edge_index, edge_attr, frag_index, x_frags, atom_to_frag_ids,
                 bond_nodes, bond_graph_index, bond_graph_attr, fbond_nodes, fbond_graph_index, fbond_graph_attr):
         H = self.num_heads
@@ -122,6 +124,10 @@ class FragNetLayerA(nn.Module):
 
         # L3: atom -> fragment sum (the incoming x_frags is overwritten) -- :234
         frags = scatter_add(atoms_new, atom_to_frag_ids, dim=0)
+        if self.lite:            # model_version gat2_lite stops here (gat2_lite.py:65-150): no fragment(-bond) graphs
+            if self.return_attentions:
+                return atoms_new, frags, new_bond, None, attn_a, None, attn_b, None
+            return atoms_new, frags, new_bond, None
 
         # L4a: fragment-bond graph -- :239-272
         dst, src = fbond_graph_index
@@ -146,8 +152,11 @@ class FragNetLayerA(nn.Module):
 
 class FragNet(nn.Module):
     def __init__(self, num_layer, drop_ratio=0.2, emb_dim=128, atom_features=167, frag_features=167,
-                 edge_features=17, fedge_in=6, fbond_edge_in=6, num_heads=4):
+                 edge_features=17, fedge_in=6, fbond_edge_in=6, num_heads=4, variant="gat2"):
         super().__init__()
+        if variant not in ("gat2", "gat2_lite"):
+            raise ValueError(variant)
+        self.variant = variant           # "gat2_lite": fragnet/model/gat/gat2_lite.py (same parameters, levels L1-L3)
         self.num_layer = num_layer
         self.dropout = nn.Dropout(p=drop_ratio)
         self.act = nn.ReLU()
@@ -161,6 +170,9 @@ class FragNet(nn.Module):
                                              fbond_edge_in=fbond_edge_in, num_heads=num_heads))
 
     def forward(self, batch, trace=None):
+        lite = self.variant == "gat2_lite"
+        for layer in self.layers:
+            layer.lite = lite
         drop_act = lambda t: self.act(self.dropout(t))
         x_atoms = self.dropout(batch["x_atoms"])
         x_frags = self.dropout(batch["x_frags"])
@@ -175,7 +187,8 @@ class FragNet(nn.Module):
             if trace is not None:
                 trace.append((x_atoms, x_frags, bond_nodes, fbond_nodes))
             x_atoms, x_frags = drop_act(x_atoms), drop_act(x_frags)
-            bond_nodes, fbond_nodes = drop_act(bond_nodes), drop_act(fbond_nodes)
+            bond_nodes = drop_act(bond_nodes)
+            fbond_nodes = None if lite else drop_act(fbond_nodes)     # gat2_lite.py:197-214
             e_attr = bond_nodes          # layers 1.. receive the bond features as edge_attr too (gat2.py:424)
         return x_atoms, x_frags, bond_nodes, fbond_nodes
 
@@ -224,10 +237,11 @@ def pool_cat(x_atoms, x_frags, batch):
 class FragNetFineTune(nn.Module):
     def __init__(self, n_classes=1, atom_features=167, frag_features=167, edge_features=17, num_layer=4,
                  num_heads=4, drop_ratio=0.15, h1=256, h2=256, h3=256, h4=256, act="celu", emb_dim=128,
-                 fthead="FTHead3"):
+                 fthead="FTHead3", variant="gat2"):
         super().__init__()
         self.pretrain = FragNet(num_layer=num_layer, drop_ratio=drop_ratio, num_heads=num_heads, emb_dim=emb_dim,
-                                atom_features=atom_features, frag_features=frag_features, edge_features=edge_features)
+                                atom_features=atom_features, frag_features=frag_features, edge_features=edge_features,
+                                variant=variant)
         if fthead == "FTHead3":
             self.fthead = FTHead3(n_classes=n_classes, input_dim=emb_dim, h1=h1, h2=h2, h3=h3, h4=h4,
                                   drop_ratio=drop_ratio, act=act)

@@ -32,12 +32,12 @@ if __name__ == "__main__":
     exp_dir = args["exp_dir"]
     os.makedirs(exp_dir, exist_ok=True)
     ft, m = args.finetune, args.finetune.model
-    if args.model_version != "gat2":
-        raise SystemExit("only model_version gat2 is on the accelerated path")
+    if args.model_version not in ("gat2", "gat2_lite"):
+        raise SystemExit("model_version gat2 and gat2_lite are on the accelerated path")
     model = FragNetFineTune(n_classes=m.n_classes, atom_features=args.atom_features, frag_features=args.frag_features,
                             edge_features=args.edge_features, num_layer=m.num_layer, drop_ratio=m.drop_ratio,
                             num_heads=m.num_heads, emb_dim=m.emb_dim, h1=m.h1, h2=m.h2, h3=m.h3, h4=m.h4, act=m.act,
-                            fthead=m.fthead)
+                            fthead=m.fthead, variant=args.model_version)
     pt = args.pretrain
     if pt.get("chkpoint_name") and os.path.exists(str(pt.chkpoint_name)):
         modelpt = FragNetPreTrain(num_layer=pt.num_layer, drop_ratio=pt.drop_ratio, num_heads=pt.num_heads, emb_dim=pt.emb_dim,

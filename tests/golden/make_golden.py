@@ -293,5 +293,38 @@ def main():
     print("layer_attn_masks_b3 written")
 
 
+def lite_case():
+    """model_version gat2_lite (fragnet/model/gat/gat2_lite.py: levels L1-L3 only): ft_lite_b6.npz.
+    Run with `python tests/golden/make_golden.py lite` -- leaves the other fixtures untouched."""
+    install_stubs()
+    with quiet():
+        from fragnet.model.gat import gat2_lite as ref_lite
+        from fragnet.dataset import data as ref_data
+    from fragnet_amd import synth
+    torch.set_num_threads(1)
+    torch.use_deterministic_algorithms(True)
+    cfg = dict(n_classes=1, atom_features=167, frag_features=167, edge_features=17, num_layer=3, num_heads=4,
+               drop_ratio=0.0, h1=64, h2=128, h3=128, h4=64, act="relu", emb_dim=128, fthead="FTHead3")
+    mols = synth.synth_molecules(6, seed=4100, profile="esol")
+    batch = ref_data.collate_fn(mols)
+    torch.manual_seed(7)
+    with quiet():
+        model = ref_lite.FragNetFineTune(**cfg)
+    zero_dead_bias(model)
+    model.train()
+    trace = []
+    hooks = [l.register_forward_hook(lambda m, i, o: trace.append([t.detach().numpy().copy() for t in o[:3]]))
+             for l in model.pretrain.layers]
+    with quiet():
+        out = model(batch)
+    for h in hooks:
+        h.remove()
+    loss = torch.nn.functional.mse_loss(out.view(-1), batch["y"])
+    loss.backward()
+    save_case("ft_lite_b6", {"kind": "finetune_lite", "ctor": cfg, "seed": 7, "loss": "mse"}, batch, model,
+              {"logits": out}, loss, trace)
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    lite_case() if sys.argv[1:] == ["lite"] else main()

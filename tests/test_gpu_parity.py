@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import check_grads, load_case
+from tests.helpers import check_grads, check_params_match, load_case
 
 pytestmark = pytest.mark.gpu
 
@@ -331,6 +331,26 @@ def test_finetune_matches_reference_golden(case, use_engine):
     loss.backward()
     torch.cuda.synchronize()
     b["_fragnet_plan"].check()
+    check_grads(model, grads, atol=ATOL, rtol=2e-3)
+
+
+def test_gat2_lite_matches_reference_golden():
+    """model_version gat2_lite: per-layer outputs, logits, loss and gradients of the reference's
+    gat2_lite.FragNetFineTune; same state-dict keys as gat2."""
+    from fragnet_amd.model import FragNetFineTuneLite
+    cfg, batch, out, grads, pkeys, psums = load_case("ft_lite_b6")
+    torch.manual_seed(cfg["seed"])
+    model = FragNetFineTuneLite(**cfg["ctor"])
+    check_params_match(model, pkeys, psums)
+    model = model.to(DEV).train()
+    b = _to_dev(batch)
+    x_atoms, x_frags, bond, fbond = model.pretrain(b)
+    assert fbond is None
+    logits = model(b)
+    torch.testing.assert_close(logits.detach().cpu(), torch.from_numpy(out["logits"]), atol=ATOL, rtol=1e-4)
+    loss = torch.nn.functional.mse_loss(logits.view(-1), b["y"])
+    assert abs(float(loss) - float(out["loss"])) < ATOL
+    loss.backward()
     check_grads(model, grads, atol=ATOL, rtol=2e-3)
 
 

@@ -39,6 +39,28 @@ def test_finetune_oracle_matches_reference(case):
     check_grads(model, grads, atol=1e-6, rtol=1e-4)
 
 
+def test_gat2_lite_oracle_matches_reference():
+    """model_version gat2_lite: fixture written from fragnet/model/gat/gat2_lite.py (make_golden.py lite)."""
+    torch.set_num_threads(1)
+    cfg, batch, out, grads, pkeys, psums = load_case("ft_lite_b6")
+    torch.manual_seed(cfg["seed"])
+    model = ref.FragNetFineTune(**cfg["ctor"], variant="gat2_lite")
+    check_params_match(model, pkeys, psums)
+    model.train()
+    trace = []
+    x_atoms, x_frags, bond, fbond = model.pretrain(batch, trace=trace)
+    assert fbond is None
+    logits = model.fthead(ref.pool_cat(x_atoms, x_frags, batch))
+    for li, outs in enumerate(trace):
+        for nm, t in zip(("x_atoms", "x_frags", "bond"), outs):
+            torch.testing.assert_close(t.detach(), torch.from_numpy(out[f"layer{li}/{nm}"]), atol=2e-6, rtol=1e-5)
+    torch.testing.assert_close(logits.detach(), torch.from_numpy(out["logits"]), atol=2e-6, rtol=1e-5)
+    loss = ref.finetune_regr_loss(logits, batch["y"])
+    assert abs(float(loss) - float(out["loss"])) < 1e-6
+    loss.backward()
+    check_grads(model, grads, atol=1e-6, rtol=1e-4)
+
+
 def test_pretrain_oracle_matches_reference():
     torch.set_num_threads(1)
     cfg, batch, out, grads, pkeys, psums = load_case("pt_esol_b4")
