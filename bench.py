@@ -271,8 +271,23 @@ def main():
 
     opt = parallel.FlatAdam.for_live_parameters(model, lambda: fwd_bwd(pool[0]), lr=1e-4)
     bucket = opt
-    gstep = None
-    if args.eager:
+    gstep, capture_note = None, None
+    if not args.eager:
+        from fragnet_amd import graphstep
+        try:
+            shapes = graphstep.StaticShapes.from_batches(pool, margin=args.margin, heads=MODEL_CFG["num_heads"])
+            gstep = graphstep.GraphedTrainStep(model, opt, shapes, pool[0], loss="regr")
+            torch.cuda.synchronize()
+        except Exception as exc:      # never lose the measurement to a capture problem: run the same step eagerly
+            gstep, capture_note = None, f"hipGraph capture failed ({type(exc).__name__}: {exc}); eager step"
+            print(f"[bench rank {rank}] {capture_note}", file=sys.stderr, flush=True)
+        if world > 1:                 # all ranks take the same path
+            ok = torch.tensor([int(gstep is not None)], device=dev)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+            if not int(ok.item()) and gstep is not None:
+                gstep, capture_note = None, "another rank could not capture the step; eager step"
+    if gstep is None:
+        args.eager = True
         graphed_head = fragnet_amd.graph_capture_head(model, PER_GPU_BATCH) if not args.eager_head else False
 
         def step(i):
@@ -281,10 +296,6 @@ def main():
             opt.step()                                   # one cat + (N>1: one all-reduce) + one fused Adam
             return loss
     else:
-        from fragnet_amd import graphstep
-        shapes = graphstep.StaticShapes.from_batches(pool, margin=args.margin, heads=MODEL_CFG["num_heads"])
-        gstep = graphstep.GraphedTrainStep(model, opt, shapes, pool[0], loss="regr")
-
         def step(i):
             return gstep(pool[i % len(pool)])            # stage (1 kernel) + graph replay + (all-reduce) + Adam
 
@@ -320,6 +331,7 @@ def main():
                        "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world, "parallelism": f"dp{world}",
                        "mode": "eager launches, head " + ("hipGraph-captured" if graphed_head else "eager") if args.eager else
                                "whole-step hipGraph over static shapes (stage+plan+fwd+mse+bwd+grad gather in the graph)",
+                       "capture_note": capture_note,
                        "static_capacity": None if gstep is None else gstep.shapes.cap,
                        "graph_replays": None if gstep is None else gstep.replays,
                        "eager_fallbacks": None if gstep is None else gstep.fallbacks,
