@@ -2113,7 +2113,17 @@ __global__ void k_stage_padded(StageFields F) {
         const float* src = static_cast<const float*>(f.src);
         float* dst = static_cast<float*>(f.dst);
         const int64_t real = f.n_real * f.width, all = f.cap * f.width;
-        for (int64_t i = t0; i < all; i += stride) dst[i] = i < real ? src[i] : 0.f;
+        if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+            // rows are contiguous: copy as one flat array, 16 bytes per thread; the group that straddles the end of the
+            // real data and the tail of the buffer go element by element
+            const int64_t all4 = all >> 2, real4 = real >> 2;
+            for (int64_t i = t0; i < all4; i += stride)
+                st4(dst + i * 4, i < real4 ? ld4(src + i * 4) : (i * 4 >= real ? make_float4(0.f, 0.f, 0.f, 0.f)
+                    : make_float4(src[i * 4], i * 4 + 1 < real ? src[i * 4 + 1] : 0.f, i * 4 + 2 < real ? src[i * 4 + 2] : 0.f, 0.f)));
+            for (int64_t i = (all4 << 2) + t0; i < all; i += stride) dst[i] = i < real ? src[i] : 0.f;
+        } else {
+            for (int64_t i = t0; i < all; i += stride) dst[i] = i < real ? src[i] : 0.f;
+        }
     } else if (f.kind == FN_STAGE_MASK) {
         float* dst = static_cast<float*>(f.dst);
         for (int64_t i = t0; i < f.cap; i += stride) dst[i] = i < f.n_real ? 1.f : 0.f;
@@ -2122,7 +2132,7 @@ __global__ void k_stage_padded(StageFields F) {
         int64_t* dst = static_cast<int64_t*>(f.dst);
         const int rows = f.kind == FN_STAGE_COLS ? 2 : 1;
         for (int64_t i = t0; i < rows * f.cap; i += stride) {
-            const int64_t r = i / f.cap, c = i - r * f.cap;
+            const int64_t r = i >= f.cap ? 1 : 0, c = i - r * f.cap;
             dst[i] = c < f.n_real ? src[r * f.n_real + c] : f.pad_hi - c % f.pad_mod;
         }
     }
