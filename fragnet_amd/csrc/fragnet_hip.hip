@@ -141,13 +141,28 @@ __device__ __forceinline__ int64_t item_other(const fn_csr_task& T, int64_t loca
     return local < T.n_real ? T.other_key[local] : local - T.n_real;
 }
 
+// Runs of equal keys in consecutive lanes (destination-sorted edge lists, batch / frag_batch vectors) are counted once
+// per run: the first lane of a run issues one atomic for the whole run.  Unsorted keys degenerate to one per lane.
+__device__ __forceinline__ int run_after(uint64_t heads, int lane) {      // lanes from `lane` to the next run head
+    const uint64_t later = lane == 63 ? 0 : heads >> (lane + 1);
+    return later ? __ffsll((unsigned long long)later) : 64 - lane;
+}
 __global__ void k_plan_hist(PlanTasks P, int32_t* __restrict__ rowptr_all, int32_t* __restrict__ status) {
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < P.total_items;
-         g += (int64_t)gridDim.x * blockDim.x) {
-        const fn_csr_task& T = P.t[find_task(P, g)];
-        int64_t k = item_key(T, g - T.item_base);
-        if (k < 0 || k >= T.n_seg) { atomicOr(status, 1); continue; }
-        atomicAdd(&rowptr_all[T.seg_base + k + 1], 1);
+    const int lane = threadIdx.x & 63;
+    const int64_t span = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g0 = (int64_t)blockIdx.x * blockDim.x; g0 < P.total_items; g0 += span) {     // uniform trip count per wave
+        const int64_t g = g0 + threadIdx.x;
+        int64_t seg = -1 - lane;                                   // distinct negative values: never equal to a neighbour
+        if (g < P.total_items) {
+            const fn_csr_task& T = P.t[find_task(P, g)];
+            const int64_t k = item_key(T, g - T.item_base);
+            if (k < 0 || k >= T.n_seg) atomicOr(status, 1);
+            else seg = T.seg_base + k;
+        }
+        const int64_t prev = __shfl_up(seg, 1);
+        const bool head = lane == 0 || seg != prev;
+        const uint64_t heads = __ballot(head);
+        if (head && seg >= 0) atomicAdd(&rowptr_all[seg + 1], run_after(heads, lane));
     }
 }
 
@@ -236,16 +251,29 @@ __global__ __launch_bounds__(256) void k_scan_apply(int32_t* __restrict__ a, int
 // unordered fill (integer atomics): tmp[pos] = task-local item id, seg_of[pos] = global segment id
 __global__ void k_plan_fill(PlanTasks P, const int32_t* __restrict__ rowptr_all, int32_t* __restrict__ cursor,
                             int32_t* __restrict__ tmp, int32_t* __restrict__ seg_of) {
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < P.total_items;
-         g += (int64_t)gridDim.x * blockDim.x) {
-        const fn_csr_task& T = P.t[find_task(P, g)];
-        const int64_t local = g - T.item_base;
-        int64_t k = item_key(T, local);
-        if (k < 0 || k >= T.n_seg) continue;
-        const int64_t seg = T.seg_base + k;
-        const int32_t pos = rowptr_all[seg] + atomicAdd(&cursor[seg], 1);
-        tmp[pos] = (int32_t)local;
-        seg_of[pos] = (int32_t)seg;
+    const int lane = threadIdx.x & 63;
+    const int64_t span = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g0 = (int64_t)blockIdx.x * blockDim.x; g0 < P.total_items; g0 += span) {
+        const int64_t g = g0 + threadIdx.x;
+        int64_t seg = -1 - lane, local = 0;
+        if (g < P.total_items) {
+            const fn_csr_task& T = P.t[find_task(P, g)];
+            local = g - T.item_base;
+            const int64_t k = item_key(T, local);
+            if (k >= 0 && k < T.n_seg) seg = T.seg_base + k;
+        }
+        const int64_t prev = __shfl_up(seg, 1);
+        const bool head = lane == 0 || seg != prev;
+        const uint64_t heads = __ballot(head);
+        int32_t base = 0;
+        if (head && seg >= 0) base = atomicAdd(&cursor[seg], run_after(heads, lane));     // one slot range per run
+        const int head_lane = 63 - __clzll((long long)(heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1))));
+        base = __shfl(base, head_lane);
+        if (seg >= 0) {
+            const int32_t pos = rowptr_all[seg] + base + (lane - head_lane);
+            tmp[pos] = (int32_t)local;
+            seg_of[pos] = (int32_t)seg;
+        }
     }
 }
 
