@@ -355,6 +355,12 @@ def main():
                                 "traffic": traffic, "us_per_launch": kr[dom]["us_per_launch"],
                                 "algorithmic_bytes_per_launch": kr[dom]["algorithmic_bytes"],
                                 "method": "50 back-to-back launches, HIP events on the launch stream", "all": kr}
+            # extra evidence (not part of the contract): the same three kernels on a 2048-molecule batch, where a launch
+            # is long enough for the per-launch fixed cost (~4 us) not to dominate
+            big = make_pool(1, rank, dev, 2048)[0]
+            kb = kernel_roofline(big, model, iters=20)
+            line["roofline"]["at_batch_2048"] = {k: {"us_per_launch": v["us_per_launch"], "GBps": v["GBps"],
+                                                     "frac": round(v["GBps"] / HBM_PEAK_GBPS, 4)} for k, v in kb.items()}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
