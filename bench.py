@@ -226,6 +226,8 @@ def main():
     ap.add_argument("--eager-head", action="store_true", help="(--eager) do not HIP-graph-capture the prediction head")
     ap.add_argument("--kernels-only", action="store_true", help="only time the bond-level scatter kernels (dev loop)")
     ap.add_argument("--kbatch", type=int, default=PER_GPU_BATCH, help="molecules per batch for --kernels-only")
+    ap.add_argument("--model-version", default="gat2", choices=["gat2", "gat2_lite"],
+                    help="gat2 (the headline metric) or gat2_lite (SURVEY f3: levels L1-L3, per-level launches)")
     ap.add_argument("--forward-sweep", action="store_true",
                     help="extra (BASELINE configs[4]): forward-only eval throughput on 40-atom/12-fragment molecules, one line per batch size")
     ap.add_argument("--scatter-blocks", type=int, default=None, help="A/B: resident workgroups of the scatter kernels (FN_TUNE_FWD_BLOCKS)")
@@ -256,7 +258,7 @@ def main():
         return
     pool = make_pool(1, rank, dev, args.kbatch) if args.kernels_only else make_pool(args.pool, rank, dev)
     torch.manual_seed(0)
-    model = FragNetFineTune(**MODEL_CFG).to(dev)
+    model = FragNetFineTune(**MODEL_CFG, variant=args.model_version).to(dev)
     if args.kernels_only:
         print(json.dumps(kernel_roofline(pool[0], model)))
         return
@@ -326,7 +328,8 @@ def main():
             "value": round(value, 1), "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "ESOL finetune batch=512 fp32 (BASELINE configs[1]): FragNetFineTune 4 layers x 4 heads, "
+            "config": {"model_version": args.model_version,
+                       "workload": "ESOL finetune batch=512 fp32 (BASELINE configs[1]): FragNetFineTune 4 layers x 4 heads, "
                                    "emb 128, FTHead3 128/1024/1024/512, drop 0.1; synthetic ESOL-shape molecules (synth.py)",
                        "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world, "parallelism": f"dp{world}",
                        "mode": "eager launches, head " + ("hipGraph-captured" if graphed_head else "eager") if args.eager else

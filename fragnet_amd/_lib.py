@@ -64,7 +64,7 @@ STAGE_ROWS, STAGE_IDS, STAGE_COLS, STAGE_MASK = 0, 1, 2, 3
 
 class Encoder(C.Structure):
     _fields_ = [("n_layers", i32), ("heads", i32), ("k_atom0", i32), ("k_bond0", i32), ("k_fbond0", i32), ("k_fattr", i32),
-                ("training", i32), ("pad_", i32), ("drop_p", f32), ("pad2_", f32), ("seed", u64), ("offset", u64), ("offset_dev", vp),
+                ("training", i32), ("variant", i32), ("drop_p", f32), ("pad2_", f32), ("seed", u64), ("offset", u64), ("offset_dev", vp),
                 ("N", i64), ("E", i64), ("F", i64), ("EF", i64),
                 ("bond", GatPlan), ("atom", GatPlan), ("fbond", GatPlan), ("frag", GatPlan), ("a2f", SegPlan),
                 ("x_atoms", vp), ("bond_nodes", vp), ("fbond_nodes", vp), ("cos_sorted", vp), ("fattr_sorted", vp),

@@ -2948,6 +2948,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
     const float p = e->training ? e->drop_p : 0.f;
     const int wide = 2 * d + FN_D;             // width of a / f
     const bool multi = g_tune[FN_TUNE_STREAMS] != 0;
+    const bool lite = e->variant == 1;
     if (multi) FN_TRY(aux_init());
     fn_stream_t st_fb = multi ? (fn_stream_t)g_aux.s[1] : st;       // the fragment-bond chain's stream
 
@@ -2993,7 +2994,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         const bool grouped = l > 0 && fuse_ns && !multi;
         if (grouped) {
             LinTasks T{};
-            T.n = 3;
+            T.n = lite ? 2 : 3;
             T.t[0] = LinTask{in_bond, bt_b, w.proj_b_b, a.h_b, e->E, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
                              NodeScalarEpi{w.a_b, lay.s_dst, lay.s_src, 3 * d, 0, 2 * d, H}, 0, 0};
             T.t[1] = LinTask{in_atoms, bt_a, w.proj_a_b, a.h_a, e->N, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
@@ -3003,7 +3004,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
             FN_TRY(launch_linear128_group(T, S(st)));
         } else {
             FN_TRY(project(in_bond, kb, bt_b, w.proj_b_b, a.h_b, e->E, w.a_b, 3 * d, 2 * d, lay.s_dst, lay.s_src, st));
-            FN_TRY(project(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, w.f_a_b, 3 * d, 2 * d, lay.s_dst_fb, lay.s_src_fb, st_fb));
+            if (!lite) FN_TRY(project(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, w.f_a_b, 3 * d, 2 * d, lay.s_dst_fb, lay.s_src_fb, st_fb));
         }
         fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
         fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
@@ -3015,9 +3016,9 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         const fn_act_epilogue ep_atoms{y_atoms, p, 1, e->seed, rng.y[l][0], e->offset_dev}, ep_frags{y_frags, p, 1, e->seed, rng.y[l][1], e->offset_dev};
         const fn_act_epilogue ep_bond{y_bond, p, 1, e->seed, rng.y[l][2], e->offset_dev}, ep_fbond{y_fbond, p, 1, e->seed, rng.y[l][3], e->offset_dev};
         // L1 bond graph and L4a fragment-bond graph: neither reads the other's output -> one launch for both
-        GatFwdArgs gb, gfb;
+        GatFwdArgs gb, gfb{};
         FN_TRY(prep_gat_fwd(a.h_b, lay.s_dst, lay.s_src, w.a_b, 3 * d, &et_b, &e->bond, 0.2f, a.new_bond, a.p_bond, nullptr, &ep_bond, H, &gb));
-        FN_TRY(prep_gat_fwd(a.h_fb, lay.s_dst_fb, lay.s_src_fb, w.f_a_b, 3 * d, &et_fb, &e->fbond, 0.2f, a.new_fbond, a.p_fbond, nullptr, &ep_fbond, H, &gfb));
+        if (!lite) FN_TRY(prep_gat_fwd(a.h_fb, lay.s_dst_fb, lay.s_src_fb, w.f_a_b, 3 * d, &et_fb, &e->fbond, 0.2f, a.new_fbond, a.p_fbond, nullptr, &ep_fbond, H, &gfb));
         if (multi) {
             FN_TRY(launch_gat_fwd(gb, H, S(st)));
             FN_TRY(launch_gat_fwd(gfb, H, S(st_fb)));
@@ -3037,7 +3038,10 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         // L4b fragment graph on the raw fragment sums.  Only the last layer's result is ever read: the next layer
         // overwrites x_frags with its own atom->fragment sum before first use (gat2.py:234), so inner
         // layers skip this level entirely (the reference computes it and throws it away).
-        if (last) {
+        if (last && lite) {      // gat2_lite: the encoder's fragment output is act(dropout(.)) of the plain fragment sums
+            FN_TRY(order_after(S(st_fb), S(st)));
+            FN_TRY(fn_dropout_act_f32(a.frags, y_frags, e->F * FN_D, p, e->seed, rng.y[l][1], e->offset_dev, 1, st));
+        } else if (last) {
             FN_TRY(order_after(S(st_fb), S(st)));            // join: the fragment graph's edge term reads new_fbond
             FN_TRY(fn_row_dots_sorted_f32(a.new_fbond, w.f, wide, d, H, &e->frag, lay.s_sorted, st));
             FN_TRY(fn_node_scalars_f32(a.frags, w.f, wide, 0, d + FN_D, lay.s_dst, lay.s_src, e->F, H, st));
@@ -3065,6 +3069,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
     const int wide = 2 * d + FN_D;
     hipStream_t hs = S(st);
     const bool multi = g_tune[FN_TUNE_STREAMS] != 0;
+    const bool lite = e->variant == 1;
     if (multi) FN_TRY(aux_init());
     // leaf: kernels nobody downstream waits for (parameter-gradient reductions, weight-gradient GEMMs);
     // fb: the fragment-bond chain, which after the last layer's fragment level never meets the others again
@@ -3118,7 +3123,11 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
 
         // ---- L4b fragment graph (only where its output is consumed: the last layer, reference fact SURVEY §0.8)
         bool have_g_frags_h = false;
-        if (have_frags) {
+        const float* g_frags_h = bw.g_frags;      // dL/d(fragment sums), scattered back to the atoms below
+        if (have_frags && lite) {
+            g_frags_h = bw.g_pre_frags;            // no fragment graph in between
+            have_g_frags_h = true;
+        } else if (have_frags) {
             fn_edge_term et_f{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
             FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_frags, a.frags, a.p_frag, &et_f, &e->frag, 0.2f, nullptr, sf.dz, sf.pz, sf.g_s_dst, nullptr, &n_e, H, st));
             FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_frags, a.frags, sf.pz, sf.g_s_dst, w.f, wide, 0, d + FN_D, &e->frag, bw.g_frags, sf.part_a, &n_a, H, st));
@@ -3138,7 +3147,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
 
         // ---- L3 atom -> fragment sum: dL/datoms_new += dL/dfrags[a2f]
         if (have_g_frags_h) {
-            hipLaunchKernelGGL(k_gather_rows4, dim3(flat_grid(e->N * 32, kGridCap)), dim3(kBlock), 0, hs, bw.g_frags, e->a2f.index,
+            hipLaunchKernelGGL(k_gather_rows4, dim3(flat_grid(e->N * 32, kGridCap)), dim3(kBlock), 0, hs, g_frags_h, e->a2f.index,
                                bw.g_pre_atoms, e->N, (int64_t)32, have_atoms ? (const float*)bw.g_pre_atoms : (const float*)nullptr);
             FN_TRY(launch_status("fn_encoder_backward: gather(a2f)"));
             have_atoms = true;

@@ -26,6 +26,7 @@ def layer_param_list(layer) -> List[torch.nn.Parameter]:
 
 NP = len(LAYER_FIELDS)
 F_IDX = LAYER_FIELDS.index("f")
+LITE_DEAD = {LAYER_FIELDS.index(n) for n in ("proj_fb_w", "proj_fb_b", "emb_fb_w", "emb_fb_b", "f", "f_a_b")}
 
 
 def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -37,12 +38,14 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 def _describe(plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, params: Sequence[torch.Tensor],
-              n_layers: int, heads: int, drop_p: float, training: bool, seed: int, offset: int, offset_dev=None) -> Encoder:
+              n_layers: int, heads: int, drop_p: float, training: bool, seed: int, offset: int, offset_dev=None,
+              variant: int = 0) -> Encoder:
     e = Encoder()
     e.n_layers, e.heads = n_layers, heads
     e.k_atom0, e.k_bond0, e.k_fbond0 = x_atoms.shape[1], bond_nodes.shape[1], fbond_nodes.shape[1]
     e.k_fattr = fattr_sorted.shape[0]
     e.training, e.drop_p = int(training), float(drop_p)
+    e.variant = int(variant)
     e.seed, e.offset = seed, offset
     e.offset_dev = None if offset_dev is None else offset_dev.data_ptr()
     L = plan.levels
@@ -61,13 +64,13 @@ def _describe(plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fat
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, plan, n_layers, heads, drop_p, training,
-                seed, offset, offset_dev, *params):
+                seed, offset, offset_dev, variant, *params):
         x_atoms, bond_nodes, fbond_nodes = _f32(x_atoms, "x_atoms"), _f32(bond_nodes, "node_features_bonds"), _f32(fbond_nodes, "node_features_fbonds")
         params = tuple(_f32(p, "parameter") for p in params)
         dev = x_atoms.device
         lib = _lib.load()
         e = _describe(plan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, params, n_layers, heads, drop_p,
-                      training, seed, offset, offset_dev)
+                      training, seed, offset, offset_dev, variant)
         ws = torch.empty(lib.fn_encoder_ws_floats(C.byref(e)), dtype=torch.float32, device=dev)
         e.ws, e.ws_floats = ws.data_ptr(), ws.numel()
         outs = [torch.empty((n, FN_D), dtype=torch.float32, device=dev) for n in (e.N, e.F, e.E, e.EF)]
@@ -75,6 +78,7 @@ class _EncoderFn(torch.autograd.Function):
         ctx.desc = e
         ctx.keep = (plan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, ws, offset_dev)
         ctx.n_layers = n_layers
+        ctx.variant = int(variant)
         ctx.save_for_backward(*params, *outs)
         ctx.set_materialize_grads(False)
         return tuple(outs)
@@ -103,12 +107,14 @@ class _EncoderFn(torch.autograd.Function):
         for l in range(n_layers):
             for k in range(NP):
                 live = any_grad and not (k == F_IDX and not (l == n_layers - 1 and have_frags))
+                if ctx.variant == 1 and k in LITE_DEAD:          # gat2_lite never reads the fragment(-bond) parameters
+                    live = False
                 out.append(grads[l * NP + k] if live else None)
-        return (None,) * 13 + tuple(out)
+        return (None,) * 14 + tuple(out)
 
 
 def encoder_forward(layers, plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, heads: int,
-                    drop_p: float, training: bool, rng) -> tuple:
+                    drop_p: float, training: bool, rng, variant: int = 0) -> tuple:
     """Runs all ``layers`` (FragNetLayerA modules) + the inter-layer act(dropout(.)); returns the four outputs."""
     params = [p for layer in layers for p in layer_param_list(layer)]
     n_layers = len(layers)
@@ -122,4 +128,4 @@ def encoder_forward(layers, plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, c
     else:
         seed, offset = 0, 0
     return _EncoderFn.apply(x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, plan, n_layers, heads, p_eff,
-                            bool(training), seed, offset, rng.dev if p_eff > 0.0 else None, *params)
+                            bool(training), seed, offset, rng.dev if p_eff > 0.0 else None, int(variant), *params)

@@ -193,13 +193,14 @@ class FragNet(nn.Module):
         lite = self.variant == "gat2_lite"
         for layer in self.layers:
             layer.lite = lite
-        if self.use_engine and not lite and not any(l.return_attentions or l.bond_mask is not None or l.frag_bond_mask is not None
+        if self.use_engine and not any(l.return_attentions or l.bond_mask is not None or l.frag_bond_mask is not None
                                        or l.atom_mask_individual is not None for l in self.layers):
             # whole encoder in two C calls (fragnet_amd/engine.py); masks / attention outputs use the per-level path
-            return engine.encoder_forward(self.layers, plan, batch["x_atoms"], batch["node_features_bonds"],
+            outs = engine.encoder_forward(self.layers, plan, batch["x_atoms"], batch["node_features_bonds"],
                                           batch["node_features_fbonds"], plan.sorted_attr("bond", batch["edge_attr_bonds"]),
                                           plan.sorted_attr("fbond", batch["edge_attr_fbonds"]), self.layers[0].num_heads,
-                                          p, train, self.rng)
+                                          p, train, self.rng, variant=1 if lite else 0)
+            return (outs[0], outs[1], outs[2], None) if lite else outs
         x_atoms = ops.dropout_act(batch["x_atoms"], p, train, False, self.rng)
         # batch["x_frags"] is dead in the reference too: every layer overwrites it with the atom->fragment
         # sum before first use (gat2.py:234); its dropout mask is drawn and discarded there (gat2.py:397).

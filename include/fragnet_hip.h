@@ -325,7 +325,9 @@ typedef struct fn_encoder {
     int32_t n_layers, heads;
     int32_t k_atom0, k_bond0, k_fbond0;    /* layer-0 feature widths (167, 17, 6); 128 afterwards */
     int32_t k_fattr;                       /* width of edge_attr_fbonds (6) */
-    int32_t training, pad_;
+    int32_t training;
+    int32_t variant;                       /* 0: gat2; 1: gat2_lite (gat2_lite.py: every layer stops after the atom -> fragment sum;
+                                            * out_fbond is not written, out_frags = relu(dropout(fragment sums))) */
     float drop_p, pad2_;
     uint64_t seed, offset;                 /* Philox stream; fn_encoder_rng_blocks() offsets are consumed */
     const uint64_t* offset_dev;            /* nullable device counter added to offset at run time (hipGraph replays) */

@@ -334,7 +334,8 @@ def test_finetune_matches_reference_golden(case, use_engine):
     check_grads(model, grads, atol=ATOL, rtol=2e-3)
 
 
-def test_gat2_lite_matches_reference_golden():
+@pytest.mark.parametrize("use_engine", [True, False], ids=["engine", "per_level_ops"])
+def test_gat2_lite_matches_reference_golden(use_engine):
     """model_version gat2_lite: per-layer outputs, logits, loss and gradients of the reference's
     gat2_lite.FragNetFineTune; same state-dict keys as gat2."""
     from fragnet_amd.model import FragNetFineTuneLite
@@ -343,6 +344,7 @@ def test_gat2_lite_matches_reference_golden():
     model = FragNetFineTuneLite(**cfg["ctor"])
     check_params_match(model, pkeys, psums)
     model = model.to(DEV).train()
+    model.pretrain.use_engine = use_engine
     b = _to_dev(batch)
     x_atoms, x_frags, bond, fbond = model.pretrain(b)
     assert fbond is None
