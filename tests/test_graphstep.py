@@ -151,13 +151,25 @@ def test_graph_step_matches_eager_step():
         torch.testing.assert_close(loss_b, loss_a.detach(), atol=1e-5, rtol=1e-4)
     assert step_b.replays == 6 and step_b.fallbacks == 0
     torch.testing.assert_close(opt_b.flat, opt_a.flat, atol=2e-5, rtol=1e-3)
+    # a SHORT batch (last batch of an epoch: fewer molecules) replays too: the molecule mask does the averaging
+    short = next(b for b in (_batches(1, n, seed=91)[0] for n in (47, 46, 45)) if shapes.fits(graphstep.batch_counts(b)))
+    short = data.batch_to(short, dev)
+    assert short["y"].shape[0] < 48
+    opt_a.zero_grad()
+    loss_a = torch.nn.functional.mse_loss(model_a(dict(short)).view(-1), short["y"])
+    loss_a.backward()
+    opt_a.step()
+    loss_b = step_b(dict(short)).clone()
+    assert step_b.replays == 7 and step_b.fallbacks == 0
+    torch.testing.assert_close(loss_b, loss_a.detach(), atol=1e-5, rtol=1e-4)
+    torch.testing.assert_close(opt_b.flat, opt_a.flat, atol=3e-5, rtol=1e-3)
     # a batch beyond the capacities takes the eager path and still updates the same optimiser state
     big = data.batch_to(_batches(1, 96, seed=77)[0], dev)
     before = opt_b.flat.detach().clone()
     step_b(dict(big))
     assert step_b.fallbacks == 1 and not torch.equal(before, opt_b.flat)
     step_b(dict(batches[1]))
-    assert step_b.replays == 7
+    assert step_b.replays == 8
 
 
 @gpu
