@@ -144,8 +144,8 @@ def load():
             fn.restype = u64
         else:
             fn.restype = C.c_int
-    if lib.fn_abi_version() != 1:
-        raise FragnetHipError(f"ABI version mismatch: library {lib.fn_abi_version()}, binding 1")
+    if lib.fn_abi_version() != 2:
+        raise FragnetHipError(f"ABI version mismatch: library {lib.fn_abi_version()}, binding 2")
     _lib = lib
     return lib
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FN_ABI_VERSION 1
+#define FN_ABI_VERSION 2
 #define FN_D 128              /* feature width of every node table on the path (emb_dim) */
 #define FN_MAX_TASKS 16       /* CSR builds fused into one fn_plan_build call */
 #define FN_MAX_EDGE_K 8       /* widest raw edge attribute folded in-kernel (6 for fragment bonds) */
