@@ -13,6 +13,7 @@ Follows (structure and arithmetic; no code copied):
   FragNetFineTune fragnet/model/gat/gat2.py:758-826
   PretrainTask    fragnet/model/gat/pretrain_heads.py:8-102
   FragNetPreTrain fragnet/model/gat/pretrain_heads.py:105-141
+  variant="gat2_lite"  fragnet/model/gat/gat2_lite.py:13-217, 467-510 (same constructors; layers stop after L3)
 
 PARITY STATUS: pinned against the reference's own Python, imported in the build
 container with stub third-party modules, on the cases frozen in tests/golden/*.npz
