@@ -245,3 +245,33 @@ def test_pretrain_graph_step_matches_eager_step():
         torch.testing.assert_close(loss_b, loss_a.detach(), atol=1e-5, rtol=1e-4)
     assert step_b.replays == 5 and step_b.fallbacks == 0
     torch.testing.assert_close(opt_b.flat, opt_a.flat, atol=2e-5, rtol=1e-3)
+
+
+@gpu
+def test_clsf_graph_step_matches_eager_step():
+    """loss="clsf": masked BCE with missing labels (target -1) over a padded multi-task batch (Tox21 shape)."""
+    from fragnet_amd import parallel, train
+    from fragnet_amd.model import FragNetFineTune
+    dev = _dev()
+    batches = [data.batch_to(data.collate_fn(synth.synth_molecules(32, seed=70 + i, profile="tox21")), dev) for i in range(3)]
+    shapes = graphstep.StaticShapes.from_batches(batches, margin=0.05)
+    cfg = dict(n_classes=12, num_layer=2, drop_ratio=0.0, h1=64, act="relu", fthead="FTHead4")
+    torch.manual_seed(9)
+    model_a = FragNetFineTune(**cfg).to(dev).train()
+    model_b = copy.deepcopy(model_a)
+
+    def probe(model):
+        return lambda: train.compute_bce_loss(model(dict(batches[0])), batches[0]["y"]).backward()
+    opt_a = parallel.FlatAdam.for_live_parameters(model_a, probe(model_a), lr=1e-3)
+    opt_b = parallel.FlatAdam.for_live_parameters(model_b, probe(model_b), lr=1e-3)
+    step_b = graphstep.GraphedTrainStep(model_b, opt_b, shapes, dict(batches[0]), loss="clsf")
+    for i in range(4):
+        b = batches[i % 3]
+        opt_a.zero_grad()
+        loss_a = train.compute_bce_loss(model_a(dict(b)), b["y"])
+        loss_a.backward()
+        opt_a.step()
+        loss_b = step_b(dict(b)).clone()
+        torch.testing.assert_close(loss_b, loss_a.detach(), atol=1e-5, rtol=1e-4)
+    assert step_b.replays == 4 and step_b.fallbacks == 0
+    torch.testing.assert_close(opt_b.flat, opt_a.flat, atol=2e-5, rtol=1e-3)
