@@ -1538,6 +1538,7 @@ constexpr int kLinLd = 64;     // k_linear128's operand tile [K][64 columns], un
 // k = kq*KQ + s at step s, so a lane's A operands are KQ consecutive floats of one row, loaded with 16-byte loads
 // straight from global memory (no LDS round trip for X) and prefetched one tile ahead.  The result tile goes
 // through LDS so that every lane stores whole 16-byte pieces of a row (scattered 4-byte stores cost 4 us a tile).
+constexpr int kLinWaves = 4, kLinThreads = 64 * kLinWaves, kLinRows = 16 * kLinWaves;   // a block: kLinRows rows x 64 columns
 constexpr int kLinOutLd = 68;      // LDS leading dimension of a wave's 16 x 64 result tile
 struct NodeScalarEpi {             // optional fused epilogue: s_dst/s_src[row, head] = <Y[row, head cols], att blocks>
     const float* att;
@@ -1548,25 +1549,26 @@ struct NodeScalarEpi {             // optional fused epilogue: s_dst/s_src[row, 
 // VEC (K == 4*KQ, KQ % 4 == 0): lane (i, kq) owns the k's {16 s + 4 kq + c}: one wave-instruction then reads 64
 // contiguous bytes of each of its 16 rows (a blocked split, k = kq*KQ + .., made every lane touch its own 128-byte
 // line and re-fetched each line eight times through a thrashing L1).  The B rows in LDS are indexed to match.
-template <int KQ, bool VEC>
+template <int KQ, bool VEC, bool PF>
 __device__ __forceinline__ void linear128_body(float* sBt, const float* __restrict__ X, int K, const float* __restrict__ Bt,
                                                const float* __restrict__ bias, float* __restrict__ Y, int64_t M,
                                                const fn_act_epilogue& mk, const NodeScalarEpi& ns, int bid, int nblk) {
-    // sBt: [4*KQ][kLinLd] operand tile; once a tile's products are done the SAME LDS holds the 8 result tiles
-    // [16][kLinOutLd] (the footprint decides how many blocks share a CU: 67 KB -> two, and with two the staging and
-    // epilogue of one block run under the MFMA chain of the other; with operand + result regions side by side it
-    // was one block per CU and the MFMA pipe sat idle 80 % of the time, PMC).  Block bid of nblk blocks of this GEMM.
+    // A block is 4 waves = 64 rows x 64 COLUMNS (column half wc = bid & 1) and walks the row tiles bid>>1, += nblk>>1.
+    // sBt: the [4*KQ][kLinLd] operand tile of this column half, staged ONCE; after that the block never synchronises
+    // again: A rows live in registers (PF: the next tile's rows are requested before this tile's MFMA chain), and
+    // with column-interleaved MFMA tiles (tile t = columns {4 i + t}) a lane's four accumulators of one row ARE a
+    // float4 of four consecutive columns, so results, bias and fused epilogues go straight from registers to global
+    // memory (16 lanes = 256 contiguous bytes of a row) — no LDS transpose, 33 KB per block, four blocks per CU whose
+    // waves drift out of phase (in-phase staging / multiply / store rounds left the MFMA pipe 70 % idle, PMC).
     const uint64_t mk_base = mk.offset + ((mk.y && mk.p > 0.f && mk.offset_dev) ? *mk.offset_dev : 0);   // read once, not per tile
-    // A block is 4 waves = 64 rows x 64 COLUMNS (column half wc = bid & 1): half the operand tile (35 KB -> four
-    // blocks per CU), one wave per SIMD and block, and twice the blocks for the small levels.
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
-    const int wr = w, wc = bid & 1;
-    float* sOut = sBt + w * 16 * kLinOutLd;
-    float* sAtt = sBt + (4 * KQ * kLinLd > 4 * 16 * kLinOutLd ? 4 * KQ * kLinLd : 4 * 16 * kLinOutLd);   // [3][64]: a_dst, a_src, bias of this column half
-    const int64_t tiles = (M + 63) / 64;
+    const int wc = bid & 1, stride = nblk >> 1;
+    const int64_t tiles = (M + kLinRows - 1) / kLinRows;
+    int64_t tile = bid >> 1;
+    if (tile >= tiles) return;                               // whole block
 
-    auto load_rows = [&](int64_t tile, float (&xa)[KQ]) {
-        int64_t row = tile * 64 + wr * 16 + i;
+    auto load_rows = [&](int64_t t, float (&xa)[KQ]) {
+        int64_t row = t * kLinRows + w * 16 + i;
         row = row < M ? row : M - 1;
         const float* src = X + row * K + (VEC ? 4 * kq : kq * KQ);
         if (VEC) {
@@ -1581,38 +1583,43 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
         }
     };
 
-    float cur[KQ];
+    float cur[KQ], nxt[KQ];
+    {   // stage Bt [4*KQ][this half's 64 columns] -> LDS with 16-byte loads; the first A rows ride in the same round trip
+        constexpr int N4 = 4 * KQ * 16;                 // float4 count
+        constexpr int PER = (N4 + kLinThreads - 1) / kLinThreads;
+        float4 v[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int idx = tid + q * kLinThreads, k = idx >> 4, n4 = idx & 15;
+            v[q] = (idx < N4 && k < K) ? ld4(Bt + (size_t)k * 128 + 64 * wc + n4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        load_rows(tile, cur);
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int idx = tid + q * kLinThreads, k = idx >> 4, n4 = idx & 15;
+            if (idx < N4) st4(sBt + k * kLinLd + n4 * 4, v[q]);
+        }
+    }
+    // this lane's four columns of bias and of the two attention vectors stay in registers for every tile
+    const int col = 64 * wc + 4 * i;
+    const float4 bv = bias ? ld4(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ns_d = ns.att ? FN_D / ns.heads : FN_D, ns_head = col / ns_d;
+    float4 a_dst = make_float4(0.f, 0.f, 0.f, 0.f), a_src = a_dst;
+    if (ns.att) {
+        a_dst = ld4(ns.att + ns_head * ns.att_w + ns.dst_off + col % ns_d);
+        a_src = ld4(ns.att + ns_head * ns.att_w + ns.src_off + col % ns_d);
+    }
+    const float ik = mk.p < 1.f ? 1.f / (1.f - mk.p) : 0.f;
+    __syncthreads();
+
     // MFMA tile t of a wave covers the columns {4 i + t}: one 16-byte LDS read per step feeds all four tiles
     const float* bbase = sBt + (VEC ? 4 * kq : kq * KQ) * kLinLd + 4 * i;
     auto brow = [](int s) { return VEC ? 16 * (s >> 2) + (s & 3) : s; };      // LDS row of MFMA step s, relative to bbase
-    for (int64_t tile = bid >> 1; tile < tiles; tile += nblk >> 1) {
-        {   // stage Bt [4*KQ][this half's 64 columns] -> LDS with 16-byte loads; the A rows ride in the same round trip
-            constexpr int N4 = 4 * KQ * 16;                 // float4 count
-            constexpr int PER = (N4 + 255) / 256;
-            float4 v[PER];
-#pragma unroll
-            for (int q = 0; q < PER; ++q) {
-                const int idx = tid + q * 256, k = idx >> 4, n4 = idx & 15;
-                v[q] = (idx < N4 && k < K) ? ld4(Bt + (size_t)k * 128 + 64 * wc + n4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            load_rows(tile, cur);
-#pragma unroll
-            for (int q = 0; q < PER; ++q) {
-                const int idx = tid + q * 256, k = idx >> 4, n4 = idx & 15;
-                if (idx < N4) st4(sBt + k * kLinLd + n4 * 4, v[q]);
-            }
-        }
-        // everything the epilogue reads from global memory is requested NOW, so that it arrives under the MFMA
-        // chain instead of after it: bias, this lane's attention-vector columns, the ReLU gate rows
-        const int64_t r0 = tile * 64 + wr * 16;
-        const int ns_q = lane & 3, ns_d = ns.att ? FN_D / ns.heads : FN_D;
-        const int ns_head = (64 * wc + 16 * ns_q) / ns_d;
-        if (ns.att && tid < 32) {        // this column half's attention-vector entries -> LDS behind the operand tile
-            const int c = (tid & 15) * 4, col = 64 * wc + c, hd = col / ns_d, within = col % ns_d;
-            st4(sAtt + (tid >> 4) * 64 + c, ld4(ns.att + hd * ns.att_w + ((tid >> 4) ? ns.src_off : ns.dst_off) + within));
-        }
-        if (tid >= 64 && tid < 128) sAtt[128 + tid - 64] = bias ? bias[64 * wc + tid - 64] : 0.f;   // and its bias
-        __syncthreads();
+    for (;;) {
+        const int64_t next = tile + stride;
+        const bool more = next < tiles;
+        if constexpr (PF) load_rows(more ? next : tile, nxt);
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1642,27 +1649,20 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
                 }
             }
         }
-        __syncthreads();                                     // every wave is done with the operand tile: reuse its LDS
-        // wave-private transpose through LDS: acc[t][r] is (row kq*4+r, col 4i+t) of the 16 x 64 tile
-        {
-            const float4 bv = *reinterpret_cast<const float4*>(sAtt + 128 + 4 * i);
+        // acc[t][r] is (row kq*4 + r, column 4 i + t) of the wave's 16 x 64 tile
+        __builtin_amdgcn_sched_barrier(0);
+        const int64_t r0 = tile * kLinRows + w * 16 + kq * 4;
+        float pd[4], ps[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                *reinterpret_cast<float4*>(sOut + (kq * 4 + r) * kLinOutLd + 4 * i) =
-                    make_float4(acc[0][r] + bv.x, acc[1][r] + bv.y, acc[2][r] + bv.z, acc[3][r] + bv.w);
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the wave's own LDS writes have landed
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {                        // 16 rows x 16 float4 = 256 pieces, 4 per lane
-            const int idx = lane + q * 64, rr = idx >> 4, c4 = idx & 15;
-            if (r0 + rr < M) {
-                float4 o = *reinterpret_cast<const float4*>(sOut + rr * kLinOutLd + c4 * 4);
+        for (int r = 0; r < 4; ++r) {
+            float4 o = make_float4(acc[0][r] + bv.x, acc[1][r] + bv.y, acc[2][r] + bv.z, acc[3][r] + bv.w);
+            pd[r] = dot4(o, a_dst);
+            ps[r] = dot4(o, a_src);
+            if (r0 + r < M) {
                 if (mk.y) {      // backward of act(dropout(.)) fused into the input-gradient GEMM: o *= mask * (y > 0)
-                    const int64_t e4 = (r0 + rr) * 32 + 16 * wc + c4;            // Philox block = element / 4
+                    const int64_t e4 = (r0 + r) * 32 + 16 * wc + i;              // Philox block = element / 4
                     if (mk.p > 0.f) {
                         const uint4 rnd = philox4x32_10(mk_base + (uint64_t)e4, mk.seed);
-                        const float ik = mk.p < 1.f ? 1.f / (1.f - mk.p) : 0.f;
                         o.x *= keep_scale(rnd.x, mk.p, ik); o.y *= keep_scale(rnd.y, mk.p, ik);
                         o.z *= keep_scale(rnd.z, mk.p, ik); o.w *= keep_scale(rnd.w, mk.p, ik);
                     }
@@ -1672,36 +1672,40 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
                         o.z = yy.z > 0.f ? o.z : 0.f; o.w = yy.w > 0.f ? o.w : 0.f;
                     }
                 }
-                st4(Y + (r0 + rr) * 128 + 64 * wc + c4 * 4, o);
+                st4(Y + (r0 + r) * 128 + col, o);
             }
+            __builtin_amdgcn_sched_barrier(0);               // one row at a time: four interleaved Philox chains cost 60 VGPRs
         }
-        if (ns.att) {        // node scalars of the finished rows straight from the LDS tile (lane = row rr, 16-column quarter q)
-            const int rr = lane >> 2, q = ns_q, d = ns_d, head = ns_head;
-            float pd = 0.f, ps = 0.f;
+        if (ns.att) {            // node scalars: a head's ns_d columns are ns_d/4 neighbouring lanes of the 16-lane DPP row
 #pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                const float4 yv = *reinterpret_cast<const float4*>(sOut + rr * kLinOutLd + 16 * q + c4 * 4);
-                pd += dot4(yv, *reinterpret_cast<const float4*>(sAtt + 16 * q + c4 * 4));
-                ps += dot4(yv, *reinterpret_cast<const float4*>(sAtt + 64 + 16 * q + c4 * 4));
-            }
-            if (d >= 32) { pd += dpp_mov<kDppXor1>(pd); ps += dpp_mov<kDppXor1>(ps); }
-            if (d >= 64) { pd += dpp_mov<kDppXor2>(pd); ps += dpp_mov<kDppXor2>(ps); }
-            const int lanes_per_head = d / 16;               // 1, 2 or 4 quarters
-            if ((q % lanes_per_head) == 0 && r0 + rr < M) {
-                ns.s_dst[(r0 + rr) * ns.heads + head] = pd;
-                ns.s_src[(r0 + rr) * ns.heads + head] = ps;
+            for (int r = 0; r < 4; ++r) {
+                if (ns_d >= 64) { pd[r] += dpp_mov<kDppMirror>(pd[r]); ps[r] += dpp_mov<kDppMirror>(ps[r]); }
+                if (ns_d >= 32) { pd[r] += dpp_mov<kDppHalfMirror>(pd[r]); ps[r] += dpp_mov<kDppHalfMirror>(ps[r]); }
+                pd[r] += dpp_mov<kDppXor2>(pd[r]); ps[r] += dpp_mov<kDppXor2>(ps[r]);
+                pd[r] += dpp_mov<kDppXor1>(pd[r]); ps[r] += dpp_mov<kDppXor1>(ps[r]);
+                if ((4 * i) % ns_d == 0 && r0 + r < M) {
+                    ns.s_dst[(r0 + r) * ns.heads + ns_head] = pd[r];
+                    ns.s_src[(r0 + r) * ns.heads + ns_head] = ps[r];
+                }
             }
         }
-        __syncthreads();                                     // result tiles consumed before the next operand tile lands
+        if (!more) break;
+        if constexpr (PF) {
+#pragma unroll
+            for (int s = 0; s < KQ; ++s) cur[s] = nxt[s];
+        } else {
+            load_rows(next, cur);
+        }
+        tile = next;
     }
 }
 
-template <int KQ, bool VEC>
-__global__ __launch_bounds__(256) void k_linear128(const float* __restrict__ X, int K, const float* __restrict__ Bt,
+template <int KQ, bool VEC, bool PF>
+__global__ __launch_bounds__(kLinThreads) void k_linear128(const float* __restrict__ X, int K, const float* __restrict__ Bt,
                                                    const float* __restrict__ bias, float* __restrict__ Y, int64_t M,
                                                    fn_act_epilogue mk, NodeScalarEpi ns) {
     extern __shared__ __attribute__((aligned(16))) float sBt[];
-    linear128_body<KQ, VEC>(sBt, X, K, Bt, bias, Y, M, mk, ns, (int)blockIdx.x, (int)gridDim.x);
+    linear128_body<KQ, VEC, PF>(sBt, X, K, Bt, bias, Y, M, mk, ns, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // up to three independent [M_i,K]·[K,128] products in one launch: the three projections of a layer (forward) or
@@ -1718,13 +1722,13 @@ struct LinTasks {
     LinTask t[3];
     int n, K;
 };
-template <int KQ, bool VEC>
-__global__ __launch_bounds__(256) void k_linear128_multi(LinTasks T) {
+template <int KQ, bool VEC, bool PF>
+__global__ __launch_bounds__(kLinThreads) void k_linear128_multi(LinTasks T) {
     extern __shared__ __attribute__((aligned(16))) float sBt[];
     int ti = 0;
     while (ti + 1 < T.n && (int)blockIdx.x >= T.t[ti + 1].first) ++ti;
     const LinTask& t = T.t[ti];
-    linear128_body<KQ, VEC>(sBt, t.X, T.K, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, (int)blockIdx.x - t.first, t.nblk);
+    linear128_body<KQ, VEC, PF>(sBt, t.X, T.K, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, (int)blockIdx.x - t.first, t.nblk);
 }
 
 // Bt[k][n] = W[n][k]  (W is nn.Linear.weight [128, K])
@@ -2063,7 +2067,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 // C-ABI
 // =====================================================================================
 namespace {
-int g_tune[FN_TUNE_COUNT] = {1792, 0, 0};   // FN_TUNE_FWD_BLOCKS, (reserved), FN_TUNE_STREAMS
+int g_tune[FN_TUNE_COUNT] = {1792, 0, 0};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -2071,40 +2075,61 @@ template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (e != hipSuccess) { (void)hipGetLastError(); return fail((int)e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); }
     return 0;
 }
+// blocks of a product with `tiles` row tiles when every block walks `iters` of them (two column halves per tile)
+inline int lin_blocks(int64_t tiles, int iters) { return 2 * (int)((tiles + iters - 1) / iters); }
+inline int lin_iters(int64_t total_tiles) {     // row tiles per block so that the launch is resident at once (four blocks per CU)
+    const int64_t slots = g_tune[FN_TUNE_GEMM_SLOTS];
+    if (slots <= 0) return 1;                   // default: one output tile per workgroup (measured best, tools/probe/gemm_probe.hip)
+    const int64_t it = (2 * total_tiles + slots - 1) / slots;
+    return (int)(it < 1 ? 1 : it);
+}
 template <int KQ>
 int launch_linear128(const float* X, int K, const float* Bt, const float* bias, float* Y, int64_t M, fn_act_epilogue mk,
                      NodeScalarEpi ns, hipStream_t st) {
-    const size_t lds = (size_t)(std::max(4 * KQ * kLinLd, 4 * 16 * kLinOutLd) + 192) * sizeof(float);
-    const int64_t tiles = (M + 63) / 64;
-    const int grid = 2 * (int)(tiles < 8192 ? tiles : 8192); // one 64 x 64 output tile per block, four blocks per CU
-    if (KQ % 4 == 0 && K == 4 * KQ) {
-        if (int rc = allow_lds(k_linear128<KQ, (KQ % 4 == 0)>, lds)) return rc;
-        hipLaunchKernelGGL((k_linear128<KQ, (KQ % 4 == 0)>), dim3(grid), dim3(256), lds, st, X, K, Bt, bias, Y, M, mk, ns);
+    const size_t lds = (size_t)(4 * KQ * kLinLd) * sizeof(float);
+    const int64_t tiles = (M + kLinRows - 1) / kLinRows;
+    const int iters = lin_iters(tiles), grid = lin_blocks(tiles, iters);
+    constexpr bool VEC = KQ % 4 == 0;
+    if (VEC && K == 4 * KQ) {
+        if (iters > 1) {
+            if (int rc = allow_lds(k_linear128<KQ, VEC, VEC>, lds)) return rc;
+            hipLaunchKernelGGL((k_linear128<KQ, VEC, VEC>), dim3(grid), dim3(kLinThreads), lds, st, X, K, Bt, bias, Y, M, mk, ns);
+        } else {
+            if (int rc = allow_lds(k_linear128<KQ, VEC, false>, lds)) return rc;
+            hipLaunchKernelGGL((k_linear128<KQ, VEC, false>), dim3(grid), dim3(kLinThreads), lds, st, X, K, Bt, bias, Y, M, mk, ns);
+        }
     } else {
-        if (int rc = allow_lds(k_linear128<KQ, false>, lds)) return rc;
-        hipLaunchKernelGGL((k_linear128<KQ, false>), dim3(grid), dim3(256), lds, st, X, K, Bt, bias, Y, M, mk, ns);
+        if (int rc = allow_lds(k_linear128<KQ, false, false>, lds)) return rc;
+        hipLaunchKernelGGL((k_linear128<KQ, false, false>), dim3(grid), dim3(kLinThreads), lds, st, X, K, Bt, bias, Y, M, mk, ns);
     }
     return 0;
 }
 // grouped launch for K == 128 (every projection beyond layer 0 and every input-gradient product)
 int launch_linear128_group(LinTasks& T, hipStream_t st) {
     constexpr int KQ = 32;
-    const size_t lds = (size_t)(std::max(4 * KQ * kLinLd, 4 * 16 * kLinOutLd) + 192) * sizeof(float);
+    const size_t lds = (size_t)(4 * KQ * kLinLd) * sizeof(float);
+    int64_t total = 0;
+    for (int i = 0; i < T.n; ++i) total += T.t[i].M > 0 ? (T.t[i].M + kLinRows - 1) / kLinRows : 0;
+    const int iters = lin_iters(total);
     int blocks = 0, live = 0;
     for (int i = 0; i < T.n; ++i) {
         if (T.t[i].M <= 0) continue;
-        const int64_t tiles = (T.t[i].M + 63) / 64;
         LinTask t = T.t[i];
         t.first = blocks;
-        t.nblk = 2 * (int)(tiles < 8192 ? tiles : 8192);
+        t.nblk = lin_blocks((t.M + kLinRows - 1) / kLinRows, iters);
         blocks += t.nblk;
         T.t[live++] = t;
     }
     T.n = live;
     T.K = 128;
     if (!live) return 0;
-    if (int rc = allow_lds(k_linear128_multi<KQ, true>, lds)) return rc;
-    hipLaunchKernelGGL((k_linear128_multi<KQ, true>), dim3(blocks), dim3(256), lds, st, T);
+    if (iters > 1) {
+        if (int rc = allow_lds(k_linear128_multi<KQ, true, true>, lds)) return rc;
+        hipLaunchKernelGGL((k_linear128_multi<KQ, true, true>), dim3(blocks), dim3(kLinThreads), lds, st, T);
+    } else {
+        if (int rc = allow_lds(k_linear128_multi<KQ, true, false>, lds)) return rc;
+        hipLaunchKernelGGL((k_linear128_multi<KQ, true, false>), dim3(blocks), dim3(kLinThreads), lds, st, T);
+    }
     return launch_status("grouped projection GEMM");
 }
 

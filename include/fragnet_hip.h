@@ -46,7 +46,9 @@ int fn_abi_version(void);
  * FN_TUNE_FWD_BLOCKS: workgroups of the attention kernels that are resident at once (default 1792 = 256 CUs x 7); a
  *   level with more row groups than that gives every half-wave several consecutive rows to software-pipeline. */
 #define FN_TUNE_FWD_BLOCKS 0
-#define FN_TUNE_RESERVED 1     /* unused */
+#define FN_TUNE_GEMM_SLOTS 1   /* > 0: cap on the workgroups of a projection GEMM launch (1024 = 256 CUs x 4 resident); a launch with
+                                * more 64x64 output tiles then walks several row tiles per workgroup, prefetching the next tile's
+                                * rows.  Default 0 = one tile per workgroup (faster at every measured size) */
 #define FN_TUNE_STREAMS 2      /* 1: the encoder forks parameter-gradient work and the fragment-bond chain onto side streams;
                                 * 0 (default): one stream -- forked hipGraph replays measured slower on ROCm 7.2 */
 #define FN_TUNE_COUNT 3

@@ -16,8 +16,11 @@ template <typename F> float time_us(F f, int iters = 30) {
 }
 
 int main() {
+  for (int slots : {0, 1024}) {
+    fn_set_tuning(FN_TUNE_GEMM_SLOTS, slots);
+    printf("-- resident-block budget %d\n", slots);
     for (int K : {128, 17, 167}) {
-        for (int64_t M : {2500, 13334, 26492}) {
+        for (int64_t M : {2500, 13334, 26492, 47000}) {
             float *X, *Bt, *bias, *Y, *ws, *dW, *db;
             (void)hipMalloc(&X, M * K * 4); (void)hipMalloc(&Bt, K * 128 * 4); (void)hipMalloc(&bias, 512); (void)hipMalloc(&Y, M * 128 * 4);
             (void)hipMalloc(&ws, fn_linear128_wgrad_ws(M, K) * 4); (void)hipMalloc(&dW, 128 * K * 4); (void)hipMalloc(&db, 512);
@@ -28,5 +31,6 @@ int main() {
             (void)hipFree(X); (void)hipFree(Bt); (void)hipFree(bias); (void)hipFree(Y); (void)hipFree(ws); (void)hipFree(dW); (void)hipFree(db);
         }
     }
+  }
     return 0;
 }
