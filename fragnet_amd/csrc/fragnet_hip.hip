@@ -1661,15 +1661,17 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
             if (r0 + r < M) {
                 if (mk.y) {      // backward of act(dropout(.)) fused into the input-gradient GEMM: o *= mask * (y > 0)
                     const int64_t e4 = (r0 + r) * 32 + 16 * wc + i;              // Philox block = element / 4
-                    if (mk.p > 0.f) {
+                    if (mk.relu) {
+                        // y = relu(dropout(x)) is positive only where the element was kept AND passed the ReLU: the saved
+                        // output already encodes the mask, so the Philox stream is not replayed (240 VALU ops a tile)
+                        const float4 yy = ld4(mk.y + e4 * 4);
+                        const float sc = mk.p > 0.f ? ik : 1.f;
+                        o.x = yy.x > 0.f ? o.x * sc : 0.f; o.y = yy.y > 0.f ? o.y * sc : 0.f;
+                        o.z = yy.z > 0.f ? o.z * sc : 0.f; o.w = yy.w > 0.f ? o.w * sc : 0.f;
+                    } else if (mk.p > 0.f) {
                         const uint4 rnd = philox4x32_10(mk_base + (uint64_t)e4, mk.seed);
                         o.x *= keep_scale(rnd.x, mk.p, ik); o.y *= keep_scale(rnd.y, mk.p, ik);
                         o.z *= keep_scale(rnd.z, mk.p, ik); o.w *= keep_scale(rnd.w, mk.p, ik);
-                    }
-                    if (mk.relu) {
-                        const float4 yy = ld4(mk.y + e4 * 4);
-                        o.x = yy.x > 0.f ? o.x : 0.f; o.y = yy.y > 0.f ? o.y : 0.f;
-                        o.z = yy.z > 0.f ? o.z : 0.f; o.w = yy.w > 0.f ? o.w : 0.f;
                     }
                 }
                 st4(Y + (r0 + r) * 128 + col, o);
