@@ -230,6 +230,7 @@ def main():
                     help="gat2 (the headline metric) or gat2_lite (SURVEY f3: levels L1-L3, per-level launches)")
     ap.add_argument("--forward-sweep", action="store_true",
                     help="extra (BASELINE configs[4]): forward-only eval throughput on 40-atom/12-fragment molecules, one line per batch size")
+    ap.add_argument("--tune", action="append", default=None, help="A/B: KEY=VALUE for fn_set_tuning (include/fragnet_hip.h FN_TUNE_*)")
     ap.add_argument("--scatter-blocks", type=int, default=None, help="A/B: resident workgroups of the scatter kernels (FN_TUNE_FWD_BLOCKS)")
     args = ap.parse_args()
 
@@ -241,6 +242,10 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    for kv in args.tune or []:         # A/B of any fn_set_tuning key: --tune 3=1024
+        k, v = kv.split("=")
+        from fragnet_amd import _lib
+        _lib.call("fn_set_tuning", int(k), int(v))
     if args.scatter_blocks is not None:
         from fragnet_amd import _lib
         _lib.call("fn_set_tuning", 0, args.scatter_blocks)

@@ -2069,7 +2069,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 // C-ABI
 // =====================================================================================
 namespace {
-int g_tune[FN_TUNE_COUNT] = {1792, 0, 0};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS
+int g_tune[FN_TUNE_COUNT] = {1792, 0, 0, 512};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -2881,6 +2881,7 @@ struct ReduceQueue {
     ReduceTasks T{};
     WgradTasks W{};
     int blocks = 0, wblocks = 0;
+    int w_reduce[kMaxWgradTasks] = {};      // index in T of each grouped product's reduction
     bool defer_wgrad = false;
     hipStream_t st = nullptr;
     int flush() {
@@ -2919,11 +2920,10 @@ struct ReduceQueue {
         }
         ReduceTask t{};
         int grid = 0;
-        if (K == FN_D && defer_wgrad && W.n < kMaxWgradTasks) {   // partial product joins the grouped launch in flush()
-            const int rpb = wgrad_rows_per_block(M);
-            grid = (int)((M + rpb - 1) / rpb);
-            W.t[W.n++] = WgradTask{dY, X, ws, M, rpb, wblocks};
-            wblocks += grid;
+        if (K == FN_D && defer_wgrad) {   // partial product joins the grouped launch in flush(); its block count is set there
+            if (W.n == kMaxWgradTasks || T.n == kMaxReduceTasks) { if (int rc = flush()) return rc; }
+            W.t[W.n] = WgradTask{dY, X, ws, M, 0, 0};
+            w_reduce[W.n++] = T.n;
             t.cls = 2;
         } else if (int rc = wgrad_partials(dY, X, K, M, ws, launch_on, &grid, &t.cls)) return rc;
         t.kind = RT_WGRAD;  t.p0 = ws;  t.n0 = grid;  t.K = K;  t.o0 = dW;  t.o1 = db;
@@ -2931,6 +2931,22 @@ struct ReduceQueue {
     }
     int flush_wgrad() {
         if (W.n == 0) return 0;
+        // rows per block from the WHOLE group: ~512 blocks (two per CU, one round) instead of ~256 per product, which for the
+        // nine products of a backward pass was 1.6 k blocks writing 104 MB of 64-KB partials (now ~30 MB); never fewer rows
+        // than the per-product rule, so the partial workspace sized by fn_linear128_wgrad_ws still fits
+        int64_t total = 0;
+        for (int i = 0; i < W.n; ++i) total += W.t[i].M;
+        const int64_t target = g_tune[FN_TUNE_WGRAD_BLOCKS] > 0 ? g_tune[FN_TUNE_WGRAD_BLOCKS] : 512;
+        const int group_rpb = (int)(((total + target - 1) / target + kWgChunk - 1) / kWgChunk * kWgChunk);
+        wblocks = 0;
+        for (int i = 0; i < W.n; ++i) {
+            WgradTask& t = W.t[i];
+            t.rpb = std::max(group_rpb, wgrad_rows_per_block(t.M));
+            t.first = wblocks;
+            const int grid = (int)((t.M + t.rpb - 1) / t.rpb);
+            T.t[w_reduce[i]].n0 = grid;
+            wblocks += grid;
+        }
         constexpr int XW = 16 * 4 * 2, XLD = XW + 16;
         const size_t lds = (size_t)2 * kWgChunk * (kBtLd + XLD) * sizeof(float);
         if (int rc = allow_lds(k_linear128_wgrad_multi<4, 2>, lds)) return rc;

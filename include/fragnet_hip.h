@@ -51,7 +51,8 @@ int fn_abi_version(void);
                                 * rows.  Default 0 = one tile per workgroup (faster at every measured size) */
 #define FN_TUNE_STREAMS 2      /* 1: the encoder forks parameter-gradient work and the fragment-bond chain onto side streams;
                                 * 0 (default): one stream -- forked hipGraph replays measured slower on ROCm 7.2 */
-#define FN_TUNE_COUNT 3
+#define FN_TUNE_WGRAD_BLOCKS 3 /* target workgroup count of the grouped weight-gradient launch of a backward pass (default 512) */
+#define FN_TUNE_COUNT 4
 int fn_set_tuning(int key, int value);
 const char* fn_last_error(void);
 
