@@ -111,6 +111,9 @@ SIGNATURES = {
     "fn_pool_cat_f32": [vp, vp, C.POINTER(SegPlan), C.POINTER(SegPlan), vp, vp],
     "fn_pool_cat_bwd_f32": [vp, vp, vp, vp, vp, i64, i64, vp],
     "fn_masked_mse_f32": [vp, vp, vp, i64, C.c_int, vp, vp, vp],
+    "fn_gate_colsum_f32": [vp, vp, vp, vp, i64, i64, f32, vp],
+    "fn_small_linear_f32": [vp, vp, vp, vp, i64, i64, i64, vp],
+    "fn_small_linear_bwd_f32": [vp, vp, vp, vp, vp, vp, i64, i64, i64, vp],
 }
 
 _lib = None
@@ -144,7 +147,7 @@ def load():
             fn.restype = u64
         else:
             fn.restype = C.c_int
-    if lib.fn_abi_version() != 2:
+    if lib.fn_abi_version() != 3:
         raise FragnetHipError(f"ABI version mismatch: library {lib.fn_abi_version()}, binding 2")
     _lib = lib
     return lib

@@ -1521,6 +1521,122 @@ __global__ void k_edge_concat(const float* __restrict__ x, const float* __restri
 }
 
 // =====================================================================================
+// Prediction-head small ops (gat2.py:631-637, 745-751: Linear -> dropout -> ReLU stacks on [molecules, width]).
+// The dense products stay library GEMMs; these are the launches around them.
+// =====================================================================================
+// g_x = (y > 0) ? g_y * scale : 0  and  colsum[c] = sum_rows g_x[:, c]   (bias gradient of the Linear below)
+// y = relu(dropout(.)) is positive only where the element was kept and passed the ReLU, so no Philox replay.
+// One block owns a strip of 32 columns for ALL rows: the column sums are deterministic and need no second pass.
+__global__ __launch_bounds__(256) void k_gate_colsum(const float* __restrict__ g_y, const float* __restrict__ y,
+                                                     float* __restrict__ g_x, float* __restrict__ colsum, int64_t rows,
+                                                     int cols, float scale) {
+    __shared__ float4 sm[32][8];
+    const int c4 = threadIdx.x & 7, rl = threadIdx.x >> 3;           // 8 float4 columns x 32 row lanes
+    const int col = blockIdx.x * 32 + c4 * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < cols) {
+        int64_t r = rl;
+        for (; r + 96 < rows; r += 128) {                           // four rows in flight per thread
+            float4 g[4], v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { g[q] = ld4(g_y + (r + 32 * q) * cols + col); v[q] = ld4(y + (r + 32 * q) * cols + col); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 o = make_float4(v[q].x > 0.f ? g[q].x * scale : 0.f, v[q].y > 0.f ? g[q].y * scale : 0.f,
+                                             v[q].z > 0.f ? g[q].z * scale : 0.f, v[q].w > 0.f ? g[q].w * scale : 0.f);
+                st4(g_x + (r + 32 * q) * cols + col, o);
+                acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+            }
+        }
+        for (; r < rows; r += 32) {
+            const float4 g = ld4(g_y + r * cols + col), v = ld4(y + r * cols + col);
+            const float4 o = make_float4(v.x > 0.f ? g.x * scale : 0.f, v.y > 0.f ? g.y * scale : 0.f,
+                                         v.z > 0.f ? g.z * scale : 0.f, v.w > 0.f ? g.w * scale : 0.f);
+            st4(g_x + r * cols + col, o);
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+    }
+    sm[rl][c4] = acc;
+    __syncthreads();
+    if (rl == 0 && col < cols) {
+        float4 t = sm[0][c4];
+        for (int q = 1; q < 32; ++q) { const float4 u = sm[q][c4]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        st4(colsum + col, t);
+    }
+}
+
+// y[m, c] = <x[m, :], w[c, :]> + b[c] for a handful of outputs (the last Linear of a head: n_classes columns).
+// One wave per row; the row stays in registers while the C weight rows stream from L1.
+__global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ b, float* __restrict__ y, int64_t M, int K, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int k4 = K / 4;                                            // K % 4 == 0
+    for (int c = 0; c < C; ++c) {
+        float acc = 0.f;
+        for (int j = lane; j < k4; j += 64) acc += dot4(ld4(x + row * K + 4 * j), ld4(w + (size_t)c * K + 4 * j));
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) y[row * C + c] = acc + (b ? b[c] : 0.f);
+    }
+}
+
+// backward of the above in one launch: g_x[m, k] = sum_c g[m, c] w[c, k];  dW[c, k] = sum_m g[m, c] x[m, k];
+// db[c] = sum_m g[m, c].  A block owns 64 columns k for all rows (deterministic sums); CM >= C bounds the registers.
+template <int CM>
+__global__ __launch_bounds__(256) void k_small_linear_bwd(const float* __restrict__ g, const float* __restrict__ x,
+                                                          const float* __restrict__ w, float* __restrict__ g_x,
+                                                          float* __restrict__ dW, float* __restrict__ db, int64_t M, int K, int C) {
+    __shared__ float4 sm[16][16];
+    const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;          // 16 float4 columns x 16 row lanes
+    const int col = blockIdx.x * 64 + c4 * 4;
+    const bool live = col < K;
+    float4 wv[CM], acc[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        wv[c] = (live && c < C) ? ld4(w + (size_t)c * K + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (live) {
+        for (int64_t m = rl; m < M; m += 16) {
+            const float4 xv = ld4(x + m * K + col);
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                if (c < C) {
+                    const float gv = g[m * C + c];
+                    o.x += gv * wv[c].x; o.y += gv * wv[c].y; o.z += gv * wv[c].z; o.w += gv * wv[c].w;
+                    acc[c].x += gv * xv.x; acc[c].y += gv * xv.y; acc[c].z += gv * xv.z; acc[c].w += gv * xv.w;
+                }
+            }
+            st4(g_x + m * K + col, o);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        if (c < C) {                                                // uniform
+            sm[rl][c4] = acc[c];
+            __syncthreads();
+            if (rl == 0 && live) {
+                float4 t = sm[0][c4];
+                for (int q = 1; q < 16; ++q) { const float4 u = sm[q][c4]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+                st4(dW + (size_t)c * K + col, t);
+            }
+            __syncthreads();
+        }
+    }
+    if (blockIdx.x == 0 && db) {                                    // bias gradient: one wave per class, fixed order
+        const int lane = threadIdx.x & 63;
+        for (int c = threadIdx.x >> 6; c < C; c += 4) {
+            float t = 0.f;
+            for (int64_t m = lane; m < M; m += 64) t += g[m * C + c];
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+            if (lane == 0) db[c] = t;
+        }
+    }
+}
+
+// =====================================================================================
 // Projection GEMMs on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains, so the 1e-4
 // parity budget is untouched).  All three node projections have N = 128 outputs and K <= 168 inputs:
 //   forward    Y[M,128]  = X[M,K]   * Bt[K,128] + bias      (Bt = W^T, transposed once per step)
@@ -2632,6 +2748,38 @@ int fn_dropout_act_bwd_f32(const float* g_y, const float* y, float* g_x, int64_t
     hipLaunchKernelGGL(k_dropout_act<true>, dim3(flat_grid((numel + 3) / 4, kGridCap)), dim3(kBlock), 0, S(stream), g_y, y, g_x,
                        numel, p, seed, offset, offset_dev, relu);
     return launch_status("fn_dropout_act_bwd_f32");
+}
+
+int fn_gate_colsum_f32(const float* g_y, const float* y, float* g_x, float* colsum, int64_t rows, int64_t cols, float scale,
+                       fn_stream_t stream) {
+    if (rows < 0 || cols < 0 || (cols & 3) || cols > INT32_MAX) return fail(FN_EINVAL, "fn_gate_colsum_f32: cols must be a multiple of 4");
+    if (cols == 0) return 0;
+    if (!colsum || (rows > 0 && (!g_y || !y || !g_x)) || (((uintptr_t)g_y | (uintptr_t)y | (uintptr_t)g_x | (uintptr_t)colsum) & 15))
+        return fail(FN_EINVAL, "fn_gate_colsum_f32: null or misaligned buffer");
+    hipLaunchKernelGGL(k_gate_colsum, dim3((unsigned)((cols + 31) / 32)), dim3(256), 0, S(stream), g_y, y, g_x, colsum, rows, (int)cols, scale);
+    return launch_status("fn_gate_colsum_f32");
+}
+
+int fn_small_linear_f32(const float* x, const float* w, const float* b, float* y, int64_t M, int64_t K, int64_t C, fn_stream_t stream) {
+    if (M < 0 || K < 4 || (K & 3) || K > INT32_MAX || C < 1 || C > FN_SMALL_LINEAR_MAX)
+        return fail(FN_EINVAL, "fn_small_linear_f32: K must be a multiple of 4 and 1 <= C <= FN_SMALL_LINEAR_MAX");
+    if (M == 0) return 0;
+    if (!x || !w || !y || (((uintptr_t)x | (uintptr_t)w) & 15)) return fail(FN_EINVAL, "fn_small_linear_f32: null or misaligned buffer");
+    hipLaunchKernelGGL(k_small_linear, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, S(stream), x, w, b, y, M, (int)K, (int)C);
+    return launch_status("fn_small_linear_f32");
+}
+
+int fn_small_linear_bwd_f32(const float* g, const float* x, const float* w, float* g_x, float* dW, float* db, int64_t M, int64_t K,
+                            int64_t C, fn_stream_t stream) {
+    if (M < 0 || K < 4 || (K & 3) || K > INT32_MAX || C < 1 || C > FN_SMALL_LINEAR_MAX)
+        return fail(FN_EINVAL, "fn_small_linear_bwd_f32: K must be a multiple of 4 and 1 <= C <= FN_SMALL_LINEAR_MAX");
+    if (!w || !dW || !db || (M > 0 && (!g || !x || !g_x)) || (((uintptr_t)x | (uintptr_t)w | (uintptr_t)g_x | (uintptr_t)dW) & 15))
+        return fail(FN_EINVAL, "fn_small_linear_bwd_f32: null or misaligned buffer");
+    const dim3 grid((unsigned)((K + 63) / 64));
+    if (C <= 1) hipLaunchKernelGGL(k_small_linear_bwd<1>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW, db, M, (int)K, (int)C);
+    else if (C <= 4) hipLaunchKernelGGL(k_small_linear_bwd<4>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW, db, M, (int)K, (int)C);
+    else hipLaunchKernelGGL(k_small_linear_bwd<FN_SMALL_LINEAR_MAX>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW, db, M, (int)K, (int)C);
+    return launch_status("fn_small_linear_bwd_f32");
 }
 
 int fn_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

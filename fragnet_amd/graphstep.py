@@ -264,6 +264,8 @@ class GraphedTrainStep:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.loss: Optional[torch.Tensor] = None
         self.replays = self.fallbacks = 0
+        from . import ops
+        self._unit = ops.unit_grad(self.static.device)
         self._capture(example, warmup)
 
     # -- pieces
@@ -274,7 +276,7 @@ class GraphedTrainStep:
             loss = masked_pretrain_loss(self.model(sb), sb)
         else:
             loss = self._masked(self.model(sb), sb["y"], sb[MASK_KEY])
-        loss.backward()
+        loss.backward(gradient=self._unit)          # persistent 1.0: no fill launch, masked_mse skips the multiply
         self.opt.gather_grads()
         return loss
 

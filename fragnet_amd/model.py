@@ -237,6 +237,8 @@ class _PredictorStack(nn.Sequential):
 
     def _run(self, enc):
         fused = self.rng is not None and isinstance(self.activation, nn.ReLU) and enc.is_cuda
+        if fused and all(l.bias is not None for l in self.predictor) and all(l.out_features % 4 == 0 for l in self.predictor[:-1]):
+            return ops.mlp_head(enc, list(self.predictor), self.dropout.p, self.training, self.rng)     # one autograd node
         for lin in self.predictor[:-1]:
             if fused:    # relu(dropout(.)) as one kernel each way instead of two (same op as between encoder layers)
                 enc = ops.dropout_act(lin(enc), self.dropout.p, self.training, True, self.rng)

@@ -317,11 +317,28 @@ class _MaskedMSE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss):
         (g,) = ctx.saved_tensors
+        unit = _UNIT_GRAD.get(g.device)
+        if unit is not None and g_loss.data_ptr() == unit.data_ptr():      # d loss / d loss = 1: nothing to multiply
+            return g.reshape(ctx.shape), None, None
         return (g * g_loss).reshape(ctx.shape), None, None
 
 
 def masked_mse(out, y, w):
     return _MaskedMSE.apply(out, y, w)
+
+
+_UNIT_GRAD = {}
+
+
+def unit_grad(device):
+    """A persistent scalar 1.0 to seed ``loss.backward(gradient=...)`` with: autograd then launches no fill kernel, and
+    ``masked_mse`` recognises it and skips the multiply (two launches of a captured step)."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if device not in _UNIT_GRAD:
+        _UNIT_GRAD[device] = torch.ones((), dtype=torch.float32, device=device)
+    return _UNIT_GRAD[device]
 
 
 class _GatherRows(torch.autograd.Function):
@@ -475,6 +492,89 @@ def dropout_act(x, p: float, training: bool, relu: bool, rng: PhiloxStream):
         return x
     seed, off = rng.take(x.numel()) if p_eff > 0.0 else (0, 0)
     return _DropoutAct.apply(x, p_eff, relu, seed, off, rng.dev if p_eff > 0.0 else None)
+
+
+# ======================================================================================
+# prediction head: Linear -> relu(dropout(.)) stack with a hand-written backward
+# ======================================================================================
+SMALL_LINEAR_MAX = 16        # FN_SMALL_LINEAR_MAX
+
+
+class _MLPHead(torch.autograd.Function):
+    """FTHead1-5's predictor stack (gat2.py:631-637, 745-751) as one autograd node.
+
+    The dense products are library GEMMs (addmm / mm); everything around them is fused: relu(dropout(.)) in place on
+    the GEMM output, its backward together with the bias gradient (``fn_gate_colsum_f32``: the saved output encodes
+    the mask, so no Philox replay and no separate column-sum launch), and the last Linear (n_classes outputs) as one
+    launch each way.  ``draws`` = the (seed, offset) of each hidden layer's mask, taken from the model's Philox stream
+    in the same order as the unfused path, so both paths produce identical numbers.
+    """
+
+    @staticmethod
+    def forward(ctx, x, p: float, draws, dev, *params):
+        n = len(params) // 2
+        st = _stream_ptr(x.device)
+        h = _f32c(x, "x")
+        acts = [h]
+        for i in range(n - 1):
+            W, b = params[2 * i], params[2 * i + 1]
+            y = torch.addmm(b, h, W.t())
+            seed, off = draws[i]
+            _lib.call("fn_dropout_act_f32", y.data_ptr(), y.data_ptr(), y.numel(), float(p), seed, off,
+                      _ptr(dev) if p > 0.0 else None, 1, st)
+            h = y
+            acts.append(h)
+        W, b = params[-2], params[-1]
+        C_out, K = W.shape
+        if C_out <= SMALL_LINEAR_MAX and K % 4 == 0:
+            out = torch.empty((h.shape[0], C_out), dtype=torch.float32, device=h.device)
+            _lib.call("fn_small_linear_f32", h.data_ptr(), _f32c(W, "W").data_ptr(), b.data_ptr(), out.data_ptr(), h.shape[0], K, C_out, st)
+        else:
+            out = torch.addmm(b, h, W.t())
+        ctx.p = float(p)
+        ctx.save_for_backward(*acts, *params[0::2])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        n = len(saved) // 2
+        acts, Ws = saved[:n], saved[n:]
+        st = _stream_ptr(g.device)
+        g = _f32c(g, "g")
+        grads = [None] * (2 * n)
+        W, h = Ws[-1], acts[-1]
+        C_out, K = W.shape
+        if C_out <= SMALL_LINEAR_MAX and K % 4 == 0:
+            gz, dW, db = torch.empty_like(h), torch.empty_like(W), torch.empty(C_out, dtype=torch.float32, device=g.device)
+            _lib.call("fn_small_linear_bwd_f32", g.data_ptr(), h.data_ptr(), W.data_ptr(), gz.data_ptr(), dW.data_ptr(), db.data_ptr(),
+                      h.shape[0], K, C_out, st)
+        else:
+            gz, dW, db = g @ W, g.t() @ h, g.sum(0)
+        grads[-2], grads[-1] = dW, db
+        scale = 1.0 / (1.0 - ctx.p) if 0.0 < ctx.p < 1.0 else (1.0 if ctx.p == 0.0 else 0.0)
+        for i in range(n - 2, -1, -1):
+            z, h_in, W = acts[i + 1], acts[i], Ws[i]
+            gy, db = torch.empty_like(z), torch.empty(z.shape[1], dtype=torch.float32, device=z.device)
+            _lib.call("fn_gate_colsum_f32", gz.data_ptr(), z.data_ptr(), gy.data_ptr(), db.data_ptr(), z.shape[0], z.shape[1], scale, st)
+            grads[2 * i], grads[2 * i + 1] = gy.t() @ h_in, db
+            if i > 0 or ctx.needs_input_grad[0]:
+                gz = gy @ W
+        return (gz if ctx.needs_input_grad[0] else None, None, None, None, *grads)
+
+
+def mlp_head(x, linears, p: float, training: bool, rng: "PhiloxStream"):
+    """Runs ``linears`` (nn.Linear modules; relu(dropout(.)) after all but the last) through ``_MLPHead``."""
+    p_eff = float(p) if training else 0.0
+    draws = []
+    for lin in linears[:-1]:
+        draws.append(rng.take(x.shape[0] * lin.out_features) if p_eff > 0.0 else (0, 0))
+    params = []
+    for lin in linears:
+        if lin.bias is None or (lin.out_features % 4 != 0 and lin is not linears[-1]):
+            raise ValueError("mlp_head: Linear layers need a bias, hidden ones an output width that is a multiple of 4")
+        params += [lin.weight, lin.bias]
+    return _MLPHead.apply(x, p_eff, tuple(draws), rng.dev if p_eff > 0.0 else None, *params)
 
 
 # ======================================================================================

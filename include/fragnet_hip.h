@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FN_ABI_VERSION 2
+#define FN_ABI_VERSION 3
 #define FN_D 128              /* feature width of every node table on the path (emb_dim) */
 #define FN_MAX_TASKS 16       /* CSR builds fused into one fn_plan_build call */
 #define FN_MAX_EDGE_K 8       /* widest raw edge attribute folded in-kernel (6 for fragment bonds) */
@@ -254,6 +254,22 @@ int fn_dropout_act_f32(const float* x, float* y, int64_t numel, float p, uint64_
                        const uint64_t* offset_dev /*nullable, see fn_act_epilogue*/, int relu, fn_stream_t stream);
 int fn_dropout_act_bwd_f32(const float* g_y, const float* y, float* g_x, int64_t numel, float p, uint64_t seed,
                            uint64_t offset, const uint64_t* offset_dev, int relu, fn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Prediction-head small ops (FTHead1-5, gat2.py:631-637, 719-725, 745-751: Linear -> dropout -> act stacks on
+ * [molecules, width]; the dense products themselves stay library GEMMs).
+ * fn_gate_colsum_f32: backward of relu(dropout(.)) fused with the bias gradient of the Linear below it:
+ *   g_x = (y > 0) ? g_y * scale : 0 (scale = 1/(1-p); the saved output encodes the mask), colsum[c] = sum_rows g_x[:, c].
+ * fn_small_linear(_bwd)_f32: the last Linear of a head (n_classes <= FN_SMALL_LINEAR_MAX outputs) as one launch each
+ *   way: y = x w^T + b;  g_x = g w, dW = g^T x, db = colsum(g).  All sums run in a fixed order (deterministic).
+ * ------------------------------------------------------------------------------------------ */
+#define FN_SMALL_LINEAR_MAX 16
+int fn_gate_colsum_f32(const float* g_y /*[rows,cols]*/, const float* y /*[rows,cols]*/, float* g_x /*[rows,cols]*/,
+                       float* colsum /*[cols]*/, int64_t rows, int64_t cols, float scale, fn_stream_t stream);
+int fn_small_linear_f32(const float* x /*[M,K]*/, const float* w /*[C,K]*/, const float* b /*[C] nullable*/, float* y /*[M,C]*/,
+                        int64_t M, int64_t K, int64_t C, fn_stream_t stream);
+int fn_small_linear_bwd_f32(const float* g /*[M,C]*/, const float* x /*[M,K]*/, const float* w /*[C,K]*/, float* g_x /*[M,K]*/,
+                            float* dW /*[C,K]*/, float* db /*[C]*/, int64_t M, int64_t K, int64_t C, fn_stream_t stream);
 
 /* torch.optim.Adam step (no amsgrad) on one flat fp32 tensor: finetune_gat2.py:257, pretrain_gat2.py:165.
  * `step` is the 1-based step count (bias corrections are computed on the host in double). */

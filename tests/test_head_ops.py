@@ -1,0 +1,96 @@
+"""Prediction-head small ops (include/fragnet_hip.h: fn_gate_colsum_f32, fn_small_linear(_bwd)_f32) and the fused
+``ops.mlp_head`` autograd node against plain torch and against the unfused layer-by-layer path."""
+import copy
+
+import pytest
+import torch
+
+gpu = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+@gpu
+@pytest.mark.parametrize("rows,cols", [(528, 1024), (37, 128), (0, 64), (1, 4), (300, 36)])
+def test_gate_colsum_matches_torch(rows, cols):
+    from fragnet_amd import _lib
+    from fragnet_amd.plan import _stream_ptr
+    dev = _dev()
+    torch.manual_seed(rows + cols)
+    g = torch.randn(rows, cols, device=dev)
+    y = torch.relu(torch.randn(rows, cols, device=dev))            # about half zeros, like relu(dropout(.))
+    gx, cs = torch.full_like(g, 7.0), torch.full((cols,), 7.0, device=dev)
+    _lib.call("fn_gate_colsum_f32", g.data_ptr(), y.data_ptr(), gx.data_ptr(), cs.data_ptr(), rows, cols, 1.25, _stream_ptr(dev))
+    ref = torch.where(y > 0, g * 1.25, torch.zeros_like(g))
+    assert torch.equal(gx, ref)
+    torch.testing.assert_close(cs, ref.double().sum(0).float(), atol=2e-4, rtol=1e-5)
+
+
+@gpu
+@pytest.mark.parametrize("M,K,C", [(528, 512, 1), (528, 512, 12), (5, 128, 3), (0, 64, 2), (100, 36, 16)])
+def test_small_linear_matches_torch(M, K, C):
+    from fragnet_amd import _lib
+    from fragnet_amd.plan import _stream_ptr
+    dev = _dev()
+    torch.manual_seed(M + K + C)
+    x, w, b = torch.randn(M, K, device=dev), torch.randn(C, K, device=dev) * 0.1, torch.randn(C, device=dev)
+    g = torch.randn(M, C, device=dev)
+    y = torch.empty(M, C, device=dev)
+    st = _stream_ptr(dev)
+    _lib.call("fn_small_linear_f32", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, K, C, st)
+    torch.testing.assert_close(y, (x.double() @ w.double().t() + b.double()).float(), atol=2e-5, rtol=1e-5)
+    gx, dW, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(b)
+    _lib.call("fn_small_linear_bwd_f32", g.data_ptr(), x.data_ptr(), w.data_ptr(), gx.data_ptr(), dW.data_ptr(), db.data_ptr(), M, K, C, st)
+    torch.testing.assert_close(gx, (g.double() @ w.double()).float(), atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(dW, (g.double().t() @ x.double()).float(), atol=2e-4, rtol=1e-5)
+    torch.testing.assert_close(db, g.double().sum(0).float(), atol=2e-4, rtol=1e-5)
+
+
+@gpu
+@pytest.mark.parametrize("p,n_classes", [(0.0, 1), (0.1, 1), (0.2, 12)])
+def test_fused_head_equals_layer_by_layer_path(p, n_classes):
+    """Same Philox draws in the same order: the fused node must reproduce the unfused path (outputs and all grads)."""
+    from fragnet_amd import ops
+    from fragnet_amd.model import FTHead3
+    dev = _dev()
+    torch.manual_seed(3)
+    head_a = FTHead3(input_dim=128, drop_ratio=p, n_classes=n_classes).to(dev).train()
+    head_b = copy.deepcopy(head_a)
+    x_a = torch.randn(64, 256, device=dev, requires_grad=True)
+    x_b = x_a.detach().clone().requires_grad_(True)
+    head_a.rng, head_b.rng = ops.PhiloxStream(seed=11), ops.PhiloxStream(seed=11)
+    out_a = head_a(x_a)                                            # fused (ops.mlp_head)
+
+    h = x_b                                                        # the loop _PredictorStack._run falls back to
+    for lin in head_b.predictor[:-1]:
+        h = ops.dropout_act(lin(h), p, True, True, head_b.rng)
+    out_b = head_b.predictor[-1](h)
+    torch.testing.assert_close(out_a, out_b, atol=1e-5, rtol=1e-5)
+    t = torch.randn_like(out_a)
+    (out_a * t).sum().backward()
+    (out_b * t).sum().backward()
+    torch.testing.assert_close(x_a.grad, x_b.grad, atol=1e-5, rtol=1e-4)
+    for (n, pa), (_, pb) in zip(head_a.named_parameters(), head_b.named_parameters()):
+        torch.testing.assert_close(pa.grad, pb.grad, atol=2e-5, rtol=1e-4, msg=lambda m, n=n: f"{n}: {m}")
+    assert head_a.rng.offset == head_b.rng.offset
+
+
+@gpu
+def test_fused_head_matches_plain_torch_without_dropout():
+    from fragnet_amd import ops
+    from fragnet_amd.model import FTHead3
+    dev = _dev()
+    torch.manual_seed(4)
+    head = FTHead3(input_dim=128, drop_ratio=0.0, n_classes=1).to(dev).train()
+    head.rng = ops.PhiloxStream(seed=1)
+    x = torch.randn(33, 256, device=dev, requires_grad=True)
+    out = head(x)
+    h = x.detach().double()
+    for lin in head.predictor[:-1]:
+        h = torch.relu(h @ lin.weight.double().t() + lin.bias.double())
+    ref = h @ head.predictor[-1].weight.double().t() + head.predictor[-1].bias.double()
+    torch.testing.assert_close(out, ref.float(), atol=1e-5, rtol=1e-5)
