@@ -148,7 +148,7 @@ def load():
         else:
             fn.restype = C.c_int
     if lib.fn_abi_version() != 3:
-        raise FragnetHipError(f"ABI version mismatch: library {lib.fn_abi_version()}, binding 2")
+        raise FragnetHipError(f"ABI version mismatch: library {lib.fn_abi_version()}, binding 3")
     _lib = lib
     return lib
 
