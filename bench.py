@@ -230,6 +230,7 @@ def main():
                     help="gat2 (the headline metric) or gat2_lite (SURVEY f3: levels L1-L3, per-level launches)")
     ap.add_argument("--forward-sweep", action="store_true",
                     help="extra (BASELINE configs[4]): forward-only eval throughput on 40-atom/12-fragment molecules, one line per batch size")
+    ap.add_argument("--no-gemm-tuning", action="store_true", help="A/B: library heuristics for the head GEMMs instead of TunableOp")
     ap.add_argument("--tune", action="append", default=None, help="A/B: KEY=VALUE for fn_set_tuning (include/fragnet_hip.h FN_TUNE_*)")
     ap.add_argument("--scatter-blocks", type=int, default=None, help="A/B: resident workgroups of the scatter kernels (FN_TUNE_FWD_BLOCKS)")
     args = ap.parse_args()
@@ -238,6 +239,8 @@ def main():
     from fragnet_amd import parallel
     from fragnet_amd.model import FragNetFineTune
     fragnet_amd.prefer_rocblas_for_dense_heads()
+    if not args.no_gemm_tuning:
+        fragnet_amd.tune_library_gemms()
     from fragnet_amd.plan import PLAN_KEY
 
     if not torch.cuda.is_available():

@@ -13,6 +13,26 @@ def prefer_rocblas_for_dense_heads() -> bool:
         return False
 
 
+def tune_library_gemms(max_ms: int = 30, filename: str = None) -> bool:
+    """Lets PyTorch's TunableOp time the rocBLAS / hipBLASLt solutions for every dense head product the first time a
+    shape is seen (M = batch size: 14 shapes for FTHead3, ~15 s once) and use the fastest from then on: +1.2 % on the
+    whole ESOL step over the library heuristics.  The first (eager) steps do the tuning, so call this before a
+    graphstep.GraphedTrainStep is captured.  ``filename``: reuse / store the selections across runs."""
+    import torch
+    try:
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tunable.set_max_tuning_duration(int(max_ms))
+        if not filename:             # TunableOp writes its selections at exit: keep them out of the working directory
+            import os, tempfile
+            filename = os.path.join(tempfile.gettempdir(), f"fragnet_amd_tunableop_{os.getuid()}.csv")
+        tunable.set_filename(filename, insert_device_ordinal=True)
+        return True
+    except Exception:                                              # older torch: library heuristics
+        return False
+
+
 def graph_capture_head(model, batch_size: int, attr: str = "fthead") -> bool:
     """Replaces ``model.<attr>`` (an MLP head with a static [batch_size, 256] input) by a HIP-graph-captured
     callable (torch.cuda.make_graphed_callables): its ~45 small launches per step become two graph launches.

@@ -1582,14 +1582,15 @@ __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ 
 }
 
 // backward of the above in one launch: g_x[m, k] = sum_c g[m, c] w[c, k];  dW[c, k] = sum_m g[m, c] x[m, k];
-// db[c] = sum_m g[m, c].  A block owns 64 columns k for all rows (deterministic sums); CM >= C bounds the registers.
+// db[c] = sum_m g[m, c].  A block owns 16 columns k for all rows (deterministic sums, 64 rows in flight);
+// CM >= C bounds the registers.
 template <int CM>
 __global__ __launch_bounds__(256) void k_small_linear_bwd(const float* __restrict__ g, const float* __restrict__ x,
                                                           const float* __restrict__ w, float* __restrict__ g_x,
                                                           float* __restrict__ dW, float* __restrict__ db, int64_t M, int K, int C) {
-    __shared__ float4 sm[16][16];
-    const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;          // 16 float4 columns x 16 row lanes
-    const int col = blockIdx.x * 64 + c4 * 4;
+    __shared__ float4 sm[64][4];
+    const int c4 = threadIdx.x & 3, rl = threadIdx.x >> 2;           // 4 float4 columns x 64 row lanes
+    const int col = blockIdx.x * 16 + c4 * 4;
     const bool live = col < K;
     float4 wv[CM], acc[CM];
 #pragma unroll
@@ -1598,7 +1599,7 @@ __global__ __launch_bounds__(256) void k_small_linear_bwd(const float* __restric
         acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (live) {
-        for (int64_t m = rl; m < M; m += 16) {
+        for (int64_t m = rl; m < M; m += 64) {
             const float4 xv = ld4(x + m * K + col);
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -1619,7 +1620,7 @@ __global__ __launch_bounds__(256) void k_small_linear_bwd(const float* __restric
             __syncthreads();
             if (rl == 0 && live) {
                 float4 t = sm[0][c4];
-                for (int q = 1; q < 16; ++q) { const float4 u = sm[q][c4]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+                for (int q = 1; q < 64; ++q) { const float4 u = sm[q][c4]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
                 st4(dW + (size_t)c * K + col, t);
             }
             __syncthreads();
@@ -2775,7 +2776,7 @@ int fn_small_linear_bwd_f32(const float* g, const float* x, const float* w, floa
         return fail(FN_EINVAL, "fn_small_linear_bwd_f32: K must be a multiple of 4 and 1 <= C <= FN_SMALL_LINEAR_MAX");
     if (!w || !dW || !db || (M > 0 && (!g || !x || !g_x)) || (((uintptr_t)x | (uintptr_t)w | (uintptr_t)g_x | (uintptr_t)dW) & 15))
         return fail(FN_EINVAL, "fn_small_linear_bwd_f32: null or misaligned buffer");
-    const dim3 grid((unsigned)((K + 63) / 64));
+    const dim3 grid((unsigned)((K + 15) / 16));
     if (C <= 1) hipLaunchKernelGGL(k_small_linear_bwd<1>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW, db, M, (int)K, (int)C);
     else if (C <= 4) hipLaunchKernelGGL(k_small_linear_bwd<4>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW, db, M, (int)K, (int)C);
     else hipLaunchKernelGGL(k_small_linear_bwd<FN_SMALL_LINEAR_MAX>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW, db, M, (int)K, (int)C);

@@ -26,6 +26,7 @@ if __name__ == "__main__":
     train.seed_everything(args.seed)
     import fragnet_amd
     fragnet_amd.prefer_rocblas_for_dense_heads()
+    fragnet_amd.tune_library_gemms()
     rank, local_rank, world = parallel.init_distributed()
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
