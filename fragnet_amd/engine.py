@@ -11,7 +11,7 @@ from typing import List, Sequence
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 from ._lib import Encoder, FN_D, LAYER_FIELDS, LayerWeights, SegPlan
 from .plan import GraphPlan, _stream_ptr
 
@@ -66,6 +66,7 @@ class _EncoderFn(torch.autograd.Function):
     def forward(ctx, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, plan, n_layers, heads, drop_p, training,
                 seed, offset, offset_dev, variant, *params):
         x_atoms, bond_nodes, fbond_nodes = _f32(x_atoms, "x_atoms"), _f32(bond_nodes, "node_features_bonds"), _f32(fbond_nodes, "node_features_fbonds")
+        ctx.param_objs, ctx.slots = params, [ops.grad_slot(p) for p in params]
         params = tuple(_f32(p, "parameter") for p in params)
         dev = x_atoms.device
         lib = _lib.load()
@@ -92,7 +93,7 @@ class _EncoderFn(torch.autograd.Function):
         dev = outs[0].device
         lib = _lib.load()
         gs = [None if g is None else _f32(g, "grad") for g in (g_atoms, g_frags, g_bond, g_fbond)]
-        grads = [torch.empty_like(p) for p in params]
+        grads = [ops.grad_buffer(p, slot) for p, slot in zip(ctx.param_objs, ctx.slots)]      # FlatAdam slots where they exist
         gw = (LayerWeights * n_layers)()
         for l in range(n_layers):
             for k, name in enumerate(LAYER_FIELDS):

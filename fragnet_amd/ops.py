@@ -34,6 +34,21 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+def grad_slot(param):
+    """The (flat gradient buffer, offset) parallel.FlatAdam assigned to ``param``, or None."""
+    return getattr(param, "_fn_grad_slot", None)
+
+
+def grad_buffer(param, slot):
+    """Where a hand-written backward writes d loss / d param: the parameter's slot of the optimiser's flat gradient
+    buffer when there is one and nothing has been accumulated yet (autograd then adopts the returned view as
+    ``param.grad`` and FlatAdam.gather_grads finds it in place), else a fresh tensor."""
+    if slot is not None and param.grad is None:
+        flat, off = slot
+        return flat[off: off + param.numel()].view(param.shape)
+    return torch.empty_like(param)
+
+
 def _part_rows(n: int) -> int:
     return max(1, min((n + 7) // 8, FN_MAX_PART))
 
@@ -532,6 +547,7 @@ class _MLPHead(torch.autograd.Function):
         else:
             out = torch.addmm(b, h, W.t())
         ctx.p = float(p)
+        ctx.params, ctx.slots = params, [grad_slot(q) for q in params]
         ctx.save_for_backward(*acts, *params[0::2])
         return out
 
@@ -545,19 +561,24 @@ class _MLPHead(torch.autograd.Function):
         grads = [None] * (2 * n)
         W, h = Ws[-1], acts[-1]
         C_out, K = W.shape
+        P, slots = ctx.params, ctx.slots
+        dW, db = grad_buffer(P[-2], slots[-2]), grad_buffer(P[-1], slots[-1])
         if C_out <= SMALL_LINEAR_MAX and K % 4 == 0:
-            gz, dW, db = torch.empty_like(h), torch.empty_like(W), torch.empty(C_out, dtype=torch.float32, device=g.device)
+            gz = torch.empty_like(h)
             _lib.call("fn_small_linear_bwd_f32", g.data_ptr(), h.data_ptr(), W.data_ptr(), gz.data_ptr(), dW.data_ptr(), db.data_ptr(),
                       h.shape[0], K, C_out, st)
         else:
-            gz, dW, db = g @ W, g.t() @ h, g.sum(0)
+            gz = g @ W
+            torch.mm(g.t(), h, out=dW)
+            torch.sum(g, 0, out=db)
         grads[-2], grads[-1] = dW, db
         scale = 1.0 / (1.0 - ctx.p) if 0.0 < ctx.p < 1.0 else (1.0 if ctx.p == 0.0 else 0.0)
         for i in range(n - 2, -1, -1):
             z, h_in, W = acts[i + 1], acts[i], Ws[i]
-            gy, db = torch.empty_like(z), torch.empty(z.shape[1], dtype=torch.float32, device=z.device)
+            gy, dW, db = torch.empty_like(z), grad_buffer(P[2 * i], slots[2 * i]), grad_buffer(P[2 * i + 1], slots[2 * i + 1])
             _lib.call("fn_gate_colsum_f32", gz.data_ptr(), z.data_ptr(), gy.data_ptr(), db.data_ptr(), z.shape[0], z.shape[1], scale, st)
-            grads[2 * i], grads[2 * i + 1] = gy.t() @ h_in, db
+            torch.mm(gy.t(), h_in, out=dW)
+            grads[2 * i], grads[2 * i + 1] = dW, db
             if i > 0 or ctx.needs_input_grad[0]:
                 gz = gy @ W
         return (gz if ctx.needs_input_grad[0] else None, None, None, None, *grads)

@@ -139,6 +139,10 @@ class FlatAdam:
                 off += n
         self.flat = torch.nn.Parameter(flat)
         self.grad = torch.zeros_like(flat)
+        off = 0
+        for p in self.params:      # producers that know about it (ops.grad_buffer) write d loss/d p straight into its slot
+            p._fn_grad_slot = (self.grad, off)
+            off += p.numel()
         self.hyper = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.steps = 0
         if flat.is_cuda:      # one HIP kernel (fn_adam_f32) over the flat tensor
@@ -168,7 +172,27 @@ class FlatAdam:
         missing = [i for i, p in enumerate(self.params) if p.grad is None]
         if missing:
             raise RuntimeError(f"{len(missing)} live parameter(s) received no gradient this step")
-        torch.cat([p.grad.reshape(-1) for p in self.params], out=self.grad)
+        # gradients that a producer already wrote into their slot of the flat buffer (ops.grad_buffer: the encoder
+        # and the fused head do) need no copy; every maximal run of the others is one cat
+        base, es = self.grad.data_ptr(), self.grad.element_size()
+        run, run_off, off = [], 0, 0
+
+        def flush():
+            if run:
+                n = sum(g.numel() for g in run)
+                torch.cat(run, out=self.grad[run_off: run_off + n])
+                run.clear()
+
+        for p in self.params:
+            n = p.numel()
+            if n and p.grad.data_ptr() != base + off * es:
+                if not run:
+                    run_off = off
+                run.append(p.grad.reshape(-1))
+            else:
+                flush()
+            off += n
+        flush()
 
     def all_reduce(self, group=None):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

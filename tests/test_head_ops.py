@@ -94,3 +94,38 @@ def test_fused_head_matches_plain_torch_without_dropout():
         h = torch.relu(h @ lin.weight.double().t() + lin.bias.double())
     ref = h @ head.predictor[-1].weight.double().t() + head.predictor[-1].bias.double()
     torch.testing.assert_close(out, ref.float(), atol=1e-5, rtol=1e-5)
+
+
+@gpu
+def test_parameter_gradients_are_written_into_the_flat_buffer():
+    """Encoder and fused head write d loss / d param straight into FlatAdam's flat gradient buffer: after backward
+    every live parameter's .grad is its slot (gather_grads has nothing to copy) and holds the same numbers as a
+    run without slots."""
+    from fragnet_amd import data, parallel, synth, train
+    from fragnet_amd.model import FragNetFineTune
+    dev = _dev()
+    batch = data.batch_to(data.collate_fn(synth.synth_molecules(24, seed=5)), dev)
+    torch.manual_seed(2)
+    model = FragNetFineTune(n_classes=1, num_layer=2, drop_ratio=0.0, act="relu").to(dev).train()     # ReLU head: fused node
+    ref = copy.deepcopy(model)
+
+    def run(m):
+        loss = train.compute_mse_loss(m(dict(batch)), batch["y"]) if hasattr(train, "compute_mse_loss") else \
+            torch.nn.functional.mse_loss(m(dict(batch)).reshape(-1), batch["y"].reshape(-1).float())
+        loss.backward()
+
+    opt = parallel.FlatAdam.for_live_parameters(model, lambda: run(model), lr=1e-3)
+    opt.zero_grad()
+    run(model)
+    names = {id(q): n for n, q in model.named_parameters()}
+    base, off, elsewhere = opt.grad.data_ptr(), 0, []
+    for p in opt.params:
+        if p.grad.data_ptr() != base + 4 * off:
+            elsewhere.append(names[id(p)])
+        off += p.numel()
+    assert not elsewhere, f"gradients not in place: {elsewhere}"
+    opt.gather_grads()
+    run(ref)                                                       # no optimiser attached: ordinary .grad tensors
+    live = [q for q in ref.parameters() if q.grad is not None]
+    flat_ref = torch.cat([q.grad.reshape(-1) for q in live])
+    torch.testing.assert_close(opt.grad, flat_ref, atol=1e-6, rtol=1e-5)
