@@ -166,64 +166,17 @@ __global__ void k_plan_hist(PlanTasks P, int32_t* __restrict__ rowptr_all, int32
     }
 }
 
-// inclusive scan of a[0..len) in place; one 1024-thread block, 8 consecutive items per thread per chunk
-__global__ __launch_bounds__(1024) void k_plan_scan(int32_t* __restrict__ a, int64_t len) {
-    __shared__ int32_t wave_tot[16];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    int32_t carry = 0;
-    for (int64_t base = 0; base < len; base += 1024 * 8) {
-        const int64_t i0 = base + (int64_t)tid * 8;
-        int32_t v[8];
-        int32_t sum = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            sum += (i0 + k < len) ? a[i0 + k] : 0;
-            v[k] = sum;
-        }
-        int32_t x = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            int32_t y = __shfl_up(x, off);
-            if (lane >= off) x += y;
-        }
-        if (lane == 63) wave_tot[wid] = x;
-        __syncthreads();
-        int32_t before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            int32_t wt = wave_tot[w];
-            before += (w < wid) ? wt : 0;
-            total += wt;
-        }
-        const int32_t excl = carry + before + (x - sum);
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (i0 + k < len) a[i0 + k] = v[k] + excl;
-        carry += total;
-        __syncthreads();
-    }
-}
-
 constexpr int kScanChunk = 2048;   // items per block in the multi-block scan (256 threads x 8)
 
-__global__ __launch_bounds__(256) void k_scan_reduce(const int32_t* __restrict__ a, int64_t len, int32_t* __restrict__ block_sums) {
-    __shared__ int32_t ws[4];
-    const int64_t i0 = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 8;
-    int32_t s = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += (i0 + k < len) ? a[i0 + k] : 0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
-}
-
-// inclusive scan of one 2048-item chunk per block, offset by the inclusive scan of the preceding block sums
-__global__ __launch_bounds__(256) void k_scan_apply(int32_t* __restrict__ a, int64_t len, const int32_t* __restrict__ block_incl) {
+// Single-pass inclusive scan (decoupled look-back): block b scans its 2048-item chunk, publishes its total as
+// state[b] = (1 << 32 | total), sums its predecessors' words 64 at a time until it meets one that already carries an
+// inclusive prefix (2 << 32 | prefix), publishes its own inclusive prefix and adds the exclusive one to its chunk.
+// A block only ever waits for lower-numbered blocks, which the dispatcher started earlier.  `state` must be zero.
+__global__ __launch_bounds__(256) void k_scan_lookback(int32_t* __restrict__ a, int64_t len, unsigned long long* __restrict__ state) {
     __shared__ int32_t wave_tot[4];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int64_t i0 = (int64_t)blockIdx.x * kScanChunk + (int64_t)tid * 8;
+    __shared__ int32_t s_prefix;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, b = blockIdx.x;
+    const int64_t i0 = (int64_t)b * kScanChunk + (int64_t)tid * 8;
     int32_t v[8];
     int32_t sum = 0;
 #pragma unroll
@@ -239,7 +192,34 @@ __global__ __launch_bounds__(256) void k_scan_apply(int32_t* __restrict__ a, int
     }
     if (lane == 63) wave_tot[wid] = x;
     __syncthreads();
-    int32_t before = blockIdx.x ? block_incl[blockIdx.x - 1] : 0;
+    const int32_t total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    if (wid == 0) {
+        if (lane == 0)
+            __hip_atomic_store(&state[b], ((unsigned long long)(b == 0 ? 2 : 1) << 32) | (uint32_t)total, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        int32_t prefix = 0;
+        for (int hi = b - 1; hi >= 0; hi -= 64) {                   // window of 64 predecessors: lane l looks at block hi - l
+            const int j = hi - lane;
+            unsigned long long w = 3ull << 32;                      // lanes below block 0: "nothing, stop"
+            if (j >= 0) {
+                do { w = __hip_atomic_load(&state[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while ((w >> 32) == 0);
+            }
+            const uint64_t done = __ballot((w >> 32) >= 2);         // inclusive prefix (or the start of the array) seen
+            const int stop = done ? __ffsll((unsigned long long)done) - 1 : 63;
+            int32_t part = (lane <= stop && j >= 0) ? (int32_t)(uint32_t)w : 0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            prefix += part;
+            if (done) break;
+        }
+        if (lane == 0) {
+            if (b > 0)
+                __hip_atomic_store(&state[b], (2ull << 32) | (uint32_t)(prefix + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix = prefix;
+        }
+    }
+    __syncthreads();
+    int32_t before = s_prefix;
 #pragma unroll
     for (int w = 0; w < 4; ++w) before += (w < wid) ? wave_tot[w] : 0;
     const int32_t excl = before + (x - sum);
@@ -2376,19 +2356,18 @@ int fn_plan_build(const fn_csr_task* tasks, int n_tasks, int32_t* rowptr_all, in
     int32_t* status = ws_i32 + segs + items;
     // zeroing by kernel, not hipMemsetAsync: the call must be capturable in a hipGraph and replayable (memset nodes
     // were observed to fault on the second replay on ROCm 7.2), and it is one launch for both regions
-    hipLaunchKernelGGL(k_zero2_i32, dim3(flat_grid(2 * segs + items + 5, kGridCap)), dim3(kBlock), 0, st, rowptr_all,
-                       segs + 1, ws_i32, segs + items + 4);
+    const int nb = (int)((segs + kScanChunk - 1) / kScanChunk);
+    int32_t* state_i32 = ws_i32 + segs + items + 4;
+    if ((uintptr_t)state_i32 & 7) ++state_i32;                      // 64-bit look-back words
+    const int64_t zero_ws = (state_i32 - ws_i32) + 2 * (int64_t)nb;
+    hipLaunchKernelGGL(k_zero2_i32, dim3(flat_grid(segs + 1 + zero_ws, kGridCap)), dim3(kBlock), 0, st, rowptr_all,
+                       segs + 1, ws_i32, zero_ws);
     if (items > 0) {
         const int g = flat_grid(items, kGridCap);
         hipLaunchKernelGGL(k_plan_hist, dim3(g), dim3(kBlock), 0, st, P, rowptr_all, status);
-        {
-            // multi-block inclusive scan of the histogram: block sums -> scan of block sums -> per-chunk scan
-            const int nb = (int)((segs + kScanChunk - 1) / kScanChunk);
-            int32_t* block_sums = ws_i32 + segs + items + 4;
-            hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, rowptr_all + 1, segs, block_sums);
-            hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, block_sums, (int64_t)nb);
-            hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, rowptr_all + 1, segs, block_sums);
-        }
+        // inclusive scan of the histogram in one launch
+        hipLaunchKernelGGL(k_scan_lookback, dim3(nb), dim3(256), 0, st, rowptr_all + 1, segs,
+                           reinterpret_cast<unsigned long long*>(state_i32));
         hipLaunchKernelGGL(k_plan_fill, dim3(g), dim3(kBlock), 0, st, P, rowptr_all, cursor, tmp, aux_a);
         hipLaunchKernelGGL(k_plan_ranksort, dim3(g), dim3(kBlock), 0, st, rowptr_all, tmp, aux_a, perm_all, items, segs);
         if (any_pair) {

@@ -87,7 +87,7 @@ class GraphPlan:
         ti, ts = tot_items.value, tot_segs.value
         # one int32 arena: rowptr | perm | aux_a | aux_b | aux_c | workspace(cursor, tmp, status, block sums)
         ta = max(ti, 1)                 # keep every region non-empty so its pointer is never null
-        arena = torch.empty(ts + 1 + 4 * ta + (ts + ti + 4 + ts // 2048 + 1), dtype=torch.int32, device=device)
+        arena = torch.empty(ts + 1 + 4 * ta + (ts + ti + 4 + 2 * (ts // 2048 + 1) + 2), dtype=torch.int32, device=device)
         self._arena = arena
         self.rowptr = arena[: ts + 1]
         self.perm = arena[ts + 1: ts + 1 + ta]
