@@ -68,6 +68,7 @@ class Encoder(C.Structure):
                 ("N", i64), ("E", i64), ("F", i64), ("EF", i64),
                 ("bond", GatPlan), ("atom", GatPlan), ("fbond", GatPlan), ("frag", GatPlan), ("a2f", SegPlan),
                 ("x_atoms", vp), ("bond_nodes", vp), ("fbond_nodes", vp), ("cos_sorted", vp), ("fattr_sorted", vp),
+                ("cos_raw", vp), ("fattr_raw", vp),
                 ("w", LayerWeights * FN_MAX_LAYERS), ("ws", vp), ("ws_floats", i64)]
 
 

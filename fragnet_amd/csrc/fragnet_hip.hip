@@ -1215,14 +1215,18 @@ __global__ __launch_bounds__(kBlock) void k_row_dots_sorted_bwd(const float* __r
 }
 
 // x_sorted[pos, :] = x[eid(pos), :] (zeros at loop positions): raw edge attributes are permuted once per batch
-__global__ void k_sort_edge_attr(const float* __restrict__ x, int K, fn_gat_plan pl, float* __restrict__ x_sorted) {
+__device__ __forceinline__ void sort_edge_attr_body(const float* __restrict__ x, int K, const fn_gat_plan& pl,
+                                                    float* __restrict__ x_sorted, int vb, int nb) {
     const int64_t total = pl.m * K;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)vb * blockDim.x + threadIdx.x; i < total; i += (int64_t)nb * blockDim.x) {
         const int64_t pos = i / K;
         const int k = (int)(i % K);
         const int eid = pl.eid_d[pos];
         x_sorted[(size_t)k * pl.m + pos] = eid < pl.m_real ? x[(size_t)eid * K + k] : 0.f;   // [K][m]
     }
+}
+__global__ void k_sort_edge_attr(const float* __restrict__ x, int K, fn_gat_plan pl, float* __restrict__ x_sorted) {
+    sort_edge_attr_body(x, K, pl, x_sorted, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // one block per column of the column-major partials [cols][FN_MAX_PART]
@@ -1423,13 +1427,13 @@ __global__ void k_segment_softmax_bwd(const float* __restrict__ probs, const flo
 // dropout + ReLU epilogue (Philox-4x32-10)
 // =====================================================================================
 template <bool BWD>
-__global__ void k_dropout_act(const float* __restrict__ a, const float* __restrict__ y_saved, float* __restrict__ o,
-                              int64_t numel, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
-                              int relu) {
+__device__ __forceinline__ void dropout_act_body(const float* __restrict__ a, const float* __restrict__ y_saved, float* __restrict__ o,
+                                                 int64_t numel, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                                 int relu, int vb, int nb) {
     const int64_t n4 = (numel + 3) / 4;
     if (offset_dev) offset += *offset_dev;
     const float inv_keep = p < 1.f ? 1.f / (1.f - p) : 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)vb * blockDim.x + threadIdx.x; i < n4; i += (int64_t)nb * blockDim.x) {
         float m[4] = {1.f, 1.f, 1.f, 1.f};
         if (p > 0.f) {
             const uint4 r = philox4x32_10(offset + (uint64_t)i, seed);
@@ -1458,6 +1462,12 @@ __global__ void k_dropout_act(const float* __restrict__ a, const float* __restri
             }
         }
     }
+}
+template <bool BWD>
+__global__ void k_dropout_act(const float* __restrict__ a, const float* __restrict__ y_saved, float* __restrict__ o,
+                              int64_t numel, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                              int relu) {
+    dropout_act_body<BWD>(a, y_saved, o, numel, p, seed, offset, offset_dev, relu, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // torch.optim.Adam's update rule (no amsgrad) on one flat tensor: the reference's optimiser, finetune_gat2.py:257
@@ -1845,17 +1855,55 @@ struct TransposeMany {
     const float* W[3 * FN_MAX_LAYERS];
     int K[3 * FN_MAX_LAYERS];
 };
-__global__ void k_transpose_many(TransposeMany tm, float* __restrict__ bt_base) {
-    __shared__ float tile[32][33];
-    const int z = blockIdx.z, K = tm.K[z];
-    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    if (k0 >= K) return;
+__device__ __forceinline__ void transpose_many_body(const TransposeMany& tm, float* __restrict__ bt_base, float (*tile)[33],
+                                                    int z, int by, int bx) {
+    const int K = tm.K[z];
+    const int k0 = bx * 32, n0 = by * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (k0 >= K) return;                                            // whole block
     const float* W = tm.W[z];
     float* Bt = bt_base + (size_t)z * 192 * FN_D;
     for (int r = ty; r < 32; r += 8) tile[r][tx] = (k0 + tx < K) ? W[(size_t)(n0 + r) * K + k0 + tx] : 0.f;
     __syncthreads();
     for (int r = ty; r < 32; r += 8)
         if (k0 + r < K) Bt[(size_t)(k0 + r) * FN_D + n0 + tx] = tile[tx][r];
+}
+__global__ void k_transpose_many(TransposeMany tm, float* __restrict__ bt_base) {
+    __shared__ float tile[32][33];
+    transpose_many_body(tm, bt_base, tile, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x);
+}
+
+// Everything the encoder's forward pass needs before its first projection, none of which depends on the other: W^T of
+// every projection, dropout of the atom features, and the permutation of the two raw edge-attribute tensors into
+// destination order.  One launch of four block ranges instead of four launches (each was 5 us of latency).
+struct EncPrologue {
+    TransposeMany tm;
+    float* bt_base;
+    int n_t;                                                        // 24 blocks per matrix
+    const float* dx;  float* dy;  int64_t dnumel;  float p;  uint64_t seed, offset;  const uint64_t* offset_dev;  int n_d;
+    const float* sx[2];  float* so[2];  int sK[2];  fn_gat_plan spl[2];  int n_s[2];
+};
+__global__ __launch_bounds__(256) void k_enc_prologue(EncPrologue A) {
+    __shared__ float tile[32][33];
+    int b = blockIdx.x;
+    if (b < A.n_t) {
+        const int z = b / 24, rem = b % 24;
+        transpose_many_body(A.tm, A.bt_base, tile, z, rem / 6, rem % 6);
+        return;
+    }
+    b -= A.n_t;
+    if (b < A.n_d) {
+        dropout_act_body<false>(A.dx, nullptr, A.dy, A.dnumel, A.p, A.seed, A.offset, A.offset_dev, 0, b, A.n_d);
+        return;
+    }
+    b -= A.n_d;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (b < A.n_s[q]) {
+            sort_edge_attr_body(A.sx[q], A.sK[q], A.spl[q], A.so[q], b, A.n_s[q]);
+            return;
+        }
+        b -= A.n_s[q];
+    }
 }
 
 // Weight gradient: block = `rows_per_block` rows in chunks of 32 staged through double-buffered LDS.  Wave w owns
@@ -3123,25 +3171,36 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
     if (multi) FN_TRY(aux_init());
     fn_stream_t st_fb = multi ? (fn_stream_t)g_aux.s[1] : st;       // the fragment-bond chain's stream
 
-    const float* in_atoms = e->x_atoms;
-    if (lay.in_atoms0) {
-        FN_TRY(fn_dropout_act_f32(e->x_atoms, lay.in_atoms0, e->N * e->k_atom0, p, e->seed, rng.in_atoms, e->offset_dev, 0, st));
-        in_atoms = lay.in_atoms0;
-    }
+    const float* in_atoms = lay.in_atoms0 ? lay.in_atoms0 : e->x_atoms;
     const float* in_bond = e->bond_nodes;
     const float* in_fbond = e->fbond_nodes;
     int ka = e->k_atom0, kb = e->k_bond0, kfb = e->k_fbond0;
 
-    {   // W^T of every projection, one launch
-        TransposeMany tm{};
+    {   // one launch: W^T of every projection, dropout(x_atoms), destination-order edge attributes
+        EncPrologue A{};
         for (int l = 0; l < e->n_layers; ++l) {
-            tm.W[3 * l] = e->w[l].proj_b_w;       tm.K[3 * l] = l ? FN_D : e->k_bond0;
-            tm.W[3 * l + 1] = e->w[l].proj_a_w;   tm.K[3 * l + 1] = l ? FN_D : e->k_atom0;
-            tm.W[3 * l + 2] = e->w[l].proj_fb_w;  tm.K[3 * l + 2] = l ? FN_D : e->k_fbond0;
-            if (!tm.W[3 * l] || !tm.W[3 * l + 1] || !tm.W[3 * l + 2]) return fail(FN_EINVAL, "fn_encoder_forward: null projection weight");
+            A.tm.W[3 * l] = e->w[l].proj_b_w;       A.tm.K[3 * l] = l ? FN_D : e->k_bond0;
+            A.tm.W[3 * l + 1] = e->w[l].proj_a_w;   A.tm.K[3 * l + 1] = l ? FN_D : e->k_atom0;
+            A.tm.W[3 * l + 2] = e->w[l].proj_fb_w;  A.tm.K[3 * l + 2] = l ? FN_D : e->k_fbond0;
+            if (!A.tm.W[3 * l] || !A.tm.W[3 * l + 1] || !A.tm.W[3 * l + 2]) return fail(FN_EINVAL, "fn_encoder_forward: null projection weight");
         }
-        hipLaunchKernelGGL(k_transpose_many, dim3(6, 4, 3 * e->n_layers), dim3(256), 0, S(st), tm, lay.bt);
-        FN_TRY(launch_status("fn_encoder_forward: transpose"));
+        A.bt_base = lay.bt;
+        A.n_t = 24 * 3 * e->n_layers;
+        if (lay.in_atoms0) {
+            A.dx = e->x_atoms;  A.dy = lay.in_atoms0;  A.dnumel = e->N * e->k_atom0;  A.p = p;  A.seed = e->seed;
+            A.offset = rng.in_atoms;  A.offset_dev = e->offset_dev;
+            A.n_d = flat_grid((A.dnumel + 3) / 4, 512);
+        }
+        if (e->cos_raw && e->bond.m > 0) {
+            A.sx[0] = e->cos_raw;  A.so[0] = const_cast<float*>(e->cos_sorted);  A.sK[0] = 1;  A.spl[0] = e->bond;
+            A.n_s[0] = flat_grid(e->bond.m, 512);
+        }
+        if (e->fattr_raw && e->fbond.m > 0) {
+            A.sx[1] = e->fattr_raw;  A.so[1] = const_cast<float*>(e->fattr_sorted);  A.sK[1] = e->k_fattr;  A.spl[1] = e->fbond;
+            A.n_s[1] = flat_grid(e->fbond.m * e->k_fattr, 512);
+        }
+        hipLaunchKernelGGL(k_enc_prologue, dim3(A.n_t + A.n_d + A.n_s[0] + A.n_s[1]), dim3(256), 0, S(st), A);
+        FN_TRY(launch_status("fn_encoder_forward: prologue"));
     }
     FN_TRY(order_after(S(st), S(st_fb)));      // fork: the fragment-bond levels of ALL layers depend on nothing else
 

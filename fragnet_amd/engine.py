@@ -55,6 +55,9 @@ def _describe(plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fat
     e.a2f = SegPlan(s.rowptr.data_ptr(), s.perm.data_ptr(), s.index.data_ptr(), s.n_seg, s.n_items, s.pos_base, 0)
     e.x_atoms, e.bond_nodes, e.fbond_nodes = x_atoms.data_ptr(), bond_nodes.data_ptr(), fbond_nodes.data_ptr()
     e.cos_sorted, e.fattr_sorted = cos_sorted.data_ptr(), fattr_sorted.data_ptr()
+    raw_b, raw_f = plan.pending.get("bond"), plan.pending.get("fbond")      # sorted copies not filled yet: the forward does it
+    e.cos_raw = None if raw_b is None else raw_b.data_ptr()
+    e.fattr_raw = None if raw_f is None else raw_f.data_ptr()
     for l in range(n_layers):
         for k, name in enumerate(LAYER_FIELDS):
             setattr(e.w[l], name, params[l * NP + k].data_ptr())
@@ -76,6 +79,9 @@ class _EncoderFn(torch.autograd.Function):
         e.ws, e.ws_floats = ws.data_ptr(), ws.numel()
         outs = [torch.empty((n, FN_D), dtype=torch.float32, device=dev) for n in (e.N, e.F, e.E, e.EF)]
         _lib.check(lib.fn_encoder_forward(C.byref(e), *(o.data_ptr() for o in outs), _stream_ptr(dev)), "fn_encoder_forward")
+        plan.pending.pop("bond", None)
+        plan.pending.pop("fbond", None)
+        e.cos_raw = e.fattr_raw = None           # the backward pass reads the sorted copies only
         ctx.desc = e
         ctx.keep = (plan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, ws, offset_dev)
         ctx.n_layers = n_layers

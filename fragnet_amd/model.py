@@ -197,8 +197,8 @@ class FragNet(nn.Module):
                                        or l.atom_mask_individual is not None for l in self.layers):
             # whole encoder in two C calls (fragnet_amd/engine.py); masks / attention outputs use the per-level path
             outs = engine.encoder_forward(self.layers, plan, batch["x_atoms"], batch["node_features_bonds"],
-                                          batch["node_features_fbonds"], plan.sorted_attr("bond", batch["edge_attr_bonds"]),
-                                          plan.sorted_attr("fbond", batch["edge_attr_fbonds"]), self.layers[0].num_heads,
+                                          batch["node_features_fbonds"], plan.sorted_attr("bond", batch["edge_attr_bonds"], defer=True),
+                                          plan.sorted_attr("fbond", batch["edge_attr_fbonds"], defer=True), self.layers[0].num_heads,
                                           p, train, self.rng, variant=1 if lite else 0)
             return (outs[0], outs[1], outs[2], None) if lite else outs
         x_atoms = ops.dropout_act(batch["x_atoms"], p, train, False, self.rng)

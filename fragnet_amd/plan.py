@@ -101,6 +101,7 @@ class GraphPlan:
                    "fn_plan_build")
         self._keep = keep
         self._sorted = {}
+        self.pending = {}           # level name -> raw edge attribute whose sorted copy fn_encoder_forward still has to fill
         self.levels: Dict[str, Level] = {}
         self.segs: Dict[str, Segments] = {}
         for ent in layout:
@@ -121,9 +122,11 @@ class GraphPlan:
                                            self.perm[t.item_base: t.item_base + t.n_real], int(t.item_base),
                                            int(t.n_seg), int(t.n_real), key)
 
-    def sorted_attr(self, name: str, x: torch.Tensor) -> torch.Tensor:
+    def sorted_attr(self, name: str, x: torch.Tensor, defer: bool = False) -> torch.Tensor:
         """Raw edge attribute of level ``name`` permuted into destination-sorted order, once per batch
-        (the reference feeds the same edge_attr_bonds / edge_attr_fbonds to every layer, gat2.py:430,433)."""
+        (the reference feeds the same edge_attr_bonds / edge_attr_fbonds to every layer, gat2.py:430,433).
+        ``defer``: only allocate the buffer and remember ``x`` in ``self.pending[name]``; the caller hands both to
+        fn_encoder_forward, which does the permutation inside its prologue launch (engine.py)."""
         key = (name, x.data_ptr(), x._version)
         hit = self._sorted.get(name)
         if hit is not None and hit[0] == key:
@@ -136,7 +139,10 @@ class GraphPlan:
         if x.numel() != lv.m_real * K:
             raise ValueError(f"edge attribute of level {name} has {x.shape[0]} rows, the plan has {lv.m_real} edges")
         out = torch.empty((K, lv.m), dtype=torch.float32, device=x.device)      # [K][m]: a lane's two edges are adjacent
-        _lib.call("fn_sort_edge_attr_f32", x.data_ptr(), K, C.byref(lv.c), out.data_ptr(), _stream_ptr(x.device))
+        if defer:
+            self.pending[name] = x
+        else:
+            _lib.call("fn_sort_edge_attr_f32", x.data_ptr(), K, C.byref(lv.c), out.data_ptr(), _stream_ptr(x.device))
         self._sorted[name] = (key, out)
         return out
 

@@ -354,7 +354,11 @@ typedef struct fn_encoder {
     fn_gat_plan bond, atom, fbond, frag;
     fn_seg_plan a2f;
     const float *x_atoms, *bond_nodes, *fbond_nodes;     /* layer-0 inputs */
-    const float *cos_sorted, *fattr_sorted;              /* fn_sort_edge_attr_f32 outputs */
+    const float *cos_sorted, *fattr_sorted;              /* fn_sort_edge_attr_f32 outputs: [1, bond.m] and [k_fattr, fbond.m] */
+    const float *cos_raw, *fattr_raw;                    /* nullable.  When set (edge order of the batch: [bond.m_real] and
+                                                          * [fbond.m_real, k_fattr]) fn_encoder_forward permutes them into
+                                                          * cos_sorted / fattr_sorted itself, inside its one prologue launch;
+                                                          * the two *_sorted buffers must then be writable */
     fn_layer_weights w[FN_MAX_LAYERS];
     float* ws;
     int64_t ws_floats;                     /* >= fn_encoder_ws_floats() */
