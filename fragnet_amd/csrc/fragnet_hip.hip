@@ -1555,6 +1555,30 @@ __global__ __launch_bounds__(256) void k_gate_colsum(const float* __restrict__ g
     }
 }
 
+// g_x = (y > 0) ? g_y * scale : 0 for up to four tensors (numel % 4 == 0, 16-byte aligned) in one launch
+struct GateTask {
+    const float *g, *y;
+    float* o;
+    int64_t n4;
+    int first, nblk;
+};
+struct GateTasks {
+    GateTask t[4];
+    int n, blocks;
+    float scale;
+};
+__global__ void k_gate_many(GateTasks G) {
+    int ti = 0;
+    while (ti + 1 < G.n && (int)blockIdx.x >= G.t[ti + 1].first) ++ti;
+    const GateTask& t = G.t[ti];
+    const float sc = G.scale;
+    for (int64_t i = (int64_t)((int)blockIdx.x - t.first) * blockDim.x + threadIdx.x; i < t.n4; i += (int64_t)t.nblk * blockDim.x) {
+        const float4 g = ld4(t.g + 4 * i), v = ld4(t.y + 4 * i);
+        st4(t.o + 4 * i, make_float4(v.x > 0.f ? g.x * sc : 0.f, v.y > 0.f ? g.y * sc : 0.f, v.z > 0.f ? g.z * sc : 0.f,
+                                     v.w > 0.f ? g.w * sc : 0.f));
+    }
+}
+
 // y[m, c] = <x[m, :], w[c, :]> + b[c] for a handful of outputs (the last Linear of a head: n_classes columns).
 // One wave per row; the row stays in registers while the C weight rows stream from L1.
 __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ x, const float* __restrict__ w,
@@ -3345,10 +3369,24 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         // (mask and ReLU gate fused into their epilogue), flagged by pre_* below.
         bool have_atoms = gy_atoms != nullptr || pre_atoms, have_frags = gy_frags != nullptr;
         bool have_bond = gy_bond != nullptr || pre_bond, have_fbond = gy_fbond != nullptr || pre_fbond;
-        if (gy_atoms) FN_TRY(fn_dropout_act_bwd_f32(gy_atoms, y_atoms, bw.g_pre_atoms, e->N * FN_D, p, e->seed, rng.y[l][0], e->offset_dev, 1, st));
-        if (gy_frags) FN_TRY(fn_dropout_act_bwd_f32(gy_frags, y_frags, bw.g_pre_frags, e->F * FN_D, p, e->seed, rng.y[l][1], e->offset_dev, 1, st));
-        if (gy_bond) FN_TRY(fn_dropout_act_bwd_f32(gy_bond, y_bond, bw.g_pre_bond, e->E * FN_D, p, e->seed, rng.y[l][2], e->offset_dev, 1, st));
-        if (gy_fbond) FN_TRY(fn_dropout_act_bwd_f32(gy_fbond, y_fbond, bw.g_pre_fbond, e->EF * FN_D, p, e->seed, rng.y[l][3], e->offset_dev, 1, st));
+        {   // backward of relu(dropout(.)) of up to four layer outputs in one launch; y > 0 already encodes the mask
+            GateTasks G{};
+            auto add = [&](const float* g, const float* y, float* o, int64_t numel) {
+                if (!g) return;
+                GateTask& t = G.t[G.n++];
+                t.g = g;  t.y = y;  t.o = o;  t.n4 = (numel + 3) / 4;  t.first = G.blocks;  t.nblk = flat_grid(t.n4, 512);
+                G.blocks += t.nblk;
+            };
+            add(gy_atoms, y_atoms, bw.g_pre_atoms, e->N * FN_D);
+            add(gy_frags, y_frags, bw.g_pre_frags, e->F * FN_D);
+            add(gy_bond, y_bond, bw.g_pre_bond, e->E * FN_D);
+            add(gy_fbond, y_fbond, bw.g_pre_fbond, e->EF * FN_D);
+            if (G.blocks) {
+                G.scale = p > 0.f ? (p < 1.f ? 1.f / (1.f - p) : 0.f) : 1.f;
+                hipLaunchKernelGGL(k_gate_many, dim3(G.blocks), dim3(kBlock), 0, S(st), G);
+                FN_TRY(launch_status("fn_encoder_backward: activation backward"));
+            }
+        }
         bool nxt_atoms = false, nxt_bond = false, nxt_fbond = false;     // what this layer hands to layer l-1
 
         // ---- L4b fragment graph (only where its output is consumed: the last layer, reference fact SURVEY §0.8)
