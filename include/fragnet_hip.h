@@ -223,7 +223,9 @@ int fn_colsum_f32(const float* part, int n_rows, int cols, float* out, int ld, i
 int fn_transpose_w_f32(const float* W, int K, float* Bt, fn_stream_t stream);
 int fn_linear128_f32(const float* X, int K, const float* Bt, const float* bias /*nullable*/, float* Y, int64_t M,
                      const fn_act_epilogue* act_bwd /*nullable: Y *= dropout mask * (act_bwd->y > 0), the backward of
-                     act(dropout(.)) fused into an input-gradient GEMM*/, fn_stream_t stream);
+                     act(dropout(.)) fused into an input-gradient GEMM.  With relu set, act_bwd->y must be the SAVED OUTPUT
+                     relu(dropout(x)) of that stream: it is positive exactly where the element was kept and passed the ReLU,
+                     so the kernel scales by 1/(1-p) where y > 0 and does not replay the Philox stream*/, fn_stream_t stream);
 int64_t fn_linear128_wgrad_ws(int64_t M, int K);
 int fn_linear128_wgrad_f32(const float* dY, const float* X, int K, int64_t M, float* ws, float* dW, float* db,
                            fn_stream_t stream);
