@@ -222,6 +222,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch-by-launch step instead of the whole-step hipGraph")
+    ap.add_argument("--overlap", choices=("auto", "on", "off"), default="auto",
+                    help="two-graph step with the head's gradient all-reduce beside the encoder backward (auto: when N > 1)")
     ap.add_argument("--margin", type=float, default=0.02, help="capacity head-room of the static shapes over the pool")
     ap.add_argument("--eager-head", action="store_true", help="(--eager) do not HIP-graph-capture the prediction head")
     ap.add_argument("--kernels-only", action="store_true", help="only time the bond-level scatter kernels (dev loop)")
@@ -286,7 +288,8 @@ def main():
         from fragnet_amd import graphstep
         try:
             shapes = graphstep.StaticShapes.from_batches(pool, margin=args.margin, heads=MODEL_CFG["num_heads"])
-            gstep = graphstep.GraphedTrainStep(model, opt, shapes, pool[0], loss="regr")
+            gstep = graphstep.GraphedTrainStep(model, opt, shapes, pool[0], loss="regr",
+                                               overlap={"auto": None, "on": True, "off": False}[args.overlap])
             torch.cuda.synchronize()
         except Exception as exc:      # never lose the measurement to a capture problem: run the same step eagerly
             gstep, capture_note = None, f"hipGraph capture failed ({type(exc).__name__}: {exc}); eager step"
@@ -341,7 +344,9 @@ def main():
                                    "emb 128, FTHead3 128/1024/1024/512, drop 0.1; synthetic ESOL-shape molecules (synth.py)",
                        "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world, "parallelism": f"dp{world}",
                        "mode": "eager launches, head " + ("hipGraph-captured" if graphed_head else "eager") if args.eager else
-                               "whole-step hipGraph over static shapes (stage+plan+fwd+mse+bwd+grad gather in the graph)",
+                               ("two hipGraphs over static shapes (stage+plan+fwd+mse+head bwd | encoder bwd); the head's gradient "
+                                "all-reduce runs beside the second" if gstep.split else
+                                "whole-step hipGraph over static shapes (stage+plan+fwd+mse+bwd+grad gather in the graph)"),
                        "capture_note": capture_note,
                        "static_capacity": None if gstep is None else gstep.shapes.cap,
                        "graph_replays": None if gstep is None else gstep.replays,

@@ -203,15 +203,30 @@ class FlatAdam:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
             self.grad.div_(dist.get_world_size(group))
 
+    def all_reduce_slice(self, lo: int, hi: Optional[int], group=None, async_op: bool = False):
+        """Average ``grad[lo:hi]`` across ranks; with ``async_op`` returns the work handle (None when there is nothing to
+        do) so that the collective runs on RCCL's stream beside whatever the caller enqueues next."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return None
+        view = self.grad[lo:hi]
+        if view.numel() == 0:
+            return None
+        if view.is_cuda:
+            return dist.all_reduce(view, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
+        dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+        view.div_(dist.get_world_size(group))
+        return None
+
     def step(self, group=None):
         """gather -> all-reduce (if distributed) -> Adam."""
         self.gather_grads()
         self.apply_gathered(group)
 
-    def apply_gathered(self, group=None):
-        """all-reduce (if distributed) -> Adam on gradients that are already in the flat buffer (the captured
-        step of graphstep.GraphedTrainStep gathers them inside its hipGraph)."""
-        self.all_reduce(group)
+    def apply_gathered(self, group=None, reduced: bool = False):
+        """all-reduce (if distributed, unless the caller already ``reduced`` the buffer) -> Adam on gradients that are
+        already in the flat buffer (the captured step of graphstep.GraphedTrainStep gathers them inside its hipGraph)."""
+        if not reduced:
+            self.all_reduce(group)
         self.steps += 1
         if self.opt is not None:
             self.flat.grad = self.grad

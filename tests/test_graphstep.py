@@ -275,3 +275,38 @@ def test_clsf_graph_step_matches_eager_step():
         torch.testing.assert_close(loss_b, loss_a.detach(), atol=1e-5, rtol=1e-4)
     assert step_b.replays == 4 and step_b.fallbacks == 0
     torch.testing.assert_close(opt_b.flat, opt_a.flat, atol=2e-5, rtol=1e-3)
+
+
+@gpu
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+def test_two_graph_overlap_step_matches_single_graph_step(drop):
+    """overlap=True: (forward + loss + head backward) and (encoder backward) as two graphs with the head's gradient
+    all-reduce issued between them.  On one rank the collectives are no-ops; weights, losses and dropout streams must
+    equal the single-graph step exactly."""
+    from fragnet_amd import parallel
+    from fragnet_amd.model import FragNetFineTune
+    dev = _dev()
+    batches = [data.batch_to(b, dev) for b in _batches(3, 40, seed=33)]
+    shapes = graphstep.StaticShapes.from_batches(batches, margin=0.05)
+    torch.manual_seed(8)
+    model_a = FragNetFineTune(n_classes=1, num_layer=2, drop_ratio=drop, act="relu").to(dev).train()
+    model_b = copy.deepcopy(model_a)
+    model_b.pretrain.rng.seed = model_a.pretrain.rng.seed = 99
+
+    def probe(model):
+        def run():
+            torch.nn.functional.mse_loss(model(dict(batches[0])).view(-1), batches[0]["y"]).backward()
+        return run
+    opt_a = parallel.FlatAdam.for_live_parameters(model_a, probe(model_a), lr=1e-3)
+    opt_b = parallel.FlatAdam.for_live_parameters(model_b, probe(model_b), lr=1e-3)
+    model_a.pretrain.rng.offset = model_b.pretrain.rng.offset = 0
+    step_a = graphstep.GraphedTrainStep(model_a, opt_a, shapes, dict(batches[0]), loss="regr", overlap=False)
+    step_b = graphstep.GraphedTrainStep(model_b, opt_b, shapes, dict(batches[0]), loss="regr", overlap=True)
+    assert step_b.split and step_b.graph_b is not None and not step_a.split
+    assert 0 < step_b.head_off < opt_b.grad.numel()
+    for i in range(5):
+        la = step_a(dict(batches[i % 3])).clone()
+        lb = step_b(dict(batches[i % 3])).clone()
+        torch.testing.assert_close(lb, la, atol=0, rtol=0)
+    torch.testing.assert_close(opt_b.flat, opt_a.flat, atol=0, rtol=0)
+    assert step_b.replays == 5 and step_b.fallbacks == 0

@@ -47,10 +47,19 @@ def _worker(rank, world, port, q):
     opt = parallel.FlatAdam.for_live_parameters(
         model, lambda: torch.nn.functional.mse_loss(model(x[mine]).view(-1), y[mine]).backward(), lr=1e-2)
     n_live = len(opt.params)
-    for _ in range(3):
+    for it in range(3):
         opt.zero_grad()
         torch.nn.functional.mse_loss(model(x[mine]).view(-1), y[mine]).backward()
-        opt.step()
+        if it == 1:      # the exchange of graphstep.GraphedTrainStep(overlap=True): "head" slice first, the rest after
+            opt.gather_grads()
+            k = model.l1.weight.numel() + model.l1.bias.numel()
+            works = [opt.all_reduce_slice(k, None, async_op=True), opt.all_reduce_slice(0, k, async_op=True)]
+            for w in works:
+                if w is not None:
+                    w.wait()
+            opt.apply_gathered(reduced=True)
+        else:
+            opt.step()
     # count-weighted scale: ranks hold 5 and 11 "atoms"
     scale = parallel.weighted_loss_scale(5 if rank == 0 else 11, torch.device("cpu"))
     q.put((rank, n_live, [p.detach().numpy().tolist() for p in model.parameters()], scale))
