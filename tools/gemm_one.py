@@ -6,6 +6,8 @@ import torch
 from fragnet_amd import _lib
 from fragnet_amd.plan import _stream_ptr
 M, K = int(sys.argv[1]), int(sys.argv[2])
+if len(sys.argv) > 3:
+    _lib.call("fn_set_tuning", 1, int(sys.argv[3]))      # FN_TUNE_GEMM_SLOTS
 dev = torch.device("cuda:0")
 x = torch.randn(M, K, device=dev); bt = torch.randn(K, 128, device=dev) * 0.1; b = torch.randn(128, device=dev)
 y = torch.empty(M, 128, device=dev)
