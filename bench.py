@@ -228,8 +228,9 @@ def main():
     ap.add_argument("--eager-head", action="store_true", help="(--eager) do not HIP-graph-capture the prediction head")
     ap.add_argument("--kernels-only", action="store_true", help="only time the bond-level scatter kernels (dev loop)")
     ap.add_argument("--kbatch", type=int, default=PER_GPU_BATCH, help="molecules per batch for --kernels-only")
-    ap.add_argument("--model-version", default="gat2", choices=["gat2", "gat2_lite"],
-                    help="gat2 (the headline metric) or gat2_lite (SURVEY f3: levels L1-L3, per-level launches)")
+    ap.add_argument("--model-version", default="gat2", choices=["gat2", "gat2_lite", "gat2_edge"],
+                    help="gat2 (the headline metric), gat2_lite (SURVEY f3: levels L1-L3) or gat2_edge (f3: no fragment-bond "
+                         "graph, per-level launches; cnx_attr widened to the 8 columns that model version expects)")
     ap.add_argument("--forward-sweep", action="store_true",
                     help="extra (BASELINE configs[4]): forward-only eval throughput on 40-atom/12-fragment molecules, one line per batch size")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="A/B: library heuristics for the head GEMMs instead of TunableOp")
@@ -267,6 +268,9 @@ def main():
         forward_sweep(rank, world, dev, args)
         return
     pool = make_pool(1, rank, dev, args.kbatch) if args.kernels_only else make_pool(args.pool, rank, dev)
+    if args.model_version == "gat2_edge":      # gat2_edge.py:46 wants 8 connection features, the featuriser writes 6
+        for b in pool:
+            b["cnx_attr"] = torch.nn.functional.pad(b["cnx_attr"], (0, 8 - b["cnx_attr"].shape[1]))
     torch.manual_seed(0)
     model = FragNetFineTune(**MODEL_CFG, variant=args.model_version).to(dev)
     if args.kernels_only:

@@ -166,17 +166,88 @@ class FragNetLayerA(nn.Module):
         return atoms_new, frags_new, new_bond, new_fbond
 
 
+class FragNetLayerEdge(nn.Module):
+    """model_version gat2_edge (fragnet/model/gat/gat2_edge.py:13-177): bond graph, atom graph and atom -> fragment sum as
+    in gat2; no fragment-bond graph -- the fragment graph's edge term is <Linear(8 -> 128)(cnx_attr), f[:, d:d+128]>,
+    folded in-kernel like the bond graph's cos term (fn_edge_term mode 2 with K = 8, d_e = 128).  Same constructor
+    order and state-dict keys as the reference."""
+
+    def __init__(self, atom_in=128, atom_out=128, frag_in=128, frag_out=128, edge_in=128, edge_out=128, num_heads=2,
+                 bond_edge_in=1, return_attentions=False, add_frag_self_loops=False):
+        super().__init__()
+        if atom_out != 128 or edge_out != 128:
+            raise ValueError("the gfx950 kernels are specialised for emb_dim = 128 (every reference config)")
+        if num_heads not in (1, 2, 4, 8):
+            raise ValueError("num_heads must be 1, 2, 4 or 8")
+        if add_frag_self_loops:
+            raise NotImplementedError("gat2_edge with add_frag_self_loops=True (never set by the reference's drivers)")
+        self.add_frag_self_loops = add_frag_self_loops
+        self.return_attentions = return_attentions
+        self.edge_out = edge_out
+        self.atom_embed = nn.Linear(atom_in, atom_out)           # constructed-but-unused block (gat2_edge.py:22-35)
+        self.frag_embed = nn.Linear(frag_in, frag_out)
+        self.edge_embed = nn.Linear(edge_in, edge_out)
+        self.bond_edge_embed = nn.Linear(edge_in, edge_out)
+        self.frag_message_mlp = nn.Linear(atom_out * 2, atom_out)
+        self.atom_mlp = _two_layer(atom_out)
+        self.frag_mlp = _two_layer(atom_out)
+        self.bias = nn.Parameter(torch.zeros(atom_out))
+        self.leakyrelu = nn.LeakyReLU(0.2)
+        self.num_heads = num_heads
+        self.edge_attr_bond_embed2 = nn.Linear(edge_out, edge_out)
+        d = edge_out // num_heads
+        self.projection_b = nn.Linear(edge_in, d * num_heads)
+        self.edge_attr_bond_embed = nn.Linear(bond_edge_in, d)
+        self.cnx_attr_transform = nn.Linear(8, edge_out)
+        self.projection_a = nn.Linear(atom_in, (atom_out // num_heads) * num_heads)
+        self.a_b = nn.Parameter(torch.empty(num_heads, 3 * d))
+        self.a = nn.Parameter(torch.empty(num_heads, 2 * d + edge_out))
+        self.f = nn.Parameter(torch.empty(num_heads, 2 * d + edge_out))
+        for w in (self.projection_b.weight, self.a_b, self.a, self.f):
+            nn.init.xavier_uniform_(w.data, gain=1.414)
+
+    def run(self, x_atoms, bond_nodes, bond_cos, cnx_attr, plan):
+        H, d = self.num_heads, self.edge_out // self.num_heads
+        want = self.return_attentions
+        L = plan.levels
+        r = ops.gat_level(F.linear(bond_nodes, self.projection_b.weight, self.projection_b.bias), self.a_b, L["bond"], H,
+                          x_sorted=plan.sorted_attr("bond", bond_cos), embW=self.edge_attr_bond_embed.weight,
+                          embb=self.edge_attr_bond_embed.bias, want_probs=want)                      # L1 :74-103
+        new_bond, p_bond = (r[0], r[2]) if want else (r, None)
+        s_edge = ops.row_dots_sorted(new_bond, self.a, d, L["atom"])                                  # L2 :108-141
+        r = ops.gat_level(F.linear(x_atoms, self.projection_a.weight, self.projection_a.bias), self.a, L["atom"], H,
+                          s_sorted=s_edge, want_probs=want)
+        atoms_new, p_atom = (r[0], r[2]) if want else (r, None)
+        frags = ops.segment_sum(atoms_new, plan.segs["a2f"], plan)                                    # L3 :142
+        r = ops.gat_level(frags, self.f, L["frag"], H, x_sorted=plan.sorted_attr("frag", cnx_attr),   # L4 :148-172
+                          embW=self.cnx_attr_transform.weight, embb=self.cnx_attr_transform.bias, want_probs=want)
+        frags_new, p_frag = (r[0], r[2]) if want else (r, None)
+        if want:
+            return (atoms_new, frags_new, new_bond, ops.attn_by_src(p_atom, L["atom"], H),
+                    ops.attn_by_src(p_frag, L["frag"], H), ops.attn_by_src(p_bond, L["bond"], H))
+        return atoms_new, frags_new, new_bond
+
+
 class FragNet(nn.Module):
     def __init__(self, num_layer, drop_ratio=0.2, emb_dim=128, atom_features=167, frag_features=167,
                  edge_features=17, fedge_in=6, fbond_edge_in=6, num_heads=4, variant="gat2"):
         super().__init__()
-        if variant not in ("gat2", "gat2_lite"):
-            raise ValueError(f"model_version {variant!r}: gat2 and gat2_lite are on the accelerated path")
+        if variant not in ("gat2", "gat2_lite", "gat2_edge"):
+            raise ValueError(f"model_version {variant!r}: gat2, gat2_lite and gat2_edge are on the accelerated path")
         self.variant = variant      # gat2_lite = fragnet/model/gat/gat2_lite.py: same parameters, levels L1-L3 only
         self.num_layer = num_layer
         self.dropout = nn.Dropout(p=drop_ratio)
         self.act = nn.ReLU()
         self.layers = nn.ModuleList()
+        self.rng = ops.PhiloxStream()
+        self.use_engine = True      # False: one autograd node per level (same kernels, used by the per-op tests)
+        if variant == "gat2_edge":  # gat2_edge.py:190-196; per-level path only (fn_encoder_* knows gat2 / gat2_lite)
+            self.layers.append(FragNetLayerEdge(atom_in=atom_features, atom_out=emb_dim, frag_in=frag_features, frag_out=emb_dim,
+                                                edge_in=edge_features, edge_out=emb_dim, num_heads=num_heads))
+            for _ in range(num_layer - 1):
+                self.layers.append(FragNetLayerEdge(atom_in=emb_dim, atom_out=emb_dim, frag_in=emb_dim, frag_out=emb_dim,
+                                                    edge_in=emb_dim, edge_out=emb_dim, num_heads=num_heads))
+            return
         self.layers.append(FragNetLayerA(atom_in=atom_features, atom_out=emb_dim, frag_in=frag_features,
                                          frag_out=emb_dim, edge_in=edge_features, fedge_in=fedge_in,
                                          fbond_edge_in=fbond_edge_in, edge_out=emb_dim, num_heads=num_heads))
@@ -184,12 +255,19 @@ class FragNet(nn.Module):
             self.layers.append(FragNetLayerA(atom_in=emb_dim, atom_out=emb_dim, frag_in=emb_dim, frag_out=emb_dim,
                                              edge_in=emb_dim, edge_out=emb_dim, fedge_in=emb_dim,
                                              fbond_edge_in=fbond_edge_in, num_heads=num_heads))
-        self.rng = ops.PhiloxStream()
-        self.use_engine = True      # False: one autograd node per level (same kernels, used by the per-op tests)
 
     def forward(self, batch):
         plan = plan_for(batch)
         p, train = self.dropout.p, self.training
+        if self.variant == "gat2_edge":                      # gat2_edge.py:198-236: three tensors travel between layers
+            x_atoms = ops.dropout_act(batch["x_atoms"], p, train, False, self.rng)
+            bond_nodes, x_frags = batch["node_features_bonds"], None
+            for layer in self.layers:
+                x_atoms, x_frags, bond_nodes = layer.run(x_atoms, bond_nodes, batch["edge_attr_bonds"], batch["cnx_attr"], plan)[:3]
+                x_atoms = ops.dropout_act(x_atoms, p, train, True, self.rng)
+                x_frags = ops.dropout_act(x_frags, p, train, True, self.rng)
+                bond_nodes = ops.dropout_act(bond_nodes, p, train, True, self.rng)
+            return x_atoms, x_frags, bond_nodes, None
         lite = self.variant == "gat2_lite"
         for layer in self.layers:
             layer.lite = lite
@@ -330,6 +408,14 @@ class FragNetFineTune(nn.Module):
     def forward(self, batch):
         x_atoms, x_frags, _, _ = self.pretrain(batch)
         return self.fthead(pooled(x_atoms, x_frags, batch))
+
+
+class FragNetFineTuneEdge(FragNetFineTune):
+    """fragnet.model.gat.gat2_edge.FragNetFineTune (finetune_gat2.py:165-166, model_version "gat2_edge")."""
+
+    def __init__(self, *args, **kw):
+        kw["variant"] = "gat2_edge"
+        super().__init__(*args, **kw)
 
 
 class FragNetFineTuneLite(FragNetFineTune):

@@ -81,10 +81,10 @@ class _GatLevel(torch.autograd.Function):
             et = EdgeTerm(0, 0, 0, 0, s_sorted.data_ptr(), None, None, None)
         else:
             x_sorted, embW, embb = _f32c(x_sorted, "x_sorted"), _f32c(embW, "embW"), _f32c(embb, "embb")
-            K = x_sorted.shape[0]
-            if x_sorted.shape[1] != m or embW.shape != (FN_D // heads, K):
-                raise ValueError("edge attribute / embedding shapes do not match the plan")
-            et = EdgeTerm(2, K, FN_D // heads, mid_off, None, x_sorted.data_ptr(), embW.data_ptr(), embb.data_ptr())
+            K, d_e = x_sorted.shape[0], embW.shape[0]     # d_e = head_dim (gat2's a_b / f_a_b) or 128 (gat2_edge's f)
+            if x_sorted.shape[1] != m or embW.shape[1] != K or embb.shape[0] != d_e or mid_off + d_e > src_off:
+                raise ValueError("edge attribute / embedding shapes do not match the plan and the attention vector")
+            et = EdgeTerm(2, K, d_e, mid_off, None, x_sorted.data_ptr(), embW.data_ptr(), embb.data_ptr())
         st = _stream_ptr(dev)
         s_dst = torch.empty((n, heads), dtype=torch.float32, device=dev)
         s_src = torch.empty((n, heads), dtype=torch.float32, device=dev)
@@ -121,7 +121,7 @@ class _GatLevel(torch.autograd.Function):
             part_e = None
         else:
             K = x_sorted.shape[0]
-            et = EdgeTerm(2, K, FN_D // heads, mid_off, None, x_sorted.data_ptr(), embW.data_ptr(), embb.data_ptr())
+            et = EdgeTerm(2, K, embW.shape[0], mid_off, None, x_sorted.data_ptr(), embW.data_ptr(), embb.data_ptr())
             part_e = torch.empty((FN_MAX_PART, heads * (K + 1)), dtype=torch.float32, device=dev)
         dz = torch.empty((heads, m), dtype=torch.float32, device=dev) if mode == 0 else None
         pz = torch.empty((heads, m, 2), dtype=torch.float32, device=dev)

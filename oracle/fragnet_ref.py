@@ -14,6 +14,8 @@ Follows (structure and arithmetic; no code copied):
   PretrainTask    fragnet/model/gat/pretrain_heads.py:8-102
   FragNetPreTrain fragnet/model/gat/pretrain_heads.py:105-141
   variant="gat2_lite"  fragnet/model/gat/gat2_lite.py:13-217, 467-510 (same constructors; layers stop after L3)
+  variant="gat2_edge"  fragnet/model/gat/gat2_edge.py:13-228, 520-561 (no fragment-bond graph; the fragment graph's
+                       edge term is Linear(8 -> 128)(cnx_attr))
 
 PARITY STATUS: pinned against the reference's own Python, imported in the build
 container with stub third-party modules, on the cases frozen in tests/golden/*.npz
@@ -151,17 +153,83 @@ class FragNetLayerA(nn.Module):
         return atoms_new, frags_new, new_bond, new_fbond
 
 
+class FragNetLayerEdge(nn.Module):
+    """model_version gat2_edge: fragnet/model/gat/gat2_edge.py:13-177.  Constructor order as there (RNG / state dict)."""
+
+    def __init__(self, atom_in=128, atom_out=128, frag_in=128, frag_out=128, edge_in=128, edge_out=128, num_heads=2,
+                 bond_edge_in=1, return_attentions=False, add_frag_self_loops=False):
+        super().__init__()
+        self.add_frag_self_loops = add_frag_self_loops
+        self.return_attentions = return_attentions
+        self.edge_out = edge_out
+        self.atom_embed = nn.Linear(atom_in, atom_out)           # :22-35 never used by forward
+        self.frag_embed = nn.Linear(frag_in, frag_out)
+        self.edge_embed = nn.Linear(edge_in, edge_out)
+        self.bond_edge_embed = nn.Linear(edge_in, edge_out)
+        self.frag_message_mlp = nn.Linear(2 * atom_out, atom_out)
+        self.atom_mlp = _mlp2(atom_out)
+        self.frag_mlp = _mlp2(atom_out)
+        self.bias = nn.Parameter(torch.zeros(atom_out))
+        self.leakyrelu = nn.LeakyReLU(0.2)
+        self.num_heads = num_heads
+        self.edge_attr_bond_embed2 = nn.Linear(edge_out, edge_out)
+        d_e = edge_out // num_heads
+        self.projection_b = nn.Linear(edge_in, d_e * num_heads)
+        self.edge_attr_bond_embed = nn.Linear(bond_edge_in, d_e)
+        self.cnx_attr_transform = nn.Linear(8, self.edge_out)    # :46
+        d_a = atom_out // num_heads
+        self.projection_a = nn.Linear(atom_in, d_a * num_heads)
+        self.a_b = nn.Parameter(torch.empty(num_heads, 3 * d_e))
+        self.a = nn.Parameter(torch.empty(num_heads, 2 * d_a + d_e * num_heads))
+        self.f = nn.Parameter(torch.empty(num_heads, 2 * d_a + d_e * num_heads))
+        for t in (self.projection_b.weight, self.a_b, self.a, self.f):      # :54-58
+            nn.init.xavier_uniform_(t.data, gain=1.414)
+
+    def forward(self, x_atoms, edge_index, edge_attr, frag_index, x_frags, atom_to_frag_ids, bond_nodes,
+                bond_graph_index, bond_graph_attr, cnx_attr):
+        H = self.num_heads
+        dst, src = bond_graph_index                                              # L1 :74-103
+        h_b = self.projection_b(bond_nodes).view(bond_nodes.size(0), H, -1)
+        out_b, _, attn_b = gat_level_materialised(h_b, self.edge_attr_bond_embed(bond_graph_attr), self.a_b, dst, src, H)
+        new_bond = out_b.view(bond_nodes.size(0), -1)
+        looped, _ = add_self_loops(edge_index)                                   # L2 :108-141
+        loop_attr = torch.zeros(x_atoms.size(0), self.edge_out, dtype=torch.long).to(edge_attr)
+        attr_a = torch.cat((new_bond, loop_attr), dim=0)
+        src, dst = looped
+        h_a = self.projection_a(x_atoms)
+        n_a = h_a.size(0)
+        out_a, _, attn_a = gat_level_materialised(h_a.view(n_a, H, -1), attr_a, self.a, dst, src, H)
+        atoms_new = out_a.view(n_a, -1)
+        frags = scatter_add(atoms_new, atom_to_frag_ids, dim=0)                   # L3 :142
+        if self.add_frag_self_loops:
+            frag_index, _ = add_self_loops(frag_index)
+        src, dst = frag_index                                                    # L4 :148-172
+        n_f = frags.size(0)
+        out_f, _, attn_f = gat_level_materialised(frags.view(n_f, H, -1), self.cnx_attr_transform(cnx_attr), self.f, dst, src, H)
+        frags_new = out_f.view(n_f, -1)
+        if self.return_attentions:
+            return atoms_new, frags_new, new_bond, attn_a, attn_f, attn_b
+        return atoms_new, frags_new, new_bond
+
+
 class FragNet(nn.Module):
     def __init__(self, num_layer, drop_ratio=0.2, emb_dim=128, atom_features=167, frag_features=167,
                  edge_features=17, fedge_in=6, fbond_edge_in=6, num_heads=4, variant="gat2"):
         super().__init__()
-        if variant not in ("gat2", "gat2_lite"):
+        if variant not in ("gat2", "gat2_lite", "gat2_edge"):
             raise ValueError(variant)
         self.variant = variant           # "gat2_lite": fragnet/model/gat/gat2_lite.py (same parameters, levels L1-L3)
         self.num_layer = num_layer
         self.dropout = nn.Dropout(p=drop_ratio)
         self.act = nn.ReLU()
         self.layers = nn.ModuleList()
+        if variant == "gat2_edge":       # gat2_edge.py:190-196
+            self.layers.append(FragNetLayerEdge(atom_in=atom_features, atom_out=emb_dim, frag_in=frag_features, frag_out=emb_dim,
+                                                edge_in=edge_features, edge_out=emb_dim, num_heads=num_heads))
+            for _ in range(num_layer - 1):
+                self.layers.append(FragNetLayerEdge(atom_in=emb_dim, atom_out=emb_dim, frag_in=emb_dim, frag_out=emb_dim,
+                                                    edge_in=emb_dim, edge_out=emb_dim, num_heads=num_heads))
+            return
         self.layers.append(FragNetLayerA(atom_in=atom_features, atom_out=emb_dim, frag_in=frag_features,
                                          frag_out=emb_dim, edge_in=edge_features, fedge_in=fedge_in,
                                          fbond_edge_in=fbond_edge_in, edge_out=emb_dim, num_heads=num_heads))
@@ -171,10 +239,25 @@ class FragNet(nn.Module):
                                              fbond_edge_in=fbond_edge_in, num_heads=num_heads))
 
     def forward(self, batch, trace=None):
+        drop_act = lambda t: self.act(self.dropout(t))
+        if self.variant == "gat2_edge":                          # gat2_edge.py:198-236
+            x_atoms = self.dropout(batch["x_atoms"])
+            x_frags = self.dropout(batch["x_frags"])
+            e_attr = bond_nodes = None
+            for i, layer in enumerate(self.layers):
+                x_atoms, x_frags, bond_nodes = layer(
+                    x_atoms, batch["edge_index"], batch["edge_attr"] if i == 0 else e_attr, batch["frag_index"], x_frags,
+                    batch["atom_to_frag_ids"], batch["node_features_bonds"] if i == 0 else bond_nodes,
+                    batch["edge_index_bonds_graph"], batch["edge_attr_bonds"], batch["cnx_attr"])
+                if trace is not None:
+                    trace.append((x_atoms, x_frags, bond_nodes, None))
+                x_atoms, x_frags = drop_act(x_atoms), drop_act(x_frags)
+                bond_nodes = drop_act(bond_nodes)
+                e_attr = bond_nodes
+            return x_atoms, x_frags, bond_nodes, None
         lite = self.variant == "gat2_lite"
         for layer in self.layers:
             layer.lite = lite
-        drop_act = lambda t: self.act(self.dropout(t))
         x_atoms = self.dropout(batch["x_atoms"])
         x_frags = self.dropout(batch["x_frags"])
         e_attr = batch["edge_attr"]

@@ -33,8 +33,8 @@ if __name__ == "__main__":
     exp_dir = args["exp_dir"]
     os.makedirs(exp_dir, exist_ok=True)
     ft, m = args.finetune, args.finetune.model
-    if args.model_version not in ("gat2", "gat2_lite"):
-        raise SystemExit("model_version gat2 and gat2_lite are on the accelerated path")
+    if args.model_version not in ("gat2", "gat2_lite", "gat2_edge"):
+        raise SystemExit("model_version gat2, gat2_lite and gat2_edge are on the accelerated path")
     model = FragNetFineTune(n_classes=m.n_classes, atom_features=args.atom_features, frag_features=args.frag_features,
                             edge_features=args.edge_features, num_layer=m.num_layer, drop_ratio=m.drop_ratio,
                             num_heads=m.num_heads, emb_dim=m.emb_dim, h1=m.h1, h2=m.h2, h3=m.h3, h4=m.h4, act=m.act,

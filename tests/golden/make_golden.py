@@ -325,6 +325,43 @@ def lite_case():
               {"logits": out}, loss, trace)
 
 
+def gat2_edge_case():
+    """model_version gat2_edge (fragnet/model/gat/gat2_edge.py: no fragment-bond graph, the fragment graph's edge term is
+    Linear(8 -> 128)(cnx_attr)): ft_gat2edge_b6.npz.  The reference's featuriser writes 6 connection features while this model
+    version's Linear expects 8 (gat2_edge.py:46), so the fixture widens cnx_attr with two seeded random columns.
+    Run with `python tests/golden/make_golden.py gat2_edge` -- leaves the other fixtures untouched."""
+    install_stubs()
+    sys.path.insert(0, os.path.join(REF, "fragnet", "model", "gat"))      # gat2_edge.py:327 imports pretrain_heads by bare name
+    with quiet():
+        from fragnet.model.gat import gat2_edge as ref_edge
+        from fragnet.dataset import data as ref_data
+    from fragnet_amd import synth
+    torch.set_num_threads(1)
+    torch.use_deterministic_algorithms(True)
+    cfg = dict(n_classes=1, atom_features=167, frag_features=167, edge_features=17, num_layer=3, num_heads=4,
+               drop_ratio=0.0, h1=64, h2=128, h3=128, h4=64, act="relu", emb_dim=128, fthead="FTHead3")
+    mols = synth.synth_molecules(6, seed=4200, profile="esol")
+    batch = ref_data.collate_fn(mols)
+    g = torch.Generator().manual_seed(5)
+    batch["cnx_attr"] = torch.cat((batch["cnx_attr"].float(), torch.rand(batch["cnx_attr"].shape[0], 2, generator=g)), dim=1)
+    torch.manual_seed(9)
+    with quiet():
+        model = ref_edge.FragNetFineTune(**cfg)
+    zero_dead_bias(model)
+    model.train()
+    trace = []
+    hooks = [l.register_forward_hook(lambda m, i, o: trace.append([t.detach().numpy().copy() for t in o[:3]]))
+             for l in model.pretrain.layers]
+    with quiet():
+        out = model(batch)
+    for h in hooks:
+        h.remove()
+    loss = torch.nn.functional.mse_loss(out.view(-1), batch["y"])
+    loss.backward()
+    save_case("ft_gat2edge_b6", {"kind": "finetune_gat2_edge", "ctor": cfg, "seed": 9, "loss": "mse"}, batch, model,
+              {"logits": out}, loss, trace)
+
+
 if __name__ == "__main__":
     import sys
-    lite_case() if sys.argv[1:] == ["lite"] else main()
+    {"lite": lite_case, "gat2_edge": gat2_edge_case}.get((sys.argv[1:] or [""])[0], main)()

@@ -356,6 +356,31 @@ def test_gat2_lite_matches_reference_golden(use_engine):
     check_grads(model, grads, atol=ATOL, rtol=2e-3)
 
 
+def test_gat2_edge_matches_reference_golden():
+    """model_version gat2_edge: logits, loss, gradients and the last layer's three outputs of the
+    reference's gat2_edge.FragNetFineTune (fixture: make_golden.py gat2_edge, 8-wide cnx_attr); the fragment graph's
+    Linear(8 -> 128)(cnx_attr) edge term runs as the in-kernel folded mode-2 term (K = 8, d_e = 128)."""
+    from fragnet_amd.model import FragNetFineTuneEdge
+    cfg, batch, out, grads, pkeys, psums = load_case("ft_gat2edge_b6")
+    torch.manual_seed(cfg["seed"])
+    model = FragNetFineTuneEdge(**cfg["ctor"])
+    check_params_match(model, pkeys, psums)
+    model = model.to(DEV).train()
+    b = _to_dev(batch)
+    x_atoms, x_frags, bond, fbond = model.pretrain(b)
+    assert fbond is None
+    n_layers = cfg["ctor"]["num_layer"]
+    for nm, t in zip(("x_atoms", "x_frags", "bond"), (x_atoms, x_frags, bond)):      # relu(.) of the traced layer outputs (drop 0)
+        want = torch.relu(torch.from_numpy(out[f"layer{n_layers - 1}/{nm}"]))
+        torch.testing.assert_close(t.detach().cpu(), want, atol=ATOL, rtol=1e-4)
+    logits = model(b)
+    torch.testing.assert_close(logits.detach().cpu(), torch.from_numpy(out["logits"]), atol=ATOL, rtol=1e-4)
+    loss = torch.nn.functional.mse_loss(logits.view(-1), b["y"])
+    assert abs(float(loss) - float(out["loss"])) < ATOL
+    loss.backward()
+    check_grads(model, grads, atol=ATOL, rtol=2e-3)
+
+
 @pytest.mark.parametrize("use_engine", [True, False], ids=["engine", "per_level_ops"])
 def test_pretrain_matches_reference_golden(use_engine):
     from fragnet_amd.model import FragNetPreTrain

@@ -115,3 +115,26 @@ def test_notebook_atom_to_fragment_map_is_published_one():
     got = scatter_add(x, m.atom_id_frag_id)
     want = torch.stack([x[atoms].sum(0) for atoms in synth.NOTEBOOK_ATOMS_IN_FRAGS.values()])
     assert torch.equal(got, want)
+
+
+def test_gat2_edge_oracle_matches_reference():
+    """model_version gat2_edge: fixture written from fragnet/model/gat/gat2_edge.py (make_golden.py gat2_edge)."""
+    torch.set_num_threads(1)
+    cfg, batch, out, grads, pkeys, psums = load_case("ft_gat2edge_b6")
+    assert batch["cnx_attr"].shape[1] == 8
+    torch.manual_seed(cfg["seed"])
+    model = ref.FragNetFineTune(**cfg["ctor"], variant="gat2_edge")
+    check_params_match(model, pkeys, psums)
+    model.train()
+    trace = []
+    x_atoms, x_frags, bond, fbond = model.pretrain(batch, trace=trace)
+    assert fbond is None
+    logits = model.fthead(ref.pool_cat(x_atoms, x_frags, batch))
+    for li, outs in enumerate(trace):
+        for nm, t in zip(("x_atoms", "x_frags", "bond"), outs):
+            torch.testing.assert_close(t.detach(), torch.from_numpy(out[f"layer{li}/{nm}"]), atol=2e-6, rtol=1e-5)
+    torch.testing.assert_close(logits.detach(), torch.from_numpy(out["logits"]), atol=2e-6, rtol=1e-5)
+    loss = ref.finetune_regr_loss(logits, batch["y"])
+    assert abs(float(loss) - float(out["loss"])) < 1e-6
+    loss.backward()
+    check_grads(model, grads, atol=1e-6, rtol=1e-4)
