@@ -112,6 +112,9 @@ SIGNATURES = {
     "fn_pool_cat_f32": [vp, vp, C.POINTER(SegPlan), C.POINTER(SegPlan), vp, vp],
     "fn_pool_cat_bwd_f32": [vp, vp, vp, vp, vp, i64, i64, vp],
     "fn_masked_mse_f32": [vp, vp, vp, i64, C.c_int, vp, vp, vp],
+    "fn_bond_graph_ws": [i64, i64],
+    "fn_bond_graph_count": [vp, vp, i64, i64, i64, vp, vp, vp],
+    "fn_bond_graph_fill": [vp, vp, i64, i64, i64, vp, vp, i64, vp],
     "fn_gate_colsum_f32": [vp, vp, vp, vp, i64, i64, f32, vp],
     "fn_small_linear_f32": [vp, vp, vp, vp, i64, i64, i64, vp],
     "fn_small_linear_bwd_f32": [vp, vp, vp, vp, vp, vp, i64, i64, i64, vp],

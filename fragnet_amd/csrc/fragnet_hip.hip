@@ -1511,6 +1511,78 @@ __global__ void k_edge_concat(const float* __restrict__ x, const float* __restri
 }
 
 // =====================================================================================
+// Bond-graph topology on the GPU (reference fragnet/dataset/data.py:116-127, 157-182, 403-410):
+// edge_index_bonds_graph = ordered pairs (i, j) of directed bonds of one molecule that share exactly one atom,
+// i-major with j ascending, followed per molecule by the mutual pairs of its two-atom components ("one-bond
+// fragments", lowest atom first).  Bond id = position in the batched edge_index.  One thread per bond walks its
+// molecule's bonds (the reference's O(k^2) loop; k ~ 55 for ESOL): neighbouring threads read the same few hundred
+// bytes, and j ascending falls out of the walk, so nothing is sorted.
+// =====================================================================================
+struct BondGraphArgs {
+    const int64_t *src, *dst, *atom_mol;      // edge_index rows, molecule of every atom
+    int64_t E, B;
+    int32_t *cnt;        // [E+1] pass 1: cnt[1+i] = pairs of bond i; after the scan: cnt[i] = pairs before bond i
+    int32_t *flag;       // [E]   1 if bond i is the a -> b (a < b) direction of a two-atom component
+    int32_t *mol_first;  // [B+1] pass 1: bonds per molecule at [1+m]; after the scan: first bond of molecule m
+    int32_t *mol_ob;     // [B+1] likewise for the flagged bonds
+};
+
+__global__ void k_bg_mol_hist(BondGraphArgs A) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.E; i += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&A.mol_first[1 + A.atom_mol[A.src[i]]], 1);
+}
+
+__global__ void k_bg_count(BondGraphArgs A) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.E; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t u = A.src[i], v = A.dst[i];
+        const int64_t m = A.atom_mol[u];
+        const int32_t j0 = A.mol_first[m], j1 = A.mol_first[m + 1];
+        int c = 0, du = 0, dv = 0;
+        for (int32_t j = j0; j < j1; ++j) {
+            const int64_t a = A.src[j], b = A.dst[j];
+            const int common = (int)(a == u || a == v) + (int)(b != a && (b == u || b == v));
+            c += common == 1;                                            // |set(b_i) & set(b_j)| == 1
+            du += a == u;
+            dv += a == v;
+        }
+        A.cnt[1 + i] = c;
+        const int ob = (u < v && du == 1 && dv == 1) ? 1 : 0;
+        A.flag[i] = ob;
+        if (ob) atomicAdd(&A.mol_ob[1 + m], 1);
+    }
+}
+
+__global__ void k_bg_fill(BondGraphArgs A, int64_t* __restrict__ out, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.E; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t u = A.src[i], v = A.dst[i];
+        const int64_t m = A.atom_mol[u];
+        const int32_t j0 = A.mol_first[m], j1 = A.mol_first[m + 1];
+        int64_t pos = (int64_t)A.cnt[i] + 2 * (int64_t)A.mol_ob[m];      // pairs of earlier bonds + extras of earlier molecules
+        int rev = -1, rank = 0;
+        for (int32_t j = j0; j < j1; ++j) {
+            const int64_t a = A.src[j], b = A.dst[j];
+            const int common = (int)(a == u || a == v) + (int)(b != a && (b == u || b == v));
+            if (common == 1) {
+                out[pos] = i;
+                out[total + pos] = j;
+                ++pos;
+            }
+            if (a == v && b == u) rev = j;
+            rank += (A.flag[j] && a < u) ? 1 : 0;                        // two-atom components with a lower first atom
+        }
+        if (A.flag[i] && rev >= 0) {                                      // the molecule's extras follow ALL its pairs
+            const int64_t p = (int64_t)A.cnt[j1] + 2 * (int64_t)A.mol_ob[m] + 2 * rank;
+            out[p] = i;          out[total + p] = rev;
+            out[p + 1] = rev;    out[total + p + 1] = i;
+        }
+    }
+}
+
+__global__ void k_bg_total(BondGraphArgs A, int64_t* __restrict__ total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *total = (int64_t)A.cnt[A.E] + 2 * (int64_t)A.mol_ob[A.B];
+}
+
+// =====================================================================================
 // Prediction-head small ops (gat2.py:631-637, 745-751: Linear -> dropout -> ReLU stacks on [molecules, width]).
 // The dense products stay library GEMMs; these are the launches around them.
 // =====================================================================================
@@ -2800,6 +2872,67 @@ int fn_dropout_act_bwd_f32(const float* g_y, const float* y, float* g_x, int64_t
     hipLaunchKernelGGL(k_dropout_act<true>, dim3(flat_grid((numel + 3) / 4, kGridCap)), dim3(kBlock), 0, S(stream), g_y, y, g_x,
                        numel, p, seed, offset, offset_dev, relu);
     return launch_status("fn_dropout_act_bwd_f32");
+}
+
+namespace {
+struct BondGraphWs {
+    BondGraphArgs A;
+    unsigned long long *st_cnt, *st_mol, *st_ob;
+    int nb_cnt, nb_mol;
+    int64_t zero_from, zero_n;
+};
+// workspace (int32): cnt[E+1] | flag[E] | mol_first[B+1] | mol_ob[B+1] | pad | three look-back state arrays (64-bit words)
+BondGraphWs bond_graph_ws(const int64_t* edge_index, const int64_t* atom_mol, int64_t E, int64_t B, int32_t* ws) {
+    BondGraphWs w{};
+    w.A.src = edge_index;  w.A.dst = edge_index + E;  w.A.atom_mol = atom_mol;  w.A.E = E;  w.A.B = B;
+    w.A.cnt = ws;
+    w.A.flag = w.A.cnt + E + 1;
+    w.A.mol_first = w.A.flag + E;
+    w.A.mol_ob = w.A.mol_first + B + 1;
+    int32_t* p = w.A.mol_ob + B + 1;
+    if ((uintptr_t)p & 7) ++p;
+    w.nb_cnt = (int)((E + kScanChunk - 1) / kScanChunk);
+    w.nb_mol = (int)((B + kScanChunk - 1) / kScanChunk);
+    w.st_cnt = reinterpret_cast<unsigned long long*>(p);
+    w.st_mol = w.st_cnt + w.nb_cnt;
+    w.st_ob = w.st_mol + w.nb_mol;
+    w.zero_n = (reinterpret_cast<int32_t*>(w.st_ob + w.nb_mol) - ws);
+    return w;
+}
+}  // namespace
+
+int64_t fn_bond_graph_ws(int64_t E, int64_t B) {
+    if (E < 0 || B < 0) return 0;
+    return (2 * E + 1) + 2 * (B + 1) + 2 + 2 * ((E + kScanChunk - 1) / kScanChunk + 2 * ((B + kScanChunk - 1) / kScanChunk));
+}
+
+int fn_bond_graph_count(const int64_t* edge_index, const int64_t* atom_mol, int64_t E, int64_t N, int64_t B, int32_t* ws,
+                        int64_t* total, fn_stream_t stream) {
+    if (E < 0 || N < 0 || B < 0 || E >= (1ll << 31) - 1 || !ws || !total || (E > 0 && (!edge_index || !atom_mol)))
+        return fail(FN_EINVAL, "fn_bond_graph_count: bad argument");
+    BondGraphWs w = bond_graph_ws(edge_index, atom_mol, E, B, ws);
+    hipStream_t st = S(stream);
+    hipLaunchKernelGGL(k_zero2_i32, dim3(flat_grid(w.zero_n, kGridCap)), dim3(kBlock), 0, st, ws, w.zero_n, ws, (int64_t)0);
+    if (E > 0) {
+        const int g = flat_grid(E, kGridCap);
+        hipLaunchKernelGGL(k_bg_mol_hist, dim3(g), dim3(kBlock), 0, st, w.A);
+        hipLaunchKernelGGL(k_scan_lookback, dim3(w.nb_mol), dim3(256), 0, st, w.A.mol_first + 1, B, w.st_mol);
+        hipLaunchKernelGGL(k_bg_count, dim3(g), dim3(kBlock), 0, st, w.A);
+        hipLaunchKernelGGL(k_scan_lookback, dim3(w.nb_cnt), dim3(256), 0, st, w.A.cnt + 1, E, w.st_cnt);
+        hipLaunchKernelGGL(k_scan_lookback, dim3(w.nb_mol), dim3(256), 0, st, w.A.mol_ob + 1, B, w.st_ob);
+    }
+    hipLaunchKernelGGL(k_bg_total, dim3(1), dim3(64), 0, st, w.A, total);
+    return launch_status("fn_bond_graph_count");
+}
+
+int fn_bond_graph_fill(const int64_t* edge_index, const int64_t* atom_mol, int64_t E, int64_t N, int64_t B, const int32_t* ws,
+                       int64_t* out, int64_t total, fn_stream_t stream) {
+    if (E < 0 || N < 0 || B < 0 || total < 0 || !ws || (total > 0 && !out) || (E > 0 && (!edge_index || !atom_mol)))
+        return fail(FN_EINVAL, "fn_bond_graph_fill: bad argument");
+    if (E == 0 || total == 0) return 0;
+    BondGraphWs w = bond_graph_ws(edge_index, atom_mol, E, B, const_cast<int32_t*>(ws));
+    hipLaunchKernelGGL(k_bg_fill, dim3(flat_grid(E, kGridCap)), dim3(kBlock), 0, S(stream), w.A, out, total);
+    return launch_status("fn_bond_graph_fill");
 }
 
 int fn_gate_colsum_f32(const float* g_y, const float* y, float* g_x, float* colsum, int64_t rows, int64_t cols, float scale,

@@ -98,5 +98,11 @@ BATCH_KEYS_PT = BATCH_KEYS_FT[:-1] + ("bnd_lngth", "bnd_angl", "dh_angl", "y")
 
 
 def batch_to(batch: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]:
-    """``batch[k] = batch[k].to(device)`` for every key -- reference train/utils.py:335-336."""
-    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    """``batch[k] = batch[k].to(device)`` for every key -- reference train/utils.py:335-336.  A batch collated from a
+    store without its bond-graph index (dataset.FlatMolStore.without_bond_graph_index) gets ``edge_index_bonds_graph``
+    rebuilt from ``edge_index`` once it is on the GPU (ops.bond_graph)."""
+    out = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    if "edge_index_bonds_graph" not in out and "edge_index" in out and out["edge_index"].is_cuda:
+        from . import ops
+        out["edge_index_bonds_graph"] = ops.bond_graph(out["edge_index"], out["batch"], int(out["y"].shape[0]))
+    return out

@@ -84,6 +84,12 @@ class FlatMolStore:
         store = cls(blob["tensors"], blob["offsets"], blob["y"], blob.get("smiles"))
         return store.to(device) if device is not None else store
 
+    def without_bond_graph_index(self) -> "FlatMolStore":
+        """The same store minus ``edge_index_bonds`` -- its largest tensor (16 bytes per bond-graph edge).  ``collate``
+        then rebuilds ``edge_index_bonds_graph`` from ``edge_index`` on the GPU (ops.bond_graph, SURVEY §8 row f4: the
+        reference's pair rule in the reference's order, so the stored cos(theta) rows ``edge_attr_bonds`` still line up)."""
+        return FlatMolStore({k: v for k, v in self.t.items() if k != "edge_index_bonds"}, self.off, self.y, self.smiles)
+
     def bond_graph_edges(self) -> torch.Tensor:
         """Per-molecule bond-graph edge counts: the dominant cost, used to balance shards (parallel.shard_indices)."""
         return (self.off["bedge"][1:] - self.off["bedge"][:-1]).cpu()
@@ -109,12 +115,19 @@ class FlatMolStore:
             "frag_batch": seg["frag"],
             "atom_to_frag_ids": t["atom_id_frag_id"][rows["atom"]] + base["frag"][seg["atom"]],
             "node_features_bonds": t["node_features_bonds"][rows["edge"]],
-            "edge_index_bonds_graph": t["edge_index_bonds"][:, rows["bedge"]] + base["edge"][seg["bedge"]],
+            "edge_index_bonds_graph": None,      # filled below (stored index, or rebuilt on the device)
             "edge_attr_bonds": t["edge_attr_bonds"][rows["bedge"]],
             "node_features_fbonds": t["node_feautures_fbondg"][rows["fedge"]],
             "edge_index_fbonds": t["edge_index_fbondg"][:, rows["fbedge"]] + base["fedge"][seg["fbedge"]],
             "edge_attr_fbonds": t["edge_attr_fbondg"][rows["fbedge"]],
         }
+        if "edge_index_bonds" in t:
+            out["edge_index_bonds_graph"] = t["edge_index_bonds"][:, rows["bedge"]] + base["edge"][seg["bedge"]]
+        elif dev.type == "cuda":          # topology rebuilt on the device; a CPU store leaves it to data.batch_to(batch, gpu)
+            from . import ops
+            out["edge_index_bonds_graph"] = ops.bond_graph(out["edge_index"], out["batch"], int(idx.numel()))
+        else:
+            del out["edge_index_bonds_graph"]
         if pretrain:
             out["bnd_lngth"] = t["bnd_lngth"][rows["edge"]]
             out["bnd_angl"] = t["bnd_angl"][rows["atom"]]

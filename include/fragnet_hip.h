@@ -258,6 +258,21 @@ int fn_dropout_act_bwd_f32(const float* g_y, const float* y, float* g_x, int64_t
                            uint64_t offset, const uint64_t* offset_dev, int relu, fn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Bond-graph topology from edge_index (dataset-side; reference fragnet/dataset/data.py:116-127 get_bond_pair_bond_graph,
+ * :157-182 one-bond fragments, :403-410): edge_index_bonds_graph [2, Eb] = ordered pairs (i, j) of directed bonds of a
+ * molecule sharing exactly one atom, i-major / j ascending, then per molecule the mutual pairs of its two-atom
+ * components (lowest atom first).  Bond id = column of the batched, molecule-contiguous edge_index [2, E];
+ * atom_mol [N] = molecule of every atom (the batch vector).  Two calls because Eb is only known on the device:
+ * count (fills ws, writes *total = Eb), then fill into out [2, total].  The cos(theta) attribute needs coordinates
+ * and is not produced.  ws: fn_bond_graph_ws(E, B) int32.
+ * ------------------------------------------------------------------------------------------ */
+int64_t fn_bond_graph_ws(int64_t E, int64_t B);
+int fn_bond_graph_count(const int64_t* edge_index /*[2,E]*/, const int64_t* atom_mol /*[N]*/, int64_t E, int64_t N, int64_t B,
+                        int32_t* ws, int64_t* total /*device [1]*/, fn_stream_t stream);
+int fn_bond_graph_fill(const int64_t* edge_index, const int64_t* atom_mol, int64_t E, int64_t N, int64_t B, const int32_t* ws,
+                       int64_t* out /*[2,total]*/, int64_t total, fn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Prediction-head small ops (FTHead1-5, gat2.py:631-637, 719-725, 745-751: Linear -> dropout -> act stacks on
  * [molecules, width]; the dense products themselves stay library GEMMs).
  * fn_gate_colsum_f32: backward of relu(dropout(.)) fused with the bias gradient of the Linear below it:

@@ -362,6 +362,43 @@ def gat2_edge_case():
               {"logits": out}, loss, trace)
 
 
+def bond_graph_case():
+    """bond_graph_cases.npz: the reference's bond-graph topology builders (fragnet/dataset/data.py:116-127, 165-182) on
+    hand-made and synthetic molecules -- pins oracle/bond_graph_ref.py.  ``get_one_bond_frags`` is RDKit and cannot run here:
+    the fragment list handed to add_one_bond_frag_nodes_to_index is the restated rule (two-atom components, lowest atom
+    first).  Run with `python tests/golden/make_golden.py bond_graph`."""
+    install_stubs()
+    with quiet():
+        from fragnet.dataset import data as ref_data
+    from fragnet_amd import synth
+    from oracle.bond_graph_ref import one_bond_fragments
+
+    def both(bonds):
+        return [e for a, b in bonds for e in ((a, b), (b, a))]
+    cases = {
+        "two_atoms": (2, both([(0, 1)])),
+        "single_atom": (1, []),
+        "chain4": (4, both([(0, 1), (1, 2), (2, 3)])),
+        "ring3_plus_pair": (5, both([(0, 1), (1, 2), (2, 0), (3, 4)])),
+        "two_pairs_listed_high_first": (4, both([(2, 3), (0, 1)])),
+        "star_plus_pair_between": (7, both([(0, 2), (0, 3), (5, 6), (0, 4)])),
+    }
+    for k, m in enumerate(synth.synth_molecules(3, seed=77, profile="esol")):
+        ei = m.edge_index.numpy()
+        cases[f"synth{k}"] = (int(m.x_atoms.shape[0]), [(int(u), int(v)) for u, v in ei.T])
+    store = {"names": np.asarray(list(cases))}
+    for name, (n_atoms, ends) in cases.items():
+        idx = {i: [u, v] for i, (u, v) in enumerate(ends)}
+        pairs = ref_data.get_bond_pair_bond_graph(idx)
+        to_id = {tuple(v): i for i, v in idx.items()}
+        pairs, _ = ref_data.add_one_bond_frag_nodes_to_index(pairs, to_id, one_bond_fragments(n_atoms, ends))
+        store[f"{name}/n_atoms"] = np.asarray(n_atoms)
+        store[f"{name}/ends"] = np.asarray(ends, dtype=np.int64).reshape(-1, 2)
+        store[f"{name}/pairs"] = np.asarray(pairs, dtype=np.int64).reshape(2, -1)
+    np.savez_compressed(os.path.join(HERE, "bond_graph_cases.npz"), **store)
+    print("bond_graph_cases written:", {k: store[f"{k}/pairs"].shape[1] for k in cases})
+
+
 if __name__ == "__main__":
     import sys
-    {"lite": lite_case, "gat2_edge": gat2_edge_case}.get((sys.argv[1:] or [""])[0], main)()
+    {"lite": lite_case, "gat2_edge": gat2_edge_case, "bond_graph": bond_graph_case}.get((sys.argv[1:] or [""])[0], main)()
