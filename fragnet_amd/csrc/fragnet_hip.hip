@@ -3419,8 +3419,9 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         fn_edge_term et_a{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
         FN_TRY(fn_gat_fwd_f32(a.h_a, lay.s_dst_a, lay.s_src_a, w.a, wide, &et_a, &e->atom, 0.2f, lay.atoms_new, a.p_atom, nullptr, &ep_atoms, H, st));
 
-        // L3 atom -> fragment sum
-        FN_TRY(fn_segment_sum_f32(lay.atoms_new, FN_D, e->a2f.rowptr, e->a2f.perm, e->a2f.pos_base, a.frags, e->F, FN_D, e->N, st));
+        // L3 atom -> fragment sum.  Like L4b below it is only ever read in the last layer (the next layer recomputes its own
+        // sum from its own atoms before first use, gat2.py:234), so inner layers skip it too.
+        if (last) FN_TRY(fn_segment_sum_f32(lay.atoms_new, FN_D, e->a2f.rowptr, e->a2f.perm, e->a2f.pos_base, a.frags, e->F, FN_D, e->N, st));
 
         // L4b fragment graph on the raw fragment sums.  Only the last layer's result is ever read: the next layer
         // overwrites x_frags with its own atom->fragment sum before first use (gat2.py:234), so inner
