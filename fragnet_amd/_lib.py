@@ -115,9 +115,11 @@ SIGNATURES = {
     "fn_bond_graph_ws": [i64, i64],
     "fn_bond_graph_count": [vp, vp, i64, i64, i64, vp, vp, vp],
     "fn_bond_graph_fill": [vp, vp, i64, i64, i64, vp, vp, i64, vp],
-    "fn_gate_colsum_f32": [vp, vp, vp, vp, i64, i64, f32, vp],
+    "fn_gate_colsum_ws": [i64, i64],
+    "fn_gate_colsum_f32": [vp, vp, vp, vp, i64, i64, f32, vp, vp],
     "fn_small_linear_f32": [vp, vp, vp, vp, i64, i64, i64, vp],
-    "fn_small_linear_bwd_f32": [vp, vp, vp, vp, vp, vp, i64, i64, i64, vp],
+    "fn_small_linear_bwd_ws": [i64, i64, i64],
+    "fn_small_linear_bwd_f32": [vp, vp, vp, vp, vp, vp, i64, i64, i64, vp, vp],
 }
 
 _lib = None

@@ -1590,15 +1590,19 @@ __global__ void k_bg_total(BondGraphArgs A, int64_t* __restrict__ total) {
 // y = relu(dropout(.)) is positive only where the element was kept and passed the ReLU, so no Philox replay.
 // One block owns a strip of 32 columns for ALL rows: the column sums are deterministic and need no second pass.
 __global__ __launch_bounds__(256) void k_gate_colsum(const float* __restrict__ g_y, const float* __restrict__ y,
-                                                     float* __restrict__ g_x, float* __restrict__ colsum, int64_t rows,
-                                                     int cols, float scale) {
+                                                     float* __restrict__ g_x, float* __restrict__ sums, int64_t rows,
+                                                     int cols, float scale, int64_t rows_per_chunk) {
+    // blockIdx.y = row chunk (tall inputs: the pretrain towers run on every edge / atom); its column sums go to
+    // sums[chunk][cols] and k_sum_chunks adds the chunks in order.  One chunk: sums is the result itself.
     __shared__ float4 sm[32][8];
     const int c4 = threadIdx.x & 7, rl = threadIdx.x >> 3;           // 8 float4 columns x 32 row lanes
     const int col = blockIdx.x * 32 + c4 * 4;
+    const int64_t r_begin = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r_end = r_begin + rows_per_chunk < rows ? r_begin + rows_per_chunk : rows;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < cols) {
-        int64_t r = rl;
-        for (; r + 96 < rows; r += 128) {                           // four rows in flight per thread
+        int64_t r = r_begin + rl;
+        for (; r + 96 < r_end; r += 128) {                          // four rows in flight per thread
             float4 g[4], v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { g[q] = ld4(g_y + (r + 32 * q) * cols + col); v[q] = ld4(y + (r + 32 * q) * cols + col); }
@@ -1610,7 +1614,7 @@ __global__ __launch_bounds__(256) void k_gate_colsum(const float* __restrict__ g
                 acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
             }
         }
-        for (; r < rows; r += 32) {
+        for (; r < r_end; r += 32) {
             const float4 g = ld4(g_y + r * cols + col), v = ld4(y + r * cols + col);
             const float4 o = make_float4(v.x > 0.f ? g.x * scale : 0.f, v.y > 0.f ? g.y * scale : 0.f,
                                          v.z > 0.f ? g.z * scale : 0.f, v.w > 0.f ? g.w * scale : 0.f);
@@ -1623,7 +1627,15 @@ __global__ __launch_bounds__(256) void k_gate_colsum(const float* __restrict__ g
     if (rl == 0 && col < cols) {
         float4 t = sm[0][c4];
         for (int q = 1; q < 32; ++q) { const float4 u = sm[q][c4]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-        st4(colsum + col, t);
+        st4(sums + (size_t)blockIdx.y * cols + col, t);
+    }
+}
+// out[c] = sum over chunks (in order) of part[chunk][c]
+__global__ void k_sum_chunks(const float* __restrict__ part, int chunks, int64_t width, float* __restrict__ out) {
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < width; c += (int64_t)gridDim.x * blockDim.x) {
+        float t = 0.f;
+        for (int q = 0; q < chunks; ++q) t += part[(size_t)q * width + c];
+        out[c] = t;
     }
 }
 
@@ -1673,11 +1685,17 @@ __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ 
 template <int CM>
 __global__ __launch_bounds__(256) void k_small_linear_bwd(const float* __restrict__ g, const float* __restrict__ x,
                                                           const float* __restrict__ w, float* __restrict__ g_x,
-                                                          float* __restrict__ dW, float* __restrict__ db, int64_t M, int K, int C) {
+                                                          float* __restrict__ dW, float* __restrict__ db, int64_t M, int K, int C,
+                                                          int64_t rows_per_chunk) {
+    // blockIdx.y = row chunk: dW / db then point at per-chunk partials [chunk][C*K] / [chunk][C] (k_sum_chunks finishes)
     __shared__ float4 sm[64][4];
     const int c4 = threadIdx.x & 3, rl = threadIdx.x >> 2;           // 4 float4 columns x 64 row lanes
     const int col = blockIdx.x * 16 + c4 * 4;
     const bool live = col < K;
+    const int64_t m_begin = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t m_end = m_begin + rows_per_chunk < M ? m_begin + rows_per_chunk : M;
+    dW += (size_t)blockIdx.y * C * K;
+    db += (size_t)blockIdx.y * C;
     float4 wv[CM], acc[CM];
 #pragma unroll
     for (int c = 0; c < CM; ++c) {
@@ -1685,7 +1703,7 @@ __global__ __launch_bounds__(256) void k_small_linear_bwd(const float* __restric
         acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (live) {
-        for (int64_t m = rl; m < M; m += 64) {
+        for (int64_t m = m_begin + rl; m < m_end; m += 64) {
             const float4 xv = ld4(x + m * K + col);
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -1712,11 +1730,11 @@ __global__ __launch_bounds__(256) void k_small_linear_bwd(const float* __restric
             __syncthreads();
         }
     }
-    if (blockIdx.x == 0 && db) {                                    // bias gradient: one wave per class, fixed order
+    if (blockIdx.x == 0) {                                          // bias gradient: one wave per class, fixed order
         const int lane = threadIdx.x & 63;
         for (int c = threadIdx.x >> 6; c < C; c += 4) {
             float t = 0.f;
-            for (int64_t m = lane; m < M; m += 64) t += g[m * C + c];
+            for (int64_t m = m_begin + lane; m < m_end; m += 64) t += g[m * C + c];
             for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
             if (lane == 0) db[c] = t;
         }
@@ -2935,13 +2953,27 @@ int fn_bond_graph_fill(const int64_t* edge_index, const int64_t* atom_mol, int64
     return launch_status("fn_bond_graph_fill");
 }
 
+namespace {
+constexpr int64_t kTallRows = 2048, kTallChunk = 256;      // inputs taller than kTallRows are reduced in chunks of kTallChunk rows
+inline int64_t tall_chunks(int64_t rows) { return rows > kTallRows ? (rows + kTallChunk - 1) / kTallChunk : 1; }
+}  // namespace
+
+int64_t fn_gate_colsum_ws(int64_t rows, int64_t cols) {
+    const int64_t ch = tall_chunks(rows);
+    return ch > 1 ? ch * cols : 0;
+}
+
 int fn_gate_colsum_f32(const float* g_y, const float* y, float* g_x, float* colsum, int64_t rows, int64_t cols, float scale,
-                       fn_stream_t stream) {
+                       float* ws, fn_stream_t stream) {
     if (rows < 0 || cols < 0 || (cols & 3) || cols > INT32_MAX) return fail(FN_EINVAL, "fn_gate_colsum_f32: cols must be a multiple of 4");
     if (cols == 0) return 0;
-    if (!colsum || (rows > 0 && (!g_y || !y || !g_x)) || (((uintptr_t)g_y | (uintptr_t)y | (uintptr_t)g_x | (uintptr_t)colsum) & 15))
+    if (!colsum || (rows > 0 && (!g_y || !y || !g_x)) || (((uintptr_t)g_y | (uintptr_t)y | (uintptr_t)g_x | (uintptr_t)colsum | (uintptr_t)ws) & 15))
         return fail(FN_EINVAL, "fn_gate_colsum_f32: null or misaligned buffer");
-    hipLaunchKernelGGL(k_gate_colsum, dim3((unsigned)((cols + 31) / 32)), dim3(256), 0, S(stream), g_y, y, g_x, colsum, rows, (int)cols, scale);
+    const int64_t ch = tall_chunks(rows);
+    if (ch > 1 && !ws) return fail(FN_EINVAL, "fn_gate_colsum_f32: rows > 2048 need the fn_gate_colsum_ws() workspace");
+    hipLaunchKernelGGL(k_gate_colsum, dim3((unsigned)((cols + 31) / 32), (unsigned)ch), dim3(256), 0, S(stream), g_y, y, g_x,
+                       ch > 1 ? ws : colsum, rows, (int)cols, scale, ch > 1 ? kTallChunk : (rows > 0 ? rows : 1));
+    if (ch > 1) hipLaunchKernelGGL(k_sum_chunks, dim3(flat_grid(cols, 64)), dim3(kBlock), 0, S(stream), ws, (int)ch, cols, colsum);
     return launch_status("fn_gate_colsum_f32");
 }
 
@@ -2954,16 +2986,30 @@ int fn_small_linear_f32(const float* x, const float* w, const float* b, float* y
     return launch_status("fn_small_linear_f32");
 }
 
+int64_t fn_small_linear_bwd_ws(int64_t M, int64_t K, int64_t C) {
+    const int64_t ch = tall_chunks(M);
+    return ch > 1 ? ch * C * (K + 1) : 0;
+}
+
 int fn_small_linear_bwd_f32(const float* g, const float* x, const float* w, float* g_x, float* dW, float* db, int64_t M, int64_t K,
-                            int64_t C, fn_stream_t stream) {
+                            int64_t C, float* ws, fn_stream_t stream) {
     if (M < 0 || K < 4 || (K & 3) || K > INT32_MAX || C < 1 || C > FN_SMALL_LINEAR_MAX)
         return fail(FN_EINVAL, "fn_small_linear_bwd_f32: K must be a multiple of 4 and 1 <= C <= FN_SMALL_LINEAR_MAX");
-    if (!w || !dW || !db || (M > 0 && (!g || !x || !g_x)) || (((uintptr_t)x | (uintptr_t)w | (uintptr_t)g_x | (uintptr_t)dW) & 15))
+    if (!w || !dW || !db || (M > 0 && (!g || !x || !g_x)) || (((uintptr_t)x | (uintptr_t)w | (uintptr_t)g_x | (uintptr_t)dW | (uintptr_t)ws) & 15))
         return fail(FN_EINVAL, "fn_small_linear_bwd_f32: null or misaligned buffer");
-    const dim3 grid((unsigned)((K + 15) / 16));
-    if (C <= 1) hipLaunchKernelGGL(k_small_linear_bwd<1>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW, db, M, (int)K, (int)C);
-    else if (C <= 4) hipLaunchKernelGGL(k_small_linear_bwd<4>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW, db, M, (int)K, (int)C);
-    else hipLaunchKernelGGL(k_small_linear_bwd<FN_SMALL_LINEAR_MAX>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW, db, M, (int)K, (int)C);
+    const int64_t ch = tall_chunks(M);
+    if (ch > 1 && !ws) return fail(FN_EINVAL, "fn_small_linear_bwd_f32: M > 2048 needs the fn_small_linear_bwd_ws() workspace");
+    float* dW_o = ch > 1 ? ws : dW;
+    float* db_o = ch > 1 ? ws + ch * C * K : db;
+    const int64_t rpc = ch > 1 ? kTallChunk : (M > 0 ? M : 1);
+    const dim3 grid((unsigned)((K + 15) / 16), (unsigned)ch);
+    if (C <= 1) hipLaunchKernelGGL(k_small_linear_bwd<1>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW_o, db_o, M, (int)K, (int)C, rpc);
+    else if (C <= 4) hipLaunchKernelGGL(k_small_linear_bwd<4>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW_o, db_o, M, (int)K, (int)C, rpc);
+    else hipLaunchKernelGGL(k_small_linear_bwd<FN_SMALL_LINEAR_MAX>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW_o, db_o, M, (int)K, (int)C, rpc);
+    if (ch > 1) {
+        hipLaunchKernelGGL(k_sum_chunks, dim3(flat_grid(C * K, 64)), dim3(kBlock), 0, S(stream), ws, (int)ch, C * K, dW);
+        hipLaunchKernelGGL(k_sum_chunks, dim3(1), dim3(kBlock), 0, S(stream), ws + ch * C * K, (int)ch, C, db);
+    }
     return launch_status("fn_small_linear_bwd_f32");
 }
 

@@ -263,6 +263,8 @@ class GraphedTrainStep:
         self.device = self.static.device
         if loss == "pretrain" and "dh_angl" not in example:
             raise ValueError("pretrain step needs the collate_fn_pt batch (bnd_lngth, bnd_angl, dh_angl)")
+        if loss == "pretrain" and hasattr(getattr(model, "head", None), "need_bond_length"):
+            model.head.need_bond_length = False      # the loss never reads the bond-length prediction (pretrain_utils.py:17-24)
         self.rng = model.pretrain.rng
         self.rng.use_device_counter(self.device)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
@@ -286,22 +288,20 @@ class GraphedTrainStep:
         if self.loss_kind == "pretrain" or head is None or not hasattr(self.model, "pretrain"):
             return None
         ids = {id(p) for p in head.parameters()}
-        off, first = 0, None
-        for p in self.opt.params:
+        first = None
+        for p, off in zip(self.opt.params, self.opt.offsets):
             if id(p) in ids:
                 if first is None:
                     first = off
             elif first is not None:
                 return None                                  # an encoder parameter after a head parameter
-            off += p.numel()
         return first
 
     def _head_grads_in_place(self) -> bool:
-        base, es, off, ids = self.opt.grad.data_ptr(), self.opt.grad.element_size(), 0, {id(p) for p in self.model.fthead.parameters()}
-        for p in self.opt.params:
+        base, es, ids = self.opt.grad.data_ptr(), self.opt.grad.element_size(), {id(p) for p in self.model.fthead.parameters()}
+        for p, off in zip(self.opt.params, self.opt.offsets):
             if id(p) in ids and (p.grad is None or p.grad.data_ptr() != base + off * es):
                 return False
-            off += p.numel()
         return True
 
     def _part_a(self):

@@ -442,16 +442,23 @@ class PretrainTask(nn.Module):
         self.L = L
         self.activation = nn.ReLU()
 
+    need_bond_length = True      # False: skip the bond-length tower (graphstep / trainers: the reference's loss never reads it,
+                                 # pretrain_utils.py:17-24 overwrites that term) and return None in its place
+    _no_rng = ops.PhiloxStream(seed=0)
+
     def _tower(self, layers, x):
+        if x.is_cuda:            # Linear -> ReLU stack as one autograd node (ops.mlp_head with p = 0)
+            return ops.mlp_head(x, list(layers), 0.0, self.training, self._no_rng)
         for lin in layers[:-1]:
             x = self.activation(lin(x))
         return layers[-1](x)
 
     def forward(self, x_atoms, x_frags, edge_attr, batch):
-        plan = plan_for(batch, edge_ends=True)
-        bl = self.bl_reduce_layer(ops.edge_concat(x_atoms, edge_attr, batch["edge_index"], plan))
-        for lin in self.bl_layers:
-            bl = lin(self.activation(bl))
+        plan = plan_for(batch, edge_ends=self.need_bond_length)
+        bl = None
+        if self.need_bond_length:
+            # pretrain_heads.py:67-76: reduce -> [lin(act(.))]*: the same stack with the reduce layer in front
+            bl = self._tower([self.bl_reduce_layer] + list(self.bl_layers), ops.edge_concat(x_atoms, edge_attr, batch["edge_index"], plan))
         ba = self._tower(self.ba_layers, x_atoms)
         da = self._tower(self.da_layers, edge_attr)
         graph_rep = self._tower(self.FC_layers, pooled(x_atoms, x_frags, batch))
@@ -468,6 +475,6 @@ class FragNetPreTrain(nn.Module):
         self.head = PretrainTask(128, 1)
 
     def forward(self, batch):
-        plan_for(batch, edge_ends=True)          # build the plan once, with the bond-length head's CSRs
+        plan_for(batch, edge_ends=self.head.need_bond_length)      # build the plan once, with the bond-length head's CSRs
         x_atoms, x_frags, e_edge, _ = self.pretrain(batch)
         return self.head(x_atoms, x_frags, e_edge, batch)

@@ -515,6 +515,10 @@ def dropout_act(x, p: float, training: bool, relu: bool, rng: PhiloxStream):
 SMALL_LINEAR_MAX = 16        # FN_SMALL_LINEAR_MAX
 
 
+def _scratch(n_floats: int, device):
+    return torch.empty(n_floats, dtype=torch.float32, device=device) if n_floats else None
+
+
 class _MLPHead(torch.autograd.Function):
     """FTHead1-5's predictor stack (gat2.py:631-637, 745-751) as one autograd node.
 
@@ -565,8 +569,9 @@ class _MLPHead(torch.autograd.Function):
         dW, db = grad_buffer(P[-2], slots[-2]), grad_buffer(P[-1], slots[-1])
         if C_out <= SMALL_LINEAR_MAX and K % 4 == 0:
             gz = torch.empty_like(h)
+            ws = _scratch(_lib.load().fn_small_linear_bwd_ws(h.shape[0], K, C_out), g.device)
             _lib.call("fn_small_linear_bwd_f32", g.data_ptr(), h.data_ptr(), W.data_ptr(), gz.data_ptr(), dW.data_ptr(), db.data_ptr(),
-                      h.shape[0], K, C_out, st)
+                      h.shape[0], K, C_out, _ptr(ws), st)
         else:
             gz = g @ W
             torch.mm(g.t(), h, out=dW)
@@ -578,7 +583,9 @@ class _MLPHead(torch.autograd.Function):
         for i in range(n - 2, -1, -1):
             z, h_in, W = acts[i + 1], acts[i], Ws[i]
             gy, dW, db = torch.empty_like(z), grad_buffer(P[2 * i], slots[2 * i]), grad_buffer(P[2 * i + 1], slots[2 * i + 1])
-            _lib.call("fn_gate_colsum_f32", gz.data_ptr(), z.data_ptr(), gy.data_ptr(), db.data_ptr(), z.shape[0], z.shape[1], scale, st)
+            ws = _scratch(_lib.load().fn_gate_colsum_ws(z.shape[0], z.shape[1]), z.device)
+            _lib.call("fn_gate_colsum_f32", gz.data_ptr(), z.data_ptr(), gy.data_ptr(), db.data_ptr(), z.shape[0], z.shape[1], scale,
+                      _ptr(ws), st)
             torch.mm(gy.t(), h_in, out=dW)
             grads[2 * i], grads[2 * i + 1] = dW, db
             if i > 0 or ctx.needs_input_grad[0]:

@@ -130,19 +130,22 @@ class FlatAdam:
         self.params = [p for p in params]
         if not self.params:
             raise ValueError("FlatAdam needs at least one parameter")
+        # every parameter starts on a 16-byte boundary of the flat buffers (float4 loads in the kernels that read
+        # weights in place; a 1-element bias would otherwise misalign everything behind it); the padding stays zero
+        self.offsets, total = [], 0
+        for p in self.params:
+            self.offsets.append(total)
+            total += (p.numel() + 3) // 4 * 4
         with torch.no_grad():
-            flat = torch.cat([p.data.reshape(-1) for p in self.params])
-            off = 0
-            for p in self.params:
+            flat = torch.zeros(total, dtype=self.params[0].dtype, device=self.params[0].device)
+            for p, off in zip(self.params, self.offsets):
                 n = p.numel()
+                flat[off: off + n] = p.data.reshape(-1)
                 p.data = flat[off: off + n].view_as(p)
-                off += n
         self.flat = torch.nn.Parameter(flat)
         self.grad = torch.zeros_like(flat)
-        off = 0
-        for p in self.params:      # producers that know about it (ops.grad_buffer) write d loss/d p straight into its slot
+        for p, off in zip(self.params, self.offsets):      # producers that know about it (ops.grad_buffer) write d loss/d p straight into its slot
             p._fn_grad_slot = (self.grad, off)
-            off += p.numel()
         self.hyper = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.steps = 0
         if flat.is_cuda:      # one HIP kernel (fn_adam_f32) over the flat tensor
@@ -175,23 +178,24 @@ class FlatAdam:
         # gradients that a producer already wrote into their slot of the flat buffer (ops.grad_buffer: the encoder
         # and the fused head do) need no copy; every maximal run of the others is one cat
         base, es = self.grad.data_ptr(), self.grad.element_size()
-        run, run_off, off = [], 0, 0
+        run, run_off, run_end = [], 0, 0
 
         def flush():
             if run:
-                n = sum(g.numel() for g in run)
-                torch.cat(run, out=self.grad[run_off: run_off + n])
+                torch.cat(run, out=self.grad[run_off: run_end])
                 run.clear()
 
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             n = p.numel()
             if n and p.grad.data_ptr() != base + off * es:
+                if run and off != run_end:      # alignment padding between the two: separate copies
+                    flush()
                 if not run:
                     run_off = off
                 run.append(p.grad.reshape(-1))
+                run_end = off + n
             else:
                 flush()
-            off += n
         flush()
 
     def all_reduce(self, group=None):

@@ -281,12 +281,16 @@ int fn_bond_graph_fill(const int64_t* edge_index, const int64_t* atom_mol, int64
  *   way: y = x w^T + b;  g_x = g w, dW = g^T x, db = colsum(g).  All sums run in a fixed order (deterministic).
  * ------------------------------------------------------------------------------------------ */
 #define FN_SMALL_LINEAR_MAX 16
+/* Inputs taller than 2048 rows (the pretrain towers run on every edge / atom) are reduced in row chunks: pass a float
+ * workspace of fn_gate_colsum_ws() / fn_small_linear_bwd_ws() elements (0 = not needed, ws may be NULL). */
+int64_t fn_gate_colsum_ws(int64_t rows, int64_t cols);
 int fn_gate_colsum_f32(const float* g_y /*[rows,cols]*/, const float* y /*[rows,cols]*/, float* g_x /*[rows,cols]*/,
-                       float* colsum /*[cols]*/, int64_t rows, int64_t cols, float scale, fn_stream_t stream);
+                       float* colsum /*[cols]*/, int64_t rows, int64_t cols, float scale, float* ws, fn_stream_t stream);
 int fn_small_linear_f32(const float* x /*[M,K]*/, const float* w /*[C,K]*/, const float* b /*[C] nullable*/, float* y /*[M,C]*/,
                         int64_t M, int64_t K, int64_t C, fn_stream_t stream);
+int64_t fn_small_linear_bwd_ws(int64_t M, int64_t K, int64_t C);
 int fn_small_linear_bwd_f32(const float* g /*[M,C]*/, const float* x /*[M,K]*/, const float* w /*[C,K]*/, float* g_x /*[M,K]*/,
-                            float* dW /*[C,K]*/, float* db /*[C]*/, int64_t M, int64_t K, int64_t C, fn_stream_t stream);
+                            float* dW /*[C,K]*/, float* db /*[C]*/, int64_t M, int64_t K, int64_t C, float* ws, fn_stream_t stream);
 
 /* torch.optim.Adam step (no amsgrad) on one flat fp32 tensor: finetune_gat2.py:257, pretrain_gat2.py:165.
  * `step` is the 1-based step count (bias corrections are computed on the host in double). */

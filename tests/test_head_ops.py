@@ -15,7 +15,7 @@ def _dev():
 
 
 @gpu
-@pytest.mark.parametrize("rows,cols", [(528, 1024), (37, 128), (0, 64), (1, 4), (300, 36)])
+@pytest.mark.parametrize("rows,cols", [(528, 1024), (37, 128), (0, 64), (1, 4), (300, 36), (28104, 64), (2049, 32)])
 def test_gate_colsum_matches_torch(rows, cols):
     from fragnet_amd import _lib
     from fragnet_amd.plan import _stream_ptr
@@ -24,14 +24,18 @@ def test_gate_colsum_matches_torch(rows, cols):
     g = torch.randn(rows, cols, device=dev)
     y = torch.relu(torch.randn(rows, cols, device=dev))            # about half zeros, like relu(dropout(.))
     gx, cs = torch.full_like(g, 7.0), torch.full((cols,), 7.0, device=dev)
-    _lib.call("fn_gate_colsum_f32", g.data_ptr(), y.data_ptr(), gx.data_ptr(), cs.data_ptr(), rows, cols, 1.25, _stream_ptr(dev))
+    n_ws = _lib.load().fn_gate_colsum_ws(rows, cols)
+    ws = torch.empty(n_ws, device=dev) if n_ws else None
+    assert (n_ws > 0) == (rows > 2048)
+    _lib.call("fn_gate_colsum_f32", g.data_ptr(), y.data_ptr(), gx.data_ptr(), cs.data_ptr(), rows, cols, 1.25,
+              None if ws is None else ws.data_ptr(), _stream_ptr(dev))
     ref = torch.where(y > 0, g * 1.25, torch.zeros_like(g))
     assert torch.equal(gx, ref)
-    torch.testing.assert_close(cs, ref.double().sum(0).float(), atol=2e-4, rtol=1e-5)
+    torch.testing.assert_close(cs, ref.double().sum(0).float(), atol=2e-4 * max(1.0, rows / 500) ** 0.5, rtol=1e-5)
 
 
 @gpu
-@pytest.mark.parametrize("M,K,C", [(528, 512, 1), (528, 512, 12), (5, 128, 3), (0, 64, 2), (100, 36, 16)])
+@pytest.mark.parametrize("M,K,C", [(528, 512, 1), (528, 512, 12), (5, 128, 3), (0, 64, 2), (100, 36, 16), (28104, 32, 1), (13872, 32, 3)])
 def test_small_linear_matches_torch(M, K, C):
     from fragnet_amd import _lib
     from fragnet_amd.plan import _stream_ptr
@@ -44,10 +48,14 @@ def test_small_linear_matches_torch(M, K, C):
     _lib.call("fn_small_linear_f32", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, K, C, st)
     torch.testing.assert_close(y, (x.double() @ w.double().t() + b.double()).float(), atol=2e-5, rtol=1e-5)
     gx, dW, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(b)
-    _lib.call("fn_small_linear_bwd_f32", g.data_ptr(), x.data_ptr(), w.data_ptr(), gx.data_ptr(), dW.data_ptr(), db.data_ptr(), M, K, C, st)
+    n_ws = _lib.load().fn_small_linear_bwd_ws(M, K, C)
+    ws = torch.empty(n_ws, device=dev) if n_ws else None
+    _lib.call("fn_small_linear_bwd_f32", g.data_ptr(), x.data_ptr(), w.data_ptr(), gx.data_ptr(), dW.data_ptr(), db.data_ptr(), M, K, C,
+              None if ws is None else ws.data_ptr(), st)
     torch.testing.assert_close(gx, (g.double() @ w.double()).float(), atol=2e-5, rtol=1e-5)
-    torch.testing.assert_close(dW, (g.double().t() @ x.double()).float(), atol=2e-4, rtol=1e-5)
-    torch.testing.assert_close(db, g.double().sum(0).float(), atol=2e-4, rtol=1e-5)
+    tol = 2e-4 * max(1.0, M / 500) ** 0.5
+    torch.testing.assert_close(dW, (g.double().t() @ x.double()).float(), atol=tol, rtol=1e-5)
+    torch.testing.assert_close(db, g.double().sum(0).float(), atol=tol, rtol=1e-5)
 
 
 @gpu
@@ -118,14 +126,15 @@ def test_parameter_gradients_are_written_into_the_flat_buffer():
     opt.zero_grad()
     run(model)
     names = {id(q): n for n, q in model.named_parameters()}
-    base, off, elsewhere = opt.grad.data_ptr(), 0, []
-    for p in opt.params:
+    base, elsewhere = opt.grad.data_ptr(), []
+    for p, off in zip(opt.params, opt.offsets):
+        assert off % 4 == 0                                        # every slot starts on a 16-byte boundary
         if p.grad.data_ptr() != base + 4 * off:
             elsewhere.append(names[id(p)])
-        off += p.numel()
     assert not elsewhere, f"gradients not in place: {elsewhere}"
     opt.gather_grads()
     run(ref)                                                       # no optimiser attached: ordinary .grad tensors
     live = [q for q in ref.parameters() if q.grad is not None]
-    flat_ref = torch.cat([q.grad.reshape(-1) for q in live])
-    torch.testing.assert_close(opt.grad, flat_ref, atol=1e-6, rtol=1e-5)
+    assert len(live) == len(opt.params)
+    for q, p, off in zip(live, opt.params, opt.offsets):
+        torch.testing.assert_close(opt.grad[off: off + p.numel()].view_as(q), q.grad, atol=1e-6, rtol=1e-5)

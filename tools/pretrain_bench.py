@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Times the captured pretrain step (FragNetPreTrain + bond-length / angle / dihedral / graph heads, pretrain_gat2.py)
+on ESOL-shape batches of 512: python tools/pretrain_bench.py [--profile]   (dev tool; BASELINE configs[3] shape on one GPU)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import fragnet_amd
+from fragnet_amd import data, graphstep, parallel, synth, train
+from fragnet_amd.model import FragNetPreTrain
+
+dev = torch.device("cuda:0")
+fragnet_amd.prefer_rocblas_for_dense_heads()
+fragnet_amd.tune_library_gemms()
+B = 512
+batches = [data.batch_to(data.collate_fn_pt(synth.synth_molecules(B, seed=60 + i, profile="esol", pretrain_targets=True)), dev)
+           for i in range(4)]
+shapes = graphstep.StaticShapes.from_batches(batches, margin=0.02)
+torch.manual_seed(5)
+model = FragNetPreTrain(num_layer=4, drop_ratio=0.2, edge_features=17).to(dev).train()
+opt = parallel.FlatAdam.for_live_parameters(model, lambda: train.pretrain_loss(model(dict(batches[0])), batches[0]).backward(), lr=1e-4)
+step = graphstep.GraphedTrainStep(model, opt, shapes, dict(batches[0]), loss="pretrain")
+for i in range(5):
+    step(dict(batches[i % 4]))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 30
+for i in range(n):
+    step(dict(batches[i % 4]))
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) * 1e3 / n
+print(f"pretrain step: {ms:.3f} ms, {B / ms * 1e3:.0f} molecules/s, replays {step.replays}, fallbacks {step.fallbacks}")
