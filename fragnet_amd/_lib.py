@@ -62,6 +62,10 @@ FN_MAX_STAGE_FIELDS = 24
 STAGE_ROWS, STAGE_IDS, STAGE_COLS, STAGE_MASK = 0, 1, 2, 3
 
 
+class MseTask(C.Structure):
+    _fields_ = [("out", vp), ("y", vp), ("w", vp), ("g_out", vp), ("B", i64), ("T", i32), ("scale_idx", i32), ("coef", f32), ("pad_", f32)]
+
+
 class Encoder(C.Structure):
     _fields_ = [("n_layers", i32), ("heads", i32), ("k_atom0", i32), ("k_bond0", i32), ("k_fbond0", i32), ("k_fattr", i32),
                 ("training", i32), ("variant", i32), ("drop_p", f32), ("pad2_", f32), ("seed", u64), ("offset", u64), ("offset_dev", vp),
@@ -115,6 +119,8 @@ SIGNATURES = {
     "fn_bond_graph_ws": [i64, i64],
     "fn_bond_graph_count": [vp, vp, i64, i64, i64, vp, vp, vp],
     "fn_bond_graph_fill": [vp, vp, i64, i64, i64, vp, vp, i64, vp],
+    "fn_masked_mse_multi_ws": [C.c_int],
+    "fn_masked_mse_multi_f32": [C.POINTER(MseTask), C.c_int, vp, vp, vp, vp],
     "fn_gate_colsum_ws": [i64, i64],
     "fn_gate_colsum_f32": [vp, vp, vp, vp, i64, i64, f32, vp, vp],
     "fn_small_linear_f32": [vp, vp, vp, vp, i64, i64, i64, vp],

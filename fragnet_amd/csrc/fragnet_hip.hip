@@ -1354,6 +1354,70 @@ __global__ __launch_bounds__(1024) void k_masked_mse(const float* __restrict__ o
     for (int64_t i = threadIdx.x; i < B * T; i += 1024) g_out[i] = scale * w[i / T] * (out[i] - y[i]);
 }
 
+// ---- sum_k coef_k * masked_mse_k over up to four (prediction, target, row weight) triples in two multi-block launches:
+// pass 1 writes per-block partial (sum w d^2, sum w) of every task, pass 2 lets every block re-add the partials in a
+// fixed order (so all blocks agree bit for bit), block 0 writes the total loss and all blocks write their slice of the
+// gradients coef_k * 2 / (W_k T_k) * w * (out - y).  coef_k = c_k * (scale_dev[idx_k] if idx_k >= 0 else 1).
+constexpr int kMseBlocks = 64;
+struct MseTask {
+    const float *out, *y, *w;
+    float* g;
+    int64_t B;
+    int T, scale_idx;
+    float c;
+};
+struct MseTasks {
+    MseTask t[4];
+    int n;
+    const float* scale_dev;
+};
+__global__ __launch_bounds__(256) void k_mse_multi_partial(MseTasks M, float* __restrict__ part /*[n][kMseBlocks][2]*/) {
+    __shared__ float s4[4];
+    const MseTask& t = M.t[blockIdx.y];
+    float sq = 0.f, ws = 0.f;
+    const int64_t total = t.B * t.T;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)kMseBlocks * 256) {
+        const float d = t.out[i] - t.y[i], wi = t.w[i / t.T];
+        sq = fmaf(wi * d, d, sq);
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < t.B; i += (int64_t)kMseBlocks * 256) ws += t.w[i];
+    for (int pass = 0; pass < 2; ++pass) {
+        float v = pass ? ws : sq;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) part[((size_t)blockIdx.y * kMseBlocks + blockIdx.x) * 2 + pass] = s4[0] + s4[1] + s4[2] + s4[3];
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_mse_multi_finish(MseTasks M, const float* __restrict__ part, float* __restrict__ loss) {
+    __shared__ float sS[4], sW[4];
+    if (threadIdx.x < M.n) {
+        float S = 0.f, W = 0.f;
+        for (int b = 0; b < kMseBlocks; ++b) {
+            S += part[((size_t)threadIdx.x * kMseBlocks + b) * 2];
+            W += part[((size_t)threadIdx.x * kMseBlocks + b) * 2 + 1];
+        }
+        sS[threadIdx.x] = S;
+        sW[threadIdx.x] = W * (float)M.t[threadIdx.x].T;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        float L = 0.f;
+        for (int k = 0; k < M.n; ++k) {
+            const float coef = M.t[k].c * (M.t[k].scale_idx >= 0 ? M.scale_dev[M.t[k].scale_idx] : 1.f);
+            L += coef * (sS[k] / sW[k]);
+        }
+        loss[0] = L;
+    }
+    const MseTask& t = M.t[blockIdx.y];
+    const float coef = t.c * (t.scale_idx >= 0 ? M.scale_dev[t.scale_idx] : 1.f);
+    const float scale = coef * 2.f / sW[blockIdx.y];
+    const int64_t total = t.B * t.T;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)kMseBlocks * 256)
+        t.g[i] = scale * t.w[i / t.T] * (t.out[i] - t.y[i]);
+}
+
 __global__ void k_segment_sum_any(const float* __restrict__ src, int64_t src_ld, const int32_t* __restrict__ rowptr,
                                   const int32_t* __restrict__ perm, int32_t pos_base, float* __restrict__ out,
                                   int64_t n_seg, int64_t width) {
@@ -1630,12 +1694,21 @@ __global__ __launch_bounds__(256) void k_gate_colsum(const float* __restrict__ g
         st4(sums + (size_t)blockIdx.y * cols + col, t);
     }
 }
-// out[c] = sum over chunks (in order) of part[chunk][c]
-__global__ void k_sum_chunks(const float* __restrict__ part, int chunks, int64_t width, float* __restrict__ out) {
-    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < width; c += (int64_t)gridDim.x * blockDim.x) {
-        float t = 0.f;
-        for (int q = 0; q < chunks; ++q) t += part[(size_t)q * width + c];
-        out[c] = t;
+// out[c] = sum over chunks of part[chunk][c] in a fixed order: 16 chunk lanes each add every 16th chunk, then the 16
+// lane sums are added in lane order (a serial walk over ~110 dependent loads took 25 us)
+__global__ __launch_bounds__(256) void k_sum_chunks(const float* __restrict__ part, int chunks, int64_t width, float* __restrict__ out) {
+    __shared__ float sm[16][17];
+    const int cl = threadIdx.x & 15, ql = threadIdx.x >> 4;
+    const int64_t c = (int64_t)blockIdx.x * 16 + cl;
+    float t = 0.f;
+    if (c < width)
+        for (int q = ql; q < chunks; q += 16) t += part[(size_t)q * width + c];
+    sm[ql][cl] = t;
+    __syncthreads();
+    if (ql == 0 && c < width) {
+        float v = sm[0][cl];
+        for (int q = 1; q < 16; ++q) v += sm[q][cl];
+        out[c] = v;
     }
 }
 
@@ -2973,7 +3046,7 @@ int fn_gate_colsum_f32(const float* g_y, const float* y, float* g_x, float* cols
     if (ch > 1 && !ws) return fail(FN_EINVAL, "fn_gate_colsum_f32: rows > 2048 need the fn_gate_colsum_ws() workspace");
     hipLaunchKernelGGL(k_gate_colsum, dim3((unsigned)((cols + 31) / 32), (unsigned)ch), dim3(256), 0, S(stream), g_y, y, g_x,
                        ch > 1 ? ws : colsum, rows, (int)cols, scale, ch > 1 ? kTallChunk : (rows > 0 ? rows : 1));
-    if (ch > 1) hipLaunchKernelGGL(k_sum_chunks, dim3(flat_grid(cols, 64)), dim3(kBlock), 0, S(stream), ws, (int)ch, cols, colsum);
+    if (ch > 1) hipLaunchKernelGGL(k_sum_chunks, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, S(stream), ws, (int)ch, cols, colsum);
     return launch_status("fn_gate_colsum_f32");
 }
 
@@ -3007,8 +3080,8 @@ int fn_small_linear_bwd_f32(const float* g, const float* x, const float* w, floa
     else if (C <= 4) hipLaunchKernelGGL(k_small_linear_bwd<4>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW_o, db_o, M, (int)K, (int)C, rpc);
     else hipLaunchKernelGGL(k_small_linear_bwd<FN_SMALL_LINEAR_MAX>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW_o, db_o, M, (int)K, (int)C, rpc);
     if (ch > 1) {
-        hipLaunchKernelGGL(k_sum_chunks, dim3(flat_grid(C * K, 64)), dim3(kBlock), 0, S(stream), ws, (int)ch, C * K, dW);
-        hipLaunchKernelGGL(k_sum_chunks, dim3(1), dim3(kBlock), 0, S(stream), ws + ch * C * K, (int)ch, C, db);
+        hipLaunchKernelGGL(k_sum_chunks, dim3((unsigned)((C * K + 15) / 16)), dim3(256), 0, S(stream), ws, (int)ch, C * K, dW);
+        hipLaunchKernelGGL(k_sum_chunks, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, S(stream), ws + ch * C * K, (int)ch, C, db);
     }
     return launch_status("fn_small_linear_bwd_f32");
 }
@@ -3060,6 +3133,24 @@ int fn_masked_mse_f32(const float* out, const float* y, const float* w, int64_t 
     if (!out || !y || !w || !loss || !g_out || B < 1 || T < 1) return fail(FN_EINVAL, "fn_masked_mse_f32: bad argument");
     hipLaunchKernelGGL(k_masked_mse, dim3(1), dim3(1024), 0, S(stream), out, y, w, B, T, loss, g_out);
     return launch_status("fn_masked_mse_f32");
+}
+
+int64_t fn_masked_mse_multi_ws(int n_tasks) { return n_tasks > 0 ? (int64_t)n_tasks * kMseBlocks * 2 : 0; }
+
+int fn_masked_mse_multi_f32(const fn_mse_task* tasks, int n_tasks, const float* scale_dev, float* ws, float* loss, fn_stream_t stream) {
+    if (!tasks || n_tasks < 1 || n_tasks > 4 || !ws || !loss) return fail(FN_EINVAL, "fn_masked_mse_multi_f32: bad argument");
+    MseTasks M{};
+    M.n = n_tasks;
+    M.scale_dev = scale_dev;
+    for (int k = 0; k < n_tasks; ++k) {
+        const fn_mse_task& t = tasks[k];
+        if (!t.out || !t.y || !t.w || !t.g_out || t.B < 1 || t.T < 1 || (t.scale_idx >= 0 && !scale_dev))
+            return fail(FN_EINVAL, "fn_masked_mse_multi_f32: bad task");
+        M.t[k] = MseTask{t.out, t.y, t.w, t.g_out, t.B, t.T, t.scale_idx, t.coef};
+    }
+    hipLaunchKernelGGL(k_mse_multi_partial, dim3(kMseBlocks, n_tasks), dim3(256), 0, S(stream), M, ws);
+    hipLaunchKernelGGL(k_mse_multi_finish, dim3(kMseBlocks, n_tasks), dim3(256), 0, S(stream), M, ws, loss);
+    return launch_status("fn_masked_mse_multi_f32");
 }
 
 int fn_stage_padded(const fn_stage_field* fields, int n_fields, fn_stream_t stream) {

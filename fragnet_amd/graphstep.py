@@ -169,6 +169,10 @@ def masked_pretrain_loss(outputs, sb: Dict[str, torch.Tensor]) -> torch.Tensor:
     parallel.weighted_loss_scale applied to the per-edge and per-atom means."""
     from . import ops
     _, ba, da, graph_rep = outputs
+    if da.is_cuda:       # 2 * sc0 * MSE(dihedral) + sc1 * MSE(angle) + MSE(energy) and its gradients: two launches
+        return ops.masked_mse_multi([(2.0, 0), (1.0, 1), (1.0, -1)], sb[SCALE_KEY],
+                                    da, sb["dh_angl"], sb[MASKS["edge"]], ba, sb["bnd_angl"], sb[MASKS["atom"]],
+                                    graph_rep, sb["y"], sb[MASK_KEY])
     sc = sb[SCALE_KEY]
     l_dh = ops.masked_mse(da, sb["dh_angl"], sb[MASKS["edge"]]) * sc[0]
     return l_dh + ops.masked_mse(ba, sb["bnd_angl"], sb[MASKS["atom"]]) * sc[1] + l_dh \

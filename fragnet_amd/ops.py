@@ -342,6 +342,50 @@ def masked_mse(out, y, w):
     return _MaskedMSE.apply(out, y, w)
 
 
+class _MaskedMSEMulti(torch.autograd.Function):
+    """sum_k coef_k * masked_mse(out_k, y_k, w_k), coef_k = c_k * (scale[idx_k] if idx_k >= 0 else 1): loss and all
+    gradients in two launches (fn_masked_mse_multi_f32)."""
+
+    @staticmethod
+    def forward(ctx, spec, scale, *tensors):
+        n = len(spec)
+        dev = tensors[0].device
+        tasks = (_lib.MseTask * n)()
+        keep, grads, shapes = [], [], []
+        for k, (c, idx) in enumerate(spec):
+            out, y, w = tensors[3 * k: 3 * k + 3]
+            B = w.shape[0]
+            out2, y2, w = _f32c(out, "out").reshape(B, -1), _f32c(y, "y").reshape(B, -1), _f32c(w, "w")
+            if out2.shape != y2.shape:
+                raise ValueError(f"masked_mse_multi: prediction {tuple(out.shape)} vs target {tuple(y.shape)}")
+            g = torch.empty_like(out2)
+            tasks[k] = _lib.MseTask(out2.data_ptr(), y2.data_ptr(), w.data_ptr(), g.data_ptr(), B, out2.shape[1], int(idx), float(c), 0.0)
+            keep += [out2, y2, w]
+            grads.append(g)
+            shapes.append(out.shape)
+        scale = None if scale is None else _f32c(scale, "scale")
+        ws = torch.empty(_lib.load().fn_masked_mse_multi_ws(n), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _lib.call("fn_masked_mse_multi_f32", tasks, n, _ptr(scale), ws.data_ptr(), loss.data_ptr(), _stream_ptr(dev))
+        ctx.save_for_backward(*grads)
+        ctx.shapes = shapes
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        unit = _UNIT_GRAD.get(g_loss.device)
+        one = unit is not None and g_loss.data_ptr() == unit.data_ptr()
+        out = [None, None]
+        for g, shape in zip(ctx.saved_tensors, ctx.shapes):
+            out += [(g if one else g * g_loss).reshape(shape), None, None]
+        return tuple(out)
+
+
+def masked_mse_multi(spec, scale, *triples):
+    """``spec`` = [(c_k, scale_index_k or -1), ...]; ``triples`` = out_1, y_1, w_1, out_2, ...; ``scale`` a device vector."""
+    return _MaskedMSEMulti.apply(tuple(spec), scale, *triples)
+
+
 _UNIT_GRAD = {}
 
 

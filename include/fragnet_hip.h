@@ -313,6 +313,19 @@ int fn_pool_cat_bwd_f32(const float* g /*[B,256]*/, const int64_t* batch /*[N]*/
                         float* g_atoms /*[N,128]*/, float* g_frags /*[F,128]*/, int64_t N, int64_t F, fn_stream_t stream);
 int fn_masked_mse_f32(const float* out /*[B,T]*/, const float* y /*[B,T]*/, const float* w /*[B]*/, int64_t B, int T,
                       float* loss /*[1]*/, float* g_out /*[B,T] = dloss/dout*/, fn_stream_t stream);
+/* loss = sum_k coef_k * masked_mse_k with coef_k = tasks[k].coef * (scale_dev[tasks[k].scale_idx] if scale_idx >= 0 else 1):
+ * the pretrain loss 2*MSE(dihedral) + MSE(angle) + MSE(energy) (pretrain_utils.py:9-31) with the per-rank weights of the
+ * per-edge / per-atom means, and all three gradients, in two multi-block launches.  ws: fn_masked_mse_multi_ws(n) floats. */
+typedef struct fn_mse_task {
+    const float *out, *y, *w;   /* [B,T], [B,T], [B] */
+    float* g_out;               /* [B,T] = d loss / d out */
+    int64_t B;
+    int32_t T, scale_idx;
+    float coef, pad_;
+} fn_mse_task;
+int64_t fn_masked_mse_multi_ws(int n_tasks);
+int fn_masked_mse_multi_f32(const fn_mse_task* tasks, int n_tasks /*<= 4*/, const float* scale_dev /*nullable*/, float* ws,
+                            float* loss /*[1]*/, fn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Static-shape staging for hipGraph replay.  A training step captured in a hipGraph has fixed tensor shapes, so

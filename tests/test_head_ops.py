@@ -138,3 +138,26 @@ def test_parameter_gradients_are_written_into_the_flat_buffer():
     assert len(live) == len(opt.params)
     for q, p, off in zip(live, opt.params, opt.offsets):
         torch.testing.assert_close(opt.grad[off: off + p.numel()].view_as(q), q.grad, atol=1e-6, rtol=1e-5)
+
+
+@gpu
+def test_masked_mse_multi_matches_the_sum_of_single_losses():
+    from fragnet_amd import ops
+    dev = _dev()
+    torch.manual_seed(6)
+    sizes = [(28104, 1), (13872, 1), (528, 3)]
+    outs = [torch.randn(b, t, device=dev, requires_grad=True) for b, t in sizes]
+    ys = [torch.randn(b, t, device=dev) for b, t in sizes]
+    ws = [(torch.rand(b, device=dev) > 0.1).float() for b, _ in sizes]
+    scale = torch.tensor([0.9, 1.3], device=dev)
+    loss = ops.masked_mse_multi([(2.0, 0), (1.0, 1), (1.0, -1)], scale, outs[0], ys[0], ws[0], outs[1], ys[1], ws[1], outs[2], ys[2], ws[2])
+    loss.backward()
+    refs = [o.detach().double().requires_grad_(True) for o in outs]
+
+    def mse(o, y, w):
+        return (w.double()[:, None] * (o - y.double()) ** 2).sum() / (w.double().sum() * o.shape[1])
+    want = 2 * 0.9 * mse(refs[0], ys[0], ws[0]) + 1.3 * mse(refs[1], ys[1], ws[1]) + mse(refs[2], ys[2], ws[2])
+    want.backward()
+    assert abs(float(loss) - float(want)) < 1e-5 * max(1.0, abs(float(want)))
+    for o, r in zip(outs, refs):
+        torch.testing.assert_close(o.grad, r.grad.float(), atol=1e-7, rtol=1e-4)
