@@ -1354,6 +1354,35 @@ __global__ __launch_bounds__(1024) void k_masked_mse(const float* __restrict__ o
     for (int64_t i = threadIdx.x; i < B * T; i += 1024) g_out[i] = scale * w[i / T] * (out[i] - y[i]);
 }
 
+// multi-task classification loss (compute_bce_loss, train/utils.py:297-304): BCE-with-logits averaged over the valid
+// entries (target > -0.5 = label present, row weight > 0 = real molecule) and its gradient, one block
+__global__ __launch_bounds__(1024) void k_masked_bce(const float* __restrict__ out, const float* __restrict__ y,
+                                                     const float* __restrict__ w, int64_t B, int T, float* __restrict__ loss,
+                                                     float* __restrict__ g_out) {
+    __shared__ float s16[16];
+    __shared__ float sN;
+    float sum = 0.f, cnt = 0.f;
+    for (int64_t i = threadIdx.x; i < B * T; i += 1024) {
+        const float x = out[i], t = y[i];
+        if (t > -0.5f && w[i / T] > 0.f) {
+            const float tt = fmaxf(t, 0.f);
+            sum += fmaxf(x, 0.f) - x * tt + log1pf(expf(-fabsf(x)));
+            cnt += 1.f;
+        }
+    }
+    const float S = block_sum_1024(sum, s16);
+    __syncthreads();
+    const float N = block_sum_1024(cnt, s16);
+    if (threadIdx.x == 0) { loss[0] = S / N;  sN = N; }
+    __syncthreads();
+    const float inv = 1.f / sN;
+    for (int64_t i = threadIdx.x; i < B * T; i += 1024) {
+        const float x = out[i], t = y[i];
+        const bool valid = t > -0.5f && w[i / T] > 0.f;
+        g_out[i] = valid ? (1.f / (1.f + expf(-x)) - fmaxf(t, 0.f)) * inv : 0.f;
+    }
+}
+
 // ---- sum_k coef_k * masked_mse_k over up to four (prediction, target, row weight) triples in two multi-block launches:
 // pass 1 writes per-block partial (sum w d^2, sum w) of every task, pass 2 lets every block re-add the partials in a
 // fixed order (so all blocks agree bit for bit), block 0 writes the total loss and all blocks write their slice of the
@@ -3133,6 +3162,13 @@ int fn_masked_mse_f32(const float* out, const float* y, const float* w, int64_t 
     if (!out || !y || !w || !loss || !g_out || B < 1 || T < 1) return fail(FN_EINVAL, "fn_masked_mse_f32: bad argument");
     hipLaunchKernelGGL(k_masked_mse, dim3(1), dim3(1024), 0, S(stream), out, y, w, B, T, loss, g_out);
     return launch_status("fn_masked_mse_f32");
+}
+
+int fn_masked_bce_f32(const float* out, const float* y, const float* w, int64_t B, int T, float* loss, float* g_out,
+                      fn_stream_t stream) {
+    if (!out || !y || !w || !loss || !g_out || B < 1 || T < 1) return fail(FN_EINVAL, "fn_masked_bce_f32: bad argument");
+    hipLaunchKernelGGL(k_masked_bce, dim3(1), dim3(1024), 0, S(stream), out, y, w, B, T, loss, g_out);
+    return launch_status("fn_masked_bce_f32");
 }
 
 int64_t fn_masked_mse_multi_ws(int n_tasks) { return n_tasks > 0 ? (int64_t)n_tasks * kMseBlocks * 2 : 0; }

@@ -157,6 +157,9 @@ def masked_regr_loss(out: torch.Tensor, y: torch.Tensor, w: torch.Tensor) -> tor
 
 def masked_bce_loss(out: torch.Tensor, y: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """compute_bce_loss (train/utils.py:297-304): targets <= -0.5 are missing labels; padding molecules too."""
+    if out.is_cuda:
+        from . import ops
+        return ops.masked_bce(out, y, w)
     y = y.reshape(out.shape)
     valid = (y > -0.5) & (w[:, None] > 0)
     mat = torch.nn.functional.binary_cross_entropy_with_logits(out, y.clamp(min=0.0), reduction="none")

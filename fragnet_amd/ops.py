@@ -342,6 +342,37 @@ def masked_mse(out, y, w):
     return _MaskedMSE.apply(out, y, w)
 
 
+class _MaskedBCE(torch.autograd.Function):
+    """compute_bce_loss (train/utils.py:297-304) over a padded batch: loss and gradient from one single-block kernel."""
+
+    @staticmethod
+    def forward(ctx, out, y, w):
+        B = w.shape[0]
+        out2, y2 = _f32c(out, "out").reshape(B, -1), _f32c(y, "y").reshape(B, -1)
+        if out2.shape != y2.shape:
+            raise ValueError(f"masked_bce: prediction {tuple(out.shape)} vs target {tuple(y.shape)}")
+        w = _f32c(w, "w")
+        loss = torch.empty((), dtype=torch.float32, device=out.device)
+        g = torch.empty_like(out2)
+        _lib.call("fn_masked_bce_f32", out2.data_ptr(), y2.data_ptr(), w.data_ptr(), B, out2.shape[1], loss.data_ptr(),
+                  g.data_ptr(), _stream_ptr(out.device))
+        ctx.save_for_backward(g)
+        ctx.shape = out.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (g,) = ctx.saved_tensors
+        unit = _UNIT_GRAD.get(g.device)
+        if unit is not None and g_loss.data_ptr() == unit.data_ptr():
+            return g.reshape(ctx.shape), None, None
+        return (g * g_loss).reshape(ctx.shape), None, None
+
+
+def masked_bce(out, y, w):
+    return _MaskedBCE.apply(out, y, w)
+
+
 class _MaskedMSEMulti(torch.autograd.Function):
     """sum_k coef_k * masked_mse(out_k, y_k, w_k), coef_k = c_k * (scale[idx_k] if idx_k >= 0 else 1): loss and all
     gradients in two launches (fn_masked_mse_multi_f32)."""

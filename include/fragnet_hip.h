@@ -313,6 +313,10 @@ int fn_pool_cat_bwd_f32(const float* g /*[B,256]*/, const int64_t* batch /*[N]*/
                         float* g_atoms /*[N,128]*/, float* g_frags /*[F,128]*/, int64_t N, int64_t F, fn_stream_t stream);
 int fn_masked_mse_f32(const float* out /*[B,T]*/, const float* y /*[B,T]*/, const float* w /*[B]*/, int64_t B, int T,
                       float* loss /*[1]*/, float* g_out /*[B,T] = dloss/dout*/, fn_stream_t stream);
+/* compute_bce_loss (train/utils.py:297-304): mean over the valid entries (y > -0.5, w > 0) of BCE-with-logits(out, max(y, 0)),
+ * and its gradient; one single-block launch (B*T is ~12 k for Tox21 at batch 1024). */
+int fn_masked_bce_f32(const float* out /*[B,T]*/, const float* y /*[B,T]*/, const float* w /*[B]*/, int64_t B, int T,
+                      float* loss /*[1]*/, float* g_out /*[B,T]*/, fn_stream_t stream);
 /* loss = sum_k coef_k * masked_mse_k with coef_k = tasks[k].coef * (scale_dev[tasks[k].scale_idx] if scale_idx >= 0 else 1):
  * the pretrain loss 2*MSE(dihedral) + MSE(angle) + MSE(energy) (pretrain_utils.py:9-31) with the per-rank weights of the
  * per-edge / per-atom means, and all three gradients, in two multi-block launches.  ws: fn_masked_mse_multi_ws(n) floats. */

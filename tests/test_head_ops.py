@@ -161,3 +161,24 @@ def test_masked_mse_multi_matches_the_sum_of_single_losses():
     assert abs(float(loss) - float(want)) < 1e-5 * max(1.0, abs(float(want)))
     for o, r in zip(outs, refs):
         torch.testing.assert_close(o.grad, r.grad.float(), atol=1e-7, rtol=1e-4)
+
+
+@gpu
+def test_masked_bce_matches_the_torch_formula():
+    from fragnet_amd import ops
+    dev = _dev()
+    torch.manual_seed(8)
+    B, T = 1040, 12
+    out = torch.randn(B, T, device=dev) * 3
+    out.requires_grad_(True)
+    y = torch.randint(-1, 2, (B, T), device=dev).float()             # -1 = missing label
+    w = (torch.arange(B, device=dev) < 1024).float()                  # padded molecules at the end
+    loss = ops.masked_bce(out, y, w)
+    loss.backward()
+    ref = out.detach().double().requires_grad_(True)
+    valid = (y > -0.5) & (w[:, None] > 0)
+    mat = torch.nn.functional.binary_cross_entropy_with_logits(ref, y.clamp(min=0).double(), reduction="none")
+    want = torch.where(valid, mat, torch.zeros_like(mat)).sum() / valid.sum()
+    want.backward()
+    assert abs(float(loss) - float(want)) < 2e-6
+    torch.testing.assert_close(out.grad, ref.grad.float(), atol=1e-8, rtol=1e-4)
