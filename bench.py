@@ -222,8 +222,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch-by-launch step instead of the whole-step hipGraph")
-    ap.add_argument("--overlap", choices=("auto", "on", "off"), default="auto",
-                    help="two-graph step with the head's gradient all-reduce beside the encoder backward (auto: when N > 1)")
+    ap.add_argument("--overlap", choices=("on", "off"), default="off",
+                    help="on: two-graph step with the head's gradient all-reduce (async) beside the encoder backward")
     ap.add_argument("--margin", type=float, default=0.02, help="capacity head-room of the static shapes over the pool")
     ap.add_argument("--eager-head", action="store_true", help="(--eager) do not HIP-graph-capture the prediction head")
     ap.add_argument("--kernels-only", action="store_true", help="only time the bond-level scatter kernels (dev loop)")
@@ -293,7 +293,7 @@ def main():
         try:
             shapes = graphstep.StaticShapes.from_batches(pool, margin=args.margin, heads=MODEL_CFG["num_heads"])
             gstep = graphstep.GraphedTrainStep(model, opt, shapes, pool[0], loss="regr",
-                                               overlap={"auto": None, "on": True, "off": False}[args.overlap])
+                                               overlap=args.overlap == "on")
             torch.cuda.synchronize()
         except Exception as exc:      # never lose the measurement to a capture problem: run the same step eagerly
             gstep, capture_note = None, f"hipGraph capture failed ({type(exc).__name__}: {exc}); eager step"

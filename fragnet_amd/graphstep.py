@@ -257,10 +257,11 @@ class GraphedTrainStep:
 
     def __init__(self, model, opt, shapes: StaticShapes, example: Dict[str, torch.Tensor], loss: str = "regr",
                  group=None, warmup: int = 3, overlap: Optional[bool] = None):
-        """``overlap``: capture the step as TWO graphs -- (forward + loss + head backward) and (encoder backward) -- and
-        start the all-reduce of the head's gradients (83 % of the bytes for FTHead3) between them, so that it runs on
-        RCCL's stream beside the encoder's backward pass; the encoder's own, small slice follows the second graph.
-        Default: on when the process group has more than one rank and the model / optimiser layout allows it."""
+        """``overlap=True``: capture the step as TWO graphs -- (forward + loss + head backward) and (encoder backward) -- and
+        start an asynchronous all-reduce of the head's gradients (83 % of the bytes for FTHead3) between them, so that it
+        runs on RCCL's stream beside the encoder's backward pass; the encoder's own, small slice follows the second graph.
+        Off by default: on this stack an async collective costs ~95 us of stream fork/join against ~20 us for a blocking
+        one (tools/allreduce_probe.py), which eats what the overlap hides at 8 MB of gradients."""
         self.model, self.opt, self.shapes, self.group = model, opt, shapes, group
         self.loss_kind = loss
         if loss not in ("regr", "clsf", "pretrain"):
@@ -281,9 +282,6 @@ class GraphedTrainStep:
         self._unit = ops.unit_grad(self.static.device)
         self.graph_b: Optional[torch.cuda.CUDAGraph] = None
         self.head_off = self._head_offset()
-        if overlap is None:
-            import torch.distributed as dist
-            overlap = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.split = bool(overlap) and self.head_off is not None
         self._capture(example, warmup)
 
