@@ -111,6 +111,7 @@ SIGNATURES = {
     "fn_dropout_act_f32": [vp, vp, i64, f32, u64, u64, vp, C.c_int, vp],
     "fn_dropout_act_bwd_f32": [vp, vp, vp, i64, f32, u64, u64, vp, C.c_int, vp],
     "fn_adam_f32": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp],
+    "fn_adam_dev_f32": [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, vp],
     "fn_edge_concat_f32": [vp, vp, vp, vp, i64, vp],
     "fn_stage_padded": [C.POINTER(StageField), C.c_int, vp],
     "fn_pool_cat_f32": [vp, vp, C.POINTER(SegPlan), C.POINTER(SegPlan), vp, vp],

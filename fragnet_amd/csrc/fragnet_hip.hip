@@ -1565,7 +1565,20 @@ __global__ void k_dropout_act(const float* __restrict__ a, const float* __restri
 
 // torch.optim.Adam's update rule (no amsgrad) on one flat tensor: the reference's optimiser, finetune_gat2.py:257
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                       int64_t n, float lr_over_bc1, float beta1, float beta2, float eps, float inv_sqrt_bc2, float wd) {
+                       int64_t n, float lr_over_bc1, float beta1, float beta2, float eps, float inv_sqrt_bc2, float wd,
+                       const int64_t* __restrict__ step_dev, const float* __restrict__ lr_dev) {
+    if (step_dev) {      // captured in a hipGraph: step count and learning rate live in device memory, bias corrections here
+        __shared__ float s2[2];
+        if (threadIdx.x == 0) {
+            const double st = (double)*step_dev;
+            const double bc1 = 1.0 - pow((double)beta1, st), bc2 = 1.0 - pow((double)beta2, st);
+            s2[0] = (float)((double)*lr_dev / bc1);
+            s2[1] = (float)(1.0 / sqrt(bc2));
+        }
+        __syncthreads();
+        lr_over_bc1 = s2[0];
+        inv_sqrt_bc2 = s2[1];
+    }
     const int64_t n4 = n / 4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float4 pp = ld4(p + i * 4), gg = ld4(g + i * 4), mm = ld4(m + i * 4), vv = ld4(v + i * 4);
@@ -3123,8 +3136,20 @@ int fn_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float l
         return fail(FN_EINVAL, "fn_adam_f32: null or misaligned buffer");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(k_adam, dim3(flat_grid((n + 3) / 4, kGridCap)), dim3(kBlock), 0, S(stream), p, g, m, v, n,
-                       (float)((double)lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), weight_decay);
+                       (float)((double)lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), weight_decay,
+                       (const int64_t*)nullptr, (const float*)nullptr);
     return launch_status("fn_adam_f32");
+}
+
+int fn_adam_dev_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
+                    float eps, float weight_decay, const int64_t* step_dev, fn_stream_t stream) {
+    if (n < 0 || !lr_dev || !step_dev) return fail(FN_EINVAL, "fn_adam_dev_f32: bad argument");
+    if (n == 0) return 0;
+    if (!p || !g || !m || !v || (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15))
+        return fail(FN_EINVAL, "fn_adam_dev_f32: null or misaligned buffer");
+    hipLaunchKernelGGL(k_adam, dim3(flat_grid((n + 3) / 4, kGridCap)), dim3(kBlock), 0, S(stream), p, g, m, v, n, 0.f, beta1, beta2,
+                       eps, 0.f, weight_decay, step_dev, lr_dev);
+    return launch_status("fn_adam_dev_f32");
 }
 
 int fn_edge_concat_f32(const float* x, const float* e_attr, const int64_t* edge_index, float* out, int64_t E,

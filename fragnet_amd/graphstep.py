@@ -256,7 +256,7 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, opt, shapes: StaticShapes, example: Dict[str, torch.Tensor], loss: str = "regr",
-                 group=None, warmup: int = 3, overlap: Optional[bool] = None):
+                 group=None, warmup: int = 3, overlap: Optional[bool] = None, capture_adam: bool = True):
         """``overlap=True``: capture the step as TWO graphs -- (forward + loss + head backward) and (encoder backward) -- and
         start an asynchronous all-reduce of the head's gradients (83 % of the bytes for FTHead3) between them, so that it
         runs on RCCL's stream beside the encoder's backward pass; the encoder's own, small slice follows the second graph.
@@ -274,7 +274,16 @@ class GraphedTrainStep:
         if loss == "pretrain" and hasattr(getattr(model, "head", None), "need_bond_length"):
             model.head.need_bond_length = False      # the loss never reads the bond-length prediction (pretrain_utils.py:17-24)
         self.rng = model.pretrain.rng
-        self.rng.use_device_counter(self.device)
+        # [Philox blocks consumed, Adam steps done]: one captured vector add moves both on every replay
+        self._counters = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self.rng.dev = self._counters[0:1]
+        import torch.distributed as dist
+        single = not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1
+        # one rank, fused HIP Adam: the update is captured too (step count and learning rate live in device memory)
+        self.adam_in_graph = bool(capture_adam) and single and getattr(opt, "opt", 1) is None
+        self._lr_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._lr_host = None
+        self._dev_steps = -1
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.loss: Optional[torch.Tensor] = None
         self.replays = self.fallbacks = 0
@@ -343,9 +352,11 @@ class GraphedTrainStep:
             raise ValueError(f"the example batch {batch_counts(example)} does not fit {self.shapes}")
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
+        per_step = 0
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self.opt.zero_grad()
+                before = self.rng.offset
                 if self.split:
                     _, pooled_t, leaf = self._part_a()
                     if not self._head_grads_in_place():      # e.g. a non-ReLU head (torch's own backward): one graph
@@ -354,9 +365,15 @@ class GraphedTrainStep:
                     del pooled_t, leaf
                 else:
                     self._fwd_bwd_static()
+                per_step = self.rng.offset - before              # Philox blocks one step draws (fixed by the static shapes)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self.opt.zero_grad()
+        if self.split:
+            self.adam_in_graph = False
+        # what one replay adds to [Philox blocks consumed, Adam steps done]; built here because a captured region cannot copy from the host
+        inc = self._inc = torch.tensor([per_step, 1 if self.adam_in_graph else 0], dtype=torch.int64, device=self.device)      # kept alive: replays read it
+        self._sync_adam_state()
         graph = torch.cuda.CUDAGraph()
         off0 = self.rng.offset
         if self.split:
@@ -373,10 +390,26 @@ class GraphedTrainStep:
         else:
             with torch.cuda.graph(graph):
                 loss = self._fwd_bwd_static()
-                consumed = self.rng.offset - off0
-                if consumed:
-                    self.rng.advance_device(consumed)   # fresh dropout masks on every replay
+                if self.rng.offset - off0 != per_step:
+                    raise RuntimeError("the captured step drew a different number of Philox blocks than the warm-up steps")
+                if per_step or self.adam_in_graph:
+                    self._counters += inc               # fresh dropout masks (and the next Adam step number) on every replay
+                if self.adam_in_graph:
+                    self.opt.adam_in_graph(self._counters[1:2], self._lr_dev)
         self.graph, self.loss = graph, loss.detach()
+
+    def _sync_adam_state(self):
+        """Device copies of the optimiser's step count and learning rate follow the host values (an eager fallback step,
+        a scheduler or a restored checkpoint may have moved them)."""
+        if not self.adam_in_graph:
+            return
+        if self._dev_steps != self.opt.steps:
+            self._counters[1:2].fill_(self.opt.steps)
+            self._dev_steps = self.opt.steps
+        lr = float(self.opt.hyper["lr"])
+        if self._lr_host != lr:
+            self._lr_dev.fill_(lr)
+            self._lr_host = lr
 
     def _rank_scales(self, batch) -> Optional[torch.Tensor]:
         """(per-edge, per-atom) loss weights local_count * world / global_count as a device tensor (no host sync)."""
@@ -410,8 +443,12 @@ class GraphedTrainStep:
         sc = self._rank_scales(batch)
         if sc is not None:
             self.static.t[SCALE_KEY].copy_(sc)
+        self._sync_adam_state()
         self.graph.replay()
-        if self.split:
+        if self.adam_in_graph:                       # the update ran inside the graph
+            self.opt.steps += 1
+            self._dev_steps += 1
+        elif self.split:
             head = self.opt.all_reduce_slice(self.head_off, None, self.group, async_op=True)     # beside graph_b
             self.graph_b.replay()
             rest = self.opt.all_reduce_slice(0, self.head_off, self.group, async_op=True)

@@ -226,6 +226,15 @@ class FlatAdam:
         self.gather_grads()
         self.apply_gathered(group)
 
+    def adam_in_graph(self, step_dev: torch.Tensor, lr_dev: torch.Tensor):
+        """Enqueues the fused Adam update reading the step count and the learning rate from device memory
+        (fn_adam_dev_f32) -- the form graphstep.GraphedTrainStep captures inside its hipGraph on a single rank."""
+        from . import _lib
+        h = self.hyper
+        _lib.call("fn_adam_dev_f32", self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                  self.flat.numel(), lr_dev.data_ptr(), float(h["betas"][0]), float(h["betas"][1]), float(h["eps"]),
+                  float(h["weight_decay"]), step_dev.data_ptr(), torch.cuda.current_stream(self.flat.device).cuda_stream)
+
     def apply_gathered(self, group=None, reduced: bool = False):
         """all-reduce (if distributed, unless the caller already ``reduced`` the buffer) -> Adam on gradients that are
         already in the flat buffer (the captured step of graphstep.GraphedTrainStep gathers them inside its hipGraph)."""

@@ -296,6 +296,10 @@ int fn_small_linear_bwd_f32(const float* g /*[M,C]*/, const float* x /*[M,K]*/, 
  * `step` is the 1-based step count (bias corrections are computed on the host in double). */
 int fn_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                 float weight_decay, int64_t step, fn_stream_t stream);
+/* the same update with the 1-based step count and the learning rate read from device memory (bias corrections computed
+ * in the kernel), so that the launch can sit inside a captured hipGraph and still see a new step / rate on every replay */
+int fn_adam_dev_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev /*[1]*/, float beta1,
+                    float beta2, float eps, float weight_decay, const int64_t* step_dev /*[1]*/, fn_stream_t stream);
 
 /* cat(x[src_e], x[dst_e], e_attr[e]) -> [E, 384] for the bond-length head (pretrain_heads.py:67-70) */
 int fn_edge_concat_f32(const float* x /*[N,128]*/, const float* e_attr /*[E,128]*/, const int64_t* edge_index /*[2,E]*/,

@@ -300,7 +300,7 @@ def test_two_graph_overlap_step_matches_single_graph_step(drop):
     opt_a = parallel.FlatAdam.for_live_parameters(model_a, probe(model_a), lr=1e-3)
     opt_b = parallel.FlatAdam.for_live_parameters(model_b, probe(model_b), lr=1e-3)
     model_a.pretrain.rng.offset = model_b.pretrain.rng.offset = 0
-    step_a = graphstep.GraphedTrainStep(model_a, opt_a, shapes, dict(batches[0]), loss="regr", overlap=False)
+    step_a = graphstep.GraphedTrainStep(model_a, opt_a, shapes, dict(batches[0]), loss="regr", overlap=False, capture_adam=False)
     step_b = graphstep.GraphedTrainStep(model_b, opt_b, shapes, dict(batches[0]), loss="regr", overlap=True)
     assert step_b.split and step_b.graph_b is not None and not step_a.split
     assert 0 < step_b.head_off < opt_b.grad.numel()
@@ -310,3 +310,37 @@ def test_two_graph_overlap_step_matches_single_graph_step(drop):
         torch.testing.assert_close(lb, la, atol=0, rtol=0)
     torch.testing.assert_close(opt_b.flat, opt_a.flat, atol=0, rtol=0)
     assert step_b.replays == 5 and step_b.fallbacks == 0
+
+
+@gpu
+def test_adam_captured_in_the_graph_matches_the_eager_update():
+    """One rank: the fused Adam launch sits inside the hipGraph (step count and learning rate in device memory).  Weights
+    must follow the host-side update to round-off, across a learning-rate change and an eager fallback step."""
+    from fragnet_amd import parallel
+    dev = _dev()
+    batches = [data.batch_to(b, dev) for b in _batches(3, 40, seed=52)]
+    shapes = graphstep.StaticShapes.from_batches(batches, margin=0.05)
+    model_a, parallel_, lr = _make(dev, drop=0.1)
+    model_b = copy.deepcopy(model_a)
+    model_a.pretrain.rng.seed = model_b.pretrain.rng.seed = 77
+
+    def probe(model):
+        def run():
+            torch.nn.functional.mse_loss(model(dict(batches[0])).view(-1), batches[0]["y"]).backward()
+        return run
+    opt_a = parallel.FlatAdam.for_live_parameters(model_a, probe(model_a), lr=lr)
+    opt_b = parallel.FlatAdam.for_live_parameters(model_b, probe(model_b), lr=lr)
+    model_a.pretrain.rng.offset = model_b.pretrain.rng.offset = 0
+    step_a = graphstep.GraphedTrainStep(model_a, opt_a, shapes, dict(batches[0]), loss="regr", capture_adam=False)
+    step_b = graphstep.GraphedTrainStep(model_b, opt_b, shapes, dict(batches[0]), loss="regr")
+    assert step_b.adam_in_graph and not step_a.adam_in_graph
+    big = data.batch_to(_batches(1, 96, seed=78)[0], dev)
+    for i in range(7):
+        if i == 3:
+            opt_a.hyper["lr"] = opt_b.hyper["lr"] = lr * 0.5
+        b = big if i == 5 else batches[i % 3]                      # step 5 exceeds the capacities: eager fallback
+        la, lb = step_a(dict(b)).clone(), step_b(dict(b)).clone()
+        torch.testing.assert_close(lb, la, atol=1e-6, rtol=1e-5)
+    assert step_b.fallbacks == 1 and opt_b.steps == opt_a.steps == 7
+    torch.testing.assert_close(opt_b.flat, opt_a.flat, atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(opt_b.exp_avg_sq, opt_a.exp_avg_sq, atol=1e-9, rtol=1e-5)
