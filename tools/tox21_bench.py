@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""BASELINE configs[2] on one GPU: Tox21-shape multi-task finetune (12 tasks, missing labels), batch 1024, captured step.
+dev tool: python tools/tox21_bench.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import fragnet_amd
+from fragnet_amd import data, graphstep, parallel, synth, train
+from fragnet_amd.model import FragNetFineTune
+
+dev = torch.device("cuda:0")
+fragnet_amd.prefer_rocblas_for_dense_heads()
+fragnet_amd.tune_library_gemms()
+B = 1024
+batches = [data.batch_to(data.collate_fn(synth.synth_molecules(B, seed=80 + i, profile="tox21")), dev) for i in range(3)]
+shapes = graphstep.StaticShapes.from_batches(batches, margin=0.02)
+torch.manual_seed(5)
+model = FragNetFineTune(n_classes=12, num_layer=4, drop_ratio=0.1, h1=128, h2=1024, h3=1024, h4=512, act="relu").to(dev).train()
+opt = parallel.FlatAdam.for_live_parameters(model, lambda: train.compute_bce_loss(model(dict(batches[0])), batches[0]["y"]).backward(), lr=1e-4)
+step = graphstep.GraphedTrainStep(model, opt, shapes, dict(batches[0]), loss="clsf")
+for i in range(5):
+    step(dict(batches[i % 3]))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 30
+for i in range(n):
+    step(dict(batches[i % 3]))
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) * 1e3 / n
+b = batches[0]
+print(f"tox21 B={B}: {ms:.3f} ms/step, {B / ms * 1e3:.0f} molecules/s, atoms {b['x_atoms'].shape[0]}, bond-graph edges "
+      f"{b['edge_index_bonds_graph'].shape[1]}, replays {step.replays}, fallbacks {step.fallbacks}, loss {float(step.loss):.4f}")
