@@ -460,3 +460,50 @@ class GraphedTrainStep:
             self.opt.apply_gathered(self.group)
         self.replays += 1
         return self.loss
+
+
+class GraphedForward:
+    """Inference counterpart of GraphedTrainStep: stage + plan build + ``model(batch)`` (eval mode, no autograd) as one
+    hipGraph over static shapes.  ``__call__`` returns the predictions of the real molecules (a view of a buffer the next
+    call overwrites); batches beyond the capacities run eagerly.  Useful when the host is the bottleneck (small batches,
+    busy CPU); on an idle host the eager forward is already GPU-bound and the staging copy makes this path 5-10 % slower
+    (745 k vs 784 k molecules/s at 512 molecules, 1.15 M vs 1.27 M at 8192), so bench.py's forward sweep stays eager."""
+
+    def __init__(self, model, shapes: StaticShapes, example: Dict[str, torch.Tensor], warmup: int = 2):
+        if model.training:
+            raise RuntimeError("GraphedForward captures an inference pass: call model.eval() first")
+        self.model, self.shapes = model, shapes
+        self.static = StaticBatch(shapes, example)
+        self.device = self.static.device
+        self.replays = self.fallbacks = 0
+        if not self.static.load(example):
+            raise ValueError(f"the example batch {batch_counts(example)} does not fit {self.shapes}")
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                self._run()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.out = self._run()
+
+    def _run(self):
+        sb = self.static.t
+        sb.pop(PLAN_KEY, None)
+        return self.model(sb)
+
+    def __call__(self, batch: Dict[str, torch.Tensor]):
+        n = batch[COUNT_FIELD["mol"]].shape[0] if COUNT_FIELD["mol"] in batch else int(batch["batch"].max()) + 1
+        if not self.static.load(batch):
+            self.fallbacks += 1
+            batch.pop(PLAN_KEY, None)
+            with torch.no_grad():
+                return self.model(batch)
+        self.graph.replay()
+        self.replays += 1
+        out = self.out
+        return tuple(o[:n] if torch.is_tensor(o) and o.shape[0] == self.shapes.cap["mol"] else o for o in out) \
+            if isinstance(out, tuple) else out[:n]
+

@@ -344,3 +344,29 @@ def test_adam_captured_in_the_graph_matches_the_eager_update():
     assert step_b.fallbacks == 1 and opt_b.steps == opt_a.steps == 7
     torch.testing.assert_close(opt_b.flat, opt_a.flat, atol=1e-6, rtol=1e-5)
     torch.testing.assert_close(opt_b.exp_avg_sq, opt_a.exp_avg_sq, atol=1e-9, rtol=1e-5)
+
+
+@gpu
+def test_graphed_forward_matches_eager_inference():
+    """GraphedForward: eval-mode predictions from the captured graph equal the eager forward, for full, short and
+    over-capacity batches."""
+    dev = _dev()
+    batches = [data.batch_to(b, dev) for b in _batches(3, 48, seed=41)]
+    shapes = graphstep.StaticShapes.from_batches(batches, margin=0.05)
+    model, _, _ = _make(dev)
+    model.eval()
+    gf = graphstep.GraphedForward(model, shapes, dict(batches[0]))
+    for b in batches + [data.batch_to(_batches(1, 30, seed=43)[0], dev)]:
+        if not shapes.fits(graphstep.batch_counts(b)):
+            continue
+        with torch.no_grad():
+            want = model(dict(b))
+        got = gf(dict(b)).clone()
+        assert got.shape == want.shape
+        torch.testing.assert_close(got, want, atol=1e-6, rtol=1e-5)
+    assert gf.replays >= 3 and gf.fallbacks == 0
+    big = data.batch_to(_batches(1, 96, seed=44)[0], dev)
+    with torch.no_grad():
+        want = model(dict(big))
+    torch.testing.assert_close(gf(dict(big)), want, atol=1e-6, rtol=1e-5)
+    assert gf.fallbacks == 1
