@@ -118,8 +118,8 @@ SIGNATURES = {
     "fn_pool_cat_bwd_f32": [vp, vp, vp, vp, vp, i64, i64, vp],
     "fn_masked_mse_f32": [vp, vp, vp, i64, C.c_int, vp, vp, vp],
     "fn_bond_graph_ws": [i64, i64],
-    "fn_bond_graph_count": [vp, vp, i64, i64, i64, vp, vp, vp],
-    "fn_bond_graph_fill": [vp, vp, i64, i64, i64, vp, vp, i64, vp],
+    "fn_bond_graph_count": [vp, vp, i64, i64, i64, C.c_int, vp, vp, vp],
+    "fn_bond_graph_fill": [vp, vp, i64, i64, i64, C.c_int, vp, vp, i64, vp],
     "fn_masked_bce_f32": [vp, vp, vp, i64, C.c_int, vp, vp, vp],
     "fn_masked_mse_multi_ws": [C.c_int],
     "fn_masked_mse_multi_f32": [C.POINTER(MseTask), C.c_int, vp, vp, vp, vp],

@@ -1631,6 +1631,8 @@ struct BondGraphArgs {
     int32_t *flag;       // [E]   1 if bond i is the a -> b (a < b) direction of a two-atom component
     int32_t *mol_first;  // [B+1] pass 1: bonds per molecule at [1+m]; after the scan: first bond of molecule m
     int32_t *mol_ob;     // [B+1] likewise for the flagged bonds
+    int mode;            // 0: bond graph (data.py:116-127 + one-bond fragments); 1: fragment-bond graph (data.py:131-154: a molecule
+                         // with exactly two connection nodes pairs those whose (begin, end) differ, no extras)
 };
 
 __global__ void k_bg_mol_hist(BondGraphArgs A) {
@@ -1644,15 +1646,16 @@ __global__ void k_bg_count(BondGraphArgs A) {
         const int64_t m = A.atom_mol[u];
         const int32_t j0 = A.mol_first[m], j1 = A.mol_first[m + 1];
         int c = 0, du = 0, dv = 0;
+        const bool two = A.mode == 1 && j1 - j0 == 2;
         for (int32_t j = j0; j < j1; ++j) {
             const int64_t a = A.src[j], b = A.dst[j];
             const int common = (int)(a == u || a == v) + (int)(b != a && (b == u || b == v));
-            c += common == 1;                                            // |set(b_i) & set(b_j)| == 1
+            c += two ? (a != u || b != v) : common == 1;                 // |set(b_i) & set(b_j)| == 1
             du += a == u;
             dv += a == v;
         }
         A.cnt[1 + i] = c;
-        const int ob = (u < v && du == 1 && dv == 1) ? 1 : 0;
+        const int ob = (A.mode == 0 && u < v && du == 1 && dv == 1) ? 1 : 0;
         A.flag[i] = ob;
         if (ob) atomicAdd(&A.mol_ob[1 + m], 1);
     }
@@ -1665,10 +1668,11 @@ __global__ void k_bg_fill(BondGraphArgs A, int64_t* __restrict__ out, int64_t to
         const int32_t j0 = A.mol_first[m], j1 = A.mol_first[m + 1];
         int64_t pos = (int64_t)A.cnt[i] + 2 * (int64_t)A.mol_ob[m];      // pairs of earlier bonds + extras of earlier molecules
         int rev = -1, rank = 0;
+        const bool two = A.mode == 1 && j1 - j0 == 2;
         for (int32_t j = j0; j < j1; ++j) {
             const int64_t a = A.src[j], b = A.dst[j];
             const int common = (int)(a == u || a == v) + (int)(b != a && (b == u || b == v));
-            if (common == 1) {
+            if (two ? (a != u || b != v) : common == 1) {
                 out[pos] = i;
                 out[total + pos] = j;
                 ++pos;
@@ -3015,8 +3019,9 @@ struct BondGraphWs {
     int64_t zero_from, zero_n;
 };
 // workspace (int32): cnt[E+1] | flag[E] | mol_first[B+1] | mol_ob[B+1] | pad | three look-back state arrays (64-bit words)
-BondGraphWs bond_graph_ws(const int64_t* edge_index, const int64_t* atom_mol, int64_t E, int64_t B, int32_t* ws) {
+BondGraphWs bond_graph_ws(const int64_t* edge_index, const int64_t* atom_mol, int64_t E, int64_t B, int32_t* ws, int mode) {
     BondGraphWs w{};
+    w.A.mode = mode;
     w.A.src = edge_index;  w.A.dst = edge_index + E;  w.A.atom_mol = atom_mol;  w.A.E = E;  w.A.B = B;
     w.A.cnt = ws;
     w.A.flag = w.A.cnt + E + 1;
@@ -3039,11 +3044,11 @@ int64_t fn_bond_graph_ws(int64_t E, int64_t B) {
     return (2 * E + 1) + 2 * (B + 1) + 2 + 2 * ((E + kScanChunk - 1) / kScanChunk + 2 * ((B + kScanChunk - 1) / kScanChunk));
 }
 
-int fn_bond_graph_count(const int64_t* edge_index, const int64_t* atom_mol, int64_t E, int64_t N, int64_t B, int32_t* ws,
+int fn_bond_graph_count(const int64_t* edge_index, const int64_t* atom_mol, int64_t E, int64_t N, int64_t B, int mode, int32_t* ws,
                         int64_t* total, fn_stream_t stream) {
-    if (E < 0 || N < 0 || B < 0 || E >= (1ll << 31) - 1 || !ws || !total || (E > 0 && (!edge_index || !atom_mol)))
+    if (E < 0 || N < 0 || B < 0 || E >= (1ll << 31) - 1 || !ws || !total || (E > 0 && (!edge_index || !atom_mol)) || (mode != 0 && mode != 1))
         return fail(FN_EINVAL, "fn_bond_graph_count: bad argument");
-    BondGraphWs w = bond_graph_ws(edge_index, atom_mol, E, B, ws);
+    BondGraphWs w = bond_graph_ws(edge_index, atom_mol, E, B, ws, mode);
     hipStream_t st = S(stream);
     hipLaunchKernelGGL(k_zero2_i32, dim3(flat_grid(w.zero_n, kGridCap)), dim3(kBlock), 0, st, ws, w.zero_n, ws, (int64_t)0);
     if (E > 0) {
@@ -3058,12 +3063,12 @@ int fn_bond_graph_count(const int64_t* edge_index, const int64_t* atom_mol, int6
     return launch_status("fn_bond_graph_count");
 }
 
-int fn_bond_graph_fill(const int64_t* edge_index, const int64_t* atom_mol, int64_t E, int64_t N, int64_t B, const int32_t* ws,
+int fn_bond_graph_fill(const int64_t* edge_index, const int64_t* atom_mol, int64_t E, int64_t N, int64_t B, int mode, const int32_t* ws,
                        int64_t* out, int64_t total, fn_stream_t stream) {
-    if (E < 0 || N < 0 || B < 0 || total < 0 || !ws || (total > 0 && !out) || (E > 0 && (!edge_index || !atom_mol)))
+    if (E < 0 || N < 0 || B < 0 || total < 0 || !ws || (total > 0 && !out) || (E > 0 && (!edge_index || !atom_mol)) || (mode != 0 && mode != 1))
         return fail(FN_EINVAL, "fn_bond_graph_fill: bad argument");
     if (E == 0 || total == 0) return 0;
-    BondGraphWs w = bond_graph_ws(edge_index, atom_mol, E, B, const_cast<int32_t*>(ws));
+    BondGraphWs w = bond_graph_ws(edge_index, atom_mol, E, B, const_cast<int32_t*>(ws), mode);
     hipLaunchKernelGGL(k_bg_fill, dim3(flat_grid(E, kGridCap)), dim3(kBlock), 0, S(stream), w.A, out, total);
     return launch_status("fn_bond_graph_fill");
 }

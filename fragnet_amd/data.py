@@ -105,4 +105,9 @@ def batch_to(batch: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]:
     if "edge_index_bonds_graph" not in out and "edge_index" in out and out["edge_index"].is_cuda:
         from . import ops
         out["edge_index_bonds_graph"] = ops.bond_graph(out["edge_index"], out["batch"], int(out["y"].shape[0]))
+    if "edge_index_fbonds" not in out and "frag_index" in out and out["frag_index"].is_cuda:
+        from . import ops
+        eifb = ops.bond_graph(out["frag_index"], out["frag_batch"], int(out["y"].shape[0]), fragments=True)
+        out["edge_index_fbonds"] = eifb
+        out["edge_attr_fbonds"] = out["node_features_fbonds"][eifb[0]] + out["node_features_fbonds"][eifb[1]]
     return out

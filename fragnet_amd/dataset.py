@@ -84,11 +84,15 @@ class FlatMolStore:
         store = cls(blob["tensors"], blob["offsets"], blob["y"], blob.get("smiles"))
         return store.to(device) if device is not None else store
 
+    DERIVED = ("edge_index_bonds", "edge_index_fbondg", "edge_attr_fbondg")
+
     def without_bond_graph_index(self) -> "FlatMolStore":
-        """The same store minus ``edge_index_bonds`` -- its largest tensor (16 bytes per bond-graph edge).  ``collate``
-        then rebuilds ``edge_index_bonds_graph`` from ``edge_index`` on the GPU (ops.bond_graph, SURVEY §8 row f4: the
-        reference's pair rule in the reference's order, so the stored cos(theta) rows ``edge_attr_bonds`` still line up)."""
-        return FlatMolStore({k: v for k, v in self.t.items() if k != "edge_index_bonds"}, self.off, self.y, self.smiles)
+        """The same store minus the tensors that are pure functions of the rest: ``edge_index_bonds`` (its largest tensor, 16
+        bytes per bond-graph edge), ``edge_index_fbondg`` and ``edge_attr_fbondg``.  ``collate`` then rebuilds
+        ``edge_index_bonds_graph`` from ``edge_index`` and ``edge_index_fbonds`` / ``edge_attr_fbonds`` from ``frag_index``
+        and the connection features on the GPU (ops.bond_graph, SURVEY §8 row f4: the reference's pair rules in the
+        reference's order, so the stored cos(theta) rows ``edge_attr_bonds`` still line up)."""
+        return FlatMolStore({k: v for k, v in self.t.items() if k not in self.DERIVED}, self.off, self.y, self.smiles)
 
     def bond_graph_edges(self) -> torch.Tensor:
         """Per-molecule bond-graph edge counts: the dominant cost, used to balance shards (parallel.shard_indices)."""
@@ -118,8 +122,8 @@ class FlatMolStore:
             "edge_index_bonds_graph": None,      # filled below (stored index, or rebuilt on the device)
             "edge_attr_bonds": t["edge_attr_bonds"][rows["bedge"]],
             "node_features_fbonds": t["node_feautures_fbondg"][rows["fedge"]],
-            "edge_index_fbonds": t["edge_index_fbondg"][:, rows["fbedge"]] + base["fedge"][seg["fbedge"]],
-            "edge_attr_fbonds": t["edge_attr_fbondg"][rows["fbedge"]],
+            "edge_index_fbonds": None,           # filled below too
+            "edge_attr_fbonds": None,
         }
         if "edge_index_bonds" in t:
             out["edge_index_bonds_graph"] = t["edge_index_bonds"][:, rows["bedge"]] + base["edge"][seg["bedge"]]
@@ -128,6 +132,16 @@ class FlatMolStore:
             out["edge_index_bonds_graph"] = ops.bond_graph(out["edge_index"], out["batch"], int(idx.numel()))
         else:
             del out["edge_index_bonds_graph"]
+        if "edge_index_fbondg" in t:
+            out["edge_index_fbonds"] = t["edge_index_fbondg"][:, rows["fbedge"]] + base["fedge"][seg["fbedge"]]
+            out["edge_attr_fbonds"] = t["edge_attr_fbondg"][rows["fbedge"]]
+        elif dev.type == "cuda":
+            from . import ops
+            eifb = ops.bond_graph(out["frag_index"], out["frag_batch"], int(idx.numel()), fragments=True)
+            out["edge_index_fbonds"] = eifb
+            out["edge_attr_fbonds"] = out["node_features_fbonds"][eifb[0]] + out["node_features_fbonds"][eifb[1]]      # data.py:291-303
+        else:
+            del out["edge_index_fbonds"], out["edge_attr_fbonds"]
         if pretrain:
             out["bnd_lngth"] = t["bnd_lngth"][rows["edge"]]
             out["bnd_angl"] = t["bnd_angl"][rows["atom"]]

@@ -721,20 +721,21 @@ def edge_concat(x, e_attr, edge_index, plan: GraphPlan):
 # ======================================================================================
 # bond-graph topology from edge_index (dataset side)
 # ======================================================================================
-def bond_graph(edge_index: torch.Tensor, atom_batch: torch.Tensor, n_mols: int) -> torch.Tensor:
+def bond_graph(edge_index: torch.Tensor, atom_batch: torch.Tensor, n_mols: int, fragments: bool = False) -> torch.Tensor:
     """``edge_index_bonds_graph`` [2, Eb] (int64, global bond ids) of a collated batch from its ``edge_index`` [2, E] and
     ``batch`` vector -- the reference's get_bond_pair_bond_graph + one-bond-fragment rule (dataset/data.py:116-127,
     157-182) on the GPU, in the reference's order, so a dataset can ship without its largest tensor (the per-pair
-    cos(theta) attribute still has to be stored: it needs 3-D coordinates).  One host sync to learn Eb."""
+    cos(theta) attribute still has to be stored: it needs 3-D coordinates).  ``fragments=True``: ``edge_index_fbonds`` from
+    ``frag_index`` and ``frag_batch`` (get_bond_pair_fbond_graph, data.py:131-154).  One host sync to learn Eb."""
     if not edge_index.is_cuda or edge_index.dtype != torch.int64 or atom_batch.dtype != torch.int64:
         raise _lib.FragnetHipError("bond_graph: int64 GPU tensors expected (there is no CPU fallback)")
     edge_index, atom_batch = edge_index.contiguous(), atom_batch.contiguous()
     E, N, dev = edge_index.shape[1], atom_batch.shape[0], edge_index.device
-    st = _stream_ptr(dev)
+    st, mode = _stream_ptr(dev), int(bool(fragments))
     ws = torch.empty(_lib.load().fn_bond_graph_ws(E, n_mols), dtype=torch.int32, device=dev)
     total = torch.zeros(1, dtype=torch.int64, device=dev)
-    _lib.call("fn_bond_graph_count", edge_index.data_ptr(), atom_batch.data_ptr(), E, N, n_mols, ws.data_ptr(), total.data_ptr(), st)
+    _lib.call("fn_bond_graph_count", edge_index.data_ptr(), atom_batch.data_ptr(), E, N, n_mols, mode, ws.data_ptr(), total.data_ptr(), st)
     n = int(total.item())
     out = torch.empty((2, n), dtype=torch.int64, device=dev)
-    _lib.call("fn_bond_graph_fill", edge_index.data_ptr(), atom_batch.data_ptr(), E, N, n_mols, ws.data_ptr(), out.data_ptr(), n, st)
+    _lib.call("fn_bond_graph_fill", edge_index.data_ptr(), atom_batch.data_ptr(), E, N, n_mols, mode, ws.data_ptr(), out.data_ptr(), n, st)
     return out

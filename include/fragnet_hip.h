@@ -266,11 +266,17 @@ int fn_dropout_act_bwd_f32(const float* g_y, const float* y, float* g_x, int64_t
  * count (fills ws, writes *total = Eb), then fill into out [2, total].  The cos(theta) attribute needs coordinates
  * and is not produced.  ws: fn_bond_graph_ws(E, B) int32.
  * ------------------------------------------------------------------------------------------ */
+/* mode FN_GRAPH_BONDS: the rule above on edge_index / batch.  mode FN_GRAPH_FBONDS: the fragment-bond graph of
+ * data.py:131-154 on frag_index / frag_batch -- a molecule with exactly two connection nodes pairs the ones whose
+ * (begin, end) differ, every other molecule uses the share-exactly-one rule, no extras.  (Its edge attribute is the sum
+ * of the two node features, data.py:291-303, a plain gather-add.) */
+#define FN_GRAPH_BONDS 0
+#define FN_GRAPH_FBONDS 1
 int64_t fn_bond_graph_ws(int64_t E, int64_t B);
 int fn_bond_graph_count(const int64_t* edge_index /*[2,E]*/, const int64_t* atom_mol /*[N]*/, int64_t E, int64_t N, int64_t B,
-                        int32_t* ws, int64_t* total /*device [1]*/, fn_stream_t stream);
-int fn_bond_graph_fill(const int64_t* edge_index, const int64_t* atom_mol, int64_t E, int64_t N, int64_t B, const int32_t* ws,
-                       int64_t* out /*[2,total]*/, int64_t total, fn_stream_t stream);
+                        int mode, int32_t* ws, int64_t* total /*device [1]*/, fn_stream_t stream);
+int fn_bond_graph_fill(const int64_t* edge_index, const int64_t* atom_mol, int64_t E, int64_t N, int64_t B, int mode,
+                       const int32_t* ws, int64_t* out /*[2,total]*/, int64_t total, fn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Prediction-head small ops (FTHead1-5, gat2.py:631-637, 719-725, 745-751: Linear -> dropout -> act stacks on

@@ -395,8 +395,23 @@ def bond_graph_case():
         store[f"{name}/n_atoms"] = np.asarray(n_atoms)
         store[f"{name}/ends"] = np.asarray(ends, dtype=np.int64).reshape(-1, 2)
         store[f"{name}/pairs"] = np.asarray(pairs, dtype=np.int64).reshape(2, -1)
+    # fragment-bond graph (data.py:131-154) on connection lists: single fragment, one connection, chains, synthetic molecules
+    fcases = {
+        "f_single_fragment": [(0, 0)],
+        "f_one_connection": both([(0, 1)]),
+        "f_chain3": both([(0, 1), (1, 2)]),
+        "f_star4": both([(0, 1), (0, 2), (0, 3)]),
+        "f_two_self": [(0, 0), (0, 0)],
+    }
+    for k, m in enumerate(synth.synth_molecules(4, seed=91, profile="esol", p_salt=0.5)):
+        fcases[f"f_synth{k}"] = [(int(u), int(v)) for u, v in m.frag_index.numpy().T]
+    store["fnames"] = np.asarray(list(fcases))
+    for name, ends in fcases.items():
+        idx = {i: [u, v] for i, (u, v) in enumerate(ends)}
+        store[f"{name}/ends"] = np.asarray(ends, dtype=np.int64).reshape(-1, 2)
+        store[f"{name}/pairs"] = np.asarray(ref_data.get_bond_pair_fbond_graph(idx), dtype=np.int64).reshape(2, -1)
     np.savez_compressed(os.path.join(HERE, "bond_graph_cases.npz"), **store)
-    print("bond_graph_cases written:", {k: store[f"{k}/pairs"].shape[1] for k in cases})
+    print("bond_graph_cases written:", {k: store[f"{k}/pairs"].shape[1] for k in list(cases) + list(fcases)})
 
 
 if __name__ == "__main__":

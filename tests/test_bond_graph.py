@@ -18,9 +18,17 @@ def _cases():
     return {str(n): (int(z[f"{n}/n_atoms"]), z[f"{n}/ends"], z[f"{n}/pairs"]) for n in z["names"]}
 
 
+def _fcases():
+    z = np.load(GOLD)
+    return {str(n): (z[f"{n}/ends"], z[f"{n}/pairs"]) for n in z["fnames"]}
+
+
 def test_oracle_matches_the_reference_functions():
     for name, (n_atoms, ends, pairs) in _cases().items():
         got = ref.bond_graph_one_molecule(n_atoms, [tuple(map(int, e)) for e in ends])
+        assert np.array_equal(got, pairs), name
+    for name, (ends, pairs) in _fcases().items():
+        got = ref.fbond_graph_one_molecule([tuple(map(int, e)) for e in ends])
         assert np.array_equal(got, pairs), name
 
 
@@ -62,6 +70,39 @@ def test_hip_builder_matches_golden_cases_bit_exact():
         assert np.array_equal(got.cpu().numpy(), want)
 
 
+def _fbatch_of(cases):
+    src, dst, batch, want, f0, e0 = [], [], [], [], 0, 0
+    for m, (ends, pairs) in enumerate(cases):
+        n_frag = int(ends.max()) + 1 if len(ends) else 1
+        src += [int(u) + f0 for u, _ in ends]
+        dst += [int(v) + f0 for _, v in ends]
+        batch += [m] * n_frag
+        want.append(pairs + e0)
+        f0 += n_frag
+        e0 += len(ends)
+    return (np.asarray([src, dst], dtype=np.int64).reshape(2, -1), np.asarray(batch, dtype=np.int64),
+            np.concatenate(want, axis=1) if want else np.zeros((2, 0), np.int64))
+
+
+@gpu
+def test_hip_builder_fragment_mode_matches_golden_and_collate():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from fragnet_amd import data, ops, synth
+    dev = torch.device("cuda:0")
+    cases = list(_fcases().values())
+    for order in (cases, cases[::-1], cases[:1], cases[1:2]):
+        fi, fb, want = _fbatch_of(order)
+        assert np.array_equal(ref.bond_graph_batch(fi, fb, len(order), fragments=True), want)
+        got = ops.bond_graph(torch.from_numpy(fi).to(dev), torch.from_numpy(fb).to(dev), len(order), fragments=True)
+        assert np.array_equal(got.cpu().numpy(), want)
+    b = data.collate_fn(synth.synth_molecules(300, seed=14, p_salt=0.2))
+    got = ops.bond_graph(b["frag_index"].to(dev), b["frag_batch"].to(dev), int(b["y"].shape[0]), fragments=True)
+    assert torch.equal(got.cpu(), b["edge_index_fbonds"])
+    attr = b["node_features_fbonds"].to(dev)[got[0]] + b["node_features_fbonds"].to(dev)[got[1]]      # data.py:291-303
+    assert torch.equal(attr.cpu(), b["edge_attr_fbonds"])
+
+
 @gpu
 @pytest.mark.parametrize("n_mols,profile,seed", [(64, "esol", 1), (512, "esol", 2), (256, "tox21", 3)])
 def test_hip_builder_reproduces_the_collated_bond_graph(n_mols, profile, seed):
@@ -83,9 +124,10 @@ def test_store_without_bond_graph_index_collates_the_same_batches():
         pytest.skip("needs an MI355X")
     from fragnet_amd import data, dataset, synth
     dev = torch.device("cuda:0")
-    full = dataset.FlatMolStore.from_records(synth.synth_molecules(96, seed=31))
+    full = dataset.FlatMolStore.from_records(synth.synth_molecules(96, seed=31, p_salt=0.15))
     lean = full.without_bond_graph_index()
-    assert "edge_index_bonds" not in lean.t and lean.t["edge_attr_bonds"].shape == full.t["edge_attr_bonds"].shape
+    assert not any(k in lean.t for k in ("edge_index_bonds", "edge_index_fbondg", "edge_attr_fbondg"))
+    assert lean.t["edge_attr_bonds"].shape == full.t["edge_attr_bonds"].shape
     idx = [5, 90, 17, 3, 44, 45, 46, 0]
     want = full.collate(idx)
     got_gpu = lean.to(dev).collate(idx)
