@@ -3341,7 +3341,7 @@ BwdLayout bwd_layout(const fn_encoder* e, float* ws) {
         level(o.atom[l], e->N, e->atom.m, e->k_atom0, false, true, true);
         level(o.fbond[l], e->EF, e->fbond.m, e->k_fbond0, true, false, true);
     }
-    level(o.frag, e->F, e->frag.m, 0, false, true, false);
+    level(o.frag, e->F, e->frag.m, 0, e->variant == 2, true, false);      // gat2_edge: the fragment graph has edge-embedding partials
     o.total = b.used;
     return o;
 }
@@ -3497,6 +3497,7 @@ int enc_check(const fn_encoder* e) {
     if (!e) return fail(FN_EINVAL, "fn_encoder: null descriptor");
     if (e->n_layers < 1 || e->n_layers > FN_MAX_LAYERS) return fail(FN_EINVAL, "fn_encoder: n_layers out of range");
     if (e->heads != 1 && e->heads != 2 && e->heads != 4 && e->heads != 8) return fail(FN_EUNSUPPORTED, "fn_encoder: heads must be 1, 2, 4 or 8");
+    if (e->variant < 0 || e->variant > 2) return fail(FN_EUNSUPPORTED, "fn_encoder: variant must be 0 (gat2), 1 (gat2_lite) or 2 (gat2_edge)");
     if (e->k_atom0 < 1 || e->k_atom0 > 168 || e->k_bond0 < 1 || e->k_bond0 > 168 || e->k_fbond0 < 1 || e->k_fbond0 > 168)
         return fail(FN_EUNSUPPORTED, "fn_encoder: layer-0 feature widths must be in [1, 168]");
     if (e->k_fattr < 1 || e->k_fattr > FN_MAX_EDGE_K) return fail(FN_EUNSUPPORTED, "fn_encoder: fragment-bond attribute width");
@@ -3527,7 +3528,8 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
     const float p = e->training ? e->drop_p : 0.f;
     const int wide = 2 * d + FN_D;             // width of a / f
     const bool multi = g_tune[FN_TUNE_STREAMS] != 0;
-    const bool lite = e->variant == 1;
+    const bool lite = e->variant == 1, edge = e->variant == 2;      // gat2_lite / gat2_edge: neither has a fragment-bond graph
+    const bool no_fb = lite || edge;
     if (multi) FN_TRY(aux_init());
     fn_stream_t st_fb = multi ? (fn_stream_t)g_aux.s[1] : st;       // the fragment-bond chain's stream
 
@@ -3555,9 +3557,10 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
             A.sx[0] = e->cos_raw;  A.so[0] = const_cast<float*>(e->cos_sorted);  A.sK[0] = 1;  A.spl[0] = e->bond;
             A.n_s[0] = flat_grid(e->bond.m, 512);
         }
-        if (e->fattr_raw && e->fbond.m > 0) {
-            A.sx[1] = e->fattr_raw;  A.so[1] = const_cast<float*>(e->fattr_sorted);  A.sK[1] = e->k_fattr;  A.spl[1] = e->fbond;
-            A.n_s[1] = flat_grid(e->fbond.m * e->k_fattr, 512);
+        const fn_gat_plan& fattr_plan = edge ? e->frag : e->fbond;     // gat2_edge: cnx_attr rides on the fragment graph's edges
+        if (e->fattr_raw && fattr_plan.m > 0) {
+            A.sx[1] = e->fattr_raw;  A.so[1] = const_cast<float*>(e->fattr_sorted);  A.sK[1] = e->k_fattr;  A.spl[1] = fattr_plan;
+            A.n_s[1] = flat_grid(fattr_plan.m * e->k_fattr, 512);
         }
         hipLaunchKernelGGL(k_enc_prologue, dim3(A.n_t + A.n_d + A.n_s[0] + A.n_s[1]), dim3(256), 0, S(st), A);
         FN_TRY(launch_status("fn_encoder_forward: prologue"));
@@ -3584,7 +3587,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         const bool grouped = l > 0 && fuse_ns && !multi;
         if (grouped) {
             LinTasks T{};
-            T.n = lite ? 2 : 3;
+            T.n = no_fb ? 2 : 3;
             T.t[0] = LinTask{in_bond, bt_b, w.proj_b_b, a.h_b, e->E, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
                              NodeScalarEpi{w.a_b, lay.s_dst, lay.s_src, 3 * d, 0, 2 * d, H}, 0, 0};
             T.t[1] = LinTask{in_atoms, bt_a, w.proj_a_b, a.h_a, e->N, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
@@ -3594,7 +3597,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
             FN_TRY(launch_linear128_group(T, S(st)));
         } else {
             FN_TRY(project(in_bond, kb, bt_b, w.proj_b_b, a.h_b, e->E, w.a_b, 3 * d, 2 * d, lay.s_dst, lay.s_src, st));
-            if (!lite) FN_TRY(project(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, w.f_a_b, 3 * d, 2 * d, lay.s_dst_fb, lay.s_src_fb, st_fb));
+            if (!no_fb) FN_TRY(project(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, w.f_a_b, 3 * d, 2 * d, lay.s_dst_fb, lay.s_src_fb, st_fb));
         }
         fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
         fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
@@ -3608,7 +3611,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         // L1 bond graph and L4a fragment-bond graph: neither reads the other's output -> one launch for both
         GatFwdArgs gb, gfb{};
         FN_TRY(prep_gat_fwd(a.h_b, lay.s_dst, lay.s_src, w.a_b, 3 * d, &et_b, &e->bond, 0.2f, a.new_bond, a.p_bond, nullptr, &ep_bond, H, &gb));
-        if (!lite) FN_TRY(prep_gat_fwd(a.h_fb, lay.s_dst_fb, lay.s_src_fb, w.f_a_b, 3 * d, &et_fb, &e->fbond, 0.2f, a.new_fbond, a.p_fbond, nullptr, &ep_fbond, H, &gfb));
+        if (!no_fb) FN_TRY(prep_gat_fwd(a.h_fb, lay.s_dst_fb, lay.s_src_fb, w.f_a_b, 3 * d, &et_fb, &e->fbond, 0.2f, a.new_fbond, a.p_fbond, nullptr, &ep_fbond, H, &gfb));
         if (multi) {
             FN_TRY(launch_gat_fwd(gb, H, S(st)));
             FN_TRY(launch_gat_fwd(gfb, H, S(st_fb)));
@@ -3632,6 +3635,10 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         if (last && lite) {      // gat2_lite: the encoder's fragment output is act(dropout(.)) of the plain fragment sums
             FN_TRY(order_after(S(st_fb), S(st)));
             FN_TRY(fn_dropout_act_f32(a.frags, y_frags, e->F * FN_D, p, e->seed, rng.y[l][1], e->offset_dev, 1, st));
+        } else if (last && edge) {   // gat2_edge (gat2_edge.py:148-172): edge term = <Linear(8 -> 128)(cnx_attr), f[:, d:d+128]>, folded in-kernel
+            FN_TRY(fn_node_scalars_f32(a.frags, w.f, wide, 0, d + FN_D, lay.s_dst, lay.s_src, e->F, H, st));
+            fn_edge_term et_f{2, e->k_fattr, FN_D, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
+            FN_TRY(fn_gat_fwd_f32(a.frags, lay.s_dst, lay.s_src, w.f, wide, &et_f, &e->frag, 0.2f, nullptr, a.p_frag, nullptr, &ep_frags, H, st));
         } else if (last) {
             FN_TRY(order_after(S(st_fb), S(st)));            // join: the fragment graph's edge term reads new_fbond
             FN_TRY(fn_row_dots_sorted_f32(a.new_fbond, w.f, wide, d, H, &e->frag, lay.s_sorted, st));
@@ -3660,7 +3667,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
     const int wide = 2 * d + FN_D;
     hipStream_t hs = S(st);
     const bool multi = g_tune[FN_TUNE_STREAMS] != 0;
-    const bool lite = e->variant == 1;
+    const bool lite = e->variant == 1, edge = e->variant == 2;
     if (multi) FN_TRY(aux_init());
     // leaf: kernels nobody downstream waits for (parameter-gradient reductions, weight-gradient GEMMs);
     // fb: the fragment-bond chain, which after the last layer's fragment level never meets the others again
@@ -3731,6 +3738,12 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         const float* g_frags_h = bw.g_frags;      // dL/d(fragment sums), scattered back to the atoms below
         if (have_frags && lite) {
             g_frags_h = bw.g_pre_frags;            // no fragment graph in between
+            have_g_frags_h = true;
+        } else if (have_frags && edge) {   // gat2_edge: the edge term's parameters are the cnx_attr Linear (emb_fb_*) and f's middle block
+            fn_edge_term et_f{2, e->k_fattr, FN_D, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_frags, a.frags, a.p_frag, &et_f, &e->frag, 0.2f, nullptr, nullptr, sf.pz, sf.g_s_dst, sf.part_e, &n_e, H, st));
+            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_frags, a.frags, sf.pz, sf.g_s_dst, w.f, wide, 0, d + FN_D, &e->frag, bw.g_frags, sf.part_a, &n_a, H, st));
+            FN_TRY(rq.finalize(sf.part_a, n_a, sf.part_e, n_e, et_f, w.f, wide, 0, d + FN_D, g.f, g.emb_fb_w, g.emb_fb_b, H));
             have_g_frags_h = true;
         } else if (have_frags) {
             fn_edge_term et_f{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};

@@ -18,6 +18,11 @@ from .plan import GraphPlan, _stream_ptr
 
 def layer_param_list(layer) -> List[torch.nn.Parameter]:
     """Parameters of one FragNetLayerA in the order of fn_layer_weights."""
+    if hasattr(layer, "cnx_attr_transform"):        # gat2_edge layer: no fragment-bond parameters, the cnx_attr Linear sits in emb_fb_*
+        ph = layer.engine_placeholders()
+        return [layer.projection_b.weight, layer.projection_b.bias, layer.projection_a.weight, layer.projection_a.bias,
+                ph["proj_fb_w"], ph["proj_fb_b"], layer.edge_attr_bond_embed.weight, layer.edge_attr_bond_embed.bias,
+                layer.cnx_attr_transform.weight, layer.cnx_attr_transform.bias, layer.a_b, layer.a, layer.f, ph["f_a_b"]]
     return [layer.projection_b.weight, layer.projection_b.bias, layer.projection_a.weight, layer.projection_a.bias,
             layer.projection_fb.weight, layer.projection_fb.bias, layer.edge_attr_bond_embed.weight,
             layer.edge_attr_bond_embed.bias, layer.edge_attr_fbond_embed.weight, layer.edge_attr_fbond_embed.bias,
@@ -27,6 +32,8 @@ def layer_param_list(layer) -> List[torch.nn.Parameter]:
 NP = len(LAYER_FIELDS)
 F_IDX = LAYER_FIELDS.index("f")
 LITE_DEAD = {LAYER_FIELDS.index(n) for n in ("proj_fb_w", "proj_fb_b", "emb_fb_w", "emb_fb_b", "f", "f_a_b")}
+EDGE_DEAD = {LAYER_FIELDS.index(n) for n in ("proj_fb_w", "proj_fb_b", "f_a_b")}          # placeholders of a gat2_edge layer
+EDGE_LAST_ONLY = {LAYER_FIELDS.index(n) for n in ("emb_fb_w", "emb_fb_b", "f")}             # read by the last layer's fragment graph only
 
 
 def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -55,7 +62,7 @@ def _describe(plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fat
     e.a2f = SegPlan(s.rowptr.data_ptr(), s.perm.data_ptr(), s.index.data_ptr(), s.n_seg, s.n_items, s.pos_base, 0)
     e.x_atoms, e.bond_nodes, e.fbond_nodes = x_atoms.data_ptr(), bond_nodes.data_ptr(), fbond_nodes.data_ptr()
     e.cos_sorted, e.fattr_sorted = cos_sorted.data_ptr(), fattr_sorted.data_ptr()
-    raw_b, raw_f = plan.pending.get("bond"), plan.pending.get("fbond")      # sorted copies not filled yet: the forward does it
+    raw_b, raw_f = plan.pending.get("bond"), plan.pending.get("frag" if variant == 2 else "fbond")      # sorted copies not filled yet: the forward does it
     e.cos_raw = None if raw_b is None else raw_b.data_ptr()
     e.fattr_raw = None if raw_f is None else raw_f.data_ptr()
     for l in range(n_layers):
@@ -80,7 +87,7 @@ class _EncoderFn(torch.autograd.Function):
         outs = [torch.empty((n, FN_D), dtype=torch.float32, device=dev) for n in (e.N, e.F, e.E, e.EF)]
         _lib.check(lib.fn_encoder_forward(C.byref(e), *(o.data_ptr() for o in outs), _stream_ptr(dev)), "fn_encoder_forward")
         plan.pending.pop("bond", None)
-        plan.pending.pop("fbond", None)
+        plan.pending.pop("frag" if variant == 2 else "fbond", None)
         e.cos_raw = e.fattr_raw = None           # the backward pass reads the sorted copies only
         ctx.desc = e
         ctx.keep = (plan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, ws, offset_dev)
@@ -115,6 +122,8 @@ class _EncoderFn(torch.autograd.Function):
             for k in range(NP):
                 live = any_grad and not (k == F_IDX and not (l == n_layers - 1 and have_frags))
                 if ctx.variant == 1 and k in LITE_DEAD:          # gat2_lite never reads the fragment(-bond) parameters
+                    live = False
+                if ctx.variant == 2 and (k in EDGE_DEAD or (k in EDGE_LAST_ONLY and not (l == n_layers - 1 and have_frags))):
                     live = False
                 out.append(grads[l * NP + k] if live else None)
         return (None,) * 14 + tuple(out)

@@ -206,6 +206,16 @@ class FragNetLayerEdge(nn.Module):
         for w in (self.projection_b.weight, self.a_b, self.a, self.f):
             nn.init.xavier_uniform_(w.data, gain=1.414)
 
+    def engine_placeholders(self):
+        """Zero stand-ins for the fragment-bond parameters fn_layer_weights has slots for (never read for variant 2)."""
+        ph = getattr(self, "_engine_ph", None)
+        dev = self.f.device
+        if ph is None or ph["f_a_b"].device != dev:
+            # [128, 168]: covers every width the transposing prologue may read for this slot; never multiplied
+            ph = self._engine_ph = {"proj_fb_w": torch.zeros(self.edge_out, 168, device=dev), "proj_fb_b": torch.zeros(self.edge_out, device=dev),
+                                    "f_a_b": torch.zeros(self.num_heads, 3 * (self.edge_out // self.num_heads), device=dev)}
+        return ph
+
     def run(self, x_atoms, bond_nodes, bond_cos, cnx_attr, plan):
         H, d = self.num_heads, self.edge_out // self.num_heads
         want = self.return_attentions
@@ -259,6 +269,13 @@ class FragNet(nn.Module):
     def forward(self, batch):
         plan = plan_for(batch)
         p, train = self.dropout.p, self.training
+        if self.variant == "gat2_edge" and self.use_engine and not any(l.return_attentions for l in self.layers):
+            # whole encoder in two C calls (fn_encoder.variant = 2); the placeholder fragment-bond input is never multiplied
+            outs = engine.encoder_forward(self.layers, plan, batch["x_atoms"], batch["node_features_bonds"],
+                                          batch["node_features_fbonds"], plan.sorted_attr("bond", batch["edge_attr_bonds"], defer=True),
+                                          plan.sorted_attr("frag", batch["cnx_attr"], defer=True), self.layers[0].num_heads,
+                                          p, train, self.rng, variant=2)
+            return outs[0], outs[1], outs[2], None
         if self.variant == "gat2_edge":                      # gat2_edge.py:198-236: three tensors travel between layers
             x_atoms = ops.dropout_act(batch["x_atoms"], p, train, False, self.rng)
             bond_nodes, x_frags = batch["node_features_bonds"], None

@@ -394,7 +394,11 @@ typedef struct fn_encoder {
     int32_t k_fattr;                       /* width of edge_attr_fbonds (6) */
     int32_t training;
     int32_t variant;                       /* 0: gat2; 1: gat2_lite (gat2_lite.py: every layer stops after the atom -> fragment sum;
-                                            * out_fbond is not written, out_frags = relu(dropout(fragment sums))) */
+                                            * out_fbond is not written, out_frags = relu(dropout(fragment sums)));
+                                            * 2: gat2_edge (gat2_edge.py: no fragment-bond graph; the fragment graph's edge term is
+                                            * <Linear(k_fattr -> 128)(cnx_attr), f[:, d:d+128]> with the Linear in w[l].emb_fb_w/_b
+                                            * ([128, k_fattr], [128]) and cnx_attr sorted by the FRAGMENT graph in fattr_sorted
+                                            * [k_fattr, frag.m]; proj_fb_* and f_a_b are placeholders, out_fbond is not written) */
     float drop_p, pad2_;
     uint64_t seed, offset;                 /* Philox stream; fn_encoder_rng_blocks() offsets are consumed */
     const uint64_t* offset_dev;            /* nullable device counter added to offset at run time (hipGraph replays) */

@@ -356,7 +356,8 @@ def test_gat2_lite_matches_reference_golden(use_engine):
     check_grads(model, grads, atol=ATOL, rtol=2e-3)
 
 
-def test_gat2_edge_matches_reference_golden():
+@pytest.mark.parametrize("use_engine", [True, False], ids=["engine", "per_level_ops"])
+def test_gat2_edge_matches_reference_golden(use_engine):
     """model_version gat2_edge: logits, loss, gradients and the last layer's three outputs of the
     reference's gat2_edge.FragNetFineTune (fixture: make_golden.py gat2_edge, 8-wide cnx_attr); the fragment graph's
     Linear(8 -> 128)(cnx_attr) edge term runs as the in-kernel folded mode-2 term (K = 8, d_e = 128)."""
@@ -366,6 +367,7 @@ def test_gat2_edge_matches_reference_golden():
     model = FragNetFineTuneEdge(**cfg["ctor"])
     check_params_match(model, pkeys, psums)
     model = model.to(DEV).train()
+    model.pretrain.use_engine = use_engine
     b = _to_dev(batch)
     x_atoms, x_frags, bond, fbond = model.pretrain(b)
     assert fbond is None
