@@ -198,14 +198,22 @@ class FlatAdam:
                 flush()
         flush()
 
+    _avg_ok = None           # does the backend's all-reduce take ReduceOp.AVG (RCCL does; learnt at the first call)
+
     def all_reduce(self, group=None):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return
-        if self.grad.is_cuda:
-            dist.all_reduce(self.grad, op=dist.ReduceOp.AVG, group=group)
-        else:
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
-            self.grad.div_(dist.get_world_size(group))
+        if self.grad.is_cuda and FlatAdam._avg_ok is not False:
+            try:
+                dist.all_reduce(self.grad, op=dist.ReduceOp.AVG, group=group)
+                FlatAdam._avg_ok = True
+                return
+            except RuntimeError:              # a collective library without ncclAvg: sum, then scale
+                if FlatAdam._avg_ok:
+                    raise
+                FlatAdam._avg_ok = False
+        dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+        self.grad.div_(dist.get_world_size(group))
 
     def all_reduce_slice(self, lo: int, hi: Optional[int], group=None, async_op: bool = False):
         """Average ``grad[lo:hi]`` across ranks; with ``async_op`` returns the work handle (None when there is nothing to
