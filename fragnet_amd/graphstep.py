@@ -52,6 +52,11 @@ MASKS = {"mol": MASK_KEY, "atom": "atom_weight", "edge": "edge_weight"}     # 1/
 SCALE_KEY = "loss_scales"         # float32 [2]: (per-edge, per-atom) rank weights of the pretrain loss, 1 on one GPU
 
 
+# "thread_local": HIP calls of OTHER threads (the collective library's watchdog, a data-loader thread) do not invalidate
+# a capture in progress; everything the captured step itself does runs on the capturing thread
+_CAPTURE_MODE = "thread_local"
+
+
 def _gat_limit(heads: int) -> int:
     """Padding in-degree that stays on the kernels' one-pass path (in-degree <= 2 * 32/heads, self loop included)."""
     return max(2, min(12, (2 * (32 // heads) * 3) // 4))
@@ -378,17 +383,17 @@ class GraphedTrainStep:
         off0 = self.rng.offset
         if self.split:
             pool = torch.cuda.graph_pool_handle()
-            with torch.cuda.graph(graph, pool=pool):
+            with torch.cuda.graph(graph, pool=pool, capture_error_mode=_CAPTURE_MODE):
                 loss, pooled_t, leaf = self._part_a()
                 consumed = self.rng.offset - off0
                 if consumed:
                     self.rng.advance_device(consumed)
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=pool):
+            with torch.cuda.graph(self.graph_b, pool=pool, capture_error_mode=_CAPTURE_MODE):
                 self._part_b(pooled_t, leaf)
             del pooled_t, leaf
         else:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=_CAPTURE_MODE):
                 loss = self._fwd_bwd_static()
                 if self.rng.offset - off0 != per_step:
                     raise RuntimeError("the captured step drew a different number of Philox blocks than the warm-up steps")
@@ -486,7 +491,7 @@ class GraphedForward:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
             self.out = self._run()
 
     def _run(self):
