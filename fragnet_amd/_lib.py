@@ -11,6 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfragnet_hip.so")
 
+ABI_VERSION = 4
 FN_D = 128
 FN_MAX_TASKS = 16
 FN_MAX_EDGE_K = 8
@@ -59,7 +60,7 @@ class StageField(C.Structure):
 
 
 FN_MAX_STAGE_FIELDS = 24
-STAGE_ROWS, STAGE_IDS, STAGE_COLS, STAGE_MASK = 0, 1, 2, 3
+STAGE_ROWS, STAGE_IDS, STAGE_COLS, STAGE_MASK, STAGE_COUNT = 0, 1, 2, 3, 4
 
 
 class MseTask(C.Structure):
@@ -73,7 +74,8 @@ class Encoder(C.Structure):
                 ("bond", GatPlan), ("atom", GatPlan), ("fbond", GatPlan), ("frag", GatPlan), ("a2f", SegPlan),
                 ("x_atoms", vp), ("bond_nodes", vp), ("fbond_nodes", vp), ("cos_sorted", vp), ("fattr_sorted", vp),
                 ("cos_raw", vp), ("fattr_raw", vp),
-                ("w", LayerWeights * FN_MAX_LAYERS), ("ws", vp), ("ws_floats", i64)]
+                ("w", LayerWeights * FN_MAX_LAYERS), ("ws", vp), ("ws_floats", i64),
+                ("mol_atoms", SegPlan), ("mol_frags", SegPlan), ("n_mols", i64), ("counts_dev", vp), ("status", vp)]
 
 
 # name -> argtypes; every function returns int (0 ok / <0 argument error / >0 hipError_t) unless noted.
@@ -161,8 +163,8 @@ def load():
             fn.restype = u64
         else:
             fn.restype = C.c_int
-    if lib.fn_abi_version() != 3:
-        raise FragnetHipError(f"ABI version mismatch: library {lib.fn_abi_version()}, binding 3")
+    if lib.fn_abi_version() != ABI_VERSION:
+        raise FragnetHipError(f"ABI version mismatch: library {lib.fn_abi_version()}, binding {ABI_VERSION}")
     _lib = lib
     return lib
 

@@ -2105,6 +2105,8 @@ __global__ void k_transpose_many(TransposeMany tm, float* __restrict__ bt_base) 
     transpose_many_body(tm, bt_base, tile, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x);
 }
 
+#include "mol_fused.inc"
+
 // Everything the encoder's forward pass needs before its first projection, none of which depends on the other: W^T of
 // every projection, dropout of the atom features, and the permutation of the two raw edge-attribute tensors into
 // destination order.  One launch of four block ranges instead of four launches (each was 5 us of latency).
@@ -2114,6 +2116,7 @@ struct EncPrologue {
     int n_t;                                                        // 24 blocks per matrix
     const float* dx;  float* dy;  int64_t dnumel;  float p;  uint64_t seed, offset;  const uint64_t* offset_dev;  int n_d;
     const float* sx[2];  float* so[2];  int sK[2];  fn_gat_plan spl[2];  int n_s[2];
+    MolExtArgs mx;  int n_x;                                        // molecule extents for the fused kernels (256 molecules per block)
 };
 __global__ __launch_bounds__(256) void k_enc_prologue(EncPrologue A) {
     __shared__ float tile[32][33];
@@ -2137,6 +2140,7 @@ __global__ __launch_bounds__(256) void k_enc_prologue(EncPrologue A) {
         }
         b -= A.n_s[q];
     }
+    if (b < A.n_x) mol_extents_body(A.mx, b);
 }
 
 // Weight gradient: block = `rows_per_block` rows in chunks of 32 staged through double-buffered LDS.  Wave w owns
@@ -2447,7 +2451,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 // C-ABI
 // =====================================================================================
 namespace {
-int g_tune[FN_TUNE_COUNT] = {1792, 0, 0, 512};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS
+int g_tune[FN_TUNE_COUNT] = {1792, 0, 0, 512, 1};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -2560,6 +2564,8 @@ __global__ void k_stage_padded(StageFields F) {
     } else if (f.kind == FN_STAGE_MASK) {
         float* dst = static_cast<float*>(f.dst);
         for (int64_t i = t0; i < f.cap; i += stride) dst[i] = i < f.n_real ? 1.f : 0.f;
+    } else if (f.kind == FN_STAGE_COUNT) {
+        if (t0 == 0) *static_cast<int32_t*>(f.dst) = (int32_t)f.n_real;
     } else {
         const int64_t* src = static_cast<const int64_t*>(f.src);
         int64_t* dst = static_cast<int64_t*>(f.dst);
@@ -3226,6 +3232,12 @@ int fn_stage_padded(const fn_stage_field* fields, int n_fields, fn_stream_t stre
     int64_t most = 0;
     for (int i = 0; i < n_fields; ++i) {
         const fn_stage_field& f = fields[i];
+        if (f.kind == FN_STAGE_COUNT) {
+            if (f.n_real < 0 || !f.dst) return fail(FN_EINVAL, "fn_stage_padded: bad count field");
+            F.f[i] = f;
+            most = most > 1 ? most : 1;
+            continue;
+        }
         if (f.n_real < 0 || f.cap < f.n_real || f.width < 1 || f.kind < 0 || f.kind > FN_STAGE_MASK || (f.cap > 0 && !f.dst) ||
             (f.n_real > 0 && f.kind != FN_STAGE_MASK && !f.src) ||
             ((f.kind == FN_STAGE_IDS || f.kind == FN_STAGE_COLS) && f.cap > f.n_real && f.pad_mod < 1))
@@ -3269,6 +3281,7 @@ struct EncLayout {
     float* in_atoms0;        // dropout(x_atoms) when training with p > 0, else null (use x_atoms)
     // forward scratch
     float *atoms_new, *frags_new, *s_sorted, *s_dst, *s_src, *s_dst_a, *s_src_a, *s_dst_fb, *s_src_fb, *bt;
+    float* mol_ext;          // MolExt[n_mols] for the fused molecule kernels (null without molecule CSRs)
     int64_t total;
 };
 
@@ -3302,8 +3315,15 @@ EncLayout enc_layout(const fn_encoder* e, float* ws) {
     o.s_dst_fb = b.take(e->EF * H);
     o.s_src_fb = b.take(e->EF * H);
     o.bt = b.take((int64_t)3 * e->n_layers * 192 * FN_D);
+    o.mol_ext = e->n_mols > 0 ? b.take(e->n_mols * (int64_t)(sizeof(MolExt) / sizeof(float))) : nullptr;
     o.total = b.used;
     return o;
+}
+
+// the molecule-resident fused kernels apply when the caller handed over the molecule CSRs (and the tuning switch is on)
+bool mol_fused(const fn_encoder* e) {
+    return g_tune[FN_TUNE_FUSED] != 0 && e->heads == 4 && e->n_mols > 0 && e->mol_atoms.rowptr && e->mol_frags.rowptr &&
+           e->mol_atoms.n_seg == e->n_mols && e->mol_frags.n_seg == e->n_mols && g_tune[FN_TUNE_STREAMS] == 0;
 }
 
 // Backward scratch.  Nothing is reused across levels or layers: the kernels that only produce parameter gradients
@@ -3530,6 +3550,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
     const bool multi = g_tune[FN_TUNE_STREAMS] != 0;
     const bool lite = e->variant == 1, edge = e->variant == 2;      // gat2_lite / gat2_edge: neither has a fragment-bond graph
     const bool no_fb = lite || edge;
+    const bool fused = mol_fused(e);
     if (multi) FN_TRY(aux_init());
     fn_stream_t st_fb = multi ? (fn_stream_t)g_aux.s[1] : st;       // the fragment-bond chain's stream
 
@@ -3562,12 +3583,49 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
             A.sx[1] = e->fattr_raw;  A.so[1] = const_cast<float*>(e->fattr_sorted);  A.sK[1] = e->k_fattr;  A.spl[1] = fattr_plan;
             A.n_s[1] = flat_grid(fattr_plan.m * e->k_fattr, 512);
         }
-        hipLaunchKernelGGL(k_enc_prologue, dim3(A.n_t + A.n_d + A.n_s[0] + A.n_s[1]), dim3(256), 0, S(st), A);
+        if (fused) {
+            A.mx = MolExtArgs{e->mol_atoms.rowptr, e->mol_frags.rowptr, e->mol_atoms.pos_base, e->mol_frags.pos_base,
+                              e->bond, e->atom, no_fb ? fn_gat_plan{} : e->fbond, e->frag, (int)e->n_mols,
+                              reinterpret_cast<MolExt*>(lay.mol_ext)};
+            A.n_x = (int)((e->n_mols + 255) / 256);
+        }
+        hipLaunchKernelGGL(k_enc_prologue, dim3(A.n_t + A.n_d + A.n_s[0] + A.n_s[1] + A.n_x), dim3(256), 0, S(st), A);
         FN_TRY(launch_status("fn_encoder_forward: prologue"));
     }
     FN_TRY(order_after(S(st), S(st_fb)));      // fork: the fragment-bond levels of ALL layers depend on nothing else
 
-    for (int l = 0; l < e->n_layers; ++l) {
+    if (fused) {
+        // bond graph, atom graph and fragment-bond graph of EVERY layer: one launch, one workgroup per molecule (mol_fused.inc);
+        // only the last layer's atom -> fragment sum and fragment graph (a few rows per molecule) follow as per-level kernels
+        MolFwdArgs M{};
+        M.n_mol = (int)e->n_mols;  M.n_zero = e->counts_dev ? 64 : 0;  M.l0 = 0;  M.l1 = e->n_layers;
+        M.has_fbond = no_fb ? 0 : 1;  M.k_fattr = e->k_fattr;  M.drop_p = p;  M.seed = e->seed;  M.offset_dev = e->offset_dev;
+        M.counts_dev = e->counts_dev;  M.ext = reinterpret_cast<const MolExt*>(lay.mol_ext);
+        M.plan[MOL_BOND] = e->bond;  M.plan[MOL_ATOM] = e->atom;  M.plan[MOL_FBOND] = no_fb ? fn_gat_plan{} : e->fbond;
+        M.xattr[MOL_BOND] = e->cos_sorted;  M.xattr[MOL_ATOM] = nullptr;  M.xattr[MOL_FBOND] = e->fattr_sorted;
+        M.s_edge_g = lay.s_sorted;  M.status = e->status;
+        M.rows[MOL_BOND] = e->E;  M.rows[MOL_ATOM] = e->N;  M.rows[MOL_FBOND] = e->EF;
+        for (int l = 0; l < e->n_layers; ++l) {
+            const fn_layer_weights& w = e->w[l];
+            const LayerActs& a = lay.L[l];
+            const bool last = l + 1 == e->n_layers;
+            MolLayer& Y = M.L[l];
+            Y.lev[MOL_BOND] = MolLevel{l ? lay.L[l - 1].y_bond : e->bond_nodes, w.proj_b_w, w.proj_b_b, w.a_b, w.emb_b_w, w.emb_b_b, a.h_b, a.new_bond,
+                                       a.p_bond, last ? out_bond : a.y_bond, lay.s_dst, lay.s_src, rng.y[l][2], l ? FN_D : e->k_bond0, 3 * d, 2 * d, d, 1, 0};
+            Y.lev[MOL_ATOM] = MolLevel{l ? lay.L[l - 1].y_atoms : in_atoms, w.proj_a_w, w.proj_a_b, w.a, nullptr, nullptr, a.h_a, last ? lay.atoms_new : nullptr,
+                                       a.p_atom, last ? out_atoms : a.y_atoms, lay.s_dst_a, lay.s_src_a, rng.y[l][0], l ? FN_D : e->k_atom0, wide, d + FN_D, d, 0, 0};
+            if (!no_fb)
+                Y.lev[MOL_FBOND] = MolLevel{l ? lay.L[l - 1].y_fbond : e->fbond_nodes, w.proj_fb_w, w.proj_fb_b, w.f_a_b, w.emb_fb_w, w.emb_fb_b, a.h_fb, a.new_fbond,
+                                            a.p_fbond, last ? out_fbond : a.y_fbond, lay.s_dst_fb, lay.s_src_fb, rng.y[l][3], l ? FN_D : e->k_fbond0, 3 * d, 2 * d, d, e->k_fattr, 0};
+            Y.a_mid = w.a + d;
+        }
+        const size_t lds = kMolFwdLds(4);
+        FN_TRY(allow_lds(k_mol_fwd<4>, lds));
+        hipLaunchKernelGGL(k_mol_fwd<4>, dim3(M.n_mol + M.n_zero), dim3(kMolThreads), lds, S(st), M);
+        FN_TRY(launch_status("fn_encoder_forward: fused molecule kernel"));
+    }
+
+    for (int l = fused ? e->n_layers - 1 : 0; l < e->n_layers; ++l) {
         const fn_layer_weights& w = e->w[l];
         const LayerActs& a = lay.L[l];
         const bool last = l + 1 == e->n_layers;
@@ -3575,6 +3633,14 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         const float* bt_a = lay.bt + (size_t)(3 * l + 1) * 192 * FN_D;
         const float* bt_fb = lay.bt + (size_t)(3 * l + 2) * 192 * FN_D;
 
+        float* y_atoms = last ? out_atoms : a.y_atoms;
+        float* y_frags = last ? out_frags : a.y_frags;
+        float* y_bond = last ? out_bond : a.y_bond;
+        float* y_fbond = last ? out_fbond : a.y_fbond;
+        // act(dropout(.)) of the four layer outputs rides in the producing kernels' epilogues
+        const fn_act_epilogue ep_atoms{y_atoms, p, 1, e->seed, rng.y[l][0], e->offset_dev}, ep_frags{y_frags, p, 1, e->seed, rng.y[l][1], e->offset_dev};
+        const fn_act_epilogue ep_bond{y_bond, p, 1, e->seed, rng.y[l][2], e->offset_dev}, ep_fbond{y_fbond, p, 1, e->seed, rng.y[l][3], e->offset_dev};
+        if (!fused) {
         // L1 bond graph
         const bool fuse_ns = H >= 2;         // a head's columns fit one wave's 64-column half for H >= 2
         auto project = [&](const float* x, int k, const float* bt, const float* bias, float* hout, int64_t rows,
@@ -3601,13 +3667,6 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         }
         fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
         fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
-        float* y_atoms = last ? out_atoms : a.y_atoms;
-        float* y_frags = last ? out_frags : a.y_frags;
-        float* y_bond = last ? out_bond : a.y_bond;
-        float* y_fbond = last ? out_fbond : a.y_fbond;
-        // act(dropout(.)) of the four layer outputs rides in the producing kernels' epilogues
-        const fn_act_epilogue ep_atoms{y_atoms, p, 1, e->seed, rng.y[l][0], e->offset_dev}, ep_frags{y_frags, p, 1, e->seed, rng.y[l][1], e->offset_dev};
-        const fn_act_epilogue ep_bond{y_bond, p, 1, e->seed, rng.y[l][2], e->offset_dev}, ep_fbond{y_fbond, p, 1, e->seed, rng.y[l][3], e->offset_dev};
         // L1 bond graph and L4a fragment-bond graph: neither reads the other's output -> one launch for both
         GatFwdArgs gb, gfb{};
         FN_TRY(prep_gat_fwd(a.h_b, lay.s_dst, lay.s_src, w.a_b, 3 * d, &et_b, &e->bond, 0.2f, a.new_bond, a.p_bond, nullptr, &ep_bond, H, &gb));
@@ -3624,6 +3683,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         FN_TRY(fn_row_dots_sorted_f32(a.new_bond, w.a, wide, d, H, &e->atom, lay.s_sorted, st));
         fn_edge_term et_a{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
         FN_TRY(fn_gat_fwd_f32(a.h_a, lay.s_dst_a, lay.s_src_a, w.a, wide, &et_a, &e->atom, 0.2f, lay.atoms_new, a.p_atom, nullptr, &ep_atoms, H, st));
+        }   // !fused
 
         // L3 atom -> fragment sum.  Like L4b below it is only ever read in the last layer (the next layer recomputes its own
         // sum from its own atoms before first use, gat2.py:234), so inner layers skip it too.

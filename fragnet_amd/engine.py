@@ -68,6 +68,15 @@ def _describe(plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fat
     for l in range(n_layers):
         for k, name in enumerate(LAYER_FIELDS):
             setattr(e.w[l], name, params[l * NP + k].data_ptr())
+    # molecule CSRs: with them fn_encoder_* runs the molecule-resident fused kernels (include/fragnet_hip.h, fn_encoder.n_mols)
+    ma, mf = plan.segs.get("mol_atoms"), plan.segs.get("mol_frags")
+    if ma is not None and mf is not None and ma.n_seg == mf.n_seg:
+        e.mol_atoms = SegPlan(ma.rowptr.data_ptr(), ma.perm.data_ptr(), ma.index.data_ptr(), ma.n_seg, ma.n_items, ma.pos_base, 0)
+        e.mol_frags = SegPlan(mf.rowptr.data_ptr(), mf.perm.data_ptr(), mf.index.data_ptr(), mf.n_seg, mf.n_items, mf.pos_base, 0)
+        e.n_mols = ma.n_seg
+        counts = getattr(plan, "real_mols", None)
+        e.counts_dev = None if counts is None else counts.data_ptr()
+        e.status = plan._status.data_ptr()
     return e
 
 

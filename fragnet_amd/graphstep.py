@@ -31,7 +31,7 @@ from typing import Callable, Dict, Iterable, Optional
 import torch
 
 from . import _lib
-from .plan import PLAN_KEY
+from .plan import PLAN_KEY, REAL_MOLS_KEY
 
 # field -> (index space of the ragged axis, layout, index space its VALUES point into)
 FIELDS = {
@@ -224,7 +224,11 @@ class StaticBatch:
         for q, space in enumerate(self._mask_spaces):
             m = self._fields[len(self._desc) + q]
             m.dst, m.cap, m.width, m.kind, m.pad_hi, m.pad_mod = self.t[MASKS[space]].data_ptr(), shapes.cap[space], 1, _lib.STAGE_MASK, 0, 1
-        self.n_fields = len(self._desc) + len(self._mask_spaces)
+        # device-side copy of the number of real molecules: the fused encoder kernels skip the padding behind them
+        self.t[REAL_MOLS_KEY] = torch.zeros(1, dtype=torch.int32, device=dev)
+        c = self._fields[len(self._desc) + len(self._mask_spaces)]
+        c.dst, c.cap, c.width, c.kind, c.pad_hi, c.pad_mod = self.t[REAL_MOLS_KEY].data_ptr(), 1, 1, _lib.STAGE_COUNT, 0, 1
+        self.n_fields = len(self._desc) + len(self._mask_spaces) + 1
         if self.n_fields > _lib.FN_MAX_STAGE_FIELDS:
             raise ValueError("too many batch fields for one staging launch")
         self.counts: Optional[Dict[str, int]] = None
@@ -247,6 +251,8 @@ class StaticBatch:
         for q, space in enumerate(self._mask_spaces):
             m = self._fields[len(self._desc) + q]
             m.src, m.n_real = None, counts[space]
+        c = self._fields[len(self._desc) + len(self._mask_spaces)]
+        c.src, c.n_real = None, counts["mol"]
         _lib.call("fn_stage_padded", self._fields, self.n_fields, torch.cuda.current_stream(self.device).cuda_stream)
         self.counts = counts
         return True

@@ -148,8 +148,12 @@ class GraphPlan:
 
     def check(self):
         """Synchronising validation: raises if any index was outside its segment range."""
-        if int(self._status.item()) != 0:
+        st = int(self._status.item())
+        if st & 1:
             raise IndexError("graph plan: an index tensor holds values outside [0, num_nodes)")
+        if st & 2:
+            raise IndexError("graph plan: the batch is not molecule-contiguous (an edge joins nodes of different molecules, or "
+                             "molecules are interleaved); the fused encoder needs collate_fn's layout (dataset/data.py:877-948)")
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -183,6 +187,7 @@ class GraphPlan:
                       dict(kind="seg", name="edge_dst", key=ei[1], n_seg=N)]
         plan = cls(specs, dev)
         plan.n_mols = n_mols
+        plan.real_mols = batch.get(REAL_MOLS_KEY)      # int32 [1] on the device when the batch is padded to static shapes
         return plan
 
     @classmethod
@@ -192,6 +197,7 @@ class GraphPlan:
 
 
 PLAN_KEY = "_fragnet_plan"
+REAL_MOLS_KEY = "_real_mols"      # StaticBatch: device-side count of the real molecules of a padded batch
 
 
 def plan_for(batch: Dict[str, torch.Tensor], edge_ends: bool = False) -> GraphPlan:

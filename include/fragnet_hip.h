@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FN_ABI_VERSION 3
+#define FN_ABI_VERSION 4
 #define FN_D 128              /* feature width of every node table on the path (emb_dim) */
 #define FN_MAX_TASKS 16       /* CSR builds fused into one fn_plan_build call */
 #define FN_MAX_EDGE_K 8       /* widest raw edge attribute folded in-kernel (6 for fragment bonds) */
@@ -52,7 +52,9 @@ int fn_abi_version(void);
 #define FN_TUNE_STREAMS 2      /* 1: the encoder forks parameter-gradient work and the fragment-bond chain onto side streams;
                                 * 0 (default): one stream -- forked hipGraph replays measured slower on ROCm 7.2 */
 #define FN_TUNE_WGRAD_BLOCKS 3 /* target workgroup count of the grouped weight-gradient launch of a backward pass (default 512) */
-#define FN_TUNE_COUNT 4
+#define FN_TUNE_FUSED 4        /* 1 (default): fn_encoder_forward / _backward run the molecule-resident fused layer kernels when the
+                                * descriptor carries the molecule CSRs (mol_atoms / mol_frags) and heads == 4; 0: per-level kernels */
+#define FN_TUNE_COUNT 5
 int fn_set_tuning(int key, int value);
 const char* fn_last_error(void);
 
@@ -353,6 +355,7 @@ int fn_masked_mse_multi_f32(const fn_mse_task* tasks, int n_tasks /*<= 4*/, cons
 #define FN_STAGE_IDS 1  /* int64   [cap]        <- [n_real], pad ids after                                 */
 #define FN_STAGE_COLS 2 /* int64   [2,cap]      <- [2,n_real] (edge_index layout), pad ids in both rows    */
 #define FN_STAGE_MASK 3 /* float32 [cap]        =  1 for i < n_real, 0 after (loss weights); src unused    */
+#define FN_STAGE_COUNT 4 /* int32 [1]           =  n_real (device-side copy of a count for the fused encoder)  */
 typedef struct fn_stage_field {
     const void* src;
     void* dst;
@@ -414,6 +417,16 @@ typedef struct fn_encoder {
     fn_layer_weights w[FN_MAX_LAYERS];
     float* ws;
     int64_t ws_floats;                     /* >= fn_encoder_ws_floats() */
+    /* Molecule CSRs (optional; n_mols = 0: absent).  collate_fn concatenates molecules, so the atoms / bonds / fragments /
+     * connections / graph edges of molecule i are contiguous ranges (dataset/data.py:877-948).  When they are given (and
+     * heads == 4) the encoder runs as molecule-resident fused kernels: one workgroup carries one molecule through all
+     * levels of all layers with its rows in LDS.  A batch that violates the contiguity sets bit 1 of *status. */
+    fn_seg_plan mol_atoms, mol_frags;      /* atoms / fragments keyed by molecule (batch, frag_batch: gat2.py:820-821) */
+    int64_t n_mols;
+    const int32_t* counts_dev;             /* nullable device [1]: number of REAL molecules (the first ones) when the batch is
+                                            * padded to static shapes (fn_stage_padded, FN_STAGE_COUNT); outputs of padding rows
+                                            * are zero */
+    int32_t* status;                       /* nullable device word, bits OR-ed in on malformed batches */
 } fn_encoder;
 
 int64_t fn_encoder_ws_floats(const fn_encoder* e);
