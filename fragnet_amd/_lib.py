@@ -83,6 +83,7 @@ SIGNATURES = {
     "fn_abi_version": [],
     "fn_last_error": [],
     "fn_set_tuning": [C.c_int, C.c_int],
+    "fn_debug_set_stamps": [vp, i64],
     "fn_plan_layout": [C.POINTER(CsrTask), C.c_int, C.POINTER(i64), C.POINTER(i64)],
     "fn_plan_build": [C.POINTER(CsrTask), C.c_int, vp, vp, vp, vp, vp, vp, vp],
     "fn_node_scalars_f32": [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, i64, C.c_int, vp],

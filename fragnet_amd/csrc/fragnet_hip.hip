@@ -93,8 +93,8 @@ __device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t seed) {
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint64_t m0 = (uint64_t)0xD2511F53u * c0, m1 = (uint64_t)0xCD9E8D57u * c2;       // one v_mad_u64_u32 each
+        const uint32_t hi0 = (uint32_t)(m0 >> 32), lo0 = (uint32_t)m0, hi1 = (uint32_t)(m1 >> 32), lo1 = (uint32_t)m1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -2117,6 +2117,7 @@ struct EncPrologue {
     const float* dx;  float* dy;  int64_t dnumel;  float p;  uint64_t seed, offset;  const uint64_t* offset_dev;  int n_d;
     const float* sx[2];  float* so[2];  int sK[2];  fn_gat_plan spl[2];  int n_s[2];
     MolExtArgs mx;  int n_x;                                        // molecule extents for the fused kernels (256 molecules per block)
+    MolFoldArgs fold;  int n_f;                                     // folded edge-embedding weights, one block per (layer, level)
 };
 __global__ __launch_bounds__(256) void k_enc_prologue(EncPrologue A) {
     __shared__ float tile[32][33];
@@ -2140,7 +2141,9 @@ __global__ __launch_bounds__(256) void k_enc_prologue(EncPrologue A) {
         }
         b -= A.n_s[q];
     }
-    if (b < A.n_x) mol_extents_body(A.mx, b);
+    if (b < A.n_x) { mol_extents_body(A.mx, b);  return; }
+    b -= A.n_x;
+    if (b < A.n_f) mol_fold_body(A.fold, b);
 }
 
 // Weight gradient: block = `rows_per_block` rows in chunks of 32 staged through double-buffered LDS.  Wave w owns
@@ -2451,7 +2454,9 @@ bool bad_edge_term(const fn_edge_term* et) {
 // C-ABI
 // =====================================================================================
 namespace {
-int g_tune[FN_TUNE_COUNT] = {1792, 0, 0, 512, 1};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
+unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
+int64_t g_mol_stamps_n = 0;
+int g_tune[FN_TUNE_COUNT] = {1792, 0, 0, 512, 0, 0};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -2587,6 +2592,12 @@ __global__ void k_zero2_i32(int32_t* __restrict__ a, int64_t na, int32_t* __rest
 extern "C" {
 
 int fn_abi_version(void) { return FN_ABI_VERSION; }
+
+int fn_debug_set_stamps(void* buf, int64_t n_u64) {
+    g_mol_stamps = static_cast<unsigned long long*>(buf);
+    g_mol_stamps_n = buf ? n_u64 : 0;
+    return 0;
+}
 
 int fn_set_tuning(int key, int value) {
     if (key < 0 || key >= FN_TUNE_COUNT) return fail(FN_EINVAL, "fn_set_tuning: unknown key");
@@ -3282,6 +3293,8 @@ struct EncLayout {
     // forward scratch
     float *atoms_new, *frags_new, *s_sorted, *s_dst, *s_src, *s_dst_a, *s_src_a, *s_dst_fb, *s_src_fb, *bt;
     float* mol_ext;          // MolExt[n_mols] for the fused molecule kernels (null without molecule CSRs)
+    float* wf_tab;           // [n_layers][2][8][kWfLd] folded edge-embedding weights (bond, fbond) for the fused kernels
+    float* mol_args;         // MolFwdArgs of the fused forward kernel (its out-of-line level functions read it from memory)
     int64_t total;
 };
 
@@ -3316,6 +3329,8 @@ EncLayout enc_layout(const fn_encoder* e, float* ws) {
     o.s_src_fb = b.take(e->EF * H);
     o.bt = b.take((int64_t)3 * e->n_layers * 192 * FN_D);
     o.mol_ext = e->n_mols > 0 ? b.take(e->n_mols * (int64_t)(sizeof(MolExt) / sizeof(float))) : nullptr;
+    o.wf_tab = e->n_mols > 0 ? b.take((int64_t)e->n_layers * 2 * 8 * kWfLd) : nullptr;
+    o.mol_args = e->n_mols > 0 ? b.take((int64_t)((sizeof(MolFwdArgs) + 3) / 4)) : nullptr;
     o.total = b.used;
     return o;
 }
@@ -3588,8 +3603,15 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
                               e->bond, e->atom, no_fb ? fn_gat_plan{} : e->fbond, e->frag, (int)e->n_mols,
                               reinterpret_cast<MolExt*>(lay.mol_ext)};
             A.n_x = (int)((e->n_mols + 255) / 256);
+            for (int l = 0; l < e->n_layers; ++l) {
+                A.fold.att[2 * l] = e->w[l].a_b;  A.fold.embW[2 * l] = e->w[l].emb_b_w;  A.fold.embb[2 * l] = e->w[l].emb_b_b;  A.fold.Ke[2 * l] = 1;
+                A.fold.att[2 * l + 1] = e->w[l].f_a_b;  A.fold.embW[2 * l + 1] = e->w[l].emb_fb_w;  A.fold.embb[2 * l + 1] = e->w[l].emb_fb_b;
+                A.fold.Ke[2 * l + 1] = no_fb ? 0 : e->k_fattr;
+            }
+            A.fold.att_w = 3 * d;  A.fold.mid_off = d;  A.fold.H = H;  A.fold.n = 2 * e->n_layers;  A.fold.out = lay.wf_tab;
+            A.n_f = 2 * e->n_layers;
         }
-        hipLaunchKernelGGL(k_enc_prologue, dim3(A.n_t + A.n_d + A.n_s[0] + A.n_s[1] + A.n_x), dim3(256), 0, S(st), A);
+        hipLaunchKernelGGL(k_enc_prologue, dim3(A.n_t + A.n_d + A.n_s[0] + A.n_s[1] + A.n_x + A.n_f), dim3(256), 0, S(st), A);
         FN_TRY(launch_status("fn_encoder_forward: prologue"));
     }
     FN_TRY(order_after(S(st), S(st_fb)));      // fork: the fragment-bond levels of ALL layers depend on nothing else
@@ -3599,11 +3621,12 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         // only the last layer's atom -> fragment sum and fragment graph (a few rows per molecule) follow as per-level kernels
         MolFwdArgs M{};
         M.n_mol = (int)e->n_mols;  M.n_zero = e->counts_dev ? 64 : 0;  M.l0 = 0;  M.l1 = e->n_layers;
+        M.skew = g_tune[FN_TUNE_MOL_SKEW];
         M.has_fbond = no_fb ? 0 : 1;  M.k_fattr = e->k_fattr;  M.drop_p = p;  M.seed = e->seed;  M.offset_dev = e->offset_dev;
         M.counts_dev = e->counts_dev;  M.ext = reinterpret_cast<const MolExt*>(lay.mol_ext);
         M.plan[MOL_BOND] = e->bond;  M.plan[MOL_ATOM] = e->atom;  M.plan[MOL_FBOND] = no_fb ? fn_gat_plan{} : e->fbond;
         M.xattr[MOL_BOND] = e->cos_sorted;  M.xattr[MOL_ATOM] = nullptr;  M.xattr[MOL_FBOND] = e->fattr_sorted;
-        M.s_edge_g = lay.s_sorted;  M.status = e->status;
+        M.s_edge_g = lay.s_sorted;  M.status = e->status;  M.wf_tab = lay.wf_tab;
         M.rows[MOL_BOND] = e->E;  M.rows[MOL_ATOM] = e->N;  M.rows[MOL_FBOND] = e->EF;
         for (int l = 0; l < e->n_layers; ++l) {
             const fn_layer_weights& w = e->w[l];
@@ -3619,6 +3642,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
                                             a.p_fbond, last ? out_fbond : a.y_fbond, lay.s_dst_fb, lay.s_src_fb, rng.y[l][3], l ? FN_D : e->k_fbond0, 3 * d, 2 * d, d, e->k_fattr, 0};
             Y.a_mid = w.a + d;
         }
+        M.stamps = g_mol_stamps_n >= (int64_t)M.n_mol * kMolStampsPerMol ? g_mol_stamps : nullptr;
         const size_t lds = kMolFwdLds(4);
         FN_TRY(allow_lds(k_mol_fwd<4>, lds));
         hipLaunchKernelGGL(k_mol_fwd<4>, dim3(M.n_mol + M.n_zero), dim3(kMolThreads), lds, S(st), M);

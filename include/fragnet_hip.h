@@ -52,10 +52,18 @@ int fn_abi_version(void);
 #define FN_TUNE_STREAMS 2      /* 1: the encoder forks parameter-gradient work and the fragment-bond chain onto side streams;
                                 * 0 (default): one stream -- forked hipGraph replays measured slower on ROCm 7.2 */
 #define FN_TUNE_WGRAD_BLOCKS 3 /* target workgroup count of the grouped weight-gradient launch of a backward pass (default 512) */
-#define FN_TUNE_FUSED 4        /* 1 (default): fn_encoder_forward / _backward run the molecule-resident fused layer kernels when the
-                                * descriptor carries the molecule CSRs (mol_atoms / mol_frags) and heads == 4; 0: per-level kernels */
-#define FN_TUNE_COUNT 5
+#define FN_TUNE_FUSED 4        /* 1: fn_encoder_forward runs the molecule-resident fused layer kernel (csrc/mol_fused.inc) when the
+                                * descriptor carries the molecule CSRs (mol_atoms / mol_frags) and heads == 4; 0 (default): per-level
+                                * kernels -- measured on MI355X the fused kernel only matches them at 512 molecules */
+#define FN_TUNE_MOL_SKEW 5     /* fused kernels: workgroups with bit (value - 1) of their index set run the fragment-bond level FIRST in
+                                * every layer, so that the two workgroups of a CU are in different phases (MFMA vs. VALU); 0 = off */
+#define FN_TUNE_COUNT 6
 int fn_set_tuning(int key, int value);
+/* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * molecules 64-bit words) is
+ * set, every workgroup of the fused molecule kernels writes s_memtime stamps of its phases into it (tools/mol_phase_times.py).
+ * NULL switches it off (the default: the kernels then pay one uniform branch per phase). */
+#define FN_MOL_STAMPS 128
+int fn_debug_set_stamps(void* buf, int64_t n_u64);
 const char* fn_last_error(void);
 
 /* ------------------------------------------------------------------------------------------

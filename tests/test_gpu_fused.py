@@ -1,0 +1,172 @@
+"""GPU parity of the molecule-resident fused encoder forward (csrc/mol_fused.inc, FN_TUNE_FUSED = 1): against the
+reference's golden vectors, against the per-level engine (same Philox stream => same dropout masks), on molecules that
+overflow the LDS row tile (chunked projection, global twins), on a padded static-shape step (hipGraph replay), and the
+contiguity check on a batch whose molecules are interleaved."""
+import copy
+
+import pytest
+import torch
+
+from tests.helpers import check_grads, load_case
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+ATOL = 1e-4
+FN_TUNE_FUSED = 4
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from fragnet_amd import _lib
+    from fragnet_amd.build import build_lib
+    build_lib()
+    _lib.load()
+
+
+@pytest.fixture()
+def fused():
+    from fragnet_amd import _lib
+    _lib.call("fn_set_tuning", FN_TUNE_FUSED, 1)
+    yield
+    _lib.call("fn_set_tuning", FN_TUNE_FUSED, 0)
+
+
+def _set_fused(on):
+    from fragnet_amd import _lib
+    _lib.call("fn_set_tuning", FN_TUNE_FUSED, int(on))
+
+
+def _encoder_run(model, batch, offset):
+    model.zero_grad(set_to_none=True)
+    model.pretrain.rng.offset = offset
+    batch.pop("_fragnet_plan", None)
+    outs = model.pretrain(batch)
+    loss = sum(t.square().mean() for t in outs if t is not None)
+    loss.backward()
+    torch.cuda.synchronize()
+    batch["_fragnet_plan"].check()
+    return [t.detach().clone() for t in outs if t is not None], {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("case", ["ft_esol_b8", "ft_edge_b6", "ft_tox21_b4"])
+def test_fused_forward_matches_reference_golden(case, fused):
+    from fragnet_amd.data import batch_to
+    from fragnet_amd.model import FragNetFineTune
+    from oracle import fragnet_ref as ref
+    cfg, batch, out, grads, pkeys, psums = load_case(case)
+    torch.manual_seed(cfg["seed"])
+    model = FragNetFineTune(**cfg["ctor"]).to(DEV)
+    model.train()
+    b = batch_to(batch, DEV)
+    logits = model(b)
+    torch.testing.assert_close(logits.detach().cpu(), torch.from_numpy(out["logits"]), atol=ATOL, rtol=1e-4)
+    loss = torch.nn.functional.mse_loss(logits.view(-1), b["y"]) if cfg["loss"] == "mse" else ref.finetune_bce_loss(logits, b["y"])
+    assert abs(loss.item() - float(out["loss"])) < ATOL
+    loss.backward()
+    torch.cuda.synchronize()
+    b["_fragnet_plan"].check()
+    check_grads(model, grads, atol=ATOL, rtol=2e-3)
+
+
+@pytest.mark.parametrize("profile,B,variant", [("esol", 512, "gat2"), ("tox21", 200, "gat2"), ("esol", 64, "gat2_lite"), ("esol", 64, "gat2_edge")])
+def test_fused_forward_equals_per_level_engine_with_dropout(profile, B, variant):
+    from fragnet_amd import data, model as M, synth
+    torch.manual_seed(0)
+    cls = {"gat2": M.FragNetFineTune, "gat2_lite": M.FragNetFineTuneLite, "gat2_edge": M.FragNetFineTuneEdge}[variant]
+    model = cls(n_classes=1, num_layer=3, drop_ratio=0.1, h1=32, h2=32, h3=32, h4=32, act="relu", fthead="FTHead3").to(DEV)
+    model.train()
+    batch = data.batch_to(data.collate_fn(synth.synth_molecules(B, seed=7, profile=profile)), DEV)
+    if variant == "gat2_edge" and batch["cnx_attr"].shape[1] < 8:
+        batch["cnx_attr"] = torch.nn.functional.pad(batch["cnx_attr"], (0, 8 - batch["cnx_attr"].shape[1]))
+    try:
+        _set_fused(0)
+        o0, g0 = _encoder_run(model, batch, 4321)
+        _set_fused(1)
+        o1, g1 = _encoder_run(model, batch, 4321)
+    finally:
+        _set_fused(0)
+    for a, b in zip(o0, o1):
+        torch.testing.assert_close(b, a, atol=1e-5, rtol=1e-5)
+    assert set(g0) == set(g1)
+    for n in g0:
+        torch.testing.assert_close(g1[n], g0[n], atol=1e-5, rtol=2e-3, msg=lambda m: f"{n}: {m}")
+
+
+def test_fused_forward_handles_molecules_beyond_the_lds_tile():
+    """Molecules with more directed bonds / atoms than the 112-row LDS tile: chunked projections, neighbour rows and node
+    scalars read back from their global copies, CSRs read from the plan when they do not fit the LDS arena."""
+    import numpy as np
+    from fragnet_amd import data, synth
+    from fragnet_amd.model import FragNetFineTune
+    rng = np.random.default_rng(5)
+    mols = [synth.make_molecule(rng, mu, 0.35, 0, False, 0.0) for mu in (60.0, 10.0, 45.0, 90.0, 12.0, 70.0)]
+    assert max(m.edge_index.shape[1] for m in mols) > 224 and max(m.x_atoms.shape[0] for m in mols) > 112
+    batch = data.batch_to(data.collate_fn(mols), DEV)
+    torch.manual_seed(1)
+    model = FragNetFineTune(n_classes=1, num_layer=2, drop_ratio=0.0, h1=32, h2=32, h3=32, h4=32, act="relu", fthead="FTHead3").to(DEV)
+    model.train()
+    try:
+        _set_fused(0)
+        o0, g0 = _encoder_run(model, batch, 0)
+        _set_fused(1)
+        o1, g1 = _encoder_run(model, batch, 0)
+    finally:
+        _set_fused(0)
+    for a, b in zip(o0, o1):
+        torch.testing.assert_close(b, a, atol=2e-5, rtol=1e-5)
+    for n in g0:
+        torch.testing.assert_close(g1[n], g0[n], atol=2e-5, rtol=2e-3, msg=lambda m: f"{n}: {m}")
+
+
+def test_fused_forward_in_a_padded_graph_step(fused):
+    """Static-shape hipGraph step: the fused kernel reads the number of real molecules from device memory, skips the padding
+    and zeroes the padding rows every later kernel reads; losses and weights follow the unfused eager steps."""
+    from fragnet_amd import data, graphstep, parallel, synth
+    from fragnet_amd.model import FragNetFineTune
+    batches = [data.batch_to(data.collate_fn(synth.synth_molecules(48, seed=50 + i, profile="esol")), DEV) for i in range(3)]
+    shapes = graphstep.StaticShapes.from_batches(batches, margin=0.05)
+    torch.manual_seed(3)
+    model_a = FragNetFineTune(n_classes=1, num_layer=2, drop_ratio=0.0, h1=32, h2=64, h3=64, h4=32, act="relu", fthead="FTHead3").to(DEV)
+    model_a.train()
+    model_b = copy.deepcopy(model_a)
+
+    def probe(model):
+        return lambda: torch.nn.functional.mse_loss(model(dict(batches[0])).view(-1), batches[0]["y"]).backward()
+    opt_a = parallel.FlatAdam.for_live_parameters(model_a, probe(model_a), lr=1e-3)
+    opt_b = parallel.FlatAdam.for_live_parameters(model_b, probe(model_b), lr=1e-3)
+    step_b = graphstep.GraphedTrainStep(model_b, opt_b, shapes, dict(batches[0]), loss="regr")       # captured with the fused kernel
+    for i in range(5):
+        b = batches[i % 3]
+        _set_fused(0)                                       # reference: eager, per-level kernels
+        opt_a.zero_grad()
+        loss_a = torch.nn.functional.mse_loss(model_a(dict(b)).view(-1), b["y"])
+        loss_a.backward()
+        opt_a.step()
+        _set_fused(1)
+        loss_b = step_b(dict(b)).clone()
+        torch.testing.assert_close(loss_b, loss_a.detach(), atol=1e-5, rtol=1e-4)
+    assert step_b.replays == 5 and step_b.fallbacks == 0
+    torch.testing.assert_close(opt_b.flat, opt_a.flat, atol=3e-5, rtol=1e-3)
+
+
+def test_fused_forward_flags_a_batch_that_is_not_molecule_contiguous(fused):
+    from fragnet_amd import data, synth
+    from fragnet_amd.model import FragNetFineTune
+    batch = data.batch_to(data.collate_fn(synth.synth_molecules(4, seed=9, profile="esol")), DEV)
+    ei = batch["edge_index"]
+    perm = torch.arange(ei.shape[1] - 1, -1, -1, device=ei.device)          # reverse the bond order: bonds of molecule 0 now come last
+    batch["edge_index"] = ei[:, perm].contiguous()
+    batch["node_features_bonds"] = batch["node_features_bonds"][perm].contiguous()
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(perm.numel(), device=perm.device)
+    batch["edge_index_bonds_graph"] = inv[batch["edge_index_bonds_graph"]]
+    torch.manual_seed(0)
+    model = FragNetFineTune(n_classes=1, num_layer=1, drop_ratio=0.0, h1=16, h2=16, h3=16, h4=16, act="relu", fthead="FTHead3").to(DEV)
+    with torch.no_grad():
+        model(batch)
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError, match="molecule-contiguous"):
+        batch["_fragnet_plan"].check()

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--variant", default="gat2")
     ap.add_argument("--seed", type=int, default=1000)
+    ap.add_argument("--tune", action="append", default=[], help="KEY=VALUE for fn_set_tuning, timed after the comparison (fused on)")
     args = ap.parse_args()
     dev = "cuda:0"
     torch.manual_seed(0)
@@ -97,9 +98,37 @@ def main():
         a, f, b, fb = model.pretrain(batch)
         (a.sum() + f.sum()).backward()
 
+    def graphed(fn):
+        """GPU time of fn() replayed as a hipGraph (no host launch overhead), ms."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 20
+
     for fused in (0, 1):
         _lib.call("fn_set_tuning", FN_TUNE_FUSED, fused)
-        print(f"fused={fused}: forward {timeit(fwd):.3f} ms, forward+backward {timeit(fwdbwd):.3f} ms (eager, host-inclusive)")
+        print(f"fused={fused}: forward {timeit(fwd):.3f} ms, forward+backward {timeit(fwdbwd):.3f} ms (eager, host-inclusive); "
+              f"graphed forward {graphed(fwd):.3f} ms")
+    for spec in args.tune:
+        k, v = spec.split("=")
+        _lib.call("fn_set_tuning", int(k), int(v))
+        print(f"tune {k}={v}: graphed forward {graphed(fwd):.3f} ms")
 
 
 if __name__ == "__main__":

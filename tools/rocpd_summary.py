@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Per-kernel table from a rocprofv3 results .db (rocpd sqlite, the default output of rocprofv3 --kernel-trace on ROCm 7.2).
+
+usage: tools/rocpd_summary.py <..._results.db> [last_n_per_kernel] > profiles/rNN_kernel_trace_summary.md
+"""
+import re
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    base = name.split("(")[0]
+    if base.startswith("Cijk_"):
+        mt = re.search(r"MT\d+x\d+x\d+", base)
+        return "rocBLAS/hipBLASLt GEMM " + (mt.group(0) if mt else "")
+    if base.startswith("at::native::"):
+        f = re.search(r"(CUDAFunctor_add|FillFunctor|sum_functor|MulFunctor|[A-Za-z]+Functor[A-Za-z_]*|multi_tensor_apply_kernel|mse|threshold)", name)
+        return "torch " + base[len("at::native::"):].split("<")[0] + (":" + f.group(1) if f else "")
+    return base
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    disp = next(t for t in tabs if t.startswith("rocpd_kernel_dispatch"))
+    sym = next(t for t in tabs if t.startswith("rocpd_info_kernel_symbol"))
+    cols = [c[1] for c in cur.execute(f"pragma table_info({sym})")]
+    namecol = "kernel_name" if "kernel_name" in cols else ("display_name" if "display_name" in cols else cols[-1])
+    names = {r[0]: r[1] for r in cur.execute(f"select id, {namecol} from {sym}")}
+    rows = list(cur.execute(f"select kernel_id, start, end, grid_size_x, workgroup_size_x, private_segment_size, group_segment_size from {disp} order by start"))
+    per, per_grid, meta = defaultdict(list), defaultdict(list), {}
+    for kid, s, e, gx, wx, priv, lds in rows:
+        k = short(names.get(kid, str(kid)))
+        per[k].append(e - s)
+        per_grid[(k, gx // max(1, wx))].append(e - s)
+        meta[k] = (wx, priv, lds)
+    total = sum(sum(v) for v in per.values())
+    t0, t1 = min(r[1] for r in rows), max(r[2] for r in rows)
+    print(f"# {sys.argv[1]}\n")
+    print(f"dispatches: {len(rows)}; GPU busy {total/1e6:.2f} ms of {(t1-t0)/1e6:.2f} ms traced wall\n")
+    print("| kernel | calls | total ms | avg us | % busy | wg | scratch B | LDS B |")
+    print("|---|---|---|---|---|---|---|---|")
+    for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+        wx, priv, lds = meta[k]
+        print(f"| {k} | {len(v)} | {sum(v)/1e6:.3f} | {sum(v)/len(v)/1e3:.2f} | {100*sum(v)/total:.1f} | {wx} | {priv} | {lds} |")
+    print("\n## fragnet kernels by launch grid (workgroups)\n")
+    print("| kernel | grid | calls | avg us | min us | max us |")
+    print("|---|---|---|---|---|---|")
+    for (k, g), v in sorted(per_grid.items(), key=lambda kv: (kv[0][0], -kv[0][1])):
+        if k.startswith("k_"):
+            print(f"| {k} | {g} | {len(v)} | {sum(v)/len(v)/1e3:.2f} | {min(v)/1e3:.2f} | {max(v)/1e3:.2f} |")
+
+
+if __name__ == "__main__":
+    main()
