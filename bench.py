@@ -8,7 +8,9 @@ FTHead3 128/1024/1024/512, drop 0.1, fp32), synthetic data already resident in H
 
 A step = graph plan build + zero grads + forward + MSE loss + backward + (N>1: one flat-bucket
 gradient all-reduce over RCCL) + Adam step, on a batch the model has not seen in the previous step
-(a pool of pre-collated batches, seeds 1000+i).  Weak scaling: every rank owns 512 molecules per step.
+(a pool of pre-collated batches, seeds 1000+i).  `--scaling weak` (default): every rank owns 512 molecules per step;
+`--scaling strong`: the GLOBAL batch is 512 molecules (what SURVEY.md §8d quotes the metric on), split over the ranks
+by parallel.shard_indices (rank r owns molecules r::N of the same 512).  At N = 1 the two are the same run.
 
 Default mode "graph": the batch is staged into fixed-capacity buffers (one kernel; the few % of padding are
 disconnected dummy rows, see fragnet_amd/graphstep.py) and plan + forward + loss + backward + gradient gather
@@ -16,10 +18,14 @@ replay as ONE hipGraph; all-reduce and Adam follow on the stream.  `--eager` run
 (hipGraph only around the prediction head).  Both count only the 512 real molecules per step.
 
 Besides the contract fields the JSON line carries
-  roofline      for the dominant scatter kernel (bond-graph level, the largest of the four): algorithmic
-                bytes (SURVEY.md §8d closed form on this batch's n, m) / launch time, measured here with
-                HIP events on the launch stream over back-to-back launches on a resident batch
-  cpu_baseline  the oracle (reference-faithful pure-torch restatement) timed on this host's cores.
+  roofline      for the dominant scatter work (bond-graph level, the largest of the four): algorithmic bytes (SURVEY.md
+                §8d closed forms B_agg / B_agg' on this batch's n, m -- the backward counted ONCE for its two passes
+                together) / launch time, measured here with HIP events on the launch stream over back-to-back launches
+                on a resident batch ("standalone"); "in_graph" uses the per-kernel durations of the replayed step from the
+                committed rocprof summary named in `in_graph.source`; `traffic` comes from the PMC file named in
+                `traffic_source` (not collected in this run)
+  cpu_baseline  the oracle (reference-faithful pure-torch restatement) timed on this host's cores (BASELINE.md §3:
+                1 thread and all cores, 2 warm-up + 5 timed steps, median, CPU model named).
 """
 import argparse
 import json
@@ -71,17 +77,36 @@ def step_bytes(batch):
     return total
 
 
-def make_pool(n_batches, rank, device, batch=PER_GPU_BATCH):
-    from fragnet_amd import data, synth
+def make_pool(n_batches, rank, device, batch=PER_GPU_BATCH, world=1, scaling="weak"):
+    """weak: ``batch`` molecules per rank, rank-specific seeds.  strong: the same ``batch`` molecules on every rank (seeds do
+    not depend on the rank), of which this rank collates its shard parallel.shard_indices(batch, rank, world)."""
+    from fragnet_amd import data, parallel, synth
     pool = []
     for i in range(n_batches):
-        mols = synth.synth_molecules(batch, seed=1000 + 97 * rank + i, profile="esol")
+        if scaling == "strong" and world > 1:
+            mols = synth.synth_molecules(batch, seed=1000 + i, profile="esol")
+            mols = [mols[j] for j in parallel.shard_indices(len(mols), rank, world)]
+        else:
+            mols = synth.synth_molecules(batch, seed=1000 + 97 * rank + i, profile="esol")
         pool.append(data.batch_to(data.collate_fn(mols), device))
     return pool
 
 
-def cpu_baseline(budget_s=25.0):
-    """Oracle (reference-faithful CPU path), same model, same step, bounded sample."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(budget_s=28.0):
+    """Oracle (reference-faithful CPU path), same model, same step.  BASELINE.md §3 protocol on a bounded sample: at the
+    reference's own CPU batch (32 molecules, BASELINE configs[0]) 2 warm-up + 5 timed steps, median, with 1 thread and with
+    all cores; at the headline batch (512) as many all-core steps as the remaining budget allows (at least one)."""
+    import statistics
     from fragnet_amd import data, synth
     from oracle import fragnet_ref as ref
     torch.manual_seed(0)
@@ -95,20 +120,34 @@ def cpu_baseline(budget_s=25.0):
         loss.backward()
         opt.step()
 
-    step(data.collate_fn(synth.synth_molecules(32, seed=999, profile="esol")))      # warm-up, untimed
+    t_all = time.perf_counter()
+    all_cores = torch.get_num_threads()
+    small = data.collate_fn(synth.synth_molecules(32, seed=999, profile="esol"))
+    b32 = {}
+    for threads in (all_cores, 1):
+        torch.set_num_threads(threads)
+        for _ in range(2):
+            step(small)
+        times = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            step(small)
+            times.append(time.perf_counter() - t0)
+        b32[f"threads_{threads}"] = {"median_s_per_step": round(statistics.median(times), 4),
+                                     "molecules_per_s": round(32 / statistics.median(times), 1)}
+    torch.set_num_threads(all_cores)
     batch = data.collate_fn(synth.synth_molecules(PER_GPU_BATCH, seed=1000, profile="esol"))
     times = []
-    t_all = time.perf_counter()
-    while len(times) < 3 and (time.perf_counter() - t_all) < budget_s:
+    while not times or (len(times) < 5 and (time.perf_counter() - t_all) + statistics.median(times) < budget_s):
         t0 = time.perf_counter()
         step(batch)
         times.append(time.perf_counter() - t0)
-    best = min(times)
-    return {"value": round(PER_GPU_BATCH / best, 2), "unit": "molecules/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{len(times)} training step(s) of one ESOL-shape batch of {PER_GPU_BATCH} (best of {len(times)}, "
-                      f"{best:.2f} s/step) after a 32-molecule warm-up; oracle/fragnet_ref.py, torch {torch.__version__} CPU",
-            "host_cpus": os.cpu_count()}
+    med = statistics.median(times)
+    return {"value": round(PER_GPU_BATCH / med, 2), "unit": "molecules/s", "cores": all_cores, "kind": "port",
+            "sample": f"{len(times)} all-core training step(s) of one ESOL-shape batch of {PER_GPU_BATCH} (median {med:.2f} s/step; "
+                      f"the first doubles as warm-up) + 2 warm-up / 5 timed steps of a 32-molecule batch at 1 and {all_cores} threads; "
+                      f"oracle/fragnet_ref.py, torch {torch.__version__} CPU",
+            "batch_32": b32, "cpu_model": _cpu_model(), "host_cpus": os.cpu_count()}
 
 
 def kernel_roofline(batch, model, iters=50):
@@ -151,10 +190,11 @@ def kernel_roofline(batch, model, iters=50):
                   att.data_ptr(), 96, 0, 64, C.byref(lv.c), g_h.data_ptr(), part_a.data_ptr(), C.byref(n_a), H, st)
 
     D = 128
-    fwd_b = 4 * ((n + 1) + m + m * H + 2 * n * H + n * D + n * D + m * H)
-    # backward split of B_agg' (§8d) over the two passes: each operand read once, each result written once
-    bwd_dst_b = 4 * (2 * n * D + m * H + m + m * H + n * H)            # g_out, h, probs, idx -> dz, g_s_dst (as in §8d)
-    bwd_src_b = 4 * (2 * n * D + 2 * m * H + m + n * H + n * D)        # g_out, h, probs, dz, idx, g_s_dst -> g_h
+    fwd_b, bwd_b = level_bytes(n, m, H, D)         # B_agg (forward), B_agg' (the WHOLE backward of the level)
+    # B_agg' counts g_out and h once.  The two passes both read them, so per-pass figures are only a split of B_agg' for
+    # orientation (dst pass: g_out, h, probs, idx -> dz, g_s_dst; src pass: the rest); the roofline uses the sum over both.
+    bwd_dst_b = 4 * (2 * n * D + m * H + m + m * H + n * H)
+    bwd_src_b = bwd_b - bwd_dst_b
     res = {}
     fwd()
     for name, fn, nbytes in (("k_gat_fwd", fwd, fwd_b), ("k_gat_bwd_dst", bwd_dst, bwd_dst_b), ("k_gat_bwd_src", bwd_src, bwd_src_b)):
@@ -170,6 +210,9 @@ def kernel_roofline(batch, model, iters=50):
         us = a.elapsed_time(b) * 1000.0 / iters
         res[name] = {"us_per_launch": round(us, 2), "algorithmic_bytes": nbytes, "GBps": round(nbytes / us / 1e3, 1),
                      "n": n, "m": m}
+    us_bwd = res["k_gat_bwd_dst"]["us_per_launch"] + res["k_gat_bwd_src"]["us_per_launch"]
+    res["k_gat_bwd(dst+src)"] = {"us_per_launch": round(us_bwd, 2), "algorithmic_bytes": bwd_b, "GBps": round(bwd_b / us_bwd / 1e3, 1),
+                                 "n": n, "m": m}
     return res
 
 
@@ -219,6 +262,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-collated batches cycled through")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: 512 molecules per rank and step; strong: 512 molecules per step in total, sharded over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch-by-launch step instead of the whole-step hipGraph")
@@ -267,7 +312,9 @@ def main():
     if args.forward_sweep:
         forward_sweep(rank, world, dev, args)
         return
-    pool = make_pool(1, rank, dev, args.kbatch) if args.kernels_only else make_pool(args.pool, rank, dev)
+    pool = make_pool(1, rank, dev, args.kbatch) if args.kernels_only else make_pool(args.pool, rank, dev, PER_GPU_BATCH, world, args.scaling)
+    local_batch = int(pool[0]["y"].shape[0])
+    global_batch = PER_GPU_BATCH if args.scaling == "strong" else PER_GPU_BATCH * world
     if args.model_version == "gat2_edge":      # gat2_edge.py:46 wants 8 connection features, the featuriser writes 6
         for b in pool:
             b["cnx_attr"] = torch.nn.functional.pad(b["cnx_attr"], (0, 8 - b["cnx_attr"].shape[1]))
@@ -305,7 +352,7 @@ def main():
                 gstep, capture_note = None, "another rank could not capture the step; eager step"
     if gstep is None:
         args.eager = True
-        graphed_head = fragnet_amd.graph_capture_head(model, PER_GPU_BATCH) if not args.eager_head else False
+        graphed_head = fragnet_amd.graph_capture_head(model, local_batch) if not args.eager_head else False
 
         def step(i):
             opt.zero_grad()
@@ -336,17 +383,17 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        value = PER_GPU_BATCH * world * args.steps / elapsed
+        value = global_batch * args.steps / elapsed
         sb = step_bytes(pool[0])
         line = {
-            "metric": "molecules/sec fwd+bwd (full training step), ESOL-shape batch=512 per GPU",
+            "metric": "molecules/sec fwd+bwd (full training step), ESOL-shape batch=512 " + ("per GPU" if args.scaling == "weak" else "global"),
             "value": round(value, 1), "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"model_version": args.model_version,
                        "workload": "ESOL finetune batch=512 fp32 (BASELINE configs[1]): FragNetFineTune 4 layers x 4 heads, "
                                    "emb 128, FTHead3 128/1024/1024/512, drop 0.1; synthetic ESOL-shape molecules (synth.py)",
-                       "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world, "parallelism": f"dp{world}",
+                       "per_gpu_batch": local_batch, "global_batch": global_batch, "parallelism": f"dp{world}",
                        "mode": "eager launches, head " + ("hipGraph-captured" if graphed_head else "eager") if args.eager else
                                ("two hipGraphs over static shapes (stage+plan+fwd+mse+head bwd | encoder bwd); the head's gradient "
                                 "all-reduce runs beside the second" if gstep.split else
@@ -364,18 +411,45 @@ def main():
         }
         if not args.no_roofline:
             kr = kernel_roofline(pool[0], model)
-            kr = {k: v for k, v in kr.items() if not k.startswith("_")}
-            dom = max(kr, key=lambda k: kr[k]["us_per_launch"])
-            traffic = None
+            passes = ("k_gat_fwd", "k_gat_bwd(dst+src)")
+            dom = max(passes, key=lambda k: kr[k]["us_per_launch"])
+            traffic, traffic_source = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_per_launch.json")
             if os.path.exists(pmc):
-                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                parts = ("k_gat_fwd",) if dom == "k_gat_fwd" else ("k_gat_bwd_dst", "k_gat_bwd_src")
+                if all(k in pj for k in parts):
+                    traffic = sum(pj[k]["hbm_bytes_per_launch"] for k in parts)
+                    traffic_source = ("profiles/pmc_per_launch.json (" + pj.get("_collected", "round 1, profiles/r01g; kernels unchanged since") +
+                                      "): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --kernels-only`, NOT this run")
             line["roofline"] = {"bound": "hbm", "kernel": dom + "<4> @ bond-graph level", "achieved": kr[dom]["GBps"],
                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(kr[dom]["GBps"] / HBM_PEAK_GBPS, 4),
-                                "traffic": traffic, "us_per_launch": kr[dom]["us_per_launch"],
+                                "traffic": traffic, "traffic_source": traffic_source, "us_per_launch": kr[dom]["us_per_launch"],
                                 "algorithmic_bytes_per_launch": kr[dom]["algorithmic_bytes"],
-                                "method": "50 back-to-back launches, HIP events on the launch stream", "all": kr}
-            # extra evidence (not part of the contract): the same three kernels on a 2048-molecule batch, where a launch
+                                "bytes_model": "SURVEY.md 8d: B_agg = 4[(n+1)+m+mH+2nH+nD+nD+mH] forward; B_agg' = 4[2nD+2mH+2m+nD+mH+2nH] for "
+                                               "the whole backward of the level (destination + source pass together)",
+                                "method": "standalone: 50 back-to-back launches, HIP events on the launch stream",
+                                "standalone": {k: {"us": kr[k]["us_per_launch"], "GBps": kr[k]["GBps"],
+                                                   "frac": round(kr[k]["GBps"] / HBM_PEAK_GBPS, 4)} for k in passes},
+                                "all": kr}
+            ig = os.path.join(ROOT, "profiles", "in_graph_kernels.json")       # tools/rocpd_summary.py --json of the replayed step
+            if os.path.exists(ig):
+                gj = json.load(open(ig))
+                ks = gj.get("kernels", {})
+                # inside the step the bond and fragment-bond levels share a launch (k_gat_*_pair): bytes of both levels
+                fb_n, fb_m = int(pool[0]["node_features_fbonds"].shape[0]), int(pool[0]["edge_index_fbonds"].shape[1])
+                f2, b2 = level_bytes(fb_n, fb_m)
+                nb, mb = kr["k_gat_fwd"]["n"], kr["k_gat_fwd"]["m"]
+                f1, b1 = level_bytes(nb, mb)
+                inside = {}
+                if "k_gat_fwd_pair" in ks:
+                    us = ks["k_gat_fwd_pair"]["avg_us"]
+                    inside["k_gat_fwd_pair"] = {"us": us, "frac": round((f1 + f2) / us / 1e3 / HBM_PEAK_GBPS, 4)}
+                if "k_gat_bwd_dst_pair" in ks and "k_gat_bwd_src_pair" in ks:
+                    us = ks["k_gat_bwd_dst_pair"]["avg_us"] + ks["k_gat_bwd_src_pair"]["avg_us"]
+                    inside["k_gat_bwd_pair(dst+src)"] = {"us": round(us, 2), "frac": round((b1 + b2) / us / 1e3 / HBM_PEAK_GBPS, 4)}
+                line["roofline"]["in_graph"] = {"source": "profiles/in_graph_kernels.json <- " + gj.get("source", "?"), **inside}
+            # extra evidence (not part of the contract): the same kernels on a 2048-molecule batch, where a launch
             # is long enough for the per-launch fixed cost (~4 us) not to dominate
             big = make_pool(1, rank, dev, 2048)[0]
             kb = kernel_roofline(big, model, iters=20)

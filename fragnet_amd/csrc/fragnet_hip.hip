@@ -2053,6 +2053,7 @@ __global__ __launch_bounds__(kLinThreads) void k_linear128(const float* __restri
 // up to three independent [M_i,K]·[K,128] products in one launch: the three projections of a layer (forward) or
 // their three input-gradient products (backward) depend only on the previous layer, never on each other
 struct LinTask {
+    const float* Wn;          // the same weight n-major ([128 n][K]) for k_proj128; null: only the k_linear128 form is available
     const float *X, *Bt, *bias;
     float* Y;
     int64_t M;
@@ -2106,6 +2107,7 @@ __global__ void k_transpose_many(TransposeMany tm, float* __restrict__ bt_base) 
 }
 
 #include "mol_fused.inc"
+#include "proj128.inc"
 
 // Everything the encoder's forward pass needs before its first projection, none of which depends on the other: W^T of
 // every projection, dropout of the atom features, and the permutation of the two raw edge-attribute tensors into
@@ -2456,7 +2458,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 namespace {
 unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
 int64_t g_mol_stamps_n = 0;
-int g_tune[FN_TUNE_COUNT] = {1792, 0, 0, 512, 0, 0};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
+int g_tune[FN_TUNE_COUNT] = {1792, 0, 0, 512, 0, 0, 0};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -2494,7 +2496,41 @@ int launch_linear128(const float* X, int K, const float* Bt, const float* bias, 
     return 0;
 }
 // grouped launch for K == 128 (every projection beyond layer 0 and every input-gradient product)
+int launch_proj128_group(const LinTasks& T, hipStream_t st) {
+    ProjTasks P{};
+    int blocks = 0;
+    for (int i = 0; i < T.n; ++i) {
+        const LinTask& s = T.t[i];
+        if (s.M <= 0) continue;
+        ProjTask& t = P.t[P.n++];
+        t.X = s.X;  t.Wn = s.Wn;  t.bias = s.bias;  t.Y = s.Y;  t.M = s.M;  t.ns = s.ns;
+        t.gate_y = s.mk.y;
+        t.gate_scale = s.mk.p > 0.f ? (s.mk.p < 1.f ? 1.f / (1.f - s.mk.p) : 0.f) : 1.f;
+        t.first_block = blocks;
+        t.n_blocks = (int)((s.M + kProjRows - 1) / kProjRows);
+        blocks += t.n_blocks;
+    }
+    if (!P.n) return 0;
+    P.total_blocks = blocks;
+    const int cap = g_tune[FN_TUNE_PROJ] > 1 ? g_tune[FN_TUNE_PROJ] : 768;     // persistent workgroups (three per CU by default)
+    const int grid = blocks < cap ? blocks : cap;
+    hipLaunchKernelGGL(k_proj128, dim3(grid), dim3(kProjThreads), (size_t)kProjRows * FN_D * sizeof(float), st, P);
+    return launch_status("grouped projection GEMM (register-resident W)");
+}
+// can the register-resident-W kernel take this group?  (needs the n-major weights, 16-byte alignment, and a relu gate if any)
+bool proj128_ok(const LinTasks& T) {
+    if (!g_tune[FN_TUNE_PROJ]) return false;
+    for (int i = 0; i < T.n; ++i) {
+        const LinTask& s = T.t[i];
+        if (!s.Wn || (((uintptr_t)s.Wn | (uintptr_t)s.X | (uintptr_t)s.Y) & 15)) return false;
+        if (s.mk.y && !s.mk.relu) return false;
+        if (s.mk.y && ((uintptr_t)s.mk.y & 15)) return false;
+    }
+    return true;
+}
+
 int launch_linear128_group(LinTasks& T, hipStream_t st) {
+    if (proj128_ok(T)) return launch_proj128_group(T, st);
     constexpr int KQ = 32;
     const size_t lds = (size_t)(4 * KQ * kLinLd) * sizeof(float);
     int64_t total = 0;
@@ -3678,11 +3714,11 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         if (grouped) {
             LinTasks T{};
             T.n = no_fb ? 2 : 3;
-            T.t[0] = LinTask{in_bond, bt_b, w.proj_b_b, a.h_b, e->E, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
+            T.t[0] = LinTask{w.proj_b_w, in_bond, bt_b, w.proj_b_b, a.h_b, e->E, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
                              NodeScalarEpi{w.a_b, lay.s_dst, lay.s_src, 3 * d, 0, 2 * d, H}, 0, 0};
-            T.t[1] = LinTask{in_atoms, bt_a, w.proj_a_b, a.h_a, e->N, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
+            T.t[1] = LinTask{w.proj_a_w, in_atoms, bt_a, w.proj_a_b, a.h_a, e->N, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
                              NodeScalarEpi{w.a, lay.s_dst_a, lay.s_src_a, wide, 0, d + FN_D, H}, 0, 0};
-            T.t[2] = LinTask{in_fbond, bt_fb, w.proj_fb_b, a.h_fb, e->EF, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
+            T.t[2] = LinTask{w.proj_fb_w, in_fbond, bt_fb, w.proj_fb_b, a.h_fb, e->EF, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
                              NodeScalarEpi{w.f_a_b, lay.s_dst_fb, lay.s_src_fb, 3 * d, 0, 2 * d, H}, 0, 0};
             FN_TRY(launch_linear128_group(T, S(st)));
         } else {
@@ -3786,11 +3822,15 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         int n_a = 0, n_e = 0;
         // the three input-gradient products of a layer feed layer l-1 only: one grouped launch at the end of the layer
         LinTasks dxT{};
-        auto input_grad = [&](const float* gh, const float* W, float* gy, int64_t rows, const fn_act_epilogue& mk, fn_stream_t sq) -> int {
+        // Wt: the transposed copy the forward prologue left in the workspace (k_proj128 wants the weight n-major)
+        auto input_grad = [&](const float* gh, const float* W, const float* Wt, float* gy, int64_t rows, const fn_act_epilogue& mk, fn_stream_t sq) -> int {
             if (multi) return fn_linear128_f32(gh, FN_D, W, nullptr, gy, rows, &mk, sq);
-            dxT.t[dxT.n++] = LinTask{gh, W, nullptr, gy, rows, mk, NodeScalarEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0}, 0, 0};
+            dxT.t[dxT.n++] = LinTask{Wt, gh, W, nullptr, gy, rows, mk, NodeScalarEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0}, 0, 0};
             return 0;
         };
+        const float* bt_b = lay.bt + (size_t)(3 * l) * 192 * FN_D;
+        const float* bt_a = lay.bt + (size_t)(3 * l + 1) * 192 * FN_D;
+        const float* bt_fb = lay.bt + (size_t)(3 * l + 2) * 192 * FN_D;
 
         // ---- through act(dropout(.)): gradients of the pre-activation tensors.  For the last layer they come from
         // the caller's output gradients; for inner layers the input-gradient GEMMs of layer l+1 already wrote them
@@ -3874,7 +3914,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             FN_TRY(rq.wgrad(sa.g_h, in_atoms, ka, e->N, sa.wg_ws, g.proj_a_w, g.proj_a_b, S(st_leaf)));
             if (l) {
                 const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_atoms), p, 1, e->seed, rng.y[l - 1][0], e->offset_dev};
-                FN_TRY(input_grad(sa.g_h, w.proj_a_w, bw.g_pre_atoms, e->N, mk, st));
+                FN_TRY(input_grad(sa.g_h, w.proj_a_w, bt_a, bw.g_pre_atoms, e->N, mk, st));
                 nxt_atoms = true;
             }
         }
@@ -3908,7 +3948,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             if (have_fbond) {
                 if (l) {     // dL/d(pre-activation fbond output of layer l-1), gated by that layer's dropout mask and ReLU
                     const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_fbond), p, 1, e->seed, rng.y[l - 1][3], e->offset_dev};
-                    FN_TRY(input_grad(sfb.g_h, w.proj_fb_w, bw.g_pre_fbond, e->EF, mk, st_fb));
+                    FN_TRY(input_grad(sfb.g_h, w.proj_fb_w, bt_fb, bw.g_pre_fbond, e->EF, mk, st_fb));
                     nxt_fbond = true;
                 }
                 FN_TRY(rq.finalize(sfb.part_a, n_a_fb, sfb.part_e, n_e_fb, et_fb, w.f_a_b, 3 * d, 0, 2 * d, g.f_a_b, g.emb_fb_w, g.emb_fb_b, H));
@@ -3920,7 +3960,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
                 FN_TRY(rq.wgrad(sb.g_h, in_bond, kb, e->E, sb.wg_ws, g.proj_b_w, g.proj_b_b, S(st_leaf)));
                 if (l) {
                     const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_bond), p, 1, e->seed, rng.y[l - 1][2], e->offset_dev};
-                    FN_TRY(input_grad(sb.g_h, w.proj_b_w, bw.g_pre_bond, e->E, mk, st));
+                    FN_TRY(input_grad(sb.g_h, w.proj_b_w, bt_b, bw.g_pre_bond, e->E, mk, st));
                     nxt_bond = true;
                 }
             }

@@ -154,6 +154,8 @@ class BatchSampler:
     """``DataLoader(shuffle=..., drop_last=...)`` semantics over molecule indices, optionally one shard per rank."""
 
     def __init__(self, n: int, batch_size: int, shuffle: bool, drop_last: bool, seed: int = 0, rank: int = 0, world: int = 1):
+        if world > 1 and batch_size < world:
+            raise ValueError(f"batch_size {batch_size} < world size {world}: some ranks would get empty batches")
         self.n, self.bs, self.shuffle, self.drop_last = n, batch_size, shuffle, drop_last
         self.gen = torch.Generator().manual_seed(seed)
         self.rank, self.world = rank, world
@@ -164,7 +166,12 @@ class BatchSampler:
             chunk = order[b: b + self.bs]
             if chunk.numel() < self.bs and self.drop_last:
                 break
+            if self.world > 1 and chunk.numel() < self.world:
+                break           # a trailing chunk that cannot give every rank a molecule is dropped on ALL ranks (no rank may skip a collective)
             yield chunk[self.rank:: self.world] if self.world > 1 else chunk
 
     def __len__(self):
-        return self.n // self.bs if self.drop_last else (self.n + self.bs - 1) // self.bs
+        if self.drop_last:
+            return self.n // self.bs
+        full, rest = divmod(self.n, self.bs)
+        return full + (1 if rest and not (self.world > 1 and rest < self.world) else 0)

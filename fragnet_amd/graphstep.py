@@ -267,13 +267,19 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, opt, shapes: StaticShapes, example: Dict[str, torch.Tensor], loss: str = "regr",
-                 group=None, warmup: int = 3, overlap: Optional[bool] = None, capture_adam: bool = True):
+                 group=None, warmup: int = 3, overlap: Optional[bool] = None, capture_adam: bool = True,
+                 force_distributed: bool = False):
         """``overlap=True``: capture the step as TWO graphs -- (forward + loss + head backward) and (encoder backward) -- and
         start an asynchronous all-reduce of the head's gradients (83 % of the bytes for FTHead3) between them, so that it
         runs on RCCL's stream beside the encoder's backward pass; the encoder's own, small slice follows the second graph.
         Off by default: on this stack an async collective costs ~95 us of stream fork/join against ~20 us for a blocking
         one (tools/allreduce_probe.py), which eats what the overlap hides at 8 MB of gradients."""
         self.model, self.opt, self.shapes, self.group = model, opt, shapes, group
+        # force_distributed: run the N>1 step sequence (graph replay -> RCCL all-reduce -> Adam outside the graph, rank loss
+        # weights through an all-reduce) even in a 1-rank process group, so that one GPU can test it
+        self.force_distributed = bool(force_distributed)
+        if self.force_distributed:
+            opt.force_collective = True
         self.loss_kind = loss
         if loss not in ("regr", "clsf", "pretrain"):
             raise ValueError(f"unknown loss kind {loss!r}")
@@ -289,7 +295,7 @@ class GraphedTrainStep:
         self._counters = torch.zeros(2, dtype=torch.int64, device=self.device)
         self.rng.dev = self._counters[0:1]
         import torch.distributed as dist
-        single = not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1
+        single = (not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1) and not self.force_distributed
         # one rank, fused HIP Adam: the update is captured too (step count and learning rate live in device memory)
         self.adam_in_graph = bool(capture_adam) and single and getattr(opt, "opt", 1) is None
         self._lr_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -386,7 +392,7 @@ class GraphedTrainStep:
         inc = self._inc = torch.tensor([per_step, 1 if self.adam_in_graph else 0], dtype=torch.int64, device=self.device)      # kept alive: replays read it
         self._sync_adam_state()
         graph = torch.cuda.CUDAGraph()
-        off0 = self.rng.offset
+        off0 = self._rng_base = self.rng.offset
         if self.split:
             pool = torch.cuda.graph_pool_handle()
             with torch.cuda.graph(graph, pool=pool, capture_error_mode=_CAPTURE_MODE):
@@ -425,7 +431,8 @@ class GraphedTrainStep:
     def _rank_scales(self, batch) -> Optional[torch.Tensor]:
         """(per-edge, per-atom) loss weights local_count * world / global_count as a device tensor (no host sync)."""
         import torch.distributed as dist
-        if self.loss_kind != "pretrain" or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if self.loss_kind != "pretrain" or not (dist.is_available() and dist.is_initialized()) or \
+                (dist.get_world_size(self.group) == 1 and not self.force_distributed):
             return None
         local = torch.tensor([float(batch["dh_angl"].shape[0]), float(batch["bnd_angl"].shape[0])], device=self.device)
         total = local.clone()
@@ -434,6 +441,11 @@ class GraphedTrainStep:
 
     def _eager(self, batch):
         self.opt.zero_grad()
+        # draw from the same base offsets the captured step has baked in (the device counter, which the eager kernels add as
+        # well, makes them this step's own), then move the device counter past what was drawn: fallback steps and replays
+        # never share Philox blocks
+        host_after = self.rng.offset
+        self.rng.offset = self._rng_base
         if self.loss_kind == "pretrain":
             from .train import pretrain_loss
             sc = self._rank_scales(batch)
@@ -443,7 +455,21 @@ class GraphedTrainStep:
             w = torch.ones(batch["y"].shape[0], dtype=torch.float32, device=out.device)
             loss = self._masked(out, batch["y"], w)
         loss.backward()
-        self.opt.step(self.group)
+        if self.split:
+            # the ranks that replay the two graphs issue two slice all-reduces (head, then encoder): a rank that fell back to
+            # the eager step must issue the same collectives, in the same order and sizes
+            self.opt.gather_grads()
+            self.opt.all_reduce_slice(self.head_off, None, self.group)
+            self.opt.all_reduce_slice(0, self.head_off, self.group)
+            self.opt.apply_gathered(self.group, reduced=True)
+        else:
+            self.opt.step(self.group)
+        # Philox blocks this eager step drew are gone for the replays too: without this the fallback step and the replay after
+        # next would share dropout random numbers (the graph adds the device counter to offsets baked in at capture)
+        drawn = self.rng.offset - self._rng_base
+        if drawn:
+            self._counters[0] += drawn
+        self.rng.offset = host_after
         return loss.detach()
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:

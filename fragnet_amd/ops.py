@@ -41,10 +41,14 @@ def grad_slot(param):
 
 def grad_buffer(param, slot):
     """Where a hand-written backward writes d loss / d param: the parameter's slot of the optimiser's flat gradient
-    buffer when there is one and nothing has been accumulated yet (autograd then adopts the returned view as
-    ``param.grad`` and FlatAdam.gather_grads finds it in place), else a fresh tensor."""
-    if slot is not None and param.grad is None:
+    buffer when there is one, nothing has been accumulated yet and no other node of this backward pass has taken it
+    (autograd then adopts the returned view as ``param.grad`` and FlatAdam.gather_grads finds it in place), else a
+    fresh tensor.  The slot is handed out once per pass: a parameter that feeds two custom nodes (the model called on two
+    batches before one ``backward()``) would otherwise have both kernels write the same memory and autograd add the
+    tensor to its own alias (2 x the second gradient).  FlatAdam.zero_grad / gather_grads release the claims."""
+    if slot is not None and param.grad is None and not getattr(param, "_fn_slot_claimed", False):
         flat, off = slot
+        param._fn_slot_claimed = True
         return flat[off: off + param.numel()].view(param.shape)
     return torch.empty_like(param)
 

@@ -148,6 +148,7 @@ class FlatAdam:
             p._fn_grad_slot = (self.grad, off)
         self.hyper = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.steps = 0
+        self.force_collective = False      # True: issue the gradient collectives even in a 1-rank group (exercises the N>1 step on one GPU)
         if flat.is_cuda:      # one HIP kernel (fn_adam_f32) over the flat tensor
             self.exp_avg, self.exp_avg_sq, self.opt = torch.zeros_like(flat), torch.zeros_like(flat), None
         else:                 # CPU (gloo tests of the exchange logic): stock torch Adam on the flat tensor
@@ -170,6 +171,7 @@ class FlatAdam:
     def zero_grad(self):
         for p in self.params:
             p.grad = None
+            p._fn_slot_claimed = False          # ops.grad_buffer hands the flat slot out once per backward pass
 
     def gather_grads(self):
         missing = [i for i, p in enumerate(self.params) if p.grad is None]
@@ -187,6 +189,7 @@ class FlatAdam:
 
         for p, off in zip(self.params, self.offsets):
             n = p.numel()
+            p._fn_slot_claimed = False
             if n and p.grad.data_ptr() != base + off * es:
                 if run and off != run_end:      # alignment padding between the two: separate copies
                     flush()
@@ -200,8 +203,13 @@ class FlatAdam:
 
     _avg_ok = None           # does the backend's all-reduce take ReduceOp.AVG (RCCL does; learnt at the first call)
 
+    def _distributed(self, group=None) -> bool:
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(group) > 1 or self.force_collective
+
     def all_reduce(self, group=None):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not self._distributed(group):
             return
         if self.grad.is_cuda and FlatAdam._avg_ok is not False:
             try:
@@ -218,7 +226,7 @@ class FlatAdam:
     def all_reduce_slice(self, lo: int, hi: Optional[int], group=None, async_op: bool = False):
         """Average ``grad[lo:hi]`` across ranks; with ``async_op`` returns the work handle (None when there is nothing to
         do) so that the collective runs on RCCL's stream beside whatever the caller enqueues next."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not self._distributed(group):
             return None
         view = self.grad[lo:hi]
         if view.numel() == 0:

@@ -168,6 +168,15 @@ class TrainerFineTune:
             return self.loss_fn(out.view(-1), batch["y"])
         return self.loss_fn(out, batch["y"].view(out.shape))
 
+    @staticmethod
+    def _shard_scale(batch):
+        """local molecules * world / global molecules: rank-averaged gradients of per-rank MEAN losses then equal the gradient
+        of the global mean when a batch does not divide evenly over the ranks (1.0 on a single rank)."""
+        d = parallel.dist
+        if not (d.is_available() and d.is_initialized()) or d.get_world_size() == 1:
+            return 1.0
+        return parallel.weighted_loss_scale(batch["y"].shape[0], batch["y"].device)
+
     def train(self, model, loader, optimizer, scheduler=None, device=None, val_loader=None, graph_step=None):
         """``optimizer``: torch.optim.Optimizer or parallel.FlatAdam.  ``graph_step``: a graphstep.GraphedTrainStep over
         the same model and optimiser -- every batch then costs one staging kernel, one hipGraph replay and the Adam
@@ -181,7 +190,8 @@ class TrainerFineTune:
                 continue
             optimizer.zero_grad()
             loss = self._loss(model, batch)
-            loss.backward()
+            scale = self._shard_scale(batch)
+            (loss * scale if scale != 1.0 else loss).backward()
             optimizer.step()
             losses.append(loss.detach())
         if losses:
@@ -198,7 +208,9 @@ class TrainerFineTune:
 
     @torch.no_grad()
     def test(self, model, loader, device=None):
-        """regr: (mse, true, pred); clsf: (mean ROC-AUC over tasks with both classes, true, pred)."""
+        """regr: (mse, true, pred); clsf: (-mean ROC-AUC over tasks with both classes, true, pred) -- a LOSS, lower is
+        better, exactly as the reference's test_clsf_bce returns it (train/utils.py:494-521), so a reference-style
+        ``early_stopping(val_loss, model)`` loop keeps the best model."""
         model.eval()
         true, pred = [], []
         for batch in loader:
@@ -214,7 +226,7 @@ class TrainerFineTune:
             ok = t[:, c] > -0.5
             if ok.any() and len(np.unique(t[ok, c])) == 2:
                 aucs.append(roc_auc_score(t[ok, c], p[ok, c]))
-        return float(np.mean(aucs)) if aucs else float("nan"), t, p
+        return -float(np.mean(aucs)) if aucs else float("nan"), t, p
 
 
 class PretrainTrainer:

@@ -57,7 +57,10 @@ int fn_abi_version(void);
                                 * kernels -- measured on MI355X the fused kernel only matches them at 512 molecules */
 #define FN_TUNE_MOL_SKEW 5     /* fused kernels: workgroups with bit (value - 1) of their index set run the fragment-bond level FIRST in
                                 * every layer, so that the two workgroups of a CU are in different phases (MFMA vs. VALU); 0 = off */
-#define FN_TUNE_COUNT 6
+#define FN_TUNE_PROJ 6         /* > 0: the 128 -> 128 projections and their input-gradient products inside fn_encoder_* run as k_proj128
+                                * (W pieces register-resident, X staged in LDS, persistent workgroups; value > 1 = workgroup cap);
+                                * 0 (default): k_linear128 -- measured 1-4 % faster per step on MI355X */
+#define FN_TUNE_COUNT 7
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * molecules 64-bit words) is
  * set, every workgroup of the fused molecule kernels writes s_memtime stamps of its phases into it (tools/mol_phase_times.py).

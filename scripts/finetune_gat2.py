@@ -84,8 +84,7 @@ if __name__ == "__main__":
             print("epoch: ", epoch, train_loss, val_loss, "" if graph_step is None else f"(graph replays {graph_step.replays}, eager fallbacks {graph_step.fallbacks})")
             log.write(json.dumps({"epoch": epoch, "Loss/train": train_loss, "Loss/val": val_loss}) + "\n")
             log.flush()
-        score = -val_loss if ft.target_type == "clsf" else val_loss      # AUC: higher is better
-        stopper(score, model) if rank == 0 else None
+        stopper(val_loss, model) if rank == 0 else None       # clsf: test() returns -AUC, a loss like the reference's test_clsf_bce
         stop = torch.tensor([int(stopper.early_stop)], device=device)
         if world > 1:
             torch.distributed.broadcast(stop, 0)
@@ -96,4 +95,4 @@ if __name__ == "__main__":
         model.load_state_dict(torch.load(ft.chkpoint_name, map_location=device))
         for name, loader in (("val_res", val_loader), ("test_res", test_loader)):
             acc = train.save_predictions(trainer, loader, model, exp_dir, name, ft.loss, args.seed)
-            print(f"{name} {'rmse' if ft.loss == 'mse' else 'auc'}: {acc}")
+            print(f"{name} {'rmse' if ft.loss == 'mse' else '-auc'}: {acc}")

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Per-kernel table from a rocprofv3 results .db (rocpd sqlite, the default output of rocprofv3 --kernel-trace on ROCm 7.2).
 
-usage: tools/rocpd_summary.py <..._results.db> [last_n_per_kernel] > profiles/rNN_kernel_trace_summary.md
+usage: tools/rocpd_summary.py <..._results.db> > profiles/rNN_kernel_trace_summary.md
+       tools/rocpd_summary.py <..._results.db> --json "<what was profiled>" > profiles/in_graph_kernels.json
 """
+import json
 import re
 import sqlite3
 import sys
@@ -10,6 +12,9 @@ from collections import defaultdict
 
 
 def short(name):
+    m = re.match(r"_ZN\d+_GLOBAL__N_1\d+(k_[a-z0-9_]+)", name)       # mangled kernels of libfragnet_hip: keep the base name
+    if m:
+        return m.group(1)
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
     base = name.split("(")[0]
@@ -40,6 +45,10 @@ def main():
         meta[k] = (wx, priv, lds)
     total = sum(sum(v) for v in per.values())
     t0, t1 = min(r[1] for r in rows), max(r[2] for r in rows)
+    if len(sys.argv) > 2 and sys.argv[2] == "--json":
+        print(json.dumps({"source": sys.argv[3] if len(sys.argv) > 3 else sys.argv[1],
+                          "kernels": {k: {"calls": len(v), "avg_us": round(sum(v) / len(v) / 1e3, 2)} for k, v in sorted(per.items())}}, indent=1))
+        return
     print(f"# {sys.argv[1]}\n")
     print(f"dispatches: {len(rows)}; GPU busy {total/1e6:.2f} ms of {(t1-t0)/1e6:.2f} ms traced wall\n")
     print("| kernel | calls | total ms | avg us | % busy | wg | scratch B | LDS B |")
