@@ -256,6 +256,64 @@ def forward_sweep(rank, world, dev, args):
         torch.distributed.destroy_process_group()
 
 
+def forward_sweep_store(rank, world, dev, args):
+    """BASELINE configs[4] end to end: a FlatMolStore of ``--store`` synthetic 40-atom / 12-fragment molecules resident in
+    HBM; every step = GPU collate of a fresh batch (StoreLoader, shuffled) + plan build + forward (eval mode).  Reports
+    molecules/s for the whole pipeline and the share of the time spent in collate (timed alone over the same index lists).
+    The store is ``distinct`` generated molecules replicated (the generator is Python: ~1.5 ms per molecule)."""
+    from fragnet_amd import synth
+    from fragnet_amd.dataset import FlatMolStore
+    from fragnet_amd.model import FragNetFineTune
+    from fragnet_amd.train import StoreLoader
+    torch.manual_seed(0)
+    model = FragNetFineTune(**MODEL_CFG).to(dev).eval()
+    distinct = min(args.store, 8192)
+    reps = max(1, args.store // distinct)
+    t0 = time.perf_counter()
+    base = FlatMolStore.from_records(synth.synth_molecules(distinct, seed=7000 + rank, profile="synth40")).to(dev)
+    store = base.replicate(reps)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    store_gb = (sum(v.numel() * v.element_size() for v in store.t.values()) + sum(v.numel() * 8 for v in store.off.values())) / 1e9
+    for B in (2048, 8192):
+        steps = max(4, min(args.steps, len(store) // B))
+        loader = StoreLoader(store, B, shuffle=True, drop_last=True, seed=11 + rank)
+        it = iter(loader.sampler)
+        idx_lists = [next(it).to(dev) for _ in range(steps + 2)]
+        with torch.no_grad():
+            for idx in idx_lists[:2]:
+                model(store.collate(idx))
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for idx in idx_lists[2:]:
+                model(store.collate(idx))
+            torch.cuda.synchronize()
+            total = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            for idx in idx_lists[2:]:
+                store.collate(idx)
+            torch.cuda.synchronize()
+            coll = time.perf_counter() - t0
+        if world > 1:
+            torch.distributed.barrier()
+        el = torch.tensor([total, coll], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+        if rank == 0:
+            total, coll = float(el[0]), float(el[1])
+            print(json.dumps({"metric": "molecules/sec forward only (eval) from a resident store: collate + plan + forward",
+                              "value": round(B * world * steps / total, 1), "unit": "molecules/s", "n_gpus": world,
+                              "per_gpu_batch": B, "steps": steps, "ms_per_step": round(total / steps * 1e3, 3),
+                              "collate_ms_per_step": round(coll / steps * 1e3, 3), "collate_share": round(coll / total, 3),
+                              "store_molecules": len(store), "store_distinct_molecules": distinct, "store_GB": round(store_gb, 2),
+                              "store_build_s": round(build_s, 1), "dtype": "f32", "data": "synthetic (synth40 profile)", "scaling": "weak"}),
+                  flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,6 +336,9 @@ def main():
                          "graph, per-level launches; cnx_attr widened to the 8 columns that model version expects)")
     ap.add_argument("--forward-sweep", action="store_true",
                     help="extra (BASELINE configs[4]): forward-only eval throughput on 40-atom/12-fragment molecules, one line per batch size")
+    ap.add_argument("--store", type=int, default=0,
+                    help="with --forward-sweep: molecules in a FlatMolStore resident in HBM (1048576 = config[4] as written); every "
+                         "step then collates a fresh shuffled batch on the GPU before plan + forward")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="A/B: library heuristics for the head GEMMs instead of TunableOp")
     ap.add_argument("--tune", action="append", default=None, help="A/B: KEY=VALUE for fn_set_tuning (include/fragnet_hip.h FN_TUNE_*)")
     ap.add_argument("--scatter-blocks", type=int, default=None, help="A/B: resident workgroups of the scatter kernels (FN_TUNE_FWD_BLOCKS)")
@@ -310,7 +371,7 @@ def main():
     torch.cuda.set_device(dev)
 
     if args.forward_sweep:
-        forward_sweep(rank, world, dev, args)
+        (forward_sweep_store if args.store > 0 else forward_sweep)(rank, world, dev, args)
         return
     pool = make_pool(1, rank, dev, args.kbatch) if args.kernels_only else make_pool(args.pool, rank, dev, PER_GPU_BATCH, world, args.scaling)
     local_batch = int(pool[0]["y"].shape[0])

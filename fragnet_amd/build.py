@@ -1,6 +1,12 @@
-"""Builds libfragnet_hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+"""Builds libfragnet_hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU).
+
+Staleness is decided by CONTENT: the SHA-256 of every source / header / include file plus the compile command is stored
+next to the library (``libfragnet_hip.so.sha256``); a checkout whose library merely looks newer than its sources (archive
+extraction, a snapshot copied to another box) is rebuilt when the digests disagree."""
 from __future__ import annotations
 
+import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -9,8 +15,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SOURCES = [os.path.join(HERE, "csrc", "fragnet_hip.hip")]
+INCLUDED = sorted(glob.glob(os.path.join(HERE, "csrc", "*.inc")))          # #include'd into the one translation unit
 HEADERS = [os.path.join(ROOT, "include", "fragnet_hip.h")]
 OUT = os.path.join(HERE, "lib", "libfragnet_hip.so")
+STAMP = OUT + ".sha256"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"]
 
 
 def _hipcc() -> str:
@@ -20,24 +29,35 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (expected on PATH or at /opt/rocm/bin/hipcc)")
 
 
+def source_digest() -> str:
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    for p in SOURCES + INCLUDED + HEADERS:
+        h.update(os.path.relpath(p, ROOT).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def stale() -> bool:
-    if not os.path.exists(OUT):
+    if not (os.path.exists(OUT) and os.path.exists(STAMP)):
         return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+    with open(STAMP) as f:
+        return f.read().strip() != source_digest()
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-I", os.path.join(ROOT, "include"), *SOURCES, "-o", OUT]
+    cmd = [_hipcc(), *FLAGS, "-I", os.path.join(ROOT, "include"), *SOURCES, "-o", OUT]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
+    with open(STAMP, "w") as f:
+        f.write(source_digest() + "\n")
     return OUT
 
 

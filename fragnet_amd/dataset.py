@@ -84,6 +84,19 @@ class FlatMolStore:
         store = cls(blob["tensors"], blob["offsets"], blob["y"], blob.get("smiles"))
         return store.to(device) if device is not None else store
 
+    def replicate(self, k: int) -> "FlatMolStore":
+        """A store holding ``k`` back-to-back copies of every molecule (molecule i of copy j = index j * n + i): builds the
+        million-molecule stores of the throughput sweeps from a few thousand distinct synthetic molecules."""
+        if k < 1:
+            raise ValueError("replicate: k must be >= 1")
+        tensors = {f: (v.repeat(1, k) if f in _COL_FIELDS else v.repeat((k,) + (1,) * (v.dim() - 1))) for f, v in self.t.items()}
+        offsets = {}
+        for space, off in self.off.items():
+            total = off[-1]
+            offsets[space] = torch.cat([off[:1]] + [off[1:] + j * total for j in range(k)])
+        y = self.y.repeat((k,) + (1,) * (self.y.dim() - 1))
+        return FlatMolStore(tensors, offsets, y, None if self.smiles is None else self.smiles * k)
+
     DERIVED = ("edge_index_bonds", "edge_index_fbondg", "edge_attr_fbondg")
 
     def without_bond_graph_index(self) -> "FlatMolStore":
@@ -175,3 +188,24 @@ class BatchSampler:
             return self.n // self.bs
         full, rest = divmod(self.n, self.bs)
         return full + (1 if rest and not (self.world > 1 and rest < self.world) else 0)
+
+
+# ---------------------------------------------------------------------------------------- pickled datasets
+def load_pickle_dataset(path):
+    """A pickled list of per-molecule records (the reference's on-disk format, dataset/dataset.py:273-277): entries the
+    featuriser rejected are stored as None / empty and dropped here.  Unpickling torch_geometric ``Data`` items needs
+    torch_geometric installed; plain records (synth.MolRecord) need nothing."""
+    import pickle
+    with open(path, "rb") as f:
+        items = pickle.load(f)
+    return [it for it in items if it]
+
+
+def load_data_parts(path, select_name=None):
+    """Concatenation of every pickled part file in ``path`` whose name contains ``select_name`` (dataset/dataset.py:280-292)."""
+    import os
+    names = sorted(n for n in os.listdir(path) if not select_name or select_name in n)
+    out = []
+    for n in names:
+        out += load_pickle_dataset(os.path.join(path, n))
+    return out

@@ -180,7 +180,11 @@ class FragNetLayerEdge(nn.Module):
         if num_heads not in (1, 2, 4, 8):
             raise ValueError("num_heads must be 1, 2, 4 or 8")
         if add_frag_self_loops:
-            raise NotImplementedError("gat2_edge with add_frag_self_loops=True (never set by the reference's drivers)")
+            # the reference cannot run this option either: gat2_edge.py:144-156 appends the loop edges to frag_index but not to
+            # the connection attributes, and its forward dies with a RuntimeError (shape mismatch in torch.cat; recorded in
+            # tests/golden/head5_direct.npz).  NotImplementedError is a RuntimeError.
+            raise NotImplementedError("gat2_edge with add_frag_self_loops=True fails in the reference too (gat2_edge.py:144-156: "
+                                      "no connection attributes for the loop edges); never set by its drivers")
         self.add_frag_self_loops = add_frag_self_loops
         self.return_attentions = return_attentions
         self.edge_out = edge_out

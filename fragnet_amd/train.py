@@ -152,6 +152,13 @@ class StoreLoader:
 
 
 # ------------------------------------------------------------------------------------ trainers
+def _on(batch, device):
+    """The reference's trainers move every batch to ``device`` themselves (train/utils.py:335-336); so do these."""
+    if device is None or batch["x_atoms"].device == torch.device(device):
+        return batch
+    return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
 class TrainerFineTune:
     def __init__(self, target_pos=None, target_type="regr", n_multi_task_heads=0):
         self.target_type = target_type
@@ -185,6 +192,7 @@ class TrainerFineTune:
         total = 0.0
         losses = []
         for batch in loader:
+            batch = _on(batch, device)
             if graph_step is not None:
                 losses.append(graph_step(batch).clone())
                 continue
@@ -203,7 +211,7 @@ class TrainerFineTune:
     @torch.no_grad()
     def validate(self, model, loader, device=None):
         model.eval()
-        losses = [self._loss(model, batch) for batch in loader]
+        losses = [self._loss(model, _on(batch, device)) for batch in loader]
         return float(torch.stack(losses).sum()) / len(loader.dataset) if losses else 0.0
 
     @torch.no_grad()
@@ -214,6 +222,7 @@ class TrainerFineTune:
         model.eval()
         true, pred = [], []
         for batch in loader:
+            batch = _on(batch, device)
             out = model(batch)
             true.append(batch["y"].reshape(out.shape[0], -1).cpu())
             pred.append(out.reshape(out.shape[0], -1).cpu())
@@ -237,6 +246,7 @@ class PretrainTrainer:
         model.train()
         losses = []
         for batch in loader:
+            batch = _on(batch, device)
             if graph_step is not None:          # graphstep.GraphedTrainStep(..., loss="pretrain")
                 losses.append(graph_step(batch).clone())
                 continue
@@ -255,7 +265,7 @@ class PretrainTrainer:
     @torch.no_grad()
     def validate(self, loader, model, device=None):
         model.eval()
-        losses = [pretrain_loss(model(batch), batch) for batch in loader]
+        losses = [pretrain_loss(model(b), b) for b in (_on(batch, device) for batch in loader)]
         return float(torch.stack(losses).sum()) / len(loader.dataset) if losses else 0.0
 
 

@@ -10,7 +10,10 @@
  *   - every pointer is a DEVICE pointer into caller-owned memory; the library never allocates,
  *     frees or retains pointers; workspaces are caller-provided.
  *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no
- *     internal synchronisation, no default-stream use; stateless and re-entrant.
+ *     internal synchronisation, no default-stream use; stateless and re-entrant -- with two documented
+ *     exceptions that are process-wide settings, meant to be set once before the first compute call and not
+ *     changed while another thread is inside the library: the tuning table (fn_set_tuning) and the profiling
+ *     stamp buffer (fn_debug_set_stamps).  Kernels never read either; only launch decisions on the host do.
  *   - return 0 on success, a negative FN_E* code for an argument error, or a positive
  *     hipError_t taken right after the launch.  fn_last_error() describes the last failure
  *     on the calling thread.

@@ -10,6 +10,7 @@ Follows (structure and arithmetic; no code copied):
   FragNetLayerA   fragnet/model/gat/gat2.py:40-330   (ctor order :59-119 = RNG order)
   FragNet         fragnet/model/gat/gat2.py:333-442
   FTHead3/FTHead4 fragnet/model/gat/gat2.py:678-725 / 640-675
+  FTHead1/2/5     fragnet/model/gat/gat2.py:569-587 / 727-751 / 590-637
   FragNetFineTune fragnet/model/gat/gat2.py:758-826
   PretrainTask    fragnet/model/gat/pretrain_heads.py:8-102
   FragNetPreTrain fragnet/model/gat/pretrain_heads.py:105-141
@@ -311,6 +312,56 @@ class FTHead4(nn.Module):
         return self.out_proj(self.dropout(self.activation(self.dense(self.dropout(x)))))
 
 
+class FTHead1(nn.Sequential):
+    """dropout -> lin1 -> relu -> dropout -> out, dropout rate fixed by the constructor default -- gat2.py:569-587."""
+
+    def __init__(self, emb_dim=128, h1=128, drop_ratio=0.2, n_classes=1):
+        super().__init__()
+        self.lin1 = nn.Linear(emb_dim * 2, h1)
+        self.out = nn.Linear(h1, n_classes)
+        self.dropout = nn.Dropout(p=drop_ratio)
+        self.activation = nn.ReLU()
+
+    def forward(self, enc):
+        return self.out(self.dropout(self.activation(self.lin1(self.dropout(enc)))))
+
+
+class FTHead2(nn.Sequential):
+    """relu(dropout(linear)) stack 256 -> 1024 -> 1024 -> 512 -> n_classes with p = 0.1; ``lin1`` / ``out`` are constructed
+    (RNG order, state dict) but never used -- gat2.py:727-751."""
+
+    def __init__(self, input_dim=128, h1=128, drop_ratio=0.2, n_classes=1):
+        super().__init__()
+        self.lin1 = nn.Linear(input_dim * 2, h1)
+        self.out = nn.Linear(h1, n_classes)
+        self.dropout = nn.Dropout(p=drop_ratio)
+        self.activation = nn.ReLU()
+        dims = [input_dim * 2, 1024, 1024, 512, n_classes]
+        self.predictor = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+        self.dropout = nn.Dropout(p=0.1)
+
+    def forward(self, enc):
+        for lin in self.predictor[:-1]:
+            enc = torch.relu(self.dropout(lin(enc)))
+        return self.predictor[-1](enc)
+
+
+class FTHead5(nn.Sequential):
+    """act(dropout(linear)) twice, then a plain Linear (``h4`` is accepted and ignored) -- gat2.py:590-637."""
+
+    def __init__(self, input_dim=128, h1=128, h2=1024, h4=512, drop_ratio=0.2, n_classes=1, act="relu"):
+        super().__init__()
+        self.dropout = nn.Dropout(p=drop_ratio)
+        self.activation = _ACTS[act]()
+        dims = [input_dim * 2, h1, h2, n_classes]
+        self.predictor = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+
+    def forward(self, enc):
+        for lin in self.predictor[:-1]:
+            enc = self.activation(self.dropout(lin(enc)))
+        return self.predictor[-1](enc)
+
+
 def pool_cat(x_atoms, x_frags, batch):
     """cat(sum-pool atoms by molecule, sum-pool fragments by molecule) -- gat2.py:820-823."""
     frags = scatter_add(x_frags, batch["frag_batch"], dim=0)
@@ -331,8 +382,12 @@ class FragNetFineTune(nn.Module):
                                   drop_ratio=drop_ratio, act=act)
         elif fthead == "FTHead4":
             self.fthead = FTHead4(n_classes=n_classes, h1=h1, drop_ratio=drop_ratio, act=act)
+        elif fthead == "FTHead1":                      # gat2.py:795-799: constructor defaults except n_classes
+            self.fthead = FTHead1(n_classes=n_classes)
+        elif fthead == "FTHead2":
+            self.fthead = FTHead2(n_classes=n_classes)
         else:
-            raise ValueError(f"oracle covers FTHead3/FTHead4, got {fthead}")
+            raise ValueError(f"FragNetFineTune selects FTHead1-4 (gat2.py:795-814), got {fthead}")
 
     def forward(self, batch):
         x_atoms, x_frags, _, _ = self.pretrain(batch)

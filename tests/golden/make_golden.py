@@ -80,6 +80,11 @@ def install_stubs():
     sys.modules["torch_geometric.utils"].add_self_loops = _stub_add_self_loops
     sys.modules["torch_geometric"].utils = sys.modules["torch_geometric.utils"]
     sys.path.insert(0, REF)
+    # the reference's ``fragnet`` directory is a namespace package (no __init__.py); this repository's ``fragnet/`` alias
+    # package (a regular package) would shadow it wherever it sits on sys.path, so pin the name to the reference explicitly
+    ref_pkg = types.ModuleType("fragnet")
+    ref_pkg.__path__ = [os.path.join(REF, "fragnet")]
+    sys.modules["fragnet"] = ref_pkg
 
 
 # ----------------------------------------------------------------------------- helpers
@@ -414,6 +419,76 @@ def bond_graph_case():
     print("bond_graph_cases written:", {k: store[f"{k}/pairs"].shape[1] for k in list(cases) + list(fcases)})
 
 
+def heads_case():
+    """The prediction heads the other fixtures do not pin (gat2.py:569-637, 727-751): FTHead1 and FTHead2 through
+    FragNetFineTune (eval mode: both hard-code their dropout rates), FTHead5 -- which FragNetFineTune cannot select -- applied
+    directly to a seeded [5, 256] readout.  Also records what the reference does with gat2_edge's ``add_frag_self_loops=True``
+    (it cannot run: the connection attributes are not extended to the loop edges).  ft_head1_b4.npz, ft_head2_b4.npz,
+    head5_direct.npz.  Run with `python tests/golden/make_golden.py heads`."""
+    install_stubs()
+    sys.path.insert(0, os.path.join(REF, "fragnet", "model", "gat"))
+    with quiet():
+        from fragnet.model.gat import gat2 as ref_gat2
+        from fragnet.model.gat import gat2_edge as ref_edge
+        from fragnet.dataset import data as ref_data
+    from fragnet_amd import synth
+    torch.set_num_threads(1)
+    torch.use_deterministic_algorithms(True)
+    for name, head, seed in (("ft_head1_b4", "FTHead1", 21), ("ft_head2_b4", "FTHead2", 22)):
+        cfg = dict(n_classes=1, atom_features=167, frag_features=167, edge_features=17, num_layer=2, num_heads=4,
+                   drop_ratio=0.0, emb_dim=128, fthead=head)
+        batch = ref_data.collate_fn(synth.synth_molecules(4, seed=4300 + seed, profile="esol"))
+        torch.manual_seed(seed)
+        with quiet():
+            model = ref_gat2.FragNetFineTune(**cfg)
+        zero_dead_bias(model)
+        model.eval()                     # FTHead1 / FTHead2 draw dropout masks at fixed rates in train mode
+        trace, hooks = run_layer_trace(model, batch)
+        with quiet():
+            out = model(batch)
+        for h in hooks:
+            h.remove()
+        loss = torch.nn.functional.mse_loss(out.view(-1), batch["y"])
+        loss.backward()
+        save_case(name, {"kind": "finetune", "ctor": cfg, "seed": seed, "loss": "mse", "mode": "eval"}, batch, model,
+                  {"logits": out}, loss, trace)
+    # FTHead5 directly
+    cfg5 = dict(input_dim=128, h1=64, h2=96, h4=32, drop_ratio=0.0, n_classes=3, act="silu")
+    torch.manual_seed(23)
+    head = ref_gat2.FTHead5(**cfg5)
+    g = torch.Generator().manual_seed(24)
+    x = torch.randn(5, 256, generator=g, requires_grad=True)
+    y = head(x)
+    (y * torch.arange(1, 16, dtype=torch.float32).view(5, 3)).sum().backward()
+    store = {"cfg": np.asarray(json.dumps({"ctor": cfg5, "seed": 23})), "x": x.detach().numpy(), "y": y.detach().numpy(),
+             "gx": x.grad.numpy()}
+    keys, sums = [], []
+    for k, v in head.state_dict().items():
+        keys.append(k)
+        sums.append([float(v.double().sum()), float(v.double().abs().sum())])
+        store[f"g/{k}"] = dict(head.named_parameters())[k].grad.numpy()
+    store["pkeys"] = np.asarray(json.dumps(keys))
+    store["psums"] = np.asarray(sums)
+    # gat2_edge with add_frag_self_loops=True: what does the reference do?
+    batch = ref_data.collate_fn(synth.synth_molecules(3, seed=4400, profile="esol"))
+    batch["cnx_attr"] = torch.cat((batch["cnx_attr"].float(), torch.zeros(batch["cnx_attr"].shape[0], 2)), dim=1)
+    torch.manual_seed(25)
+    with quiet():
+        layer = ref_edge.FragNetLayerA(atom_in=167, atom_out=128, frag_in=167, frag_out=128, edge_in=17, edge_out=128, num_heads=4,
+                                       add_frag_self_loops=True)
+    try:
+        with quiet():
+            layer(batch["x_atoms"], batch["edge_index"], batch["edge_attr"], batch["frag_index"], batch["x_frags"],
+                  batch["atom_to_frag_ids"], batch["node_features_bonds"], batch["edge_index_bonds_graph"], batch["edge_attr_bonds"],
+                  batch["cnx_attr"])
+        outcome = "ran"
+    except Exception as exc:          # noqa: BLE001
+        outcome = type(exc).__name__
+    store["edge_self_loops_outcome"] = np.asarray(outcome)
+    np.savez_compressed(os.path.join(HERE, "head5_direct.npz"), **store)
+    print("head5_direct written; gat2_edge add_frag_self_loops=True in the reference ->", outcome)
+
+
 if __name__ == "__main__":
     import sys
-    {"lite": lite_case, "gat2_edge": gat2_edge_case, "bond_graph": bond_graph_case}.get((sys.argv[1:] or [""])[0], main)()
+    {"lite": lite_case, "gat2_edge": gat2_edge_case, "bond_graph": bond_graph_case, "heads": heads_case}.get((sys.argv[1:] or [""])[0], main)()

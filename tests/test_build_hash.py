@@ -1,0 +1,35 @@
+"""build.py decides staleness by content, not by mtime (a snapshot whose .so looks newer must still rebuild)."""
+import os
+
+from fragnet_amd import build
+
+
+def test_digest_covers_every_source_and_flags(tmp_path, monkeypatch):
+    d0 = build.source_digest()
+    assert len(d0) == 64 and d0 == build.source_digest()
+    assert any(p.endswith("mol_fused.inc") for p in build.INCLUDED)
+    fake = tmp_path / "extra.inc"
+    fake.write_text("// x\n")
+    monkeypatch.setattr(build, "INCLUDED", build.INCLUDED + [str(fake)])
+    d1 = build.source_digest()
+    assert d1 != d0
+    fake.write_text("// y\n")
+    assert build.source_digest() != d1
+    monkeypatch.setattr(build, "FLAGS", build.FLAGS + ["-DX"])
+    assert build.source_digest() != d1
+
+
+def test_stale_follows_the_stamp_not_the_clock(tmp_path, monkeypatch):
+    out = tmp_path / "lib.so"
+    monkeypatch.setattr(build, "OUT", str(out))
+    monkeypatch.setattr(build, "STAMP", str(out) + ".sha256")
+    assert build.stale()                               # nothing there
+    out.write_bytes(b"\x7fELF")
+    assert build.stale()                               # library without a stamp
+    with open(build.STAMP, "w") as f:
+        f.write("0" * 64)
+    os.utime(out, (4102444800, 4102444800))            # year 2100: "newer" than any source
+    assert build.stale()                               # wrong digest wins over the clock
+    with open(build.STAMP, "w") as f:
+        f.write(build.source_digest())
+    assert not build.stale()

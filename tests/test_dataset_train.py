@@ -62,3 +62,17 @@ def test_masked_bce_and_pretrain_loss_match_oracle():
     outs = tuple(torch.randn(n, 1, generator=g) for n in (9, 6, 9, 3))
     batch = {"dh_angl": torch.randn(9, 1, generator=g), "bnd_angl": torch.randn(6, 1, generator=g), "y": torch.randn(3, generator=g)}
     assert torch.equal(train.pretrain_loss(outs, batch), ref.pretrain_loss(outs, batch))
+
+
+def test_store_replicate_matches_collate_of_the_copied_records():
+    import torch
+    from fragnet_amd import data, synth
+    from fragnet_amd.dataset import FlatMolStore
+    recs = synth.synth_molecules(5, seed=3, profile="esol")
+    store = FlatMolStore.from_records(recs).replicate(3)
+    assert len(store) == 15
+    got = store.collate([1, 7, 13])                      # molecule 1 of copy 0, molecule 2 of copy 1, molecule 3 of copy 2
+    want = data.collate_fn([recs[1], recs[2], recs[3]])
+    assert set(got) == set(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
