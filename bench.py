@@ -279,20 +279,22 @@ def forward_sweep_store(rank, world, dev, args):
         steps = max(4, min(args.steps, len(store) // B))
         loader = StoreLoader(store, B, shuffle=True, drop_last=True, seed=11 + rank)
         it = iter(loader.sampler)
-        idx_lists = [next(it).to(dev) for _ in range(steps + 2)]
+        WU = 8                 # batches differ in size: the caching allocator needs a few steps to stop calling hipMalloc
+        steps = max(4, min(steps, len(store) // B - WU))
+        idx_lists = [next(it).to(dev) for _ in range(steps + WU)]
         with torch.no_grad():
-            for idx in idx_lists[:2]:
+            for idx in idx_lists[:WU]:
                 model(store.collate(idx))
             if world > 1:
                 torch.distributed.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for idx in idx_lists[2:]:
+            for idx in idx_lists[WU:]:
                 model(store.collate(idx))
             torch.cuda.synchronize()
             total = time.perf_counter() - t0
             t0 = time.perf_counter()
-            for idx in idx_lists[2:]:
+            for idx in idx_lists[WU:]:
                 store.collate(idx)
             torch.cuda.synchronize()
             coll = time.perf_counter() - t0
