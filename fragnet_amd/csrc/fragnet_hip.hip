@@ -431,8 +431,16 @@ struct GatFwdArgs {
     float *out, *p_sorted, *probs_orig;
     fn_act_epilogue ep;
     int rows_per_hw, nblk;
+    // optional fused "row dots" of the level that consumes this one's raw output as its edge attribute (bond graph -> atom
+    // graph, gat2.py:203-208): rd_out[j * rd_m + rd_pos[t]] = <out[t, :], rd_A[j * rd_lda : +128]>, j < rd_J -- the edge term
+    // of the next level, written straight into ITS destination-sorted order (rd_pos = that level's inv_d)
+    const float* rd_A;
+    float* rd_out;
+    const int32_t* rd_pos;
+    int64_t rd_m;
+    int rd_lda, rd_J;
 };
-template <int H, int KL>
+template <int H, int KL, bool RD = false>
 __device__ __forceinline__ void gat_fwd_body(const GatFwdArgs& A, float (*sWf)[kWfLd], int bid, int nblk) {
     const float* __restrict__ h = A.h;
     const float* __restrict__ s_dst = A.s_dst;
@@ -518,6 +526,7 @@ __device__ __forceinline__ void gat_fwd_body(const GatFwdArgs& A, float (*sWf)[k
         // one round trip: next row's edge data, the row after's extent, this row's source rows and source scalars
         issue_edges(nxt, raw);
         const FwdExtent nn = load_extent(t + 2 * kRows);
+        const int rd_p = RD ? A.rd_pos[t < n ? t : n - 1] : 0;            // requested with the gathers, consumed after them
         const bool wide = __any(fast && deg > 4);
         float4 r0[8];
 #pragma unroll
@@ -599,6 +608,14 @@ __device__ __forceinline__ void gat_fwd_body(const GatFwdArgs& A, float (*sWf)[k
         }
         if (deg >= 0) {
             if (out) st4(out + (size_t)t * FN_D + lane * 4, acc);
+            if (RD) {            // the next level's edge term from the row in registers (saves a launch that re-reads every row)
+                float mine = 0.f;
+                for (int q = 0; q < A.rd_J; ++q) {
+                    const float dsum = head_sum<32>(dot4(acc, ld4(A.rd_A + q * A.rd_lda + lane * 4)));
+                    if (lane == q) mine = dsum;
+                }
+                if (lane < A.rd_J) A.rd_out[(size_t)lane * A.rd_m + rd_p] = mine;
+            }
             if (ep.y) {          // fused act(dropout(.)): same Philox block index (element / 4) as k_dropout_act
                 float4 r = acc;
                 if (ep.p > 0.f) {
@@ -620,11 +637,16 @@ __global__ __launch_bounds__(kBlock) void k_gat_fwd(GatFwdArgs A) {
     gat_fwd_body<H, KL>(A, sWf, (int)blockIdx.x, (int)gridDim.x);
 }
 // two independent levels in one launch (bond graph + fragment-bond graph: neither reads the other's output)
-template <int H, int KLA, int KLB>
+template <int H, int KLA, int KLB, bool RDA = false>
 __global__ __launch_bounds__(kBlock) void k_gat_fwd_pair(GatFwdArgs A, GatFwdArgs B) {
     __shared__ float sWf[8][kWfLd];
-    if ((int)blockIdx.x < A.nblk) gat_fwd_body<H, KLA>(A, sWf, (int)blockIdx.x, A.nblk);
+    if ((int)blockIdx.x < A.nblk) gat_fwd_body<H, KLA, RDA>(A, sWf, (int)blockIdx.x, A.nblk);
     else gat_fwd_body<H, KLB>(B, sWf, (int)blockIdx.x - A.nblk, B.nblk);
+}
+template <int H>
+__global__ __launch_bounds__(kBlock) void k_gat_fwd_rd(GatFwdArgs A) {          // single bond-graph level with the row-dots epilogue
+    __shared__ float sWf[8][kWfLd];
+    gat_fwd_body<H, 1, true>(A, sWf, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Backward kernels use RB rows (half-waves) per block.
@@ -2118,6 +2140,7 @@ struct EncPrologue {
     int n_t;                                                        // 24 blocks per matrix
     const float* dx;  float* dy;  int64_t dnumel;  float p;  uint64_t seed, offset;  const uint64_t* offset_dev;  int n_d;
     const float* sx[2];  float* so[2];  int sK[2];  fn_gat_plan spl[2];  int n_s[2];
+    float* zp;  int64_t zn;  int n_z;                               // buffer zeroed once per forward (edge-term scratch: loop positions stay 0)
     MolExtArgs mx;  int n_x;                                        // molecule extents for the fused kernels (256 molecules per block)
     MolFoldArgs fold;  int n_f;                                     // folded edge-embedding weights, one block per (layer, level)
 };
@@ -2143,6 +2166,11 @@ __global__ __launch_bounds__(256) void k_enc_prologue(EncPrologue A) {
         }
         b -= A.n_s[q];
     }
+    if (b < A.n_z) {
+        for (int64_t i = (int64_t)b * blockDim.x + threadIdx.x; i < A.zn; i += (int64_t)A.n_z * blockDim.x) A.zp[i] = 0.f;
+        return;
+    }
+    b -= A.n_z;
     if (b < A.n_x) { mol_extents_body(A.mx, b);  return; }
     b -= A.n_x;
     if (b < A.n_f) mol_fold_body(A.fold, b);
@@ -2458,7 +2486,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 namespace {
 unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
 int64_t g_mol_stamps_n = 0;
-int g_tune[FN_TUNE_COUNT] = {1792, 0, 0, 512, 0, 0, 0};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
+int g_tune[FN_TUNE_COUNT] = {1792, 0, 0, 512, 0, 0, 0, 1};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -2736,7 +2764,7 @@ static int prep_gat_fwd(const float* h, const float* s_dst, const float* s_src, 
     if (et->mode == 0 && plan->m > 0 && !et->s_sorted) return fail(FN_EINVAL, "fn_gat_fwd_f32: null s_sorted");
     if (heads != 1 && heads != 2 && heads != 4 && heads != 8) return fail(FN_EUNSUPPORTED, "heads must be 1, 2, 4 or 8 (128 = heads * head_dim)");
     *A = GatFwdArgs{h, s_dst, s_src, att, att_w, *et, *plan, neg_slope, out, p_sorted, probs_orig,
-                    act ? *act : fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr}, 1, 0};
+                    act ? *act : fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr}, 1, 0, nullptr, nullptr, nullptr, 0, 0, 0};
     if (plan->n == 0) return 0;
     if (!(neg_slope >= 0.f && neg_slope <= 1.f)) return fail(FN_EUNSUPPORTED, "fn_gat_fwd_f32: LeakyReLU slope must be in [0, 1]");
     if (plan->n > (1 << 23) || plan->m * heads > (1 << 29))
@@ -2752,6 +2780,11 @@ static int prep_gat_fwd(const float* h, const float* s_dst, const float* s_src, 
 static int launch_gat_fwd(const GatFwdArgs& A, int heads, hipStream_t st) {
     if (A.nblk == 0) return 0;
     const int kl = edge_class(&A.et);
+    if (A.rd_out) {
+        if (kl != 1) return fail(FN_EUNSUPPORTED, "attention forward: the row-dots epilogue exists for the single-attribute (bond graph) level");
+        FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_fwd_rd<HH>), dim3(A.nblk), dim3(kBlock), 0, st, A));
+        return launch_status("fn_gat_fwd_f32 (+ row dots)");
+    }
     FN_DISPATCH_H(heads, {
         if (kl == 0) hipLaunchKernelGGL((k_gat_fwd<HH, 0>), dim3(A.nblk), dim3(kBlock), 0, st, A);
         else if (kl == 1) hipLaunchKernelGGL((k_gat_fwd<HH, 1>), dim3(A.nblk), dim3(kBlock), 0, st, A);
@@ -2767,8 +2800,13 @@ static int launch_gat_fwd_pair(const GatFwdArgs& A, const GatFwdArgs& B, int hea
         return launch_gat_fwd(B, heads, st);
     }
     FN_DISPATCH_H(heads, {
-        if (kb == 1) hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, 1>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);
-        else hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, FN_MAX_EDGE_K>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);
+        if (A.rd_out) {
+            if (kb == 1) hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, 1, true>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);
+            else hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, FN_MAX_EDGE_K, true>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);
+        } else {
+            if (kb == 1) hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, 1>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);
+            else hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, FN_MAX_EDGE_K>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);
+        }
     });
     return launch_status("attention forward (two levels)");
 }
@@ -3602,6 +3640,8 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
     const bool lite = e->variant == 1, edge = e->variant == 2;      // gat2_lite / gat2_edge: neither has a fragment-bond graph
     const bool no_fb = lite || edge;
     const bool fused = mol_fused(e);
+    // the atom graph's edge term <new_bond, a[:, d:d+128]> is produced by the bond-graph kernel's epilogue (one launch less per layer)
+    const bool fuse_rd = !fused && g_tune[FN_TUNE_FUSE_ROWDOTS] != 0 && e->atom.m > 0 && e->atom.m_real == e->E;
     if (multi) FN_TRY(aux_init());
     fn_stream_t st_fb = multi ? (fn_stream_t)g_aux.s[1] : st;       // the fragment-bond chain's stream
 
@@ -3647,7 +3687,10 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
             A.fold.att_w = 3 * d;  A.fold.mid_off = d;  A.fold.H = H;  A.fold.n = 2 * e->n_layers;  A.fold.out = lay.wf_tab;
             A.n_f = 2 * e->n_layers;
         }
-        hipLaunchKernelGGL(k_enc_prologue, dim3(A.n_t + A.n_d + A.n_s[0] + A.n_s[1] + A.n_x + A.n_f), dim3(256), 0, S(st), A);
+        if (fuse_rd) {
+            A.zp = lay.s_sorted;  A.zn = e->atom.m * H;  A.n_z = flat_grid(A.zn, 64);
+        }
+        hipLaunchKernelGGL(k_enc_prologue, dim3(A.n_t + A.n_d + A.n_s[0] + A.n_s[1] + A.n_z + A.n_x + A.n_f), dim3(256), 0, S(st), A);
         FN_TRY(launch_status("fn_encoder_forward: prologue"));
     }
     FN_TRY(order_after(S(st), S(st_fb)));      // fork: the fragment-bond levels of ALL layers depend on nothing else
@@ -3731,6 +3774,9 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         GatFwdArgs gb, gfb{};
         FN_TRY(prep_gat_fwd(a.h_b, lay.s_dst, lay.s_src, w.a_b, 3 * d, &et_b, &e->bond, 0.2f, a.new_bond, a.p_bond, nullptr, &ep_bond, H, &gb));
         if (!no_fb) FN_TRY(prep_gat_fwd(a.h_fb, lay.s_dst_fb, lay.s_src_fb, w.f_a_b, 3 * d, &et_fb, &e->fbond, 0.2f, a.new_fbond, a.p_fbond, nullptr, &ep_fbond, H, &gfb));
+        if (fuse_rd) {
+            gb.rd_A = w.a + d;  gb.rd_lda = wide;  gb.rd_J = H;  gb.rd_out = lay.s_sorted;  gb.rd_pos = e->atom.inv_d;  gb.rd_m = e->atom.m;
+        }
         if (multi) {
             FN_TRY(launch_gat_fwd(gb, H, S(st)));
             FN_TRY(launch_gat_fwd(gfb, H, S(st_fb)));
@@ -3740,7 +3786,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
 
         // L2 atom graph (+ self loops), edge term = <new_bond, a[:, d:d+128]>
         if (!grouped) FN_TRY(project(in_atoms, ka, bt_a, w.proj_a_b, a.h_a, e->N, w.a, wide, d + FN_D, lay.s_dst_a, lay.s_src_a, st));
-        FN_TRY(fn_row_dots_sorted_f32(a.new_bond, w.a, wide, d, H, &e->atom, lay.s_sorted, st));
+        if (!fuse_rd) FN_TRY(fn_row_dots_sorted_f32(a.new_bond, w.a, wide, d, H, &e->atom, lay.s_sorted, st));
         fn_edge_term et_a{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
         FN_TRY(fn_gat_fwd_f32(a.h_a, lay.s_dst_a, lay.s_src_a, w.a, wide, &et_a, &e->atom, 0.2f, lay.atoms_new, a.p_atom, nullptr, &ep_atoms, H, st));
         }   // !fused

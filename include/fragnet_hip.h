@@ -63,7 +63,9 @@ int fn_abi_version(void);
 #define FN_TUNE_PROJ 6         /* > 0: the 128 -> 128 projections and their input-gradient products inside fn_encoder_* run as k_proj128
                                 * (W pieces register-resident, X staged in LDS, persistent workgroups; value > 1 = workgroup cap);
                                 * 0 (default): k_linear128 -- measured 1-4 % faster per step on MI355X */
-#define FN_TUNE_COUNT 7
+#define FN_TUNE_FUSE_ROWDOTS 7 /* 1 (default): inside fn_encoder_forward the bond-graph attention kernel also writes the atom graph's edge
+                                * term <new_bond, a[:, d:d+128]> from the row it holds in registers; 0: a separate row-dots launch */
+#define FN_TUNE_COUNT 8
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * molecules 64-bit words) is
  * set, every workgroup of the fused molecule kernels writes s_memtime stamps of its phases into it (tools/mol_phase_times.py).
