@@ -342,6 +342,7 @@ def main():
                     help="with --forward-sweep: molecules in a FlatMolStore resident in HBM (1048576 = config[4] as written); every "
                          "step then collates a fresh shuffled batch on the GPU before plan + forward")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="A/B: library heuristics for the head GEMMs instead of TunableOp")
+    ap.add_argument("--library-head", action="store_true", help="A/B: head layers as library GEMMs + element-wise kernels instead of fn_dense_*")
     ap.add_argument("--tune", action="append", default=None, help="A/B: KEY=VALUE for fn_set_tuning (include/fragnet_hip.h FN_TUNE_*)")
     ap.add_argument("--scatter-blocks", type=int, default=None, help="A/B: resident workgroups of the scatter kernels (FN_TUNE_FWD_BLOCKS)")
     args = ap.parse_args()
@@ -350,7 +351,10 @@ def main():
     from fragnet_amd import parallel
     from fragnet_amd.model import FragNetFineTune
     fragnet_amd.prefer_rocblas_for_dense_heads()
-    if not args.no_gemm_tuning:
+    if args.library_head:
+        from fragnet_amd import ops
+        ops.DENSE_HEAD = False
+    if args.library_head and not args.no_gemm_tuning:
         fragnet_amd.tune_library_gemms()
     from fragnet_amd.plan import PLAN_KEY
 

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfragnet_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 FN_D = 128
 FN_MAX_TASKS = 16
 FN_MAX_EDGE_K = 8
@@ -129,8 +129,10 @@ SIGNATURES = {
     "fn_gate_colsum_ws": [i64, i64],
     "fn_gate_colsum_f32": [vp, vp, vp, vp, i64, i64, f32, vp, vp],
     "fn_small_linear_f32": [vp, vp, vp, vp, i64, i64, i64, vp],
+    "fn_dense_fwd_f32": [vp, vp, vp, vp, i64, i64, i64, C.POINTER(ActEpilogue), vp],
+    "fn_dense_bwd_f32": [vp, vp, vp, vp, f32, vp, vp, i64, i64, i64, vp],
     "fn_small_linear_bwd_ws": [i64, i64, i64],
-    "fn_small_linear_bwd_f32": [vp, vp, vp, vp, vp, vp, i64, i64, i64, vp, vp],
+    "fn_small_linear_bwd_f32": [vp, vp, vp, vp, vp, vp, i64, i64, i64, f32, vp, vp],
 }
 
 _lib = None

@@ -1827,7 +1827,7 @@ template <int CM>
 __global__ __launch_bounds__(256) void k_small_linear_bwd(const float* __restrict__ g, const float* __restrict__ x,
                                                           const float* __restrict__ w, float* __restrict__ g_x,
                                                           float* __restrict__ dW, float* __restrict__ db, int64_t M, int K, int C,
-                                                          int64_t rows_per_chunk) {
+                                                          int64_t rows_per_chunk, float gate_scale) {
     // blockIdx.y = row chunk: dW / db then point at per-chunk partials [chunk][C*K] / [chunk][C] (k_sum_chunks finishes)
     __shared__ float4 sm[64][4];
     const int c4 = threadIdx.x & 3, rl = threadIdx.x >> 2;           // 4 float4 columns x 64 row lanes
@@ -1854,6 +1854,10 @@ __global__ __launch_bounds__(256) void k_small_linear_bwd(const float* __restric
                     o.x += gv * wv[c].x; o.y += gv * wv[c].y; o.z += gv * wv[c].z; o.w += gv * wv[c].w;
                     acc[c].x += gv * xv.x; acc[c].y += gv * xv.y; acc[c].z += gv * xv.z; acc[c].w += gv * xv.w;
                 }
+            }
+            if (gate_scale > 0.f) {                                 // x = relu(dropout(.)) of the layer below: its backward, fused
+                o.x = xv.x > 0.f ? o.x * gate_scale : 0.f;  o.y = xv.y > 0.f ? o.y * gate_scale : 0.f;
+                o.z = xv.z > 0.f ? o.z * gate_scale : 0.f;  o.w = xv.w > 0.f ? o.w * gate_scale : 0.f;
             }
             st4(g_x + m * K + col, o);
         }
@@ -2130,6 +2134,7 @@ __global__ void k_transpose_many(TransposeMany tm, float* __restrict__ bt_base) 
 
 #include "mol_fused.inc"
 #include "proj128.inc"
+#include "dense_head.inc"
 
 // Everything the encoder's forward pass needs before its first projection, none of which depends on the other: W^T of
 // every projection, dropout of the atom features, and the permutation of the two raw edge-attribute tensors into
@@ -3203,7 +3208,7 @@ int64_t fn_small_linear_bwd_ws(int64_t M, int64_t K, int64_t C) {
 }
 
 int fn_small_linear_bwd_f32(const float* g, const float* x, const float* w, float* g_x, float* dW, float* db, int64_t M, int64_t K,
-                            int64_t C, float* ws, fn_stream_t stream) {
+                            int64_t C, float gate_scale, float* ws, fn_stream_t stream) {
     if (M < 0 || K < 4 || (K & 3) || K > INT32_MAX || C < 1 || C > FN_SMALL_LINEAR_MAX)
         return fail(FN_EINVAL, "fn_small_linear_bwd_f32: K must be a multiple of 4 and 1 <= C <= FN_SMALL_LINEAR_MAX");
     if (!w || !dW || !db || (M > 0 && (!g || !x || !g_x)) || (((uintptr_t)x | (uintptr_t)w | (uintptr_t)g_x | (uintptr_t)dW | (uintptr_t)ws) & 15))
@@ -3214,14 +3219,61 @@ int fn_small_linear_bwd_f32(const float* g, const float* x, const float* w, floa
     float* db_o = ch > 1 ? ws + ch * C * K : db;
     const int64_t rpc = ch > 1 ? kTallChunk : (M > 0 ? M : 1);
     const dim3 grid((unsigned)((K + 15) / 16), (unsigned)ch);
-    if (C <= 1) hipLaunchKernelGGL(k_small_linear_bwd<1>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW_o, db_o, M, (int)K, (int)C, rpc);
-    else if (C <= 4) hipLaunchKernelGGL(k_small_linear_bwd<4>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW_o, db_o, M, (int)K, (int)C, rpc);
-    else hipLaunchKernelGGL(k_small_linear_bwd<FN_SMALL_LINEAR_MAX>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW_o, db_o, M, (int)K, (int)C, rpc);
+    if (C <= 1) hipLaunchKernelGGL(k_small_linear_bwd<1>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW_o, db_o, M, (int)K, (int)C, rpc, gate_scale);
+    else if (C <= 4) hipLaunchKernelGGL(k_small_linear_bwd<4>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW_o, db_o, M, (int)K, (int)C, rpc, gate_scale);
+    else hipLaunchKernelGGL(k_small_linear_bwd<FN_SMALL_LINEAR_MAX>, grid, dim3(256), 0, S(stream), g, x, w, g_x, dW_o, db_o, M, (int)K, (int)C, rpc, gate_scale);
     if (ch > 1) {
         hipLaunchKernelGGL(k_sum_chunks, dim3((unsigned)((C * K + 15) / 16)), dim3(256), 0, S(stream), ws, (int)ch, C * K, dW);
         hipLaunchKernelGGL(k_sum_chunks, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, S(stream), ws + ch * C * K, (int)ch, C, db);
     }
     return launch_status("fn_small_linear_bwd_f32");
+}
+
+namespace {
+bool dense_shape_ok(int64_t M, int64_t K, int64_t N) {
+    return M >= 0 && M <= FN_DENSE_MAX_ROWS && K >= 4 && N >= 4 && !(K & 3) && !(N & 3) && K <= 65536 && N <= 65536;
+}
+int dense_tiles(int64_t n, int t) { return (int)((n + t - 1) / t); }
+}  // namespace
+
+int fn_dense_fwd_f32(const float* X, const float* W, const float* bias, float* Y, int64_t M, int64_t K, int64_t N,
+                     const fn_act_epilogue* act, fn_stream_t stream) {
+    if (!dense_shape_ok(M, K, N)) return fail(FN_EINVAL, "fn_dense_fwd_f32: K and N must be multiples of 4, M <= FN_DENSE_MAX_ROWS");
+    if (M == 0) return 0;
+    if (!X || !W || !Y || (((uintptr_t)X | (uintptr_t)W | (uintptr_t)Y | (uintptr_t)bias) & 15))
+        return fail(FN_EINVAL, "fn_dense_fwd_f32: null or misaligned buffer");
+    if (act && (act->p < 0.f || act->p > 1.f)) return fail(FN_EINVAL, "fn_dense_fwd_f32: dropout probability outside [0, 1]");
+    DenseArgs T{};
+    T.A = X;  T.Bsrc = W;  T.bias = bias;  T.OUT = Y;
+    T.I = (int)M;  T.J = (int)N;  T.R = (int)K;  T.lda = (int)K;  T.ldb = (int)K;
+    if (act) { T.act = *act;  T.act.y = Y; }
+    T.tiles_i = dense_tiles(M, 32);  T.tiles_j = dense_tiles(N, kDnCols);
+    hipLaunchKernelGGL(k_dense_fwd, dim3((unsigned)(T.tiles_i * T.tiles_j)), dim3(kDnThreads), kDnLdsBytes, S(stream), T);
+    return launch_status("fn_dense_fwd_f32");
+}
+
+int fn_dense_bwd_f32(const float* g_y, const float* X, const float* W, float* g_x, float gate_scale, float* dW, float* db,
+                     int64_t M, int64_t K, int64_t N, fn_stream_t stream) {
+    if (!dense_shape_ok(M, K, N)) return fail(FN_EINVAL, "fn_dense_bwd_f32: K and N must be multiples of 4, M <= FN_DENSE_MAX_ROWS");
+    if (!W || !dW || (M > 0 && (!g_y || !X)) || gate_scale < 0.f ||
+        (((uintptr_t)g_y | (uintptr_t)X | (uintptr_t)W | (uintptr_t)g_x | (uintptr_t)dW) & 15))
+        return fail(FN_EINVAL, "fn_dense_bwd_f32: null or misaligned buffer");
+    DensePair P{};
+    DenseArgs& a = P.a;                                  // dW [N,K] = gy^T X, db = column sums of gy
+    a.A = g_y;  a.Bsrc = X;  a.OUT = dW;  a.db = db;
+    a.I = (int)N;  a.J = (int)K;  a.R = (int)M;  a.lda = (int)N;  a.ldb = (int)K;
+    a.tiles_i = dense_tiles(N, 64);  a.tiles_j = dense_tiles(K, kDnCols);
+    int blocks = a.tiles_i * a.tiles_j;
+    P.b.first_block = blocks;
+    if (g_x && M > 0) {
+        DenseArgs& b = P.b;                              // gX [M,K] = gy W, gated by X > 0
+        b.A = g_y;  b.Bsrc = W;  b.OUT = g_x;  b.Z = gate_scale > 0.f ? X : nullptr;  b.gate_scale = gate_scale;
+        b.I = (int)M;  b.J = (int)K;  b.R = (int)N;  b.lda = (int)N;  b.ldb = (int)K;
+        b.tiles_i = dense_tiles(M, 32);  b.tiles_j = dense_tiles(K, kDnCols);
+        blocks += b.tiles_i * b.tiles_j;
+    }
+    hipLaunchKernelGGL(k_dense_bwd, dim3((unsigned)blocks), dim3(kDnThreads), kDnLdsBytes, S(stream), P);
+    return launch_status("fn_dense_bwd_f32");
 }
 
 int fn_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

@@ -31,7 +31,7 @@ from typing import Callable, Dict, Iterable, Optional
 import torch
 
 from . import _lib
-from .plan import PLAN_KEY, REAL_MOLS_KEY
+from .plan import LIVE_MOLS_KEY, PLAN_KEY, REAL_MOLS_KEY
 
 # field -> (index space of the ragged axis, layout, index space its VALUES point into)
 FIELDS = {
@@ -97,6 +97,8 @@ class StaticShapes:
             slack[node] = max(8, need)
             grow = 0.0 if node == "mol" else margin
             cap[node] = _up(int(math.ceil(mx[node] * (1.0 + grow))) + slack[node], 8)
+            if node == "mol":       # the batch size is exact: every slot the rounding added is padding too (the head skips them)
+                slack[node] = cap[node] - mx[node]
         return cls(cap, slack, heads)
 
     @classmethod
@@ -229,6 +231,8 @@ class StaticBatch:
         c = self._fields[len(self._desc) + len(self._mask_spaces)]
         c.dst, c.cap, c.width, c.kind, c.pad_hi, c.pad_mod = self.t[REAL_MOLS_KEY].data_ptr(), 1, 1, _lib.STAGE_COUNT, 0, 1
         self.n_fields = len(self._desc) + len(self._mask_spaces) + 1
+        # molecule rows behind capacity - slack are padding in every batch that fits: the prediction head skips them
+        self.t[LIVE_MOLS_KEY] = shapes.cap["mol"] - shapes.slack["mol"]
         if self.n_fields > _lib.FN_MAX_STAGE_FIELDS:
             raise ValueError("too many batch fields for one staging launch")
         self.counts: Optional[Dict[str, int]] = None
@@ -343,6 +347,7 @@ class GraphedTrainStep:
         x_atoms, x_frags, _, _ = self.model.pretrain(sb)
         pooled_t = pooled(x_atoms, x_frags, sb)
         leaf = pooled_t.detach().requires_grad_(True)
+        self.model.fthead.live_rows = sb.get(LIVE_MOLS_KEY)
         loss = self._masked(self.model.fthead(leaf), sb["y"], sb[MASK_KEY])
         loss.backward(gradient=self._unit)
         return loss, pooled_t, leaf

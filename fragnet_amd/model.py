@@ -23,7 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import engine, ops
-from .plan import plan_for
+from .plan import LIVE_MOLS_KEY, plan_for
 
 _ACTS = {
     "relu": nn.ReLU, "silu": nn.SiLU, "gelu": nn.GELU, "celu": nn.CELU, "selu": nn.SELU,
@@ -333,11 +333,12 @@ class _PredictorStack(nn.Sequential):
     """act(dropout(linear(x))) between layers, plain last layer -- gat2.py:631-637, 719-725, 745-751."""
 
     rng = None       # the encoder's Philox stream when the owning model attaches it (FragNetFineTune does)
+    live_rows = None  # set per call by the owning model: input rows >= live_rows are padding, their outputs are 0
 
     def _run(self, enc):
         fused = self.rng is not None and isinstance(self.activation, nn.ReLU) and enc.is_cuda
         if fused and all(l.bias is not None for l in self.predictor) and all(l.out_features % 4 == 0 for l in self.predictor[:-1]):
-            return ops.mlp_head(enc, list(self.predictor), self.dropout.p, self.training, self.rng)     # one autograd node
+            return ops.mlp_head(enc, list(self.predictor), self.dropout.p, self.training, self.rng, self.live_rows)     # one autograd node
         for lin in self.predictor[:-1]:
             if fused:    # relu(dropout(.)) as one kernel each way instead of two (same op as between encoder layers)
                 enc = ops.dropout_act(lin(enc), self.dropout.p, self.training, True, self.rng)
@@ -428,6 +429,7 @@ class FragNetFineTune(nn.Module):
 
     def forward(self, batch):
         x_atoms, x_frags, _, _ = self.pretrain(batch)
+        self.fthead.live_rows = batch.get(LIVE_MOLS_KEY)     # static-shape batches: the rows behind it are padding molecules
         return self.fthead(pooled(x_atoms, x_frags, batch))
 
 

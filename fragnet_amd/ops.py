@@ -594,6 +594,14 @@ def dropout_act(x, p: float, training: bool, relu: bool, rng: PhiloxStream):
 SMALL_LINEAR_MAX = 16        # FN_SMALL_LINEAR_MAX
 
 
+DENSE_MAX_ROWS = 4096        # FN_DENSE_MAX_ROWS
+DENSE_HEAD = True            # hidden layers through fn_dense_fwd/bwd_f32 (False: library GEMMs + the element-wise kernels)
+
+
+def _dense_ok(rows: int, W) -> bool:
+    return DENSE_HEAD and rows <= DENSE_MAX_ROWS and W.shape[0] % 4 == 0 and W.shape[1] % 4 == 0 and W.is_contiguous()
+
+
 def _scratch(n_floats: int, device):
     return torch.empty(n_floats, dtype=torch.float32, device=device) if n_floats else None
 
@@ -601,35 +609,52 @@ def _scratch(n_floats: int, device):
 class _MLPHead(torch.autograd.Function):
     """FTHead1-5's predictor stack (gat2.py:631-637, 745-751) as one autograd node.
 
-    The dense products are library GEMMs (addmm / mm); everything around them is fused: relu(dropout(.)) in place on
-    the GEMM output, its backward together with the bias gradient (``fn_gate_colsum_f32``: the saved output encodes
-    the mask, so no Philox replay and no separate column-sum launch), and the last Linear (n_classes outputs) as one
-    launch each way.  ``draws`` = the (seed, offset) of each hidden layer's mask, taken from the model's Philox stream
-    in the same order as the unfused path, so both paths produce identical numbers.
+    On molecule-sized inputs (``_dense_ok``) every hidden layer is ONE launch each way (csrc/dense_head.inc, fp32 matrix
+    cores): forward = product + bias + relu(dropout(.)); backward = weight gradient + bias gradient + input gradient, the
+    latter already through the backward of the layer below's relu(dropout(.)) (the saved output encodes the mask, so no
+    Philox replay).  The last Linear (n_classes outputs) is one launch each way, too.  Taller inputs (the pretrain towers
+    run on every atom / bond) keep library GEMMs (addmm / mm) with the element-wise work fused around them
+    (``fn_dropout_act_f32`` in place, ``fn_gate_colsum_f32``).  ``draws`` = the (seed, offset) of each hidden layer's mask,
+    taken from the model's Philox stream in the same order as the unfused path, so both paths produce identical numbers.
+    ``live``: input rows >= live are padding (static-shape batches): they are not computed, their outputs and input
+    gradients are 0.
     """
 
     @staticmethod
-    def forward(ctx, x, p: float, draws, dev, *params):
+    def forward(ctx, x, p: float, draws, dev, live, *params):
         n = len(params) // 2
         st = _stream_ptr(x.device)
-        h = _f32c(x, "x")
+        x = _f32c(x, "x")
+        M = x.shape[0]
+        live = M if live is None else max(0, min(int(live), M))
+        h = x[:live]
         acts = [h]
+        dense = all(_dense_ok(live, params[2 * i]) for i in range(n - 1)) and params[-2].shape[0] <= SMALL_LINEAR_MAX \
+            and params[-2].shape[1] % 4 == 0
         for i in range(n - 1):
             W, b = params[2 * i], params[2 * i + 1]
-            y = torch.addmm(b, h, W.t())
             seed, off = draws[i]
-            _lib.call("fn_dropout_act_f32", y.data_ptr(), y.data_ptr(), y.numel(), float(p), seed, off,
-                      _ptr(dev) if p > 0.0 else None, 1, st)
+            if dense:
+                y = torch.empty((live, W.shape[0]), dtype=torch.float32, device=h.device)
+                act = _lib.ActEpilogue(y.data_ptr(), float(p), 1, seed, off, _ptr(dev) if p > 0.0 else None)
+                _lib.call("fn_dense_fwd_f32", h.data_ptr(), W.data_ptr(), b.data_ptr(), y.data_ptr(), live, W.shape[1], W.shape[0],
+                          C.byref(act), st)
+            else:
+                y = torch.addmm(b, h, W.t())
+                _lib.call("fn_dropout_act_f32", y.data_ptr(), y.data_ptr(), y.numel(), float(p), seed, off,
+                          _ptr(dev) if p > 0.0 else None, 1, st)
             h = y
             acts.append(h)
         W, b = params[-2], params[-1]
         C_out, K = W.shape
         if C_out <= SMALL_LINEAR_MAX and K % 4 == 0:
-            out = torch.empty((h.shape[0], C_out), dtype=torch.float32, device=h.device)
-            _lib.call("fn_small_linear_f32", h.data_ptr(), _f32c(W, "W").data_ptr(), b.data_ptr(), out.data_ptr(), h.shape[0], K, C_out, st)
+            out = (torch.empty if live == M else torch.zeros)((M, C_out), dtype=torch.float32, device=h.device)
+            _lib.call("fn_small_linear_f32", h.data_ptr(), _f32c(W, "W").data_ptr(), b.data_ptr(), out.data_ptr(), live, K, C_out, st)
         else:
             out = torch.addmm(b, h, W.t())
-        ctx.p = float(p)
+            if live < M:
+                out = torch.cat([out, out.new_zeros((M - live, C_out))])
+        ctx.p, ctx.dense, ctx.rows = float(p), dense, (M, live)
         ctx.params, ctx.slots = params, [grad_slot(q) for q in params]
         ctx.save_for_backward(*acts, *params[0::2])
         return out
@@ -640,39 +665,63 @@ class _MLPHead(torch.autograd.Function):
         n = len(saved) // 2
         acts, Ws = saved[:n], saved[n:]
         st = _stream_ptr(g.device)
-        g = _f32c(g, "g")
+        M, live = ctx.rows
+        g = _f32c(g, "g")[:live]
         grads = [None] * (2 * n)
         W, h = Ws[-1], acts[-1]
         C_out, K = W.shape
         P, slots = ctx.params, ctx.slots
+        dense, need_x = ctx.dense, ctx.needs_input_grad[0]
+        scale = 1.0 / (1.0 - ctx.p) if 0.0 < ctx.p < 1.0 else (1.0 if ctx.p == 0.0 else 0.0)
         dW, db = grad_buffer(P[-2], slots[-2]), grad_buffer(P[-1], slots[-1])
+
+        def input_grad(like, last):
+            """buffer of d loss / d (input of a layer); the head's own input gradient has all M rows (padding rows 0)"""
+            if not last or live == M:
+                return torch.empty_like(like)
+            full = torch.empty((M, like.shape[1]), dtype=torch.float32, device=like.device)
+            full[live:].zero_()
+            return full
+
         if C_out <= SMALL_LINEAR_MAX and K % 4 == 0:
-            gz = torch.empty_like(h)
-            ws = _scratch(_lib.load().fn_small_linear_bwd_ws(h.shape[0], K, C_out), g.device)
+            gz = input_grad(h, n == 1) if (n > 1 or need_x) else torch.empty_like(h)
+            ws = _scratch(_lib.load().fn_small_linear_bwd_ws(live, K, C_out), g.device)
+            # dense path: gz leaves gated by h > 0 (the backward of the top hidden layer's relu(dropout(.)))
             _lib.call("fn_small_linear_bwd_f32", g.data_ptr(), h.data_ptr(), W.data_ptr(), gz.data_ptr(), dW.data_ptr(), db.data_ptr(),
-                      h.shape[0], K, C_out, _ptr(ws), st)
+                      live, K, C_out, scale if (dense and n > 1) else 0.0, _ptr(ws), st)
         else:
             gz = g @ W
             torch.mm(g.t(), h, out=dW)
             torch.sum(g, 0, out=db)
+            if n == 1 and live < M:
+                gz = torch.cat([gz, gz.new_zeros((M - live, K))])
         grads[-2], grads[-1] = dW, db
-        scale = 1.0 / (1.0 - ctx.p) if 0.0 < ctx.p < 1.0 else (1.0 if ctx.p == 0.0 else 0.0)
         # (running the weight-gradient GEMMs on a side stream beside the gate -> input-gradient chain was measured: a
         # two-branch hipGraph replays 9 % slower on ROCm 7.2 than the serial one, DESIGN.md section 4)
         for i in range(n - 2, -1, -1):
             z, h_in, W = acts[i + 1], acts[i], Ws[i]
-            gy, dW, db = torch.empty_like(z), grad_buffer(P[2 * i], slots[2 * i]), grad_buffer(P[2 * i + 1], slots[2 * i + 1])
+            dW, db = grad_buffer(P[2 * i], slots[2 * i]), grad_buffer(P[2 * i + 1], slots[2 * i + 1])
+            grads[2 * i], grads[2 * i + 1] = dW, db
+            need_gx = i > 0 or need_x
+            if dense:                                   # gz is d loss / d (pre-activation) already: one launch for the layer
+                gx = input_grad(h_in, i == 0) if need_gx else None
+                _lib.call("fn_dense_bwd_f32", gz.data_ptr(), h_in.data_ptr(), W.data_ptr(), _ptr(gx), scale if i > 0 else 0.0, dW.data_ptr(),
+                          db.data_ptr(), live, W.shape[1], W.shape[0], st)
+                gz = gx
+                continue
+            gy = torch.empty_like(z)
             ws = _scratch(_lib.load().fn_gate_colsum_ws(z.shape[0], z.shape[1]), z.device)
             _lib.call("fn_gate_colsum_f32", gz.data_ptr(), z.data_ptr(), gy.data_ptr(), db.data_ptr(), z.shape[0], z.shape[1], scale,
                       _ptr(ws), st)
             torch.mm(gy.t(), h_in, out=dW)
-            grads[2 * i], grads[2 * i + 1] = dW, db
-            if i > 0 or ctx.needs_input_grad[0]:
+            if need_gx:
                 gz = gy @ W
-        return (gz if ctx.needs_input_grad[0] else None, None, None, None, *grads)
+                if i == 0 and live < M:
+                    gz = torch.cat([gz, gz.new_zeros((M - live, gz.shape[1]))])
+        return (gz if need_x else None, None, None, None, None, *grads)
 
 
-def mlp_head(x, linears, p: float, training: bool, rng: "PhiloxStream"):
+def mlp_head(x, linears, p: float, training: bool, rng: "PhiloxStream", live=None):
     """Runs ``linears`` (nn.Linear modules; relu(dropout(.)) after all but the last) through ``_MLPHead``."""
     p_eff = float(p) if training else 0.0
     draws = []
@@ -683,7 +732,7 @@ def mlp_head(x, linears, p: float, training: bool, rng: "PhiloxStream"):
         if lin.bias is None or (lin.out_features % 4 != 0 and lin is not linears[-1]):
             raise ValueError("mlp_head: Linear layers need a bias, hidden ones an output width that is a multiple of 4")
         params += [lin.weight, lin.bias]
-    return _MLPHead.apply(x, p_eff, tuple(draws), rng.dev if p_eff > 0.0 else None, *params)
+    return _MLPHead.apply(x, p_eff, tuple(draws), rng.dev if p_eff > 0.0 else None, live, *params)
 
 
 # ======================================================================================

@@ -198,6 +198,7 @@ class GraphPlan:
 
 PLAN_KEY = "_fragnet_plan"
 REAL_MOLS_KEY = "_real_mols"      # StaticBatch: device-side count of the real molecules of a padded batch
+LIVE_MOLS_KEY = "_live_mols"      # StaticBatch: python int, molecule rows >= this are padding in EVERY batch (capacity - slack)
 
 
 def plan_for(batch: Dict[str, torch.Tensor], edge_ends: bool = False) -> GraphPlan:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FN_ABI_VERSION 4
+#define FN_ABI_VERSION 5
 #define FN_D 128              /* feature width of every node table on the path (emb_dim) */
 #define FN_MAX_TASKS 16       /* CSR builds fused into one fn_plan_build call */
 #define FN_MAX_EDGE_K 8       /* widest raw edge attribute folded in-kernel (6 for fragment bonds) */
@@ -266,6 +266,25 @@ int fn_segment_softmax_bwd_f32(const float* probs, const float* g_probs, const i
                                int32_t pos_base, float* g_logits, int64_t n_seg, int64_t width, fn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Dense layers of the prediction heads, FTHead1-5 (gat2.py:569-751): Linear -> relu(dropout(.)) on [molecules, width],
+ * fp32 matrix cores, 32x64 output tiles, the element-wise work fused in (csrc/dense_head.inc).
+ *   fn_dense_fwd_f32   Y[M,N] = X[M,K] W[N,K]^T + bias;  with act: Y = relu?(dropout(.)), the Philox stream of
+ *                      fn_dropout_act_f32 over Y's elements (act->y is ignored: the activation is applied in place)
+ *   fn_dense_bwd_f32   g_y = dL/d(X W^T + bias), i.e. already through the backward of this layer's own activation;
+ *                      dW[N,K] = g_y^T X;  db[N] = column sums of g_y (nullable);  g_x[M,K] = g_y W (nullable: first
+ *                      layer), and with gate_scale > 0 additionally g_x = X > 0 ? g_x * gate_scale : 0 -- the backward of
+ *                      the layer BELOW's relu(dropout(.)), whose saved output X is (gate_scale = 1 / (1 - p)), so the next
+ *                      call receives its g_y ready.  One launch.
+ * K and N multiples of 4 and <= 65536, M <= FN_DENSE_MAX_ROWS (one workgroup reduces over all of M: taller inputs go through
+ * fn_gate_colsum_f32 + library GEMMs).  With M = 0, fn_dense_bwd_f32 writes zeros to dW and db.
+ * ------------------------------------------------------------------------------------------ */
+#define FN_DENSE_MAX_ROWS 4096
+int fn_dense_fwd_f32(const float* X, const float* W, const float* bias /*nullable*/, float* Y, int64_t M, int64_t K, int64_t N,
+                     const fn_act_epilogue* act /*nullable*/, fn_stream_t stream);
+int fn_dense_bwd_f32(const float* g_y, const float* X, const float* W, float* g_x /*nullable*/, float gate_scale /*0: none*/,
+                     float* dW, float* db /*nullable*/, int64_t M, int64_t K, int64_t N, fn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * act(dropout(x)) between layers (gat2.py:396-397, 414-418, 436-440): Philox-4x32-10 mask keyed by
  * (seed, offset + element/4), y = relu(keep ? x/(1-p) : 0); relu = 0 gives plain dropout.
  * Backward recomputes the mask from the same (seed, offset).
@@ -302,7 +321,7 @@ int fn_bond_graph_fill(const int64_t* edge_index, const int64_t* atom_mol, int64
  * fn_gate_colsum_f32: backward of relu(dropout(.)) fused with the bias gradient of the Linear below it:
  *   g_x = (y > 0) ? g_y * scale : 0 (scale = 1/(1-p); the saved output encodes the mask), colsum[c] = sum_rows g_x[:, c].
  * fn_small_linear(_bwd)_f32: the last Linear of a head (n_classes <= FN_SMALL_LINEAR_MAX outputs) as one launch each
- *   way: y = x w^T + b;  g_x = g w, dW = g^T x, db = colsum(g).  All sums run in a fixed order (deterministic).
+ *   way: y = x w^T + b;  g_x = g w (optionally gated by x > 0), dW = g^T x, db = colsum(g).  All sums run in a fixed order.
  * ------------------------------------------------------------------------------------------ */
 #define FN_SMALL_LINEAR_MAX 16
 /* Inputs taller than 2048 rows (the pretrain towers run on every edge / atom) are reduced in row chunks: pass a float
@@ -314,7 +333,9 @@ int fn_small_linear_f32(const float* x /*[M,K]*/, const float* w /*[C,K]*/, cons
                         int64_t M, int64_t K, int64_t C, fn_stream_t stream);
 int64_t fn_small_linear_bwd_ws(int64_t M, int64_t K, int64_t C);
 int fn_small_linear_bwd_f32(const float* g /*[M,C]*/, const float* x /*[M,K]*/, const float* w /*[C,K]*/, float* g_x /*[M,K]*/,
-                            float* dW /*[C,K]*/, float* db /*[C]*/, int64_t M, int64_t K, int64_t C, float* ws, fn_stream_t stream);
+                            float* dW /*[C,K]*/, float* db /*[C]*/, int64_t M, int64_t K, int64_t C,
+                            float gate_scale /*0: none; > 0: g_x = x > 0 ? g_x * gate_scale : 0, the backward of the
+                            relu(dropout(.)) that produced x (see fn_dense_bwd_f32)*/, float* ws, fn_stream_t stream);
 
 /* torch.optim.Adam step (no amsgrad) on one flat fp32 tensor: finetune_gat2.py:257, pretrain_gat2.py:165.
  * `step` is the 1-based step count (bias corrections are computed on the host in double). */

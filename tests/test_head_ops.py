@@ -51,11 +51,69 @@ def test_small_linear_matches_torch(M, K, C):
     n_ws = _lib.load().fn_small_linear_bwd_ws(M, K, C)
     ws = torch.empty(n_ws, device=dev) if n_ws else None
     _lib.call("fn_small_linear_bwd_f32", g.data_ptr(), x.data_ptr(), w.data_ptr(), gx.data_ptr(), dW.data_ptr(), db.data_ptr(), M, K, C,
-              None if ws is None else ws.data_ptr(), st)
+              0.0, None if ws is None else ws.data_ptr(), st)
     torch.testing.assert_close(gx, (g.double() @ w.double()).float(), atol=2e-5, rtol=1e-5)
     tol = 2e-4 * max(1.0, M / 500) ** 0.5
     torch.testing.assert_close(dW, (g.double().t() @ x.double()).float(), atol=tol, rtol=1e-5)
     torch.testing.assert_close(db, g.double().sum(0).float(), atol=tol, rtol=1e-5)
+    gx2 = torch.empty_like(x)                                        # gated: the backward of the relu(dropout(.)) that produced x
+    _lib.call("fn_small_linear_bwd_f32", g.data_ptr(), x.data_ptr(), w.data_ptr(), gx2.data_ptr(), dW.data_ptr(), db.data_ptr(), M, K, C,
+              1.25, None if ws is None else ws.data_ptr(), st)
+    assert torch.equal(gx2, torch.where(x > 0, gx * 1.25, torch.zeros_like(gx)))
+
+
+@gpu
+@pytest.mark.parametrize("M,K,N", [(528, 256, 1024), (528, 1024, 1024), (33, 128, 512), (1, 4, 4), (200, 20, 36), (0, 64, 32), (4096, 132, 68)])
+def test_dense_layer_kernels_match_torch(M, K, N):
+    """fn_dense_fwd_f32 / fn_dense_bwd_f32 (fp32 matrix cores, fused bias + dropout + ReLU / gate + bias gradient) against
+    float64 products and the standalone fn_dropout_act_f32 Philox stream."""
+    import ctypes as C
+    from fragnet_amd import _lib
+    from fragnet_amd.plan import _stream_ptr
+    dev = _dev()
+    st = _stream_ptr(dev)
+    torch.manual_seed(M + K + N)
+    x, w, b = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) / K ** 0.5, torch.randn(N, device=dev)
+    lin = (x.double() @ w.double().t() + b.double()).float()
+    y = torch.full((M, N), 7.0, device=dev)
+    _lib.call("fn_dense_fwd_f32", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, K, N, None, st)
+    torch.testing.assert_close(y, lin, atol=2e-5, rtol=1e-5)
+    off_dev = torch.tensor([40], dtype=torch.int64, device=dev)
+    act = _lib.ActEpilogue(None, 0.25, 1, 99, 1000, off_dev.data_ptr())
+    z = torch.full((M, N), 7.0, device=dev)
+    _lib.call("fn_dense_fwd_f32", x.data_ptr(), w.data_ptr(), b.data_ptr(), z.data_ptr(), M, K, N, C.byref(act), st)
+    want = torch.empty_like(y)
+    if M:
+        _lib.call("fn_dropout_act_f32", y.data_ptr(), want.data_ptr(), y.numel(), 0.25, 99, 1040, None, 1, st)
+        assert torch.equal(z > 0, want > 0) or ((z > 0) != (want > 0)).sum() <= 2          # pre-activations within rounding of 0
+        torch.testing.assert_close(z, want, atol=3e-5, rtol=1e-5)
+    g = torch.randn(M, N, device=dev)
+    xr = torch.relu(x)                                               # a layer input that is itself relu(dropout(.)): about half zeros
+    for gate in (4.0 / 3.0, 0.0):
+        gx, dW, db = torch.full_like(x, 7.0), torch.full_like(w, 7.0), torch.full_like(b, 7.0)
+        _lib.call("fn_dense_bwd_f32", g.data_ptr(), xr.data_ptr(), w.data_ptr(), gx.data_ptr(), gate, dW.data_ptr(), db.data_ptr(),
+                  M, K, N, st)
+        tol = 2e-4 * max(1.0, M / 500) ** 0.5
+        want = g.double() @ w.double()
+        if gate:
+            want = torch.where(xr > 0, want * gate, torch.zeros_like(want))
+        torch.testing.assert_close(gx, want.float(), atol=3e-5, rtol=1e-5)
+        torch.testing.assert_close(dW, (g.double().t() @ xr.double()).float(), atol=tol, rtol=1e-5)
+        torch.testing.assert_close(db, g.double().sum(0).float(), atol=tol, rtol=1e-5)
+    dW2 = torch.full_like(w, 7.0)                                    # first layer: no input gradient, no bias gradient
+    _lib.call("fn_dense_bwd_f32", g.data_ptr(), x.data_ptr(), w.data_ptr(), None, 0.0, dW2.data_ptr(), None, M, K, N, st)
+    torch.testing.assert_close(dW2, (g.double().t() @ x.double()).float(), atol=2e-4 * max(1.0, M / 500) ** 0.5, rtol=1e-5)
+
+
+@gpu
+def test_dense_layer_kernels_reject_bad_shapes():
+    from fragnet_amd import _lib
+    from fragnet_amd.plan import _stream_ptr
+    dev = _dev()
+    t = torch.zeros(64, 64, device=dev)
+    for M, K, N in [(8, 6, 8), (8, 8, 6), (4097, 8, 8)]:
+        with pytest.raises(Exception, match="fn_dense_fwd_f32"):
+            _lib.call("fn_dense_fwd_f32", t.data_ptr(), t.data_ptr(), None, t.data_ptr(), M, K, N, None, _stream_ptr(dev))
 
 
 @gpu
@@ -85,6 +143,30 @@ def test_fused_head_equals_layer_by_layer_path(p, n_classes):
     for (n, pa), (_, pb) in zip(head_a.named_parameters(), head_b.named_parameters()):
         torch.testing.assert_close(pa.grad, pb.grad, atol=2e-5, rtol=1e-4, msg=lambda m, n=n: f"{n}: {m}")
     assert head_a.rng.offset == head_b.rng.offset
+
+
+@gpu
+def test_fused_head_skips_padding_rows():
+    """live_rows (static-shape batches): rows behind it are not computed -- outputs and input gradients 0 there, everything
+    else as if the input ended at live_rows."""
+    from fragnet_amd import ops
+    from fragnet_amd.model import FTHead3
+    dev = _dev()
+    torch.manual_seed(5)
+    head_a = FTHead3(input_dim=128, drop_ratio=0.0, n_classes=1).to(dev).train()
+    head_b = copy.deepcopy(head_a)
+    x_a = torch.randn(80, 256, device=dev, requires_grad=True)
+    x_b = x_a.detach()[:64].clone().requires_grad_(True)
+    head_a.rng, head_b.rng = ops.PhiloxStream(seed=11), ops.PhiloxStream(seed=11)
+    head_a.live_rows = 64
+    out_a, out_b = head_a(x_a), head_b(x_b)
+    assert out_a.shape == (80, 1) and torch.equal(out_a[:64], out_b) and not out_a[64:].any()
+    t = torch.randn_like(out_a)
+    (out_a * t).sum().backward()
+    (out_b * t[:64]).sum().backward()
+    assert torch.equal(x_a.grad[:64], x_b.grad) and not x_a.grad[64:].any()
+    for (n, pa), (_, pb) in zip(head_a.named_parameters(), head_b.named_parameters()):
+        assert torch.equal(pa.grad, pb.grad), n
 
 
 @gpu
