@@ -128,9 +128,9 @@ SIGNATURES = {
     "fn_masked_mse_multi_f32": [C.POINTER(MseTask), C.c_int, vp, vp, vp, vp],
     "fn_gate_colsum_ws": [i64, i64],
     "fn_gate_colsum_f32": [vp, vp, vp, vp, i64, i64, f32, vp, vp],
-    "fn_small_linear_f32": [vp, vp, vp, vp, i64, i64, i64, vp],
+    "fn_small_linear_f32": [vp, vp, vp, vp, i64, i64, i64, i64, vp],
     "fn_dense_fwd_f32": [vp, vp, vp, vp, i64, i64, i64, C.POINTER(ActEpilogue), vp],
-    "fn_dense_bwd_f32": [vp, vp, vp, vp, f32, vp, vp, i64, i64, i64, vp],
+    "fn_dense_bwd_f32": [vp, vp, vp, vp, f32, vp, vp, i64, i64, i64, i64, vp],
     "fn_small_linear_bwd_ws": [i64, i64, i64],
     "fn_small_linear_bwd_f32": [vp, vp, vp, vp, vp, vp, i64, i64, i64, f32, vp, vp],
 }

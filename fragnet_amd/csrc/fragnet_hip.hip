@@ -1807,10 +1807,14 @@ __global__ void k_gate_many(GateTasks G) {
 // y[m, c] = <x[m, :], w[c, :]> + b[c] for a handful of outputs (the last Linear of a head: n_classes columns).
 // One wave per row; the row stays in registers while the C weight rows stream from L1.
 __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ x, const float* __restrict__ w,
-                                                      const float* __restrict__ b, float* __restrict__ y, int64_t M, int K, int C) {
+                                                      const float* __restrict__ b, float* __restrict__ y, int64_t M, int K, int C,
+                                                      int64_t M_out) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    if (row >= M) {                                                  // padding rows of a static-shape batch: defined, 0
+        if (row < M_out && lane < C) y[row * C + lane] = 0.f;
+        return;
+    }
     const int k4 = K / 4;                                            // K % 4 == 0
     for (int c = 0; c < C; ++c) {
         float acc = 0.f;
@@ -2301,6 +2305,7 @@ struct WgradTasks {
     WgradTask t[kMaxWgradTasks];
     int n, K;
 };
+#include "wgrad128.inc"
 template <int CTW, int NH>
 __global__ __launch_bounds__(256 * NH) void k_linear128_wgrad_multi(WgradTasks T) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -2382,7 +2387,7 @@ __device__ __forceinline__ float colmajor_sum_128(const float* __restrict__ col,
     const int c = threadIdx.x >> 7;
     return sW[2 * c] + sW[2 * c + 1];
 }
-template <int CTW, int NH>
+template <int CTW, int NH, bool PLAIN = false>
 __device__ __forceinline__ void wgrad_reduce_strip(int vb, float* sm, const float* __restrict__ part, int n_rows, int K,
                                                    float* __restrict__ dW, float* __restrict__ db) {
     constexpr int XW = 16 * CTW * NH;
@@ -2405,6 +2410,8 @@ __device__ __forceinline__ void wgrad_reduce_strip(int vb, float* sm, const floa
             for (int g = 0; g < 16; ++g) v += sm[g * 256 + threadIdx.x];
             if (col >= 128 * XW) {
                 db[col - 128 * XW] = v;
+            } else if (PLAIN) {                                                          // k_wgrad128_multi: partials are [o][k] already
+                dW[col] = v;
             } else {
                 const int r = col & 3, lane = (col >> 2) & 63, tile = col >> 8;        // tile = (w*2+u)*CTW + cc
                 const int cc = tile % CTW, wu = tile / CTW, u = wu & 1, w = wu >> 1;
@@ -2442,6 +2449,7 @@ __global__ __launch_bounds__(1024) void k_reduce_tasks(ReduceTasks T) {
             case 0: wgrad_reduce_strip<1, 1>(vb, sm, t.p0, t.n0, t.K, t.o0, t.o1); break;
             case 1: wgrad_reduce_strip<1, 2>(vb, sm, t.p0, t.n0, t.K, t.o0, t.o1); break;
             case 2: wgrad_reduce_strip<4, 2>(vb, sm, t.p0, t.n0, t.K, t.o0, t.o1); break;
+            case 4: wgrad_reduce_strip<4, 2, true>(vb, sm, t.p0, t.n0, t.K, t.o0, t.o1); break;
             default: wgrad_reduce_strip<6, 2>(vb, sm, t.p0, t.n0, t.K, t.o0, t.o1); break;
         }
     }
@@ -2491,7 +2499,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 namespace {
 unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
 int64_t g_mol_stamps_n = 0;
-int g_tune[FN_TUNE_COUNT] = {1792, 0, 0, 512, 0, 0, 0, 1};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
+int g_tune[FN_TUNE_COUNT] = {1792, 0, 0, 256, 0, 0, 0, 1, 1};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -3193,12 +3201,14 @@ int fn_gate_colsum_f32(const float* g_y, const float* y, float* g_x, float* cols
     return launch_status("fn_gate_colsum_f32");
 }
 
-int fn_small_linear_f32(const float* x, const float* w, const float* b, float* y, int64_t M, int64_t K, int64_t C, fn_stream_t stream) {
+int fn_small_linear_f32(const float* x, const float* w, const float* b, float* y, int64_t M, int64_t K, int64_t C, int64_t M_out,
+                        fn_stream_t stream) {
     if (M < 0 || K < 4 || (K & 3) || K > INT32_MAX || C < 1 || C > FN_SMALL_LINEAR_MAX)
         return fail(FN_EINVAL, "fn_small_linear_f32: K must be a multiple of 4 and 1 <= C <= FN_SMALL_LINEAR_MAX");
-    if (M == 0) return 0;
+    if (M_out < M) M_out = M;
+    if (M_out == 0) return 0;
     if (!x || !w || !y || (((uintptr_t)x | (uintptr_t)w) & 15)) return fail(FN_EINVAL, "fn_small_linear_f32: null or misaligned buffer");
-    hipLaunchKernelGGL(k_small_linear, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, S(stream), x, w, b, y, M, (int)K, (int)C);
+    hipLaunchKernelGGL(k_small_linear, dim3((unsigned)((M_out + 3) / 4)), dim3(256), 0, S(stream), x, w, b, y, M, (int)K, (int)C, M_out);
     return launch_status("fn_small_linear_f32");
 }
 
@@ -3253,7 +3263,7 @@ int fn_dense_fwd_f32(const float* X, const float* W, const float* bias, float* Y
 }
 
 int fn_dense_bwd_f32(const float* g_y, const float* X, const float* W, float* g_x, float gate_scale, float* dW, float* db,
-                     int64_t M, int64_t K, int64_t N, fn_stream_t stream) {
+                     int64_t M, int64_t K, int64_t N, int64_t M_out, fn_stream_t stream) {
     if (!dense_shape_ok(M, K, N)) return fail(FN_EINVAL, "fn_dense_bwd_f32: K and N must be multiples of 4, M <= FN_DENSE_MAX_ROWS");
     if (!W || !dW || (M > 0 && (!g_y || !X)) || gate_scale < 0.f ||
         (((uintptr_t)g_y | (uintptr_t)X | (uintptr_t)W | (uintptr_t)g_x | (uintptr_t)dW) & 15))
@@ -3265,11 +3275,13 @@ int fn_dense_bwd_f32(const float* g_y, const float* X, const float* W, float* g_
     a.tiles_i = dense_tiles(N, 64);  a.tiles_j = dense_tiles(K, kDnCols);
     int blocks = a.tiles_i * a.tiles_j;
     P.b.first_block = blocks;
-    if (g_x && M > 0) {
+    if (M_out < M) M_out = M;
+    if (M_out > FN_DENSE_MAX_ROWS) return fail(FN_EINVAL, "fn_dense_bwd_f32: M_out > FN_DENSE_MAX_ROWS");
+    if (g_x && M_out > 0) {
         DenseArgs& b = P.b;                              // gX [M,K] = gy W, gated by X > 0
         b.A = g_y;  b.Bsrc = W;  b.OUT = g_x;  b.Z = gate_scale > 0.f ? X : nullptr;  b.gate_scale = gate_scale;
-        b.I = (int)M;  b.J = (int)K;  b.R = (int)N;  b.lda = (int)N;  b.ldb = (int)K;
-        b.tiles_i = dense_tiles(M, 32);  b.tiles_j = dense_tiles(K, kDnCols);
+        b.I = (int)M;  b.I_out = (int)M_out;  b.J = (int)K;  b.R = (int)N;  b.lda = (int)N;  b.ldb = (int)K;
+        b.tiles_i = dense_tiles(M_out, 32);  b.tiles_j = dense_tiles(K, kDnCols);
         blocks += b.tiles_i * b.tiles_j;
     }
     hipLaunchKernelGGL(k_dense_bwd, dim3((unsigned)blocks), dim3(kDnThreads), kDnLdsBytes, S(stream), P);
@@ -3621,19 +3633,19 @@ struct ReduceQueue {
             if (W.n == kMaxWgradTasks || T.n == kMaxReduceTasks) { if (int rc = flush()) return rc; }
             W.t[W.n] = WgradTask{dY, X, ws, M, 0, 0};
             w_reduce[W.n++] = T.n;
-            t.cls = 2;
+            t.cls = g_tune[FN_TUNE_WGRAD_DIRECT] ? 4 : 2;
         } else if (int rc = wgrad_partials(dY, X, K, M, ws, launch_on, &grid, &t.cls)) return rc;
         t.kind = RT_WGRAD;  t.p0 = ws;  t.n0 = grid;  t.K = K;  t.o0 = dW;  t.o1 = db;
         return push(t, (int)((wgrad_part_width(K) + 255) / 256));
     }
     int flush_wgrad() {
         if (W.n == 0) return 0;
-        // rows per block from the WHOLE group: ~512 blocks (two per CU, one round) instead of ~256 per product, which for the
-        // nine products of a backward pass was 1.6 k blocks writing 104 MB of 64-KB partials (now ~30 MB); never fewer rows
+        // rows per block from the WHOLE group: ~256 blocks (one per CU) instead of ~256 per product, which for the nine
+        // products of a backward pass was 1.6 k blocks writing 104 MB of 64-KB partials (now ~16 MB); never fewer rows
         // than the per-product rule, so the partial workspace sized by fn_linear128_wgrad_ws still fits
         int64_t total = 0;
         for (int i = 0; i < W.n; ++i) total += W.t[i].M;
-        const int64_t target = g_tune[FN_TUNE_WGRAD_BLOCKS] > 0 ? g_tune[FN_TUNE_WGRAD_BLOCKS] : 512;
+        const int64_t target = g_tune[FN_TUNE_WGRAD_BLOCKS] > 0 ? g_tune[FN_TUNE_WGRAD_BLOCKS] : 256;
         const int group_rpb = (int)(((total + target - 1) / target + kWgChunk - 1) / kWgChunk * kWgChunk);
         wblocks = 0;
         for (int i = 0; i < W.n; ++i) {
@@ -3644,11 +3656,16 @@ struct ReduceQueue {
             T.t[w_reduce[i]].n0 = grid;
             wblocks += grid;
         }
-        constexpr int XW = 16 * 4 * 2, XLD = XW + 16;
-        const size_t lds = (size_t)2 * kWgChunk * (kBtLd + XLD) * sizeof(float);
-        if (int rc = allow_lds(k_linear128_wgrad_multi<4, 2>, lds)) return rc;
         W.K = FN_D;
-        hipLaunchKernelGGL((k_linear128_wgrad_multi<4, 2>), dim3(wblocks), dim3(512), lds, st, W);
+        if (g_tune[FN_TUNE_WGRAD_DIRECT]) {
+            if (int rc = allow_lds(k_wgrad128_multi, kWdLdsBytes)) return rc;
+            hipLaunchKernelGGL(k_wgrad128_multi, dim3(wblocks), dim3(kWdThreads), kWdLdsBytes, st, W);
+        } else {
+            constexpr int XW = 16 * 4 * 2, XLD = XW + 16;
+            const size_t lds = (size_t)2 * kWgChunk * (kBtLd + XLD) * sizeof(float);
+            if (int rc = allow_lds(k_linear128_wgrad_multi<4, 2>, lds)) return rc;
+            hipLaunchKernelGGL((k_linear128_wgrad_multi<4, 2>), dim3(wblocks), dim3(512), lds, st, W);
+        }
         W.n = 0;  wblocks = 0;
         return launch_status("grouped weight-gradient partials");
     }

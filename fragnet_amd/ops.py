@@ -648,8 +648,8 @@ class _MLPHead(torch.autograd.Function):
         W, b = params[-2], params[-1]
         C_out, K = W.shape
         if C_out <= SMALL_LINEAR_MAX and K % 4 == 0:
-            out = (torch.empty if live == M else torch.zeros)((M, C_out), dtype=torch.float32, device=h.device)
-            _lib.call("fn_small_linear_f32", h.data_ptr(), _f32c(W, "W").data_ptr(), b.data_ptr(), out.data_ptr(), live, K, C_out, st)
+            out = torch.empty((M, C_out), dtype=torch.float32, device=h.device)        # the kernel zeroes the padding rows
+            _lib.call("fn_small_linear_f32", h.data_ptr(), _f32c(W, "W").data_ptr(), b.data_ptr(), out.data_ptr(), live, K, C_out, M, st)
         else:
             out = torch.addmm(b, h, W.t())
             if live < M:
@@ -675,12 +675,13 @@ class _MLPHead(torch.autograd.Function):
         scale = 1.0 / (1.0 - ctx.p) if 0.0 < ctx.p < 1.0 else (1.0 if ctx.p == 0.0 else 0.0)
         dW, db = grad_buffer(P[-2], slots[-2]), grad_buffer(P[-1], slots[-1])
 
-        def input_grad(like, last):
+        def input_grad(like, last, zeroed_by_kernel=False):
             """buffer of d loss / d (input of a layer); the head's own input gradient has all M rows (padding rows 0)"""
             if not last or live == M:
                 return torch.empty_like(like)
             full = torch.empty((M, like.shape[1]), dtype=torch.float32, device=like.device)
-            full[live:].zero_()
+            if not zeroed_by_kernel:
+                full[live:].zero_()
             return full
 
         if C_out <= SMALL_LINEAR_MAX and K % 4 == 0:
@@ -704,9 +705,9 @@ class _MLPHead(torch.autograd.Function):
             grads[2 * i], grads[2 * i + 1] = dW, db
             need_gx = i > 0 or need_x
             if dense:                                   # gz is d loss / d (pre-activation) already: one launch for the layer
-                gx = input_grad(h_in, i == 0) if need_gx else None
+                gx = input_grad(h_in, i == 0, zeroed_by_kernel=True) if need_gx else None
                 _lib.call("fn_dense_bwd_f32", gz.data_ptr(), h_in.data_ptr(), W.data_ptr(), _ptr(gx), scale if i > 0 else 0.0, dW.data_ptr(),
-                          db.data_ptr(), live, W.shape[1], W.shape[0], st)
+                          db.data_ptr(), live, W.shape[1], W.shape[0], M if i == 0 else live, st)
                 gz = gx
                 continue
             gy = torch.empty_like(z)

@@ -54,7 +54,7 @@ int fn_abi_version(void);
                                 * rows.  Default 0 = one tile per workgroup (faster at every measured size) */
 #define FN_TUNE_STREAMS 2      /* 1: the encoder forks parameter-gradient work and the fragment-bond chain onto side streams;
                                 * 0 (default): one stream -- forked hipGraph replays measured slower on ROCm 7.2 */
-#define FN_TUNE_WGRAD_BLOCKS 3 /* target workgroup count of the grouped weight-gradient launch of a backward pass (default 512) */
+#define FN_TUNE_WGRAD_BLOCKS 3 /* target workgroup count of the grouped weight-gradient launch of a backward pass (default 256: one per CU; 512 wrote twice the partials and measured 1 % slower per step) */
 #define FN_TUNE_FUSED 4        /* 1: fn_encoder_forward runs the molecule-resident fused layer kernel (csrc/mol_fused.inc) when the
                                 * descriptor carries the molecule CSRs (mol_atoms / mol_frags) and heads == 4; 0 (default): per-level
                                 * kernels -- measured on MI355X the fused kernel only matches them at 512 molecules */
@@ -65,7 +65,9 @@ int fn_abi_version(void);
                                 * 0 (default): k_linear128 -- measured 1-4 % faster per step on MI355X */
 #define FN_TUNE_FUSE_ROWDOTS 7 /* 1 (default): inside fn_encoder_forward the bond-graph attention kernel also writes the atom graph's edge
                                 * term <new_bond, a[:, d:d+128]> from the row it holds in registers; 0: a separate row-dots launch */
-#define FN_TUNE_COUNT 8
+#define FN_TUNE_WGRAD_DIRECT 8 /* 1 (default): the grouped K = 128 weight-gradient partials run as k_wgrad128_multi (operands straight from
+                                * global memory in the MFMA layout, csrc/wgrad128.inc); 0: the LDS-staged k_linear128_wgrad_multi */
+#define FN_TUNE_COUNT 9
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * molecules 64-bit words) is
  * set, every workgroup of the fused molecule kernels writes s_memtime stamps of its phases into it (tools/mol_phase_times.py).
@@ -281,8 +283,9 @@ int fn_segment_softmax_bwd_f32(const float* probs, const float* g_probs, const i
 #define FN_DENSE_MAX_ROWS 4096
 int fn_dense_fwd_f32(const float* X, const float* W, const float* bias /*nullable*/, float* Y, int64_t M, int64_t K, int64_t N,
                      const fn_act_epilogue* act /*nullable*/, fn_stream_t stream);
-int fn_dense_bwd_f32(const float* g_y, const float* X, const float* W, float* g_x /*nullable*/, float gate_scale /*0: none*/,
-                     float* dW, float* db /*nullable*/, int64_t M, int64_t K, int64_t N, fn_stream_t stream);
+int fn_dense_bwd_f32(const float* g_y, const float* X, const float* W, float* g_x /*nullable, [max(M,M_out),K]*/, float gate_scale /*0: none*/,
+                     float* dW, float* db /*nullable*/, int64_t M, int64_t K, int64_t N,
+                     int64_t M_out /*rows [M, M_out) of g_x are set to 0 (padding rows); <= M: none*/, fn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * act(dropout(x)) between layers (gat2.py:396-397, 414-418, 436-440): Philox-4x32-10 mask keyed by
@@ -329,8 +332,9 @@ int fn_bond_graph_fill(const int64_t* edge_index, const int64_t* atom_mol, int64
 int64_t fn_gate_colsum_ws(int64_t rows, int64_t cols);
 int fn_gate_colsum_f32(const float* g_y /*[rows,cols]*/, const float* y /*[rows,cols]*/, float* g_x /*[rows,cols]*/,
                        float* colsum /*[cols]*/, int64_t rows, int64_t cols, float scale, float* ws, fn_stream_t stream);
-int fn_small_linear_f32(const float* x /*[M,K]*/, const float* w /*[C,K]*/, const float* b /*[C] nullable*/, float* y /*[M,C]*/,
-                        int64_t M, int64_t K, int64_t C, fn_stream_t stream);
+int fn_small_linear_f32(const float* x /*[M,K]*/, const float* w /*[C,K]*/, const float* b /*[C] nullable*/, float* y /*[max(M,M_out),C]*/,
+                        int64_t M, int64_t K, int64_t C, int64_t M_out /*rows [M, M_out) of y are set to 0: the padding
+                        molecules of a static-shape batch; <= M: none*/, fn_stream_t stream);
 int64_t fn_small_linear_bwd_ws(int64_t M, int64_t K, int64_t C);
 int fn_small_linear_bwd_f32(const float* g /*[M,C]*/, const float* x /*[M,K]*/, const float* w /*[C,K]*/, float* g_x /*[M,K]*/,
                             float* dW /*[C,K]*/, float* db /*[C]*/, int64_t M, int64_t K, int64_t C,

@@ -45,7 +45,7 @@ def test_small_linear_matches_torch(M, K, C):
     g = torch.randn(M, C, device=dev)
     y = torch.empty(M, C, device=dev)
     st = _stream_ptr(dev)
-    _lib.call("fn_small_linear_f32", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, K, C, st)
+    _lib.call("fn_small_linear_f32", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, K, C, M, st)
     torch.testing.assert_close(y, (x.double() @ w.double().t() + b.double()).float(), atol=2e-5, rtol=1e-5)
     gx, dW, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(b)
     n_ws = _lib.load().fn_small_linear_bwd_ws(M, K, C)
@@ -92,7 +92,7 @@ def test_dense_layer_kernels_match_torch(M, K, N):
     for gate in (4.0 / 3.0, 0.0):
         gx, dW, db = torch.full_like(x, 7.0), torch.full_like(w, 7.0), torch.full_like(b, 7.0)
         _lib.call("fn_dense_bwd_f32", g.data_ptr(), xr.data_ptr(), w.data_ptr(), gx.data_ptr(), gate, dW.data_ptr(), db.data_ptr(),
-                  M, K, N, st)
+                  M, K, N, M, st)
         tol = 2e-4 * max(1.0, M / 500) ** 0.5
         want = g.double() @ w.double()
         if gate:
@@ -101,8 +101,17 @@ def test_dense_layer_kernels_match_torch(M, K, N):
         torch.testing.assert_close(dW, (g.double().t() @ xr.double()).float(), atol=tol, rtol=1e-5)
         torch.testing.assert_close(db, g.double().sum(0).float(), atol=tol, rtol=1e-5)
     dW2 = torch.full_like(w, 7.0)                                    # first layer: no input gradient, no bias gradient
-    _lib.call("fn_dense_bwd_f32", g.data_ptr(), x.data_ptr(), w.data_ptr(), None, 0.0, dW2.data_ptr(), None, M, K, N, st)
+    _lib.call("fn_dense_bwd_f32", g.data_ptr(), x.data_ptr(), w.data_ptr(), None, 0.0, dW2.data_ptr(), None, M, K, N, M, st)
     torch.testing.assert_close(dW2, (g.double().t() @ x.double()).float(), atol=2e-4 * max(1.0, M / 500) ** 0.5, rtol=1e-5)
+    if 0 < M <= 4000:                                                # padding rows behind M: written as 0 by the same launch
+        gx3 = torch.full((M + 40, K), 7.0, device=dev)
+        _lib.call("fn_dense_bwd_f32", g.data_ptr(), xr.data_ptr(), w.data_ptr(), gx3.data_ptr(), 0.0, dW2.data_ptr(), None, M, K, N, M + 40, st)
+        assert torch.equal(gx3[:M], gx) and not gx3[M:].any()
+        y3 = torch.full((M + 5, N if N <= 16 else 1), 7.0, device=dev)
+        Cs = y3.shape[1]
+        _lib.call("fn_small_linear_f32", x.data_ptr(), w.data_ptr(), b.data_ptr(), y3.data_ptr(), M, K, Cs, M + 5, st)
+        torch.testing.assert_close(y3[:M], lin[:, :Cs], atol=2e-5, rtol=1e-5)
+        assert not y3[M:].any()
 
 
 @gpu
