@@ -1898,6 +1898,7 @@ __global__ __launch_bounds__(256) void k_small_linear_bwd(const float* __restric
 //   weight grad dW[128,K] = dY^T X, db = colsum(dY)           (split over row chunks, deterministic 2-stage sum)
 // =====================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) f32x4_u4 { float v[4]; };      // 16 bytes at a 4-byte-aligned address
 constexpr int kBtLd = 144;     // LDS leading dimension of the [K][128] operand: 144 % 32 == 16
 constexpr int kLinLd = 64;     // k_linear128's operand tile [K][64 columns], unpadded: a lane reads 4 consecutive columns (ds_read_b128) and the
                                // 16-lane groups of that instruction then cover all 64 banks exactly once (rows 4 apart share the bank alignment)
@@ -1937,15 +1938,32 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
     int64_t tile = bid >> 1;
     if (tile >= tiles) return;                               // whole block
 
+    // IL: the interleaved k split also for rows that are only 4-byte aligned (K % 4 != 0: the 167 atom features of layer 0):
+    // the same 64 contiguous bytes per row and instruction, loaded as unaligned 16-byte pieces; only the piece that
+    // straddles the end of the row is loaded element by element.  (The blocked split it replaces ran that projection
+    // at 22 us for 0.6 GFLOP.)
+    constexpr bool IL = VEC || (KQ % 4 == 0);
     auto load_rows = [&](int64_t t, float (&xa)[KQ]) {
         int64_t row = t * kLinRows + w * 16 + i;
         row = row < M ? row : M - 1;
-        const float* src = X + row * K + (VEC ? 4 * kq : kq * KQ);
+        const float* src = X + row * K + (IL ? 4 * kq : kq * KQ);
         if (VEC) {
 #pragma unroll
             for (int s = 0; s < KQ / 4; ++s) {
                 const float4 v = ld4(src + s * 16);
                 xa[4 * s + 0] = v.x; xa[4 * s + 1] = v.y; xa[4 * s + 2] = v.z; xa[4 * s + 3] = v.w;
+            }
+        } else if (IL) {
+#pragma unroll
+            for (int s = 0; s < KQ / 4; ++s) {
+                const int col = 16 * s + 4 * kq;
+                if (col + 3 < K) {
+                    const f32x4_u4 v = *reinterpret_cast<const f32x4_u4*>(src + s * 16);
+                    xa[4 * s + 0] = v.v[0]; xa[4 * s + 1] = v.v[1]; xa[4 * s + 2] = v.v[2]; xa[4 * s + 3] = v.v[3];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xa[4 * s + c] = (col + c < K) ? src[s * 16 + c] : 0.f;
+                }
             }
         } else {
 #pragma unroll
@@ -1983,8 +2001,8 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
     __syncthreads();
 
     // MFMA tile t of a wave covers the columns {4 i + t}: one 16-byte LDS read per step feeds all four tiles
-    const float* bbase = sBt + (VEC ? 4 * kq : kq * KQ) * kLinLd + 4 * i;
-    auto brow = [](int s) { return VEC ? 16 * (s >> 2) + (s & 3) : s; };      // LDS row of MFMA step s, relative to bbase
+    const float* bbase = sBt + (IL ? 4 * kq : kq * KQ) * kLinLd + 4 * i;
+    auto brow = [](int s) { return IL ? 16 * (s >> 2) + (s & 3) : s; };       // LDS row of MFMA step s, relative to bbase
     for (;;) {
         const int64_t next = tile + stride;
         const bool more = next < tiles;
@@ -3005,7 +3023,7 @@ static int linear128_impl(const float* X, int K, const float* Bt, const float* b
     if (K <= 8) rc = launch_linear128<2>(X, K, Bt, bias, Y, M, mk, ns, S(stream));
     else if (K <= 20) rc = launch_linear128<5>(X, K, Bt, bias, Y, M, mk, ns, S(stream));
     else if (K <= 128) rc = launch_linear128<32>(X, K, Bt, bias, Y, M, mk, ns, S(stream));
-    else if (K <= 168) rc = launch_linear128<42>(X, K, Bt, bias, Y, M, mk, ns, S(stream));
+    else if (K <= 168) rc = launch_linear128<44>(X, K, Bt, bias, Y, M, mk, ns, S(stream));
     else return fail(FN_EUNSUPPORTED, "fn_linear128_f32: K > 168");
     if (rc) return rc;
     return launch_status("fn_linear128_f32");
