@@ -1160,13 +1160,24 @@ __global__ __launch_bounds__(kBlock) void k_row_dots_sorted(const float* __restr
 }
 
 // g_feat[e,:] = sum_j g_s_sorted[inv(e), j] A[j];  part [grid, J*128]: partial sums of g_A[j,:] = sum_e g_s[e,j] feat[e,:]
-__global__ __launch_bounds__(kBlock) void k_row_dots_sorted_bwd(const float* __restrict__ g_s_sorted,
-                                                                const float* __restrict__ feat,
-                                                                const float* __restrict__ A, int lda, int off, int J,
-                                                                fn_gat_plan pl, float* g_feat,
-                                                                float* __restrict__ part, const float* addend,
-                                                                int g_is_orig) {
-    __shared__ float sR[kRows][FN_D];
+struct RowDotsBwdArgs {
+    const float *g_s_sorted, *feat, *A;
+    int lda, off, J;
+    fn_gat_plan pl;
+    float* g_feat;
+    float* part;
+    const float* addend;
+    int g_is_orig, nblk;
+};
+__device__ __forceinline__ void row_dots_sorted_bwd_body(const RowDotsBwdArgs& T, float (*sR)[FN_D], int vb, int nb) {
+    const float* __restrict__ g_s_sorted = T.g_s_sorted;
+    const float* __restrict__ feat = T.feat;
+    const float* __restrict__ A = T.A;
+    const int lda = T.lda, off = T.off, J = T.J, g_is_orig = T.g_is_orig;
+    const fn_gat_plan& pl = T.pl;
+    float* g_feat = T.g_feat;
+    float* __restrict__ part = T.part;
+    const float* addend = T.addend;
     const int lane = threadIdx.x & 31, hw = threadIdx.x >> 5;
     float4 a[8], q[8];
 #pragma unroll
@@ -1178,7 +1189,11 @@ __global__ __launch_bounds__(kBlock) void k_row_dots_sorted_bwd(const float* __r
     // original order, edge-major [m_real][J] (written that way by the destination pass: one 16-byte read), or in
     // destination-sorted head-major order [J][m] through the inverse permutation (autograd path)
     int64_t g0, g1;
-    block_groups(pl.m_real, kRows, g0, g1);
+    {   // block_groups() for a virtual block index (the kernel may share its launch with another body)
+        const int64_t groups = (pl.m_real + kRows - 1) / kRows, per = (groups + nb - 1) / nb;
+        g0 = (int64_t)xcd_block(vb, nb) * per;
+        g1 = g0 + per < groups ? g0 + per : groups;
+    }
     if (g_is_orig && J == 4) {
         // engine path: 4 heads, gradient in original edge order.  Four rows per trip, every load issued before the
         // first use (a single-row loop is one dependent round trip per row: 15 us for 28 k rows)
@@ -1229,11 +1244,24 @@ __global__ __launch_bounds__(kBlock) void k_row_dots_sorted_bwd(const float* __r
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < kRows; ++w) v += sR[w][threadIdx.x];
-                part[(size_t)(i * FN_D + threadIdx.x) * FN_MAX_PART + blockIdx.x] = v;   // column-major
+                part[(size_t)(i * FN_D + threadIdx.x) * FN_MAX_PART + vb] = v;   // column-major
             }
             __syncthreads();
         }
     }
+}
+__global__ __launch_bounds__(kBlock) void k_row_dots_sorted_bwd(RowDotsBwdArgs T) {
+    __shared__ float sR[kRows][FN_D];
+    row_dots_sorted_bwd_body(T, sR, (int)blockIdx.x, (int)gridDim.x);
+}
+// The source pass of a level and the backward of its edge term both depend on the destination pass only, never on each
+// other: one launch (a dependent launch costs ~5 us however small the kernel is; 5 such pairs per backward pass).
+template <int H, int RB>
+__global__ __launch_bounds__(RB * 32) void k_gat_bwd_src_rd(GatBwdSrcArgs A, RowDotsBwdArgs T) {
+    static_assert(RB * 32 == kBlock && RB == kRows, "both bodies run 8 half-waves per block");
+    __shared__ float sA[RB][2 * FN_D];
+    if ((int)blockIdx.x < A.nblk) gat_bwd_src_body<H, RB>(A, sA, (int)blockIdx.x, A.nblk);
+    else row_dots_sorted_bwd_body(T, reinterpret_cast<float(*)[FN_D]>(&sA[0][0]), (int)blockIdx.x - A.nblk, T.nblk);
 }
 
 // x_sorted[pos, :] = x[eid(pos), :] (zeros at loop positions): raw edge attributes are permuted once per batch
@@ -2988,8 +3016,8 @@ int fn_row_dots_sorted_bwd_f32(const float* g_s_sorted, const float* feat, const
         return fail(FN_EINVAL, "fn_row_dots_sorted_bwd_f32: null buffer");
     const int g = row_grid(plan->m_real, kRowDotsBwdBlocks);
     *n_part = g;
-    hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(g), dim3(kBlock), 0, S(stream), g_s_sorted, feat, A, lda, off, J, *plan,
-                       g_feat, part, (const float*)nullptr, 0);
+    hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(g), dim3(kBlock), 0, S(stream),
+                       RowDotsBwdArgs{g_s_sorted, feat, A, lda, off, J, *plan, g_feat, part, nullptr, 0, g});
     return launch_status("fn_row_dots_sorted_bwd_f32");
 }
 
@@ -3689,6 +3717,25 @@ struct ReduceQueue {
     }
 };
 
+// source pass of a level + backward of its edge term <feat[e], att[:, mid block]> as ONE launch (k_gat_bwd_src_rd); they
+// share nothing but their input dz.  *n_rd = blocks of the edge-term part (0: the level has no real edges).
+int bwd_src_and_edge_term(const float* g_out, const float* h, const float* pz_src, const float* g_s_dst, const float* att, int att_w,
+                          int dst_off, int src_off, const fn_gat_plan* plan, float* g_h, float* part_a, int* n_part_a,
+                          const float* dz_orig, const float* feat, int mid_off, float* g_feat, float* part_rd, bool accumulate,
+                          int* n_rd, int heads, hipStream_t st) {
+    GatBwdSrcArgs A;
+    if (int rc = prep_gat_bwd_src(g_out, h, pz_src, g_s_dst, att, att_w, dst_off, src_off, plan, g_h, part_a, n_part_a, heads, &A)) return rc;
+    *n_rd = plan->m_real > 0 ? row_grid(plan->m_real, kRowDotsBwdBlocks) : 0;
+    if (*n_rd == 0) return launch_gat_bwd_src(A, heads, st);
+    const RowDotsBwdArgs T{dz_orig, feat, att, att_w, mid_off, heads, *plan, g_feat, part_rd, accumulate ? (const float*)g_feat : nullptr, 1, *n_rd};
+    if (A.nblk == 0) {
+        hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(T.nblk), dim3(kBlock), 0, st, T);
+        return launch_status("edge-term backward");
+    }
+    FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src_rd<HH, kBwdRows>), dim3(A.nblk + T.nblk), dim3(kBlock), 0, st, A, T));
+    return launch_status("source pass + edge-term backward");
+}
+
 int enc_check(const fn_encoder* e) {
     if (!e) return fail(FN_EINVAL, "fn_encoder: null descriptor");
     if (e->n_layers < 1 || e->n_layers > FN_MAX_LAYERS) return fail(FN_EINVAL, "fn_encoder: n_layers out of range");
@@ -4005,16 +4052,11 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         } else if (have_frags) {
             fn_edge_term et_f{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
             FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_frags, a.frags, a.p_frag, &et_f, &e->frag, 0.2f, nullptr, sf.dz, sf.pz, sf.g_s_dst, nullptr, &n_e, H, st));
-            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_frags, a.frags, sf.pz, sf.g_s_dst, w.f, wide, 0, d + FN_D, &e->frag, bw.g_frags, sf.part_a, &n_a, H, st));
-            // edge term <new_fbond, f[:, d:d+128]>: dL/dnew_fbond accumulates into g_pre_fbond, dL/df mid block
+            // source pass + edge term <new_fbond, f[:, d:d+128]> (dL/dnew_fbond accumulates into g_pre_fbond, dL/df mid block)
             int gr = 0;
-            if (e->frag.m_real > 0) {
-                gr = row_grid(e->frag.m_real, kRowDotsBwdBlocks);
-                hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(gr), dim3(kBlock), 0, hs, sf.dz, a.new_fbond, w.f, wide, d, H, e->frag,
-                                   bw.g_pre_fbond, sf.part_rd, have_fbond ? (const float*)bw.g_pre_fbond : (const float*)nullptr, 1);
-                FN_TRY(launch_status("fn_encoder_backward: row_dots(frag)"));
-                have_fbond = true;
-            }
+            FN_TRY(bwd_src_and_edge_term(bw.g_pre_frags, a.frags, sf.pz, sf.g_s_dst, w.f, wide, 0, d + FN_D, &e->frag, bw.g_frags, sf.part_a, &n_a,
+                                         sf.dz, a.new_fbond, d, bw.g_pre_fbond, sf.part_rd, have_fbond, &gr, H, hs));
+            if (gr) have_fbond = true;
             FN_TRY(rq.finalize(sf.part_a, n_a, nullptr, 0, et_f, w.f, wide, 0, d + FN_D, g.f, nullptr, nullptr, H));
             if (gr) FN_TRY(rq.colsum(sf.part_rd, gr, H * FN_D, g.f, wide, d));
             have_g_frags_h = true;
@@ -4032,15 +4074,10 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         if (have_atoms) {
             fn_edge_term et_a{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
             FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_atoms, a.h_a, a.p_atom, &et_a, &e->atom, 0.2f, nullptr, sa.dz, sa.pz, sa.g_s_dst, nullptr, &n_e, H, st));
-            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_atoms, a.h_a, sa.pz, sa.g_s_dst, w.a, wide, 0, d + FN_D, &e->atom, sa.g_h, sa.part_a, &n_a, H, st));
             int gr = 0;
-            if (e->atom.m_real > 0) {
-                gr = row_grid(e->atom.m_real, kRowDotsBwdBlocks);
-                hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(gr), dim3(kBlock), 0, hs, sa.dz, a.new_bond, w.a, wide, d, H, e->atom,
-                                   bw.g_pre_bond, sa.part_rd, have_bond ? (const float*)bw.g_pre_bond : (const float*)nullptr, 1);
-                FN_TRY(launch_status("fn_encoder_backward: row_dots(atom)"));
-                have_bond = true;
-            }
+            FN_TRY(bwd_src_and_edge_term(bw.g_pre_atoms, a.h_a, sa.pz, sa.g_s_dst, w.a, wide, 0, d + FN_D, &e->atom, sa.g_h, sa.part_a, &n_a,
+                                         sa.dz, a.new_bond, d, bw.g_pre_bond, sa.part_rd, have_bond, &gr, H, hs));
+            if (gr) have_bond = true;
             FN_TRY(rq.finalize(sa.part_a, n_a, nullptr, 0, et_a, w.a, wide, 0, d + FN_D, g.a, nullptr, nullptr, H));
             if (gr) FN_TRY(rq.colsum(sa.part_rd, gr, H * FN_D, g.a, wide, d));
             if (multi) { FN_TRY(order_after(hs, S(st_leaf)));  leaf_forked = true; }

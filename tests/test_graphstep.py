@@ -115,6 +115,19 @@ def test_stage_kernel_matches_pad_batch():
     assert not sb.load(big)
 
 
+def _where(model, opt_a, opt_b):
+    """which parameters differ between two FlatAdam instances (diagnostics for a failed comparison)"""
+    names = {id(p): n for n, p in model.named_parameters()}
+    out = []
+    for p, off in zip(opt_a.params, opt_a.offsets):
+        d = (opt_a.flat[off: off + p.numel()] - opt_b.flat[off: off + p.numel()]).abs()
+        if float(d.max()) > 2e-5:
+            j = int(d.argmax())
+            out.append(f"{names[id(p)]}{tuple(p.shape)}: {int((d > 2e-5).sum())} elements, max {float(d.max()):.2e} at {j} "
+                       f"(grad a {float(opt_a.grad[off + j]):.3e} / b {float(opt_b.grad[off + j]):.3e})")
+    return "\n" + "\n".join(out)
+
+
 def _make(dev, drop=0.0, lr=1e-3):
     from fragnet_amd import parallel
     from fragnet_amd.model import FragNetFineTune
@@ -150,7 +163,7 @@ def test_graph_step_matches_eager_step():
         loss_b = step_b(dict(b)).clone()
         torch.testing.assert_close(loss_b, loss_a.detach(), atol=1e-5, rtol=1e-4)
     assert step_b.replays == 6 and step_b.fallbacks == 0
-    torch.testing.assert_close(opt_b.flat, opt_a.flat, atol=2e-5, rtol=1e-3)
+    torch.testing.assert_close(opt_b.flat, opt_a.flat, atol=2e-5, rtol=1e-3, msg=lambda m: m + _where(model_a, opt_a, opt_b))
     # a SHORT batch (last batch of an epoch: fewer molecules) replays too: the molecule mask does the averaging
     short = next(b for b in (_batches(1, n, seed=91)[0] for n in (47, 46, 45)) if shapes.fits(graphstep.batch_counts(b)))
     short = data.batch_to(short, dev)
