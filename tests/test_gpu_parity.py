@@ -148,7 +148,8 @@ def test_scatter_softmax_matches_oracle():
 
 # ------------------------------------------------------------------------------- projections (fp32 MFMA)
 @pytest.mark.parametrize("M,K,xgrad", [(1000, 128, True), (26492, 128, True), (777, 17, False), (513, 167, False),
-                                       (64, 6, False), (1, 128, True), (4099, 100, False)])
+                                       (64, 6, False), (1, 128, True), (4099, 100, False), (13872, 167, False), (63, 167, False),
+                                       (2352, 168, False)])
 def test_linear128_matches_torch(M, K, xgrad):
     from fragnet_amd import ops
     g = torch.Generator().manual_seed(M + K)
