@@ -151,6 +151,12 @@ def load():
         raise FragnetHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). fragnet_amd has no CPU/PyTorch fallback for its kernels.")
+    # a library older than its sources is refused, not used: the digest of the .hip / .inc / .h files is stored next to it
+    from . import build
+    if os.path.isdir(os.path.join(build.HERE, "csrc")) and build.stale():
+        raise FragnetHipError(
+            f"{LIB_PATH} does not match the sources it was built from (content digest differs): rebuild it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or fragnet_amd.build.build_lib()).")
     # torch ships its own libamdhip64; it must be the HIP runtime this library binds to (same streams,
     # same allocations), so torch is imported before the dlopen.
     import torch  # noqa: F401

@@ -33,3 +33,17 @@ def test_stale_follows_the_stamp_not_the_clock(tmp_path, monkeypatch):
     with open(build.STAMP, "w") as f:
         f.write(build.source_digest())
     assert not build.stale()
+
+
+def test_loading_a_stale_library_is_refused(monkeypatch):
+    """_lib.load() must not bind a library whose stamp disagrees with the sources (a bench / profile of yesterday's kernels
+    looks exactly like one of today's)."""
+    import pytest
+    from fragnet_amd import _lib
+    build.build_lib()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(build, "FLAGS", build.FLAGS + ["-DSOMETHING_ELSE"])      # the digest no longer matches the stamp
+    with pytest.raises(_lib.FragnetHipError, match="does not match the sources"):
+        _lib.load()
+    monkeypatch.undo()
+    assert _lib.load() is not None
