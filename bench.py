@@ -279,7 +279,7 @@ def forward_sweep_store(rank, world, dev, args):
         steps = max(4, min(args.steps, len(store) // B))
         loader = StoreLoader(store, B, shuffle=True, drop_last=True, seed=11 + rank)
         it = iter(loader.sampler)
-        WU = 8                 # batches differ in size: the caching allocator needs a few steps to stop calling hipMalloc
+        WU = 24                # batches differ in size: the caching allocator needs a few steps to stop calling hipMalloc
         steps = max(4, min(steps, len(store) // B - WU))
         idx_lists = [next(it).to(dev) for _ in range(steps + WU)]
         with torch.no_grad():
@@ -324,6 +324,9 @@ def main():
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-collated batches cycled through")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: 512 molecules per rank and step; strong: 512 molecules per step in total, sharded over the ranks")
+    ap.add_argument("--shard-of", type=int, default=0, metavar="R",
+                    help="dev measurement on ONE GPU: time what rank 0 of an R-GPU strong-scaling job does per step (its 512/R-molecule "
+                         "shard, no collective); the line is marked config.emulated_shard_of and is not a contract line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch-by-launch step instead of the whole-step hipGraph")
@@ -379,7 +382,10 @@ def main():
     if args.forward_sweep:
         (forward_sweep_store if args.store > 0 else forward_sweep)(rank, world, dev, args)
         return
-    pool = make_pool(1, rank, dev, args.kbatch) if args.kernels_only else make_pool(args.pool, rank, dev, PER_GPU_BATCH, world, args.scaling)
+    if args.shard_of > 1 and world == 1:
+        pool = make_pool(args.pool, 0, dev, PER_GPU_BATCH, args.shard_of, "strong")
+    else:
+        pool = make_pool(1, rank, dev, args.kbatch) if args.kernels_only else make_pool(args.pool, rank, dev, PER_GPU_BATCH, world, args.scaling)
     local_batch = int(pool[0]["y"].shape[0])
     global_batch = PER_GPU_BATCH if args.scaling == "strong" else PER_GPU_BATCH * world
     if args.model_version == "gat2_edge":      # gat2_edge.py:46 wants 8 connection features, the featuriser writes 6
@@ -451,6 +457,8 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = global_batch * args.steps / elapsed
+        if args.shard_of > 1 and world == 1:      # dev line: one rank's shard of a strong-scaling job, measured alone
+            value = local_batch * args.steps / elapsed
         sb = step_bytes(pool[0])
         line = {
             "metric": "molecules/sec fwd+bwd (full training step), ESOL-shape batch=512 " + ("per GPU" if args.scaling == "weak" else "global"),
@@ -461,6 +469,8 @@ def main():
                        "workload": "ESOL finetune batch=512 fp32 (BASELINE configs[1]): FragNetFineTune 4 layers x 4 heads, "
                                    "emb 128, FTHead3 128/1024/1024/512, drop 0.1; synthetic ESOL-shape molecules (synth.py)",
                        "per_gpu_batch": local_batch, "global_batch": global_batch, "parallelism": f"dp{world}",
+                       **({"emulated_shard_of": args.shard_of, "note": "NOT a contract line: rank 0's shard of a strong-scaling job on "
+                           "one GPU, no collective; value = this shard's molecules/s"} if args.shard_of > 1 and world == 1 else {}),
                        "mode": "eager launches, head " + ("hipGraph-captured" if graphed_head else "eager") if args.eager else
                                ("two hipGraphs over static shapes (stage+plan+fwd+mse+head bwd | encoder bwd); the head's gradient "
                                 "all-reduce runs beside the second" if gstep.split else
