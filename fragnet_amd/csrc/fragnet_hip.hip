@@ -2185,6 +2185,7 @@ __global__ void k_transpose_many(TransposeMany tm, float* __restrict__ bt_base) 
 #include "mol_fused.inc"
 #include "proj128.inc"
 #include "dense_head.inc"
+#include "proj_direct.inc"
 
 // Everything the encoder's forward pass needs before its first projection, none of which depends on the other: W^T of
 // every projection, dropout of the atom features, and the permutation of the two raw edge-attribute tensors into
@@ -2545,7 +2546,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 namespace {
 unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
 int64_t g_mol_stamps_n = 0;
-int g_tune[FN_TUNE_COUNT] = {1792, 0, 0, 256, 0, 0, 0, 1, 1};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
+int g_tune[FN_TUNE_COUNT] = {1792, 0, 0, 256, 0, 0, 0, 1, 1, 0};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -2616,8 +2617,36 @@ bool proj128_ok(const LinTasks& T) {
     return true;
 }
 
+// wave-independent form (csrc/proj_direct.inc): a block = 4 waves = 4 wave tiles of 32 rows x 64 columns
+int launch_proj_direct_group(LinTasks& T, hipStream_t st) {
+    int blocks = 0, live = 0;
+    for (int i = 0; i < T.n; ++i) {
+        if (T.t[i].M <= 0) continue;
+        LinTask t = T.t[i];
+        const int64_t tiles = 2 * ((t.M + 31) / 32);
+        t.first = blocks;
+        t.nblk = (int)((tiles + 3) / 4);
+        blocks += t.nblk;
+        T.t[live++] = t;
+    }
+    T.n = live;
+    T.K = 128;
+    if (!live) return 0;
+    hipLaunchKernelGGL(k_proj_direct, dim3(blocks), dim3(kPdThreads), 4 * kPdSlab * sizeof(float), st, T);
+    return launch_status("grouped projection GEMM (wave-independent)");
+}
+bool proj_direct_ok(const LinTasks& T) {
+    if (!g_tune[FN_TUNE_PROJ_DIRECT]) return false;
+    for (int i = 0; i < T.n; ++i) {
+        const LinTask& s = T.t[i];
+        if (s.M > (1 << 23) || (((uintptr_t)s.X | (uintptr_t)s.Bt | (uintptr_t)s.Y | (uintptr_t)s.bias | (uintptr_t)s.mk.y) & 15)) return false;
+    }
+    return true;
+}
+
 int launch_linear128_group(LinTasks& T, hipStream_t st) {
     if (proj128_ok(T)) return launch_proj128_group(T, st);
+    if (proj_direct_ok(T)) return launch_proj_direct_group(T, st);
     constexpr int KQ = 32;
     const size_t lds = (size_t)(4 * KQ * kLinLd) * sizeof(float);
     int64_t total = 0;

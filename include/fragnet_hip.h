@@ -67,7 +67,10 @@ int fn_abi_version(void);
                                 * term <new_bond, a[:, d:d+128]> from the row it holds in registers; 0: a separate row-dots launch */
 #define FN_TUNE_WGRAD_DIRECT 8 /* 1 (default): the grouped K = 128 weight-gradient partials run as k_wgrad128_multi (operands straight from
                                 * global memory in the MFMA layout, csrc/wgrad128.inc); 0: the LDS-staged k_linear128_wgrad_multi */
-#define FN_TUNE_COUNT 9
+#define FN_TUNE_PROJ_DIRECT 9  /* 1: the grouped 128 -> 128 projections / input-gradient products run as k_proj_direct (one wave per 32 x 64 tile,
+                                * weights straight from L1/L2 in the MFMA layout, no block-shared LDS tile: csrc/proj_direct.inc); 0 (default):
+                                * k_linear128_multi -- measured 1.007 against 1.020 ms per step on MI355X */
+#define FN_TUNE_COUNT 10
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * molecules 64-bit words) is
  * set, every workgroup of the fused molecule kernels writes s_memtime stamps of its phases into it (tools/mol_phase_times.py).
