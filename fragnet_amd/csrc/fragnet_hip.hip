@@ -2146,6 +2146,7 @@ struct LinTask {
     fn_act_epilogue mk;
     NodeScalarEpi ns;
     int first, nblk;
+    int K;                    // 0: the group's K (LinTasks::K); else this task's own reduction length (layer 0: 17 bond / 6 connection features)
 };
 struct LinTasks {
     LinTask t[3];
@@ -2157,7 +2158,7 @@ __global__ __launch_bounds__(kLinThreads) void k_linear128_multi(LinTasks T) {
     int ti = 0;
     while (ti + 1 < T.n && (int)blockIdx.x >= T.t[ti + 1].first) ++ti;
     const LinTask& t = T.t[ti];
-    linear128_body<KQ, VEC, PF>(sBt, t.X, T.K, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, (int)blockIdx.x - t.first, t.nblk);
+    linear128_body<KQ, VEC, PF>(sBt, t.X, t.K ? t.K : T.K, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, (int)blockIdx.x - t.first, t.nblk);
 }
 
 // Bt[k][n] = W[n][k]  (W is nn.Linear.weight [128, K])
@@ -2682,6 +2683,27 @@ int launch_linear128_group(LinTasks& T, hipStream_t st) {
         hipLaunchKernelGGL((k_linear128_multi<KQ, true, false>), dim3(blocks), dim3(kLinThreads), lds, st, T);
     }
     return launch_status("grouped projection GEMM");
+}
+
+// layer 0: the bond (K = 17) and connection (K = 6) projections in one launch of the K <= 20 variant, each task with its own K
+int launch_linear128_small_group(LinTasks& T, hipStream_t st) {
+    constexpr int KQ = 5;
+    const size_t lds = (size_t)(4 * KQ * kLinLd) * sizeof(float);
+    int blocks = 0, live = 0;
+    for (int i = 0; i < T.n; ++i) {
+        if (T.t[i].M <= 0) continue;
+        LinTask t = T.t[i];
+        if (t.K < 1 || t.K > 4 * KQ) return fail(FN_EINVAL, "small projection group: K must be 1..20");
+        t.first = blocks;
+        t.nblk = lin_blocks((t.M + kLinRows - 1) / kLinRows, 1);
+        blocks += t.nblk;
+        T.t[live++] = t;
+    }
+    T.n = live;
+    T.K = 4 * KQ;
+    if (!live) return 0;
+    hipLaunchKernelGGL((k_linear128_multi<KQ, false, false>), dim3(blocks), dim3(kLinThreads), lds, st, T);
+    return launch_status("grouped projection GEMM (layer 0, K <= 20)");
 }
 
 template <int CTW, int NH>
@@ -3934,6 +3956,14 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
             T.t[2] = LinTask{w.proj_fb_w, in_fbond, bt_fb, w.proj_fb_b, a.h_fb, e->EF, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
                              NodeScalarEpi{w.f_a_b, lay.s_dst_fb, lay.s_src_fb, 3 * d, 0, 2 * d, H}, 0, 0};
             FN_TRY(launch_linear128_group(T, S(st)));
+        } else if (l == 0 && fuse_ns && !multi && !no_fb && kb <= 20 && kfb <= 20) {
+            LinTasks T{};                               // layer 0: both edge-feature projections have K <= 20 -> one launch
+            T.n = 2;
+            T.t[0] = LinTask{w.proj_b_w, in_bond, bt_b, w.proj_b_b, a.h_b, e->E, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
+                             NodeScalarEpi{w.a_b, lay.s_dst, lay.s_src, 3 * d, 0, 2 * d, H}, 0, 0, kb};
+            T.t[1] = LinTask{w.proj_fb_w, in_fbond, bt_fb, w.proj_fb_b, a.h_fb, e->EF, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
+                             NodeScalarEpi{w.f_a_b, lay.s_dst_fb, lay.s_src_fb, 3 * d, 0, 2 * d, H}, 0, 0, kfb};
+            FN_TRY(launch_linear128_small_group(T, S(st)));
         } else {
             FN_TRY(project(in_bond, kb, bt_b, w.proj_b_b, a.h_b, e->E, w.a_b, 3 * d, 2 * d, lay.s_dst, lay.s_src, st));
             if (!no_fb) FN_TRY(project(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, w.f_a_b, 3 * d, 2 * d, lay.s_dst_fb, lay.s_src_fb, st_fb));
