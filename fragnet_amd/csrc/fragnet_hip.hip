@@ -2425,7 +2425,7 @@ struct ReduceTask {
     float *o0, *o1, *o2;
     int ld, off, cls, pad_;
 };
-constexpr int kMaxReduceTasks = 24;
+constexpr int kMaxReduceTasks = 36;      // one launch for all 30 tasks of a 4-layer backward pass (5.5 KB of kernel arguments)
 struct ReduceTasks {
     ReduceTask t[kMaxReduceTasks];
     int n;
