@@ -178,3 +178,28 @@ def test_fused_forward_flags_a_batch_that_is_not_molecule_contiguous(fused):
     torch.cuda.synchronize()
     with pytest.raises(IndexError, match="molecule-contiguous"):
         batch["_fragnet_plan"].check()
+
+
+@pytest.mark.parametrize("key,value", [(8, 0), (9, 1), (7, 0), (6, 1)])
+def test_alternative_kernels_behind_tuning_keys_stay_parity_green(key, value):
+    """The measured-and-rejected (or superseded) kernels stay selectable for A/B runs (include/fragnet_hip.h FN_TUNE_*):
+    8 = 0 the LDS-staged grouped weight-gradient kernel, 9 = 1 the wave-independent projection kernel, 7 = 0 the separate
+    row-dots launch, 6 = 1 the register-resident-W projection kernel.  Each must reproduce the default path's outputs and
+    gradients (same Philox stream) on a training step with dropout."""
+    from fragnet_amd import _lib, data, model as M, synth
+    torch.manual_seed(0)
+    net = M.FragNetFineTune(n_classes=1, num_layer=3, drop_ratio=0.1, h1=32, h2=32, h3=32, h4=32, act="relu", fthead="FTHead3").to(DEV)
+    net.train()
+    batch = data.batch_to(data.collate_fn(synth.synth_molecules(96, seed=17, profile="esol")), DEV)
+    default = {6: 0, 7: 1, 8: 1, 9: 0}[key]
+    try:
+        o0, g0 = _encoder_run(net, batch, 999)
+        _lib.call("fn_set_tuning", key, value)
+        o1, g1 = _encoder_run(net, batch, 999)
+    finally:
+        _lib.call("fn_set_tuning", key, default)
+    for a, b in zip(o0, o1):
+        torch.testing.assert_close(b, a, atol=1e-5, rtol=1e-5)
+    assert set(g0) == set(g1)
+    for n in g0:
+        torch.testing.assert_close(g1[n], g0[n], atol=1e-5, rtol=2e-3, msg=lambda m: f"{n}: {m}")
