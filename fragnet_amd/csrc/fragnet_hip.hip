@@ -3500,7 +3500,7 @@ int fn_stage_padded(const fn_stage_field* fields, int n_fields, fn_stream_t stre
         most = elems > most ? elems : most;
     }
     if (most == 0) return 0;
-    hipLaunchKernelGGL(k_stage_padded, dim3(flat_grid(most, 256), n_fields), dim3(kBlock), 0, S(stream), F);
+    hipLaunchKernelGGL(k_stage_padded, dim3(flat_grid(most, 1024), n_fields), dim3(kBlock), 0, S(stream), F);
     return launch_status("fn_stage_padded");
 }
 
