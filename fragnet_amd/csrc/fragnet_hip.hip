@@ -3377,6 +3377,10 @@ int fn_dense_bwd_f32(const float* g_y, const float* X, const float* W, float* g_
     a.A = g_y;  a.Bsrc = X;  a.OUT = dW;  a.db = db;
     a.I = (int)N;  a.J = (int)K;  a.R = (int)M;  a.lda = (int)N;  a.ldb = (int)K;
     a.tiles_i = dense_tiles(N, 64);  a.tiles_j = dense_tiles(K, kDnCols);
+    if (a.tiles_i * a.tiles_j < 192) {                   // too few 64 x 64 tiles to occupy the chip: 64 x 32 tiles (dense_dw_narrow)
+        P.a_narrow = 1;
+        a.tiles_j = dense_tiles(K, 32);
+    }
     int blocks = a.tiles_i * a.tiles_j;
     P.b.first_block = blocks;
     if (M_out < M) M_out = M;
