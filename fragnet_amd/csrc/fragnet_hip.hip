@@ -3362,7 +3362,9 @@ int fn_dense_fwd_f32(const float* X, const float* W, const float* bias, float* Y
     T.I = (int)M;  T.J = (int)N;  T.R = (int)K;  T.lda = (int)K;  T.ldb = (int)K;
     if (act) { T.act = *act;  T.act.y = Y; }
     T.tiles_i = dense_tiles(M, 32);  T.tiles_j = dense_tiles(N, kDnCols);
-    hipLaunchKernelGGL(k_dense_fwd, dim3((unsigned)(T.tiles_i * T.tiles_j)), dim3(kDnThreads), kDnLdsBytes, S(stream), T);
+    const int narrow = T.tiles_i * T.tiles_j < 192;      // too few 32 x 64 tiles to occupy the chip: 32 x 32
+    if (narrow) T.tiles_j = dense_tiles(N, 32);
+    hipLaunchKernelGGL(k_dense_fwd, dim3((unsigned)(T.tiles_i * T.tiles_j)), dim3(kDnThreads), kDnLdsBytes, S(stream), T, narrow);
     return launch_status("fn_dense_fwd_f32");
 }
 
@@ -3390,6 +3392,7 @@ int fn_dense_bwd_f32(const float* g_y, const float* X, const float* W, float* g_
         b.A = g_y;  b.Bsrc = W;  b.OUT = g_x;  b.Z = gate_scale > 0.f ? X : nullptr;  b.gate_scale = gate_scale;
         b.I = (int)M;  b.I_out = (int)M_out;  b.J = (int)K;  b.R = (int)N;  b.lda = (int)N;  b.ldb = (int)K;
         b.tiles_i = dense_tiles(M_out, 32);  b.tiles_j = dense_tiles(K, kDnCols);
+        if (b.tiles_i * b.tiles_j < 192) { P.b_narrow = 1;  b.tiles_j = dense_tiles(K, 32); }
         blocks += b.tiles_i * b.tiles_j;
     }
     hipLaunchKernelGGL(k_dense_bwd, dim3((unsigned)blocks), dim3(kDnThreads), kDnLdsBytes, S(stream), P);
