@@ -1084,8 +1084,20 @@ __device__ __forceinline__ void gat_finalize_body(int vb, float* sm, const float
         while (cp < ne) cp <<= 1;
         const int groups = 1024 / cp, col = tid % cp, grp = tid / cp;
         float acc = 0.f;
-        if (col < ne)
-            for (int r = grp; r < n_e; r += groups) acc += part_e[(size_t)r * ne + col];
+        if (col < ne) {
+            // four loads in flight per thread: with one, this single block was a chain of ~30 dependent round trips (n_e =
+            // 3888 partial rows for the bond level) and the whole deferred-reduction launch waited for it (25 -> 14 us)
+            float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int r = grp;
+            for (; r + 3 * groups < n_e; r += 4 * groups) {
+                acc += part_e[(size_t)r * ne + col];
+                a1 += part_e[(size_t)(r + groups) * ne + col];
+                a2 += part_e[(size_t)(r + 2 * groups) * ne + col];
+                a3 += part_e[(size_t)(r + 3 * groups) * ne + col];
+            }
+            for (; r < n_e; r += groups) acc += part_e[(size_t)r * ne + col];
+            acc = (acc + a1) + (a2 + a3);
+        }
         red[grp * cp + col] = acc;
         __syncthreads();
         if (tid < 128) {
@@ -2436,8 +2448,11 @@ struct ReduceTasks {
 // of ~10 k one-column blocks.
 __device__ __forceinline__ float colmajor_sum_128(const float* __restrict__ col, int n_rows, float* sW) {
     const int lane = threadIdx.x & 127;
-    float v = 0.f;
-    for (int r = lane; r < n_rows; r += 128) v += col[r];
+    float v = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int r = lane;
+    for (; r + 384 < n_rows; r += 512) { v += col[r];  v1 += col[r + 128];  v2 += col[r + 256];  v3 += col[r + 384]; }
+    for (; r < n_rows; r += 128) v += col[r];
+    v = (v + v1) + (v2 + v3);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     if ((threadIdx.x & 63) == 0) sW[threadIdx.x >> 6] = v;
