@@ -1367,6 +1367,72 @@ __global__ __launch_bounds__(kBlock) void k_segment_sum128_wide(const float* __r
     }
 }
 
+// Last layer's fragment tail, first half, as ONE launch: blocks [0, nblk_seg) = the atom -> fragment sum (the body of
+// k_segment_sum128_wide) followed by the fragment's node scalars <row, att[h, dst/src block]> from the finished row (a head's
+// 128/H columns are consecutive threads: shuffle reduction) -- two launches less than sum, node scalars, edge term; blocks
+// [nblk_seg, +nblk_rd) = the fragment graph's edge term <new_fbond[e], att[h, mid block]> (the body of k_row_dots_sorted),
+// which depends on neither.  Each of the three was a ~5 us latency-floor launch.
+struct FragTailArgs {
+    const float* src;  const int32_t* rowptr;  const int32_t* perm;  int32_t pos_base;  float* out;  int64_t n_seg;
+    const float* att;  int att_w, dst_off, src_off;  float* s_dst;  float* s_src;  int nblk_seg;
+    const float* feat;  const float* A;  int lda, off;  fn_gat_plan pl;  float* s_sorted;  int nblk_rd;
+};
+template <int H>
+__global__ __launch_bounds__(kBlock) void k_frag_tail(FragTailArgs T) {
+    __shared__ float sS[kRows][FN_D];
+    const int lane = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    if ((int)blockIdx.x < T.nblk_seg) {
+        constexpr int d = FN_D / H;
+        static_assert(d <= 64, "a head's columns must lie inside one wave");
+        const int t = threadIdx.x, head = (t & 127) / d, c = (t & 127) % d;
+        const float a_d = T.att[head * T.att_w + T.dst_off + c], a_s = T.att[head * T.att_w + T.src_off + c];
+        for (int64_t s = blockIdx.x; s < T.n_seg; s += T.nblk_seg) {
+            const int beg = T.rowptr[s] - T.pos_base, deg = T.rowptr[s + 1] - T.rowptr[s];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = hw; i < deg; i += kRows) {
+                const float4 v = ld4(T.src + (size_t)T.perm[beg + i] * FN_D + lane * 4);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            st4(&sS[hw][lane * 4], acc);
+            __syncthreads();
+            if (t < FN_D) {                                  // waves 0 and 1, whole
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < kRows; ++w) v += sS[w][t];
+                T.out[s * FN_D + t] = v;
+                float pd = v * a_d, ps = v * a_s;
+#pragma unroll
+                for (int off = d / 2; off > 0; off >>= 1) { pd += __shfl_xor(pd, off);  ps += __shfl_xor(ps, off); }
+                if (c == 0) { T.s_dst[s * H + head] = pd;  T.s_src[s * H + head] = ps; }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    const int vb = (int)blockIdx.x - T.nblk_seg, nb = T.nblk_rd;
+    const fn_gat_plan& pl = T.pl;
+    float4 a[H];
+#pragma unroll
+    for (int q = 0; q < H; ++q) a[q] = ld4(T.A + q * T.lda + T.off + lane * 4);
+    const int64_t groups = (pl.m + kRows - 1) / kRows, per = (groups + nb - 1) / nb;
+    const int64_t g0 = (int64_t)xcd_block(vb, nb) * per, g1 = g0 + per < groups ? g0 + per : groups;
+    for (int64_t gi = g0; gi < g1; ++gi) {
+        const int64_t pos = gi * kRows + hw;
+        if (pos >= pl.m) continue;
+        const int eid = pl.eid_d[pos];
+        float mine = 0.f;
+        if (eid < pl.m_real) {                               // uniform inside the half-wave
+            const float4 v = ld4(T.feat + (size_t)eid * FN_D + lane * 4);
+#pragma unroll
+            for (int q = 0; q < H; ++q) {
+                const float dd = head_sum<32>(dot4(v, a[q]));
+                if (lane == q) mine = dd;
+            }
+        }
+        if (lane < H) T.s_sorted[(size_t)lane * pl.m + pos] = mine;      // head-major [H][m]
+    }
+}
+
 // pooled = cat(sum of a molecule's atom rows, sum of its fragment rows): [B, 256] in one launch (gat2.py:820-823).
 // grid (B, 2): y = 0 atoms -> columns 0..127, y = 1 fragments -> columns 128..255; one block per molecule and half.
 __global__ __launch_bounds__(kBlock) void k_pool_cat(const float* __restrict__ x_atoms, const float* __restrict__ x_frags,
@@ -4015,7 +4081,9 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
 
         // L3 atom -> fragment sum.  Like L4b below it is only ever read in the last layer (the next layer recomputes its own
         // sum from its own atoms before first use, gat2.py:234), so inner layers skip it too.
-        if (last) FN_TRY(fn_segment_sum_f32(lay.atoms_new, FN_D, e->a2f.rowptr, e->a2f.perm, e->a2f.pos_base, a.frags, e->F, FN_D, e->N, st));
+        const bool tail_fused = last && !lite && !edge && H > 1 && e->F > 0 && e->N >= 4 * e->F && e->frag.m > 0 &&
+                                !(((uintptr_t)lay.atoms_new | (uintptr_t)a.frags) & 15);
+        if (last && !tail_fused) FN_TRY(fn_segment_sum_f32(lay.atoms_new, FN_D, e->a2f.rowptr, e->a2f.perm, e->a2f.pos_base, a.frags, e->F, FN_D, e->N, st));
 
         // L4b fragment graph on the raw fragment sums.  Only the last layer's result is ever read: the next layer
         // overwrites x_frags with its own atom->fragment sum before first use (gat2.py:234), so inner
@@ -4029,8 +4097,22 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
             FN_TRY(fn_gat_fwd_f32(a.frags, lay.s_dst, lay.s_src, w.f, wide, &et_f, &e->frag, 0.2f, nullptr, a.p_frag, nullptr, &ep_frags, H, st));
         } else if (last) {
             FN_TRY(order_after(S(st_fb), S(st)));            // join: the fragment graph's edge term reads new_fbond
+            if (tail_fused) {                                // atom -> fragment sum + node scalars + edge term: one launch
+                FragTailArgs T{};
+                T.src = lay.atoms_new;  T.rowptr = e->a2f.rowptr;  T.perm = e->a2f.perm;  T.pos_base = e->a2f.pos_base;  T.out = a.frags;
+                T.n_seg = e->F;  T.att = w.f;  T.att_w = wide;  T.dst_off = 0;  T.src_off = d + FN_D;  T.s_dst = lay.s_dst;  T.s_src = lay.s_src;
+                T.nblk_seg = (int)(e->F < 8 * kGridCap ? e->F : 8 * kGridCap);
+                T.feat = a.new_fbond;  T.A = w.f;  T.lda = wide;  T.off = d;  T.pl = e->frag;  T.s_sorted = lay.s_sorted;
+                T.nblk_rd = row_grid(e->frag.m, kGridCap);
+                const dim3 grid((unsigned)(T.nblk_seg + T.nblk_rd));
+                if (H == 2) hipLaunchKernelGGL((k_frag_tail<2>), grid, dim3(kBlock), 0, S(st), T);
+                else if (H == 4) hipLaunchKernelGGL((k_frag_tail<4>), grid, dim3(kBlock), 0, S(st), T);
+                else hipLaunchKernelGGL((k_frag_tail<8>), grid, dim3(kBlock), 0, S(st), T);
+                FN_TRY(launch_status("fragment tail (sum + node scalars + edge term)"));
+            } else {
             FN_TRY(fn_row_dots_sorted_f32(a.new_fbond, w.f, wide, d, H, &e->frag, lay.s_sorted, st));
             FN_TRY(fn_node_scalars_f32(a.frags, w.f, wide, 0, d + FN_D, lay.s_dst, lay.s_src, e->F, H, st));
+            }
             fn_edge_term et_f{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
             FN_TRY(fn_gat_fwd_f32(a.frags, lay.s_dst, lay.s_src, w.f, wide, &et_f, &e->frag, 0.2f, nullptr, a.p_frag, nullptr, &ep_frags, H, st));
         }
