@@ -59,8 +59,8 @@ class StageField(C.Structure):
                 ("pad_hi", i64), ("pad_mod", i64)]
 
 
-FN_MAX_STAGE_FIELDS = 24
-STAGE_ROWS, STAGE_IDS, STAGE_COLS, STAGE_MASK, STAGE_COUNT = 0, 1, 2, 3, 4
+FN_MAX_STAGE_FIELDS = 32
+STAGE_ROWS, STAGE_IDS, STAGE_COLS, STAGE_MASK, STAGE_COUNT, STAGE_BUMP = 0, 1, 2, 3, 4, 5
 
 
 class MseTask(C.Structure):

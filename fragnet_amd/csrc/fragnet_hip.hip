@@ -2836,6 +2836,8 @@ __global__ void k_stage_padded(StageFields F) {
         for (int64_t i = t0; i < f.cap; i += stride) dst[i] = i < f.n_real ? 1.f : 0.f;
     } else if (f.kind == FN_STAGE_COUNT) {
         if (t0 == 0) *static_cast<int32_t*>(f.dst) = (int32_t)f.n_real;
+    } else if (f.kind == FN_STAGE_BUMP) {
+        if (t0 == 0) *static_cast<int64_t*>(f.dst) += f.n_real;
     } else {
         const int64_t* src = static_cast<const int64_t*>(f.src);
         int64_t* dst = static_cast<int64_t*>(f.dst);
@@ -3573,6 +3575,12 @@ int fn_stage_padded(const fn_stage_field* fields, int n_fields, fn_stream_t stre
     int64_t most = 0;
     for (int i = 0; i < n_fields; ++i) {
         const fn_stage_field& f = fields[i];
+        if (f.kind == FN_STAGE_BUMP) {
+            if (!f.dst || ((uintptr_t)f.dst & 7)) return fail(FN_EINVAL, "fn_stage_padded: bad bump field");
+            F.f[i] = f;
+            most = most > 1 ? most : 1;
+            continue;
+        }
         if (f.kind == FN_STAGE_COUNT) {
             if (f.n_real < 0 || !f.dst) return fail(FN_EINVAL, "fn_stage_padded: bad count field");
             F.f[i] = f;

@@ -236,6 +236,18 @@ class StaticBatch:
         if self.n_fields > _lib.FN_MAX_STAGE_FIELDS:
             raise ValueError("too many batch fields for one staging launch")
         self.counts: Optional[Dict[str, int]] = None
+        self._n_static = self.n_fields
+
+    def set_bumps(self, bumps):
+        """[(int64 device tensor [1], increment)]: counters the staging launch advances on every load (FN_STAGE_BUMP) -- the
+        captured step's Philox block counter and optimiser step count -- so that the graph needs no launch of its own for them."""
+        self.n_fields = self._n_static
+        for t, inc in bumps:
+            if self.n_fields >= _lib.FN_MAX_STAGE_FIELDS:
+                raise ValueError("too many batch fields for one staging launch")
+            f = self._fields[self.n_fields]
+            f.src, f.dst, f.n_real, f.cap, f.width, f.kind, f.pad_hi, f.pad_mod = None, t.data_ptr(), int(inc), 1, 1, _lib.STAGE_BUMP, 0, 1
+            self.n_fields += 1
 
     def load(self, batch: Dict[str, torch.Tensor]) -> bool:
         """Stage ``batch`` (GPU tensors); False when it does not fit the capacities (nothing is written then)."""
@@ -414,11 +426,22 @@ class GraphedTrainStep:
                 loss = self._fwd_bwd_static()
                 if self.rng.offset - off0 != per_step:
                     raise RuntimeError("the captured step drew a different number of Philox blocks than the warm-up steps")
-                if per_step or self.adam_in_graph:
-                    self._counters += inc               # fresh dropout masks (and the next Adam step number) on every replay
+                # fresh dropout masks and the next Adam step number on every replay: the staging launch in front of the replay
+                # advances both counters (FN_STAGE_BUMP), so the graph has no launch of its own for them
                 if self.adam_in_graph:
                     self.opt.adam_in_graph(self._counters[1:2], self._lr_dev)
         self.graph, self.loss = graph, loss.detach()
+        # single-graph step: the staging launch in front of every replay advances the counters.  The Philox counter is
+        # therefore "one step behind" between replays (it starts at -per_step so that the first replay sees 0).
+        self._per_step, self._stage_bumps = int(per_step), not self.split
+        if self._stage_bumps:
+            bumps = []
+            if per_step:
+                bumps.append((self._counters[0:1], per_step))
+                self._counters[0:1] -= per_step
+            if self.adam_in_graph:
+                bumps.append((self._counters[1:2], 1))
+            self.static.set_bumps(bumps)
 
     def _sync_adam_state(self):
         """Device copies of the optimiser's step count and learning rate follow the host values (an eager fallback step,
@@ -451,6 +474,9 @@ class GraphedTrainStep:
         # never share Philox blocks
         host_after = self.rng.offset
         self.rng.offset = self._rng_base
+        behind = self._per_step if getattr(self, "_stage_bumps", False) else 0      # see _capture: the staging launch bumps the counter
+        if behind:
+            self._counters[0:1] += behind
         if self.loss_kind == "pretrain":
             from .train import pretrain_loss
             sc = self._rank_scales(batch)
@@ -472,20 +498,20 @@ class GraphedTrainStep:
         # Philox blocks this eager step drew are gone for the replays too: without this the fallback step and the replay after
         # next would share dropout random numbers (the graph adds the device counter to offsets baked in at capture)
         drawn = self.rng.offset - self._rng_base
-        if drawn:
-            self._counters[0] += drawn
+        if drawn - behind:
+            self._counters[0:1] += drawn - behind
         self.rng.offset = host_after
         return loss.detach()
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         """One optimiser step on ``batch``.  Returns the loss (a tensor that the next call overwrites)."""
+        self._sync_adam_state()                      # before the staging launch: it bumps the step counter
         if not self.static.load(batch):
             self.fallbacks += 1
             return self._eager(batch)
         sc = self._rank_scales(batch)
         if sc is not None:
             self.static.t[SCALE_KEY].copy_(sc)
-        self._sync_adam_state()
         self.graph.replay()
         if self.adam_in_graph:                       # the update ran inside the graph
             self.opt.steps += 1

@@ -394,12 +394,14 @@ int fn_masked_mse_multi_f32(const fn_mse_task* tasks, int n_tasks /*<= 4*/, cons
  * values pointing at the last `pad_mod` slots of the target index space (pad value at position i =
  * pad_hi - i % pad_mod), so padding only ever talks to padding and in-degrees stay small.  One launch, all fields.
  * ------------------------------------------------------------------------------------------ */
-#define FN_MAX_STAGE_FIELDS 24
+#define FN_MAX_STAGE_FIELDS 32
 #define FN_STAGE_ROWS 0 /* float32 [cap,width]  <- [n_real,width], zero rows after                         */
 #define FN_STAGE_IDS 1  /* int64   [cap]        <- [n_real], pad ids after                                 */
 #define FN_STAGE_COLS 2 /* int64   [2,cap]      <- [2,n_real] (edge_index layout), pad ids in both rows    */
 #define FN_STAGE_MASK 3 /* float32 [cap]        =  1 for i < n_real, 0 after (loss weights); src unused    */
 #define FN_STAGE_COUNT 4 /* int32 [1]           =  n_real (device-side copy of a count for the fused encoder)  */
+#define FN_STAGE_BUMP 5  /* int64 [1]          +=  n_real: a device-side counter of a captured step (Philox blocks, optimiser steps)
+                          *                       advanced by the staging launch that precedes every replay instead of by a launch of its own */
 typedef struct fn_stage_field {
     const void* src;
     void* dst;
