@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfragnet_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 FN_D = 128
 FN_MAX_TASKS = 16
 FN_MAX_EDGE_K = 8
@@ -59,8 +59,9 @@ class StageField(C.Structure):
                 ("pad_hi", i64), ("pad_mod", i64)]
 
 
-FN_MAX_STAGE_FIELDS = 32
-STAGE_ROWS, STAGE_IDS, STAGE_COLS, STAGE_MASK, STAGE_COUNT, STAGE_BUMP = 0, 1, 2, 3, 4, 5
+FN_MAX_STAGE_FIELDS = 40
+STAGE_ROWS, STAGE_IDS, STAGE_COLS, STAGE_MASK, STAGE_COUNT, STAGE_BUMP, STAGE_ZERO = 0, 1, 2, 3, 4, 5, 6
+PLAN_PREZEROED = 1
 
 
 class MseTask(C.Structure):
@@ -85,7 +86,7 @@ SIGNATURES = {
     "fn_set_tuning": [C.c_int, C.c_int],
     "fn_debug_set_stamps": [vp, i64],
     "fn_plan_layout": [C.POINTER(CsrTask), C.c_int, C.POINTER(i64), C.POINTER(i64)],
-    "fn_plan_build": [C.POINTER(CsrTask), C.c_int, vp, vp, vp, vp, vp, vp, vp],
+    "fn_plan_build": [C.POINTER(CsrTask), C.c_int, vp, vp, vp, vp, vp, vp, i32, vp],
     "fn_node_scalars_f32": [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, i64, C.c_int, vp],
     "fn_gat_fwd_f32": [vp, vp, vp, vp, C.c_int, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp,
                        C.POINTER(ActEpilogue), C.c_int, vp],

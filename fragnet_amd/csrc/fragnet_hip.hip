@@ -2838,6 +2838,9 @@ __global__ void k_stage_padded(StageFields F) {
         if (t0 == 0) *static_cast<int32_t*>(f.dst) = (int32_t)f.n_real;
     } else if (f.kind == FN_STAGE_BUMP) {
         if (t0 == 0) *static_cast<int64_t*>(f.dst) += f.n_real;
+    } else if (f.kind == FN_STAGE_ZERO) {
+        int32_t* dst = static_cast<int32_t*>(f.dst);
+        for (int64_t i = t0; i < f.cap; i += stride) dst[i] = 0;
     } else {
         const int64_t* src = static_cast<const int64_t*>(f.src);
         int64_t* dst = static_cast<int64_t*>(f.dst);
@@ -2894,7 +2897,7 @@ int fn_plan_layout(fn_csr_task* tasks, int n_tasks, int64_t* total_items, int64_
 }
 
 int fn_plan_build(const fn_csr_task* tasks, int n_tasks, int32_t* rowptr_all, int32_t* perm_all, int32_t* aux_a,
-                  int32_t* aux_b, int32_t* aux_c, int32_t* ws_i32, fn_stream_t stream) {
+                  int32_t* aux_b, int32_t* aux_c, int32_t* ws_i32, int32_t flags, fn_stream_t stream) {
     if (!tasks || n_tasks < 1 || !rowptr_all || !perm_all || !aux_a || !aux_b || !aux_c || !ws_i32)
         return fail(FN_EINVAL, "fn_plan_build: null argument");
     if (n_tasks > FN_MAX_TASKS) return fail(FN_ETOOMANY, "fn_plan_build: more than FN_MAX_TASKS tasks");
@@ -2925,8 +2928,9 @@ int fn_plan_build(const fn_csr_task* tasks, int n_tasks, int32_t* rowptr_all, in
     int32_t* state_i32 = ws_i32 + segs + items + 4;
     if ((uintptr_t)state_i32 & 7) ++state_i32;                      // 64-bit look-back words
     const int64_t zero_ws = (state_i32 - ws_i32) + 2 * (int64_t)nb;
-    hipLaunchKernelGGL(k_zero2_i32, dim3(flat_grid(segs + 1 + zero_ws, kGridCap)), dim3(kBlock), 0, st, rowptr_all,
-                       segs + 1, ws_i32, zero_ws);
+    if (!(flags & FN_PLAN_PREZEROED))
+        hipLaunchKernelGGL(k_zero2_i32, dim3(flat_grid(segs + 1 + zero_ws, kGridCap)), dim3(kBlock), 0, st, rowptr_all,
+                           segs + 1, ws_i32, zero_ws);
     if (items > 0) {
         const int g = flat_grid(items, kGridCap);
         hipLaunchKernelGGL(k_plan_hist, dim3(g), dim3(kBlock), 0, st, P, rowptr_all, status);
@@ -3579,6 +3583,12 @@ int fn_stage_padded(const fn_stage_field* fields, int n_fields, fn_stream_t stre
             if (!f.dst || ((uintptr_t)f.dst & 7)) return fail(FN_EINVAL, "fn_stage_padded: bad bump field");
             F.f[i] = f;
             most = most > 1 ? most : 1;
+            continue;
+        }
+        if (f.kind == FN_STAGE_ZERO) {
+            if (f.cap < 0 || (f.cap > 0 && !f.dst)) return fail(FN_EINVAL, "fn_stage_padded: bad zero field");
+            F.f[i] = f;
+            most = f.cap > most ? f.cap : most;
             continue;
         }
         if (f.kind == FN_STAGE_COUNT) {

@@ -31,7 +31,7 @@ from typing import Callable, Dict, Iterable, Optional
 import torch
 
 from . import _lib
-from .plan import LIVE_MOLS_KEY, PLAN_KEY, REAL_MOLS_KEY
+from .plan import LIVE_MOLS_KEY, PLAN_KEY, REAL_MOLS_KEY, prezeroed_plans
 
 # field -> (index space of the ragged axis, layout, index space its VALUES point into)
 FIELDS = {
@@ -238,15 +238,19 @@ class StaticBatch:
         self.counts: Optional[Dict[str, int]] = None
         self._n_static = self.n_fields
 
-    def set_bumps(self, bumps):
-        """[(int64 device tensor [1], increment)]: counters the staging launch advances on every load (FN_STAGE_BUMP) -- the
-        captured step's Philox block counter and optimiser step count -- so that the graph needs no launch of its own for them."""
+    def set_bumps(self, bumps, zeros=()):
+        """Extra work of the staging launch in front of every replay of a captured step.  ``bumps`` = [(int64 device tensor
+        [1], increment)]: counters it advances (FN_STAGE_BUMP: the step's Philox block counter and optimiser step count);
+        ``zeros`` = [(device pointer, int32 count)]: workspaces it zeroes (FN_STAGE_ZERO: those of the plans built inside the
+        graph).  The graph then needs no launch of its own for either."""
         self.n_fields = self._n_static
-        for t, inc in bumps:
+        extra = [(None, t.data_ptr(), int(inc), 1, _lib.STAGE_BUMP) for t, inc in bumps] + \
+                [(None, int(ptr), 0, int(n), _lib.STAGE_ZERO) for ptr, n in zeros]
+        for src, dst, n_real, cap, kind in extra:
             if self.n_fields >= _lib.FN_MAX_STAGE_FIELDS:
                 raise ValueError("too many batch fields for one staging launch")
             f = self._fields[self.n_fields]
-            f.src, f.dst, f.n_real, f.cap, f.width, f.kind, f.pad_hi, f.pad_mod = None, t.data_ptr(), int(inc), 1, 1, _lib.STAGE_BUMP, 0, 1
+            f.src, f.dst, f.n_real, f.cap, f.width, f.kind, f.pad_hi, f.pad_mod = src, dst, n_real, cap, 1, kind, 0, 1
             self.n_fields += 1
 
     def load(self, batch: Dict[str, torch.Tensor]) -> bool:
@@ -422,7 +426,8 @@ class GraphedTrainStep:
                 self._part_b(pooled_t, leaf)
             del pooled_t, leaf
         else:
-            with torch.cuda.graph(graph, capture_error_mode=_CAPTURE_MODE):
+            # plans built inside the capture skip their zeroing launch: the staging launch zeroes their workspaces (below)
+            with prezeroed_plans() as pz, torch.cuda.graph(graph, capture_error_mode=_CAPTURE_MODE):
                 loss = self._fwd_bwd_static()
                 if self.rng.offset - off0 != per_step:
                     raise RuntimeError("the captured step drew a different number of Philox blocks than the warm-up steps")
@@ -441,7 +446,8 @@ class GraphedTrainStep:
                 self._counters[0:1] -= per_step
             if self.adam_in_graph:
                 bumps.append((self._counters[1:2], 1))
-            self.static.set_bumps(bumps)
+            self._captured_plans = pz.plans          # keep their arenas (the regions below) alive with the graph
+            self.static.set_bumps(bumps, zeros=[r for plan in pz.plans for r in plan.zero_regions])
 
     def _sync_adam_state(self):
         """Device copies of the optimiser's step count and learning rate follow the host values (an eager fallback step,

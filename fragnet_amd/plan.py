@@ -96,8 +96,14 @@ class GraphPlan:
         self.aux_c = arena[ts + 1 + 3 * ta: ts + 1 + 4 * ta]
         ws = arena[ts + 1 + 4 * ta:]
         self._status = ws[ts + ti: ts + ti + 1]
+        # regions fn_plan_build needs zeroed: a captured step has its staging launch do it (graphstep, PREZEROED context)
+        self.zero_regions = [(self.rowptr.data_ptr(), ts + 1), (ws.data_ptr(), int(ws.numel()))]
+        self.prezeroed = bool(_PREZEROED)
+        if self.prezeroed:
+            _BUILT.append(self)
         _lib.check(lib.fn_plan_build(tasks, nt, self.rowptr.data_ptr(), self.perm.data_ptr(), self.aux_a.data_ptr(),
-                                     self.aux_b.data_ptr(), self.aux_c.data_ptr(), ws.data_ptr(), _stream_ptr(device)),
+                                     self.aux_b.data_ptr(), self.aux_c.data_ptr(), ws.data_ptr(),
+                                     _lib.PLAN_PREZEROED if self.prezeroed else 0, _stream_ptr(device)),
                    "fn_plan_build")
         self._keep = keep
         self._sorted = {}
@@ -194,6 +200,27 @@ class GraphPlan:
     def segments_only(cls, index: torch.Tensor, n_seg: int):
         plan = cls([dict(kind="seg", name="s", key=index, n_seg=n_seg)], index.device)
         return plan
+
+
+_PREZEROED = False      # True only while graphstep captures its step: plans built then skip their zeroing launch
+_BUILT = []             # the plans built inside the current prezeroed_plans() context
+
+
+class prezeroed_plans:
+    """Context: plans built inside skip fn_plan_build's zeroing launch; the caller zeroes ``plan.zero_regions`` on the same
+    stream before every use (GraphedTrainStep: the staging launch in front of each replay)."""
+
+    def __enter__(self):
+        global _PREZEROED
+        self._old, _PREZEROED = _PREZEROED, True
+        _BUILT.clear()
+        return self
+
+    def __exit__(self, *exc):
+        global _PREZEROED
+        _PREZEROED = self._old
+        self.plans = list(_BUILT)
+        _BUILT.clear()
 
 
 PLAN_KEY = "_fragnet_plan"

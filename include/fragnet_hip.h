@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FN_ABI_VERSION 5
+#define FN_ABI_VERSION 6
 #define FN_D 128              /* feature width of every node table on the path (emb_dim) */
 #define FN_MAX_TASKS 16       /* CSR builds fused into one fn_plan_build call */
 #define FN_MAX_EDGE_K 8       /* widest raw edge attribute folded in-kernel (6 for fragment bonds) */
@@ -121,7 +121,10 @@ int fn_plan_layout(fn_csr_task* tasks, int n_tasks, int64_t* total_items, int64_
 int fn_plan_build(const fn_csr_task* tasks, int n_tasks,
                   int32_t* rowptr_all /*[total_segs+1]*/, int32_t* perm_all /*[total_items]*/,
                   int32_t* aux_a /*[total_items]*/, int32_t* aux_b /*[total_items]*/, int32_t* aux_c /*[total_items]*/,
-                  int32_t* ws_i32, fn_stream_t stream);
+                  int32_t* ws_i32, int32_t flags /*FN_PLAN_**/, fn_stream_t stream);
+/* flags: the caller has already zeroed rowptr_all[0 .. total_segs] and the whole of ws_i32 on this stream (a captured step
+ * lets the staging launch in front of the replay do it, FN_STAGE_ZERO): fn_plan_build skips its zeroing launch */
+#define FN_PLAN_PREZEROED 1
 
 /* ------------------------------------------------------------------------------------------
  * One attention level (bond graph, atom graph, fragment-bond graph, fragment graph):
@@ -394,12 +397,13 @@ int fn_masked_mse_multi_f32(const fn_mse_task* tasks, int n_tasks /*<= 4*/, cons
  * values pointing at the last `pad_mod` slots of the target index space (pad value at position i =
  * pad_hi - i % pad_mod), so padding only ever talks to padding and in-degrees stay small.  One launch, all fields.
  * ------------------------------------------------------------------------------------------ */
-#define FN_MAX_STAGE_FIELDS 32
+#define FN_MAX_STAGE_FIELDS 40
 #define FN_STAGE_ROWS 0 /* float32 [cap,width]  <- [n_real,width], zero rows after                         */
 #define FN_STAGE_IDS 1  /* int64   [cap]        <- [n_real], pad ids after                                 */
 #define FN_STAGE_COLS 2 /* int64   [2,cap]      <- [2,n_real] (edge_index layout), pad ids in both rows    */
 #define FN_STAGE_MASK 3 /* float32 [cap]        =  1 for i < n_real, 0 after (loss weights); src unused    */
 #define FN_STAGE_COUNT 4 /* int32 [1]           =  n_real (device-side copy of a count for the fused encoder)  */
+#define FN_STAGE_ZERO 6  /* int32 [cap]         =  0 (workspace of a captured fn_plan_build, see FN_PLAN_PREZEROED); src unused */
 #define FN_STAGE_BUMP 5  /* int64 [1]          +=  n_real: a device-side counter of a captured step (Philox blocks, optimiser steps)
                           *                       advanced by the staging launch that precedes every replay instead of by a launch of its own */
 typedef struct fn_stage_field {
