@@ -2638,7 +2638,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 namespace {
 unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
 int64_t g_mol_stamps_n = 0;
-int g_tune[FN_TUNE_COUNT] = {1792, 0, 0, 256, 0, 0, 0, 1, 1, 0};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
+int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -2975,7 +2975,9 @@ static int prep_gat_fwd(const float* h, const float* s_dst, const float* s_src, 
         return fail(FN_EUNSUPPORTED, "fn_gat_fwd_f32: level too large for 32-bit byte offsets (n <= 2^23 rows, m*heads <= 2^29)");
     // persistent half-waves: as many as fit on the chip at once, each pipelining R rows
     const int64_t groups = (plan->n + kRows - 1) / kRows;
-    const int64_t resident = (int64_t)g_tune[FN_TUNE_FWD_BLOCKS];
+    // with the dropout epilogue (training) fewer, longer-lived half-waves win (5 rows each at B = 512: 27.7 -> 22.4 us for the
+    // bond + fragment-bond launch); the plain forward (inference) wants the chip full of them
+    const int64_t resident = (int64_t)g_tune[act && act->y && act->p > 0.f ? FN_TUNE_FWD_BLOCKS : FN_TUNE_FWD_BLOCKS_EVAL];
     A->rows_per_hw = (int)((groups + resident - 1) / resident);
     A->nblk = (int)((plan->n + (int64_t)kRows * A->rows_per_hw - 1) / ((int64_t)kRows * A->rows_per_hw));
     return 0;

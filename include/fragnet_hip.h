@@ -46,8 +46,10 @@ typedef void* fn_stream_t;    /* hipStream_t */
 int fn_abi_version(void);
 
 /* Process-wide tuning knobs (defaults are the measured best for MI355X; the bench uses them for A/B runs).
- * FN_TUNE_FWD_BLOCKS: workgroups of the attention kernels that are resident at once (default 1792 = 256 CUs x 7); a
- *   level with more row groups than that gives every half-wave several consecutive rows to software-pipeline. */
+ * FN_TUNE_FWD_BLOCKS: workgroups of the attention kernels that are resident at once in a TRAINING pass (forward with the
+ *   dropout epilogue, source pass of the backward): default 768 = 256 CUs x 3; a level with more row groups than that gives
+ *   every half-wave several consecutive rows to software-pipeline (5 at ESOL batch 512).  FN_TUNE_FWD_BLOCKS_EVAL (1792 =
+ *   256 x 7) is the same for the plain forward (inference, or training without dropout). */
 #define FN_TUNE_FWD_BLOCKS 0
 #define FN_TUNE_GEMM_SLOTS 1   /* > 0: cap on the workgroups of a projection GEMM launch (1024 = 256 CUs x 4 resident); a launch with
                                 * more 64x64 output tiles then walks several row tiles per workgroup, prefetching the next tile's
@@ -70,7 +72,8 @@ int fn_abi_version(void);
 #define FN_TUNE_PROJ_DIRECT 9  /* 1: the grouped 128 -> 128 projections / input-gradient products run as k_proj_direct (one wave per 32 x 64 tile,
                                 * weights straight from L1/L2 in the MFMA layout, no block-shared LDS tile: csrc/proj_direct.inc); 0 (default):
                                 * k_linear128_multi -- measured 1.007 against 1.020 ms per step on MI355X */
-#define FN_TUNE_COUNT 10
+#define FN_TUNE_FWD_BLOCKS_EVAL 10
+#define FN_TUNE_COUNT 11
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * molecules 64-bit words) is
  * set, every workgroup of the fused molecule kernels writes s_memtime stamps of its phases into it (tools/mol_phase_times.py).
