@@ -2638,7 +2638,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 namespace {
 unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
 int64_t g_mol_stamps_n = 0;
-int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
+int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -3044,8 +3044,12 @@ static int prep_gat_bwd_dst(const float* g_out, const float* h, const float* p_s
     // order, vmcnt counts loads and stores in one in-order queue, so every extra row per wave waits behind the
     // previous row's slow stores (B=2048: R=4 56 us, R=8 84 us; B=512: 16 us at any R)
     const int64_t groups = (plan->n + kBwdRows - 1) / kBwdRows;
-    const int64_t resident = FN_MAX_PART;
-    A->rows_per_hw = (int)((groups + resident - 1) / resident);
+    // rows per half-wave: ~groups / 1536 (three at ESOL batch 512: 0.926 -> 0.902 ms per step against one row each), but at most
+    // three -- the (p, dz) stores into source order are scattered and every further row waits behind them (B = 2048: 56 us at
+    // four rows, 84 us at eight) -- unless the level is so large that the partial rows would not fit FN_MAX_PART
+    const int64_t resident = g_tune[FN_TUNE_DST_BLOCKS] > 0 && g_tune[FN_TUNE_DST_BLOCKS] < FN_MAX_PART ? g_tune[FN_TUNE_DST_BLOCKS] : FN_MAX_PART;
+    const int64_t need = (groups + FN_MAX_PART - 1) / FN_MAX_PART, want = (groups + resident - 1) / resident;
+    A->rows_per_hw = (int)std::max<int64_t>(need, std::min<int64_t>(want, 3));
     A->nblk = (int)((plan->n + (int64_t)kBwdRows * A->rows_per_hw - 1) / ((int64_t)kBwdRows * A->rows_per_hw));
     *n_part_e = (et->mode == 2) ? A->nblk : 0;
     return 0;

@@ -73,7 +73,9 @@ int fn_abi_version(void);
                                 * weights straight from L1/L2 in the MFMA layout, no block-shared LDS tile: csrc/proj_direct.inc); 0 (default):
                                 * k_linear128_multi -- measured 1.007 against 1.020 ms per step on MI355X */
 #define FN_TUNE_FWD_BLOCKS_EVAL 10
-#define FN_TUNE_COUNT 11
+#define FN_TUNE_DST_BLOCKS 11  /* target workgroup count of the backward destination pass (default 1536: three rows per half-wave at ESOL batch
+                                * 512; never more than three rows, see prep_gat_bwd_dst) */
+#define FN_TUNE_COUNT 12
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * molecules 64-bit words) is
  * set, every workgroup of the fused molecule kernels writes s_memtime stamps of its phases into it (tools/mol_phase_times.py).
