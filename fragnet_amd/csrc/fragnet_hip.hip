@@ -2638,7 +2638,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 namespace {
 unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
 int64_t g_mol_stamps_n = 0;
-int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
+int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 256};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -3100,8 +3100,8 @@ static int prep_gat_bwd_src(const float* g_out, const float* h, const float* pz_
         return fail(FN_EUNSUPPORTED, "fn_gat_bwd_src_f32: level too large for 32-bit byte offsets (n <= 2^23 rows, m*heads <= 2^28)");
     // every block writes 256 partial sums column-major (scattered): at most 1024 blocks, each half-wave pipelining R rows
     const int64_t groups = (plan->n + kBwdRows - 1) / kBwdRows;
-    int64_t resident = (int64_t)g_tune[FN_TUNE_FWD_BLOCKS];
-    if (resident > 1024) resident = 1024;
+    int64_t resident = (int64_t)g_tune[FN_TUNE_SRC_BLOCKS];
+    if (resident > 1024 || resident < 1) resident = 1024;
     A->rows_per_hw = (int)((groups + resident - 1) / resident);
     A->nblk = (int)((plan->n + (int64_t)kBwdRows * A->rows_per_hw - 1) / ((int64_t)kBwdRows * A->rows_per_hw));
     *n_part_a = A->nblk;
@@ -3895,7 +3895,7 @@ int bwd_src_and_edge_term(const float* g_out, const float* h, const float* pz_sr
                           int* n_rd, int heads, hipStream_t st) {
     GatBwdSrcArgs A;
     if (int rc = prep_gat_bwd_src(g_out, h, pz_src, g_s_dst, att, att_w, dst_off, src_off, plan, g_h, part_a, n_part_a, heads, &A)) return rc;
-    *n_rd = plan->m_real > 0 ? row_grid(plan->m_real, kRowDotsBwdBlocks) : 0;
+    *n_rd = plan->m_real > 0 ? row_grid(plan->m_real, g_tune[FN_TUNE_RD_BLOCKS] > 0 ? g_tune[FN_TUNE_RD_BLOCKS] : kRowDotsBwdBlocks) : 0;
     if (*n_rd == 0) return launch_gat_bwd_src(A, heads, st);
     const RowDotsBwdArgs T{dz_orig, feat, att, att_w, mid_off, heads, *plan, g_feat, part_rd, accumulate ? (const float*)g_feat : nullptr, 1, *n_rd};
     if (A.nblk == 0) {

@@ -75,7 +75,9 @@ int fn_abi_version(void);
 #define FN_TUNE_FWD_BLOCKS_EVAL 10
 #define FN_TUNE_DST_BLOCKS 11  /* target workgroup count of the backward destination pass (default 1536: three rows per half-wave at ESOL batch
                                 * 512; never more than three rows, see prep_gat_bwd_dst) */
-#define FN_TUNE_COUNT 12
+#define FN_TUNE_SRC_BLOCKS 12  /* resident workgroups of the backward source pass (default 512; <= 1024: every block writes a row of partial sums) */
+#define FN_TUNE_RD_BLOCKS 13   /* (default 256) workgroups of the edge-term backward that shares the source pass's launch (each writes a row of partial sums) */
+#define FN_TUNE_COUNT 14
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * molecules 64-bit words) is
  * set, every workgroup of the fused molecule kernels writes s_memtime stamps of its phases into it (tools/mol_phase_times.py).
