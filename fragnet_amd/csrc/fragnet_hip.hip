@@ -2229,6 +2229,7 @@ struct LinTask {
 struct LinTasks {
     LinTask t[3];
     int n, K;
+    int base, total;          // co-launched with an attention pass (below): the GEMM workgroups are blocks [base, base + total) of that launch
 };
 template <int KQ, bool VEC, bool PF>
 __global__ __launch_bounds__(kLinThreads) void k_linear128_multi(LinTasks T) {
@@ -2237,6 +2238,78 @@ __global__ __launch_bounds__(kLinThreads) void k_linear128_multi(LinTasks T) {
     while (ti + 1 < T.n && (int)blockIdx.x >= T.t[ti + 1].first) ++ti;
     const LinTask& t = T.t[ti];
     linear128_body<KQ, VEC, PF>(sBt, t.X, t.K ? t.K : T.K, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, (int)blockIdx.x - t.first, t.nblk);
+}
+
+// ---- an attention pass and the projection GEMMs that do not depend on it, in ONE launch.
+// Inside a layer the chain is  projections -> bond + fragment-bond levels -> atom level, but only a third of it is a true
+// dependency: the atom projection of layer l needs layer l-1's atom level and nothing of layer l's bond levels, and the bond /
+// fragment-bond projections of layer l+1 need layer l's bond levels and nothing of its atom level (the backward mirrors this:
+// the atom input-gradient product does not wait for the bond levels' passes, and theirs not for the next layer's atom pass).
+// The attention passes are bound by dependent round trips with the matrix cores idle, the projections are a few microseconds
+// of MFMA work behind a launch floor of their own -- so the GEMM tiles ride along as extra workgroups of the attention launch
+// (one 64 x 64 tile each, the k_linear128_multi body) and the layer loses a kernel boundary per pass.
+__device__ __forceinline__ void lin_side_block(float* sBt, const LinTasks& T, int b) {
+    int ti = 0;
+    while (ti + 1 < T.n && b >= T.t[ti + 1].first) ++ti;
+    const LinTask& t = T.t[ti];
+    linear128_body<32, true, false>(sBt, t.X, 128, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, b - t.first, t.nblk);
+}
+// Which workgroup is which: the dispatcher fills a CU with CONSECUTIVE workgroups of its XCD (measured: with all GEMM workgroups
+// first or last in the launch the two kinds ended up on different CUs and the launch took as long as both alone), so the roles
+// are interleaved in units of 8 workgroups (one per XCD): of the launch's `units` units, `gemm_units` spread evenly are GEMM
+// units.  Returns the role's own block index (>= 0) in *idx; an attention index keeps blockIdx % 8, i.e. its XCD.
+struct LinMix { int units, gemm_units; };       // units == 0: not interleaved (T.base / gat_base ranges)
+__device__ __forceinline__ bool lin_mix_role(const LinMix& mx, int* idx) {     // true: GEMM workgroup
+    const int u = (int)blockIdx.x >> 3, x = (int)blockIdx.x & 7;
+    const int before = (int)(((int64_t)u * mx.gemm_units) / mx.units), after = (int)(((int64_t)(u + 1) * mx.gemm_units) / mx.units);
+    const bool gemm = after > before;
+    *idx = (gemm ? before : u - before) * 8 + x;
+    return gemm;
+}
+__device__ __forceinline__ bool lin_side_role(const LinTasks& T, int gat_base, const LinMix& mx, int* idx) {
+    if (mx.units) return lin_mix_role(mx, idx);
+    const int b = (int)blockIdx.x - T.base;
+    if ((unsigned)b < (unsigned)T.total) { *idx = b;  return true; }
+    *idx = (int)blockIdx.x - gat_base;
+    return false;
+}
+// gat_base: block id of the first attention workgroup (0 when the GEMM blocks come last, T.total when they come first).
+// __launch_bounds__(.., 4): four waves per SIMD as for the plain attention kernels -- without it the accumulators of the GEMM
+// branch go to AGPRs ON TOP of the attention branch's VGPRs and the launch drops to three (the two-level destination pass
+// with the 8-attribute edge class is at three either way and would spill, so it keeps the default).
+template <int H, int KL>
+__global__ __launch_bounds__(kBlock, 4) void k_gat_fwd_lin(GatFwdArgs A, LinTasks T, int gat_base, LinMix mx) {
+    extern __shared__ __attribute__((aligned(16))) float sBt[];
+    __shared__ float sWf[8][kWfLd];
+    int g;
+    if (lin_side_role(T, gat_base, mx, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
+    if (g < A.nblk) gat_fwd_body<H, KL>(A, sWf, g, A.nblk);
+}
+template <int H, int KLA, int KLB, bool RDA>
+__global__ __launch_bounds__(kBlock, 4) void k_gat_fwd_pair_lin(GatFwdArgs A, GatFwdArgs B, LinTasks T, int gat_base, LinMix mx) {
+    extern __shared__ __attribute__((aligned(16))) float sBt[];
+    __shared__ float sWf[8][kWfLd];
+    int g;
+    if (lin_side_role(T, gat_base, mx, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
+    if (g < A.nblk) gat_fwd_body<H, KLA, RDA>(A, sWf, g, A.nblk);
+    else if (g < A.nblk + B.nblk) gat_fwd_body<H, KLB>(B, sWf, g - A.nblk, B.nblk);
+}
+template <int H, int KL, int RB>
+__global__ __launch_bounds__(RB * 32, 4) void k_gat_bwd_dst_lin(GatBwdDstArgs A, LinTasks T, int gat_base, LinMix mx) {
+    extern __shared__ __attribute__((aligned(16))) float sBt[];
+    __shared__ float sP[RB][8][kWfLd];
+    int g;
+    if (lin_side_role(T, gat_base, mx, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
+    if (g < A.nblk) gat_bwd_dst_body<H, KL, RB>(A, sP, g, A.nblk);
+}
+template <int H, int KLA, int KLB, int RB>
+__global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst_pair_lin(GatBwdDstArgs A, GatBwdDstArgs B, LinTasks T, int gat_base, LinMix mx) {
+    extern __shared__ __attribute__((aligned(16))) float sBt[];
+    __shared__ float sP[RB][8][kWfLd];
+    int g;
+    if (lin_side_role(T, gat_base, mx, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
+    if (g < A.nblk) gat_bwd_dst_body<H, KLA, RB>(A, sP, g, A.nblk);
+    else if (g < A.nblk + B.nblk) gat_bwd_dst_body<H, KLB, RB>(B, sP, g - A.nblk, B.nblk);
 }
 
 // Bt[k][n] = W[n][k]  (W is nn.Linear.weight [128, K])
@@ -2638,7 +2711,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 namespace {
 unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
 int64_t g_mol_stamps_n = 0;
-int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 256};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
+int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 256, 2, -1};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -3076,6 +3149,123 @@ static int launch_gat_bwd_dst_pair(const GatBwdDstArgs& A, const GatBwdDstArgs& 
         else hipLaunchKernelGGL((k_gat_bwd_dst_pair<HH, 1, FN_MAX_EDGE_K, kBwdRows>), dim3(A.nblk + B.nblk), dim3(kBwdRows * 32), 0, st, A, B);
     });
     return launch_status("attention backward, destination pass (two levels)");
+}
+
+// ---- co-launches: an attention pass + independent K = 128 projection tasks (k_gat_*_lin above).  Each returns through the
+// plain launches (attention, then launch_linear128_group) whenever the combination has no kernel: the caller never needs to know.
+static_assert(kBlock == kLinThreads && kBwdRows * 32 == kLinThreads, "co-launched attention and GEMM workgroups share a block size");
+constexpr size_t kLinSideLds = (size_t)(4 * 32 * kLinLd) * sizeof(float);
+// lays the tasks' workgroups out (one 64 x 64 output tile each); false: cannot ride along (empty, co-launch off, misaligned, or the
+// register-resident / wave-independent GEMM variants are selected, which have their own launch shapes)
+static bool lin_side_prepare(LinTasks& T, int gat_blocks, int* gat_base, LinMix* mx, int* grid, bool pair) {
+    int mode = g_tune[FN_TUNE_GEMM_COLAUNCH];
+    if (mode == 4) mode = pair ? 1 : 2;           // 4 / 5: one order for the single-level launches, the other for the two-level ones
+    else if (mode == 5) mode = pair ? 2 : 1;
+    if (!mode || g_tune[FN_TUNE_PROJ] || g_tune[FN_TUNE_PROJ_DIRECT] || g_tune[FN_TUNE_GEMM_SLOTS] > 0) return false;
+    for (int i = 0; i < T.n; ++i) {
+        const LinTask& t = T.t[i];
+        if (t.M <= 0) continue;
+        if (t.K && t.K != FN_D) return false;
+        if (((uintptr_t)t.X | (uintptr_t)t.Bt | (uintptr_t)t.Y | (uintptr_t)t.bias | (uintptr_t)t.mk.y) & 15) return false;
+    }
+    // The GEMM workgroups are meant to be RESIDENT BESIDE the attention workgroups (four 256-thread workgroups per CU), so that
+    // a SIMD interleaves one wave's MFMA chain with the attention waves' round trips: as many of them as the attention pass
+    // leaves slots (at least one per CU), each walking several 64 x 64 tiles.  One tile per workgroup (the stand-alone GEMM's
+    // shape) fills the chip with GEMM workgroups first and the two kinds then run one after the other.
+    int64_t total_tiles = 0;
+    for (int i = 0; i < T.n; ++i) total_tiles += T.t[i].M > 0 ? (T.t[i].M + kLinRows - 1) / kLinRows : 0;
+    int iters = 1;
+    if (g_tune[FN_TUNE_COLAUNCH_SLOTS] >= 0) {
+        const int64_t slots = g_tune[FN_TUNE_COLAUNCH_SLOTS] > 0 ? g_tune[FN_TUNE_COLAUNCH_SLOTS] : std::max<int64_t>(256, 1024 - gat_blocks);
+        iters = (int)std::max<int64_t>(1, (2 * total_tiles + slots - 1) / slots);
+    }
+    int blocks = 0, live = 0;
+    for (int i = 0; i < T.n; ++i) {
+        if (T.t[i].M <= 0) continue;
+        LinTask t = T.t[i];
+        t.first = blocks;
+        t.nblk = lin_blocks((t.M + kLinRows - 1) / kLinRows, iters);
+        blocks += t.nblk;
+        T.t[live++] = t;
+    }
+    T.n = live;
+    T.K = FN_D;
+    if (!live) return false;
+    T.total = blocks;
+    T.base = mode == 2 ? 0 : gat_blocks;          // 2: GEMM workgroups are dispatched first; 1: after the attention workgroups
+    *gat_base = mode == 2 ? blocks : 0;
+    *mx = LinMix{0, 0};
+    *grid = gat_blocks + blocks;
+    if (mode == 3) {                              // 3: interleaved in units of 8 workgroups
+        mx->gemm_units = (blocks + 7) / 8;
+        mx->units = mx->gemm_units + (gat_blocks + 7) / 8;
+        *grid = 8 * mx->units;
+    }
+    return true;
+}
+static_assert(kLinSideLds <= 64 * 1024, "the co-launched GEMM tile fits the default dynamic LDS limit");
+
+static int launch_gat_fwd_lin(const GatFwdArgs& A, LinTasks& T, int heads, hipStream_t st) {
+    int gb = 0, grid = 0;
+    LinMix mx{};
+    if (A.nblk == 0 || A.rd_out || edge_class(&A.et) != 0 || !lin_side_prepare(T, A.nblk, &gb, &mx, &grid, false)) {
+        if (int rc = launch_gat_fwd(A, heads, st)) return rc;
+        return T.n ? launch_linear128_group(T, st) : 0;
+    }
+    FN_DISPATCH_H(heads, {
+        hipLaunchKernelGGL((k_gat_fwd_lin<HH, 0>), dim3(grid), dim3(kBlock), kLinSideLds, st, A, T, gb, mx);
+    });
+    return launch_status("attention forward + projections of the next level");
+}
+static int launch_gat_fwd_pair_lin(const GatFwdArgs& A, const GatFwdArgs& B, LinTasks& T, int heads, hipStream_t st) {
+    const int ka = edge_class(&A.et), kb = edge_class(&B.et);
+    int gb = 0, nwg = 0;
+    LinMix mx{};
+    if (A.nblk == 0 || B.nblk == 0 || ka != 1 || (kb != 1 && kb != FN_MAX_EDGE_K) || !lin_side_prepare(T, A.nblk + B.nblk, &gb, &mx, &nwg, true)) {
+        if (int rc = launch_gat_fwd_pair(A, B, heads, st)) return rc;
+        return T.n ? launch_linear128_group(T, st) : 0;
+    }
+    const dim3 grid(nwg);
+#define FN_PAIR_LIN(KB, RD)                                                                                      \
+    do {                                                                                                         \
+        hipLaunchKernelGGL((k_gat_fwd_pair_lin<HH, 1, KB, RD>), grid, dim3(kBlock), kLinSideLds, st, A, B, T, gb, mx); \
+    } while (0)
+    FN_DISPATCH_H(heads, {
+        if (A.rd_out) { if (kb == 1) FN_PAIR_LIN(1, true); else FN_PAIR_LIN(FN_MAX_EDGE_K, true); }
+        else { if (kb == 1) FN_PAIR_LIN(1, false); else FN_PAIR_LIN(FN_MAX_EDGE_K, false); }
+    });
+#undef FN_PAIR_LIN
+    return launch_status("attention forward (two levels) + atom projection");
+}
+static int launch_gat_bwd_dst_lin(const GatBwdDstArgs& A, LinTasks& T, int heads, hipStream_t st) {
+    int gb = 0, grid = 0;
+    LinMix mx{};
+    if (A.nblk == 0 || edge_class(&A.et) != 0 || !lin_side_prepare(T, A.nblk, &gb, &mx, &grid, false)) {
+        if (T.n) if (int rc = launch_linear128_group(T, st)) return rc;          // the products first: the level below reads them
+        return launch_gat_bwd_dst(A, heads, st);
+    }
+    FN_DISPATCH_H(heads, {
+        hipLaunchKernelGGL((k_gat_bwd_dst_lin<HH, 0, kBwdRows>), dim3(grid), dim3(kBwdRows * 32), kLinSideLds, st, A, T, gb, mx);
+    });
+    return launch_status("attention backward, destination pass + input-gradient products");
+}
+static int launch_gat_bwd_dst_pair_lin(const GatBwdDstArgs& A, const GatBwdDstArgs& B, LinTasks& T, int heads, hipStream_t st) {
+    const int ka = edge_class(&A.et), kb = edge_class(&B.et);
+    int gb = 0, nwg = 0;
+    LinMix mx{};
+    if (A.nblk == 0 || B.nblk == 0 || ka != 1 || (kb != 1 && kb != FN_MAX_EDGE_K) || !lin_side_prepare(T, A.nblk + B.nblk, &gb, &mx, &nwg, true)) {
+        if (int rc = launch_gat_bwd_dst_pair(A, B, heads, st)) return rc;
+        return T.n ? launch_linear128_group(T, st) : 0;
+    }
+    const dim3 grid(nwg);
+    FN_DISPATCH_H(heads, {
+        if (kb == 1) {
+            hipLaunchKernelGGL((k_gat_bwd_dst_pair_lin<HH, 1, 1, kBwdRows>), grid, dim3(kBwdRows * 32), kLinSideLds, st, A, B, T, gb, mx);
+        } else {
+            hipLaunchKernelGGL((k_gat_bwd_dst_pair_lin<HH, 1, FN_MAX_EDGE_K, kBwdRows>), grid, dim3(kBwdRows * 32), kLinSideLds, st, A, B, T, gb, mx);
+        }
+    });
+    return launch_status("attention backward, destination pass (two levels) + atom input-gradient product");
 }
 
 int fn_gat_bwd_dst_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et,
@@ -3946,6 +4136,9 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
     const bool fused = mol_fused(e);
     // the atom graph's edge term <new_bond, a[:, d:d+128]> is produced by the bond-graph kernel's epilogue (one launch less per layer)
     const bool fuse_rd = !fused && g_tune[FN_TUNE_FUSE_ROWDOTS] != 0 && e->atom.m > 0 && e->atom.m_real == e->E;
+    // projections ride along with the attention launches they do not depend on (k_gat_*_lin); needs the node scalars in the GEMM epilogue
+    const bool colaunch = !fused && !multi && H >= 2 && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;
+    const fn_act_epilogue no_act_l{nullptr, 0.f, 0, 0, 0, nullptr};
     if (multi) FN_TRY(aux_init());
     fn_stream_t st_fb = multi ? (fn_stream_t)g_aux.s[1] : st;       // the fragment-bond chain's stream
 
@@ -4056,16 +4249,24 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
             FN_TRY(fn_linear128_f32(x, k, bt, bias, hout, rows, nullptr, sq));
             return fn_node_scalars_f32(hout, att, att_w, 0, src_off, sdst, ssrc, rows, H, sq);
         };
-        // layers >= 1: the three projections (K = 128) depend only on the previous layer -> one grouped launch
+        // layers >= 1: the three projections (K = 128) depend only on the previous layer.  With co-launching (FN_TUNE_GEMM_COLAUNCH)
+        // the bond / fragment-bond projections already ran beside the previous layer's atom level and the atom projection rides
+        // with this layer's bond levels below; otherwise one grouped launch for the three
         const bool grouped = l > 0 && fuse_ns && !multi;
-        if (grouped) {
+        const fn_act_epilogue no_act{nullptr, 0.f, 0, 0, 0, nullptr};
+        LinTasks with_pair{};                      // rides with the bond + fragment-bond launch of this layer
+        if (grouped && colaunch) {
+            with_pair.n = 1;
+            with_pair.t[0] = LinTask{w.proj_a_w, in_atoms, bt_a, w.proj_a_b, a.h_a, e->N, no_act,
+                                     NodeScalarEpi{w.a, lay.s_dst_a, lay.s_src_a, wide, 0, d + FN_D, H}, 0, 0};
+        } else if (grouped) {
             LinTasks T{};
             T.n = no_fb ? 2 : 3;
-            T.t[0] = LinTask{w.proj_b_w, in_bond, bt_b, w.proj_b_b, a.h_b, e->E, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
+            T.t[0] = LinTask{w.proj_b_w, in_bond, bt_b, w.proj_b_b, a.h_b, e->E, no_act,
                              NodeScalarEpi{w.a_b, lay.s_dst, lay.s_src, 3 * d, 0, 2 * d, H}, 0, 0};
-            T.t[1] = LinTask{w.proj_a_w, in_atoms, bt_a, w.proj_a_b, a.h_a, e->N, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
+            T.t[1] = LinTask{w.proj_a_w, in_atoms, bt_a, w.proj_a_b, a.h_a, e->N, no_act,
                              NodeScalarEpi{w.a, lay.s_dst_a, lay.s_src_a, wide, 0, d + FN_D, H}, 0, 0};
-            T.t[2] = LinTask{w.proj_fb_w, in_fbond, bt_fb, w.proj_fb_b, a.h_fb, e->EF, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
+            T.t[2] = LinTask{w.proj_fb_w, in_fbond, bt_fb, w.proj_fb_b, a.h_fb, e->EF, no_act,
                              NodeScalarEpi{w.f_a_b, lay.s_dst_fb, lay.s_src_fb, 3 * d, 0, 2 * d, H}, 0, 0};
             FN_TRY(launch_linear128_group(T, S(st)));
         } else if (l == 0 && fuse_ns && !multi && !no_fb && kb <= 20 && kfb <= 20) {
@@ -4092,6 +4293,8 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         if (multi) {
             FN_TRY(launch_gat_fwd(gb, H, S(st)));
             FN_TRY(launch_gat_fwd(gfb, H, S(st_fb)));
+        } else if (with_pair.n) {
+            FN_TRY(launch_gat_fwd_pair_lin(gb, gfb, with_pair, H, S(st)));
         } else {
             FN_TRY(launch_gat_fwd_pair(gb, gfb, H, S(st)));
         }
@@ -4100,7 +4303,22 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         if (!grouped) FN_TRY(project(in_atoms, ka, bt_a, w.proj_a_b, a.h_a, e->N, w.a, wide, d + FN_D, lay.s_dst_a, lay.s_src_a, st));
         if (!fuse_rd) FN_TRY(fn_row_dots_sorted_f32(a.new_bond, w.a, wide, d, H, &e->atom, lay.s_sorted, st));
         fn_edge_term et_a{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
+        if (colaunch && !last) {
+            // the next layer's bond / fragment-bond projections read this layer's bond-level outputs, not its atom level: same launch
+            const fn_layer_weights& wn = e->w[l + 1];
+            const LayerActs& an = lay.L[l + 1];
+            LinTasks T{};
+            T.n = no_fb ? 1 : 2;
+            T.t[0] = LinTask{wn.proj_b_w, y_bond, lay.bt + (size_t)(3 * (l + 1)) * 192 * FN_D, wn.proj_b_b, an.h_b, e->E, no_act_l,
+                             NodeScalarEpi{wn.a_b, lay.s_dst, lay.s_src, 3 * d, 0, 2 * d, H}, 0, 0};
+            T.t[1] = LinTask{wn.proj_fb_w, y_fbond, lay.bt + (size_t)(3 * (l + 1) + 2) * 192 * FN_D, wn.proj_fb_b, an.h_fb, e->EF, no_act_l,
+                             NodeScalarEpi{wn.f_a_b, lay.s_dst_fb, lay.s_src_fb, 3 * d, 0, 2 * d, H}, 0, 0};
+            GatFwdArgs ga;
+            FN_TRY(prep_gat_fwd(a.h_a, lay.s_dst_a, lay.s_src_a, w.a, wide, &et_a, &e->atom, 0.2f, lay.atoms_new, a.p_atom, nullptr, &ep_atoms, H, &ga));
+            FN_TRY(launch_gat_fwd_lin(ga, T, H, S(st)));
+        } else {
         FN_TRY(fn_gat_fwd_f32(a.h_a, lay.s_dst_a, lay.s_src_a, w.a, wide, &et_a, &e->atom, 0.2f, lay.atoms_new, a.p_atom, nullptr, &ep_atoms, H, st));
+        }
         }   // !fused
 
         // L3 atom -> fragment sum.  Like L4b below it is only ever read in the last layer (the next layer recomputes its own
@@ -4172,6 +4390,8 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
     rq.st = hs;                      // all parameter-gradient reductions run as one launch at the very end
     rq.defer_wgrad = !multi;         // ... and so do the K = 128 weight-gradient partial products
 
+    const bool colaunch = !multi && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;
+    LinTasks dx_carry{};             // input-gradient products handed from layer l+1 to layer l's first attention launch
     // gradients w.r.t. the current layer's post-activation outputs (null = zero)
     bool pre_atoms = false, pre_bond = false, pre_fbond = false;   // g_pre_* already hold layer l's pre-activation grads
     const float* gy_atoms = g_atoms;
@@ -4194,12 +4414,18 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         const int ka = l ? FN_D : e->k_atom0, kb = l ? FN_D : e->k_bond0, kfb = l ? FN_D : e->k_fbond0;
         const LevelScratch &sb = bw.bond[l], &sa = bw.atom[l], &sfb = bw.fbond[l], &sf = bw.frag;
         int n_a = 0, n_e = 0;
-        // the three input-gradient products of a layer feed layer l-1 only: one grouped launch at the end of the layer
-        LinTasks dxT{};
+        // the three input-gradient products of a layer feed layer l-1 only: one grouped launch at the end of the layer -- or, with
+        // co-launching, the atom product rides with this layer's bond-level destination pass (dxA) and the bond / fragment-bond
+        // products with layer l-1's atom-level destination pass (dx_carry, launched in the next iteration)
+        LinTasks dxT{}, dxA{};
+        LinTasks dx_now = dx_carry;          // products of layer l+1 that this layer's atom level launches
+        dx_carry = LinTasks{};
         // Wt: the transposed copy the forward prologue left in the workspace (k_proj128 wants the weight n-major)
-        auto input_grad = [&](const float* gh, const float* W, const float* Wt, float* gy, int64_t rows, const fn_act_epilogue& mk, fn_stream_t sq) -> int {
+        auto input_grad = [&](const float* gh, const float* W, const float* Wt, float* gy, int64_t rows, const fn_act_epilogue& mk, fn_stream_t sq,
+                              int where) -> int {
             if (multi) return fn_linear128_f32(gh, FN_D, W, nullptr, gy, rows, &mk, sq);
-            dxT.t[dxT.n++] = LinTask{Wt, gh, W, nullptr, gy, rows, mk, NodeScalarEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0}, 0, 0};
+            LinTasks& dst = !colaunch ? dxT : (where == 0 ? dxA : dx_carry);
+            dst.t[dst.n++] = LinTask{Wt, gh, W, nullptr, gy, rows, mk, NodeScalarEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0}, 0, 0};
             return 0;
         };
         const float* bt_b = lay.bt + (size_t)(3 * l) * 192 * FN_D;
@@ -4267,7 +4493,12 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         // ---- L2 atom graph
         if (have_atoms) {
             fn_edge_term et_a{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_atoms, a.h_a, a.p_atom, &et_a, &e->atom, 0.2f, nullptr, sa.dz, sa.pz, sa.g_s_dst, nullptr, &n_e, H, st));
+            {
+                GatBwdDstArgs da{};
+                FN_TRY(prep_gat_bwd_dst(bw.g_pre_atoms, a.h_a, a.p_atom, &et_a, &e->atom, 0.2f, nullptr, sa.dz, sa.pz, sa.g_s_dst, nullptr, &n_e, H, &da));
+                FN_TRY(launch_gat_bwd_dst_lin(da, dx_now, H, hs));          // + layer l+1's bond / fragment-bond input-gradient products
+                dx_now = LinTasks{};
+            }
             int gr = 0;
             FN_TRY(bwd_src_and_edge_term(bw.g_pre_atoms, a.h_a, sa.pz, sa.g_s_dst, w.a, wide, 0, d + FN_D, &e->atom, sa.g_h, sa.part_a, &n_a,
                                          sa.dz, a.new_bond, d, bw.g_pre_bond, sa.part_rd, have_bond, &gr, H, hs));
@@ -4278,9 +4509,13 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             FN_TRY(rq.wgrad(sa.g_h, in_atoms, ka, e->N, sa.wg_ws, g.proj_a_w, g.proj_a_b, S(st_leaf)));
             if (l) {
                 const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_atoms), p, 1, e->seed, rng.y[l - 1][0], e->offset_dev};
-                FN_TRY(input_grad(sa.g_h, w.proj_a_w, bt_a, bw.g_pre_atoms, e->N, mk, st));
+                FN_TRY(input_grad(sa.g_h, w.proj_a_w, bt_a, bw.g_pre_atoms, e->N, mk, st, 0));
                 nxt_atoms = true;
             }
+        }
+        if (dx_now.n) {          // no atom level ran in this layer: the carried products still have to
+            FN_TRY(launch_linear128_group(dx_now, hs));
+            dx_now = LinTasks{};
         }
 
         // ---- L1 bond graph and L4a fragment-bond graph: independent of each other, so their destination passes
@@ -4306,13 +4541,14 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
                 FN_TRY(launch_gat_bwd_dst(dfb, H, S(st_fb)));
                 FN_TRY(launch_gat_bwd_src(sfbA, H, S(st_fb)));
             } else {
-                FN_TRY(launch_gat_bwd_dst_pair(db, dfb, H, hs));
+                FN_TRY(launch_gat_bwd_dst_pair_lin(db, dfb, dxA, H, hs));        // + this layer's atom input-gradient product
+                dxA = LinTasks{};
                 FN_TRY(launch_gat_bwd_src_pair(sbA, sfbA, H, hs));
             }
             if (have_fbond) {
                 if (l) {     // dL/d(pre-activation fbond output of layer l-1), gated by that layer's dropout mask and ReLU
                     const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_fbond), p, 1, e->seed, rng.y[l - 1][3], e->offset_dev};
-                    FN_TRY(input_grad(sfb.g_h, w.proj_fb_w, bt_fb, bw.g_pre_fbond, e->EF, mk, st_fb));
+                    FN_TRY(input_grad(sfb.g_h, w.proj_fb_w, bt_fb, bw.g_pre_fbond, e->EF, mk, st_fb, 1));
                     nxt_fbond = true;
                 }
                 FN_TRY(rq.finalize(sfb.part_a, n_a_fb, sfb.part_e, n_e_fb, et_fb, w.f_a_b, 3 * d, 0, 2 * d, g.f_a_b, g.emb_fb_w, g.emb_fb_b, H));
@@ -4324,11 +4560,12 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
                 FN_TRY(rq.wgrad(sb.g_h, in_bond, kb, e->E, sb.wg_ws, g.proj_b_w, g.proj_b_b, S(st_leaf)));
                 if (l) {
                     const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_bond), p, 1, e->seed, rng.y[l - 1][2], e->offset_dev};
-                    FN_TRY(input_grad(sb.g_h, w.proj_b_w, bt_b, bw.g_pre_bond, e->E, mk, st));
+                    FN_TRY(input_grad(sb.g_h, w.proj_b_w, bt_b, bw.g_pre_bond, e->E, mk, st, 1));
                     nxt_bond = true;
                 }
             }
         }
+        if (dxA.n) FN_TRY(launch_linear128_group(dxA, hs));          // no bond-level launch took it
         if (dxT.n) FN_TRY(launch_linear128_group(dxT, hs));
         pre_atoms = nxt_atoms;  pre_bond = nxt_bond;  pre_fbond = nxt_fbond;
         gy_atoms = gy_bond = gy_fbond = nullptr;

@@ -77,7 +77,15 @@ int fn_abi_version(void);
                                 * 512; never more than three rows, see prep_gat_bwd_dst) */
 #define FN_TUNE_SRC_BLOCKS 12  /* resident workgroups of the backward source pass (default 512; <= 1024: every block writes a row of partial sums) */
 #define FN_TUNE_RD_BLOCKS 13   /* (default 256) workgroups of the edge-term backward that shares the source pass's launch (each writes a row of partial sums) */
-#define FN_TUNE_COUNT 14
+#define FN_TUNE_GEMM_COLAUNCH 14 /* inside fn_encoder_*: the 128 -> 128 projections (forward) and input-gradient products (backward) that do
+                                 * not depend on an attention pass ride along as extra workgroups of that pass's launch (the atom projection
+                                 * beside the bond + fragment-bond levels, the next layer's bond / fragment-bond projections beside the atom
+                                 * level; mirrored in the backward).  2 (default): GEMM workgroups first in the launch, 1: after the attention
+                                 * workgroups, 0: separate grouped launches */
+#define FN_TUNE_COLAUNCH_SLOTS 15 /* workgroups the co-launched GEMM tasks get: 0 (default) = the slots the attention pass leaves free
+                                  * (1024 - its workgroups, at least 256 = one per CU), each walking several 64 x 64 tiles;
+                                  * > 0 = that many; -1 = one tile per workgroup */
+#define FN_TUNE_COUNT 16
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * molecules 64-bit words) is
  * set, every workgroup of the fused molecule kernels writes s_memtime stamps of its phases into it (tools/mol_phase_times.py).
