@@ -2240,6 +2240,18 @@ __global__ __launch_bounds__(kLinThreads) void k_linear128_multi(LinTasks T) {
     linear128_body<KQ, VEC, PF>(sBt, t.X, t.K ? t.K : T.K, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, (int)blockIdx.x - t.first, t.nblk);
 }
 
+// layer 0: all three projections read raw features only (K = 17 bond, 6 connection, 167 atom features at the reference's sizes), so
+// they share a launch although their reduction lengths need two instantiations of the body: tasks with K <= 20 run the short one,
+// the others the K <= 168 one (whose operand tile sets the launch's LDS size)
+__global__ __launch_bounds__(kLinThreads) void k_linear128_layer0(LinTasks T) {
+    extern __shared__ __attribute__((aligned(16))) float sBt[];
+    int ti = 0;
+    while (ti + 1 < T.n && (int)blockIdx.x >= T.t[ti + 1].first) ++ti;
+    const LinTask& t = T.t[ti];
+    if (t.K > 20) linear128_body<44, false, false>(sBt, t.X, t.K, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, (int)blockIdx.x - t.first, t.nblk);
+    else linear128_body<5, false, false>(sBt, t.X, t.K, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, (int)blockIdx.x - t.first, t.nblk);
+}
+
 // ---- an attention pass and the projection GEMMs that do not depend on it, in ONE launch.
 // Inside a layer the chain is  projections -> bond + fragment-bond levels -> atom level, but only a third of it is a true
 // dependency: the atom projection of layer l needs layer l-1's atom level and nothing of layer l's bond levels, and the bond /
@@ -2508,6 +2520,7 @@ struct WgradTask {
     float* part;
     int64_t M;
     int rpb, first;
+    int K;                    // k_linear128_wgrad_mixed only: this product's reduction length (0 elsewhere: WgradTasks::K)
 };
 constexpr int kMaxWgradTasks = 3 * FN_MAX_LAYERS;
 struct WgradTasks {
@@ -2522,6 +2535,20 @@ __global__ __launch_bounds__(256 * NH) void k_linear128_wgrad_multi(WgradTasks T
     while (ti + 1 < T.n && (int)blockIdx.x >= T.t[ti + 1].first) ++ti;
     const WgradTask& t = T.t[ti];
     wgrad_body<CTW, NH>(smem, t.dY, t.X, T.K, t.M, t.rpb, t.part, (int)blockIdx.x - t.first);
+}
+
+// the weight-gradient partials of layer 0 (raw-feature widths: 17 / 6 / 167 at the reference's sizes) in one launch: every
+// product picks the instantiation its K needs (all with two column groups, i.e. 512 threads); the launch's LDS size is the
+// largest product's
+__global__ __launch_bounds__(512) void k_linear128_wgrad_mixed(WgradTasks T) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int ti = 0;
+    while (ti + 1 < T.n && (int)blockIdx.x >= T.t[ti + 1].first) ++ti;
+    const WgradTask& t = T.t[ti];
+    const int bid = (int)blockIdx.x - t.first;
+    if (t.K <= 32) wgrad_body<1, 2>(smem, t.dY, t.X, t.K, t.M, t.rpb, t.part, bid);
+    else if (t.K <= 128) wgrad_body<4, 2>(smem, t.dY, t.X, t.K, t.M, t.rpb, t.part, bid);
+    else wgrad_body<6, 2>(smem, t.dY, t.X, t.K, t.M, t.rpb, t.part, bid);
 }
 
 // sums the native-layout partials over blocks and scatters them to dW [128][K] / db [128]
@@ -2842,12 +2869,14 @@ int launch_linear128_group(LinTasks& T, hipStream_t st) {
 // layer 0: the bond (K = 17) and connection (K = 6) projections in one launch of the K <= 20 variant, each task with its own K
 int launch_linear128_small_group(LinTasks& T, hipStream_t st) {
     constexpr int KQ = 5;
-    const size_t lds = (size_t)(4 * KQ * kLinLd) * sizeof(float);
+    bool mixed = false;                          // a task with 20 < K <= 168 rides along (k_linear128_layer0)
+    for (int i = 0; i < T.n; ++i) mixed |= T.t[i].M > 0 && T.t[i].K > 4 * KQ;
+    const size_t lds = (size_t)(4 * (mixed ? 44 : KQ) * kLinLd) * sizeof(float);
     int blocks = 0, live = 0;
     for (int i = 0; i < T.n; ++i) {
         if (T.t[i].M <= 0) continue;
         LinTask t = T.t[i];
-        if (t.K < 1 || t.K > 4 * KQ) return fail(FN_EINVAL, "small projection group: K must be 1..20");
+        if (t.K < 1 || t.K > 168) return fail(FN_EINVAL, "layer-0 projection group: K must be 1..168");
         t.first = blocks;
         t.nblk = lin_blocks((t.M + kLinRows - 1) / kLinRows, 1);
         blocks += t.nblk;
@@ -2856,8 +2885,9 @@ int launch_linear128_small_group(LinTasks& T, hipStream_t st) {
     T.n = live;
     T.K = 4 * KQ;
     if (!live) return 0;
-    hipLaunchKernelGGL((k_linear128_multi<KQ, false, false>), dim3(blocks), dim3(kLinThreads), lds, st, T);
-    return launch_status("grouped projection GEMM (layer 0, K <= 20)");
+    if (mixed) hipLaunchKernelGGL(k_linear128_layer0, dim3(blocks), dim3(kLinThreads), lds, st, T);
+    else hipLaunchKernelGGL((k_linear128_multi<KQ, false, false>), dim3(blocks), dim3(kLinThreads), lds, st, T);
+    return launch_status("grouped projection GEMM (layer 0)");
 }
 
 template <int CTW, int NH>
@@ -3994,8 +4024,9 @@ int wgrad_partials(const float* dY, const float* X, int K, int64_t M, float* ws,
 
 struct ReduceQueue {
     ReduceTasks T{};
-    WgradTasks W{};
-    int blocks = 0, wblocks = 0;
+    WgradTasks W{}, W0{};                   // W: the K = 128 products; W0: the others (layer 0), k_linear128_wgrad_mixed
+    int blocks = 0, wblocks = 0, w0blocks = 0;
+    bool defer_mixed = false;
     int w_reduce[kMaxWgradTasks] = {};      // index in T of each grouped product's reduction
     bool defer_wgrad = false;
     hipStream_t st = nullptr;
@@ -4040,11 +4071,30 @@ struct ReduceQueue {
             W.t[W.n] = WgradTask{dY, X, ws, M, 0, 0};
             w_reduce[W.n++] = T.n;
             t.cls = g_tune[FN_TUNE_WGRAD_DIRECT] ? 4 : 2;
+        } else if (defer_wgrad && defer_mixed && K <= 192) {      // layer 0's products: one launch for them too (flush_wgrad)
+            if (W0.n == kMaxWgradTasks || T.n == kMaxReduceTasks) { if (int rc = flush()) return rc; }
+            const int rpb = wgrad_rows_per_block(M);
+            grid = (int)((M + rpb - 1) / rpb);
+            W0.t[W0.n++] = WgradTask{dY, X, ws, M, rpb, w0blocks, K};
+            w0blocks += grid;
+            t.cls = K <= 32 ? 1 : K <= 128 ? 2 : 3;              // the instantiation k_linear128_wgrad_mixed runs for this K
         } else if (int rc = wgrad_partials(dY, X, K, M, ws, launch_on, &grid, &t.cls)) return rc;
         t.kind = RT_WGRAD;  t.p0 = ws;  t.n0 = grid;  t.K = K;  t.o0 = dW;  t.o1 = db;
-        return push(t, (int)((wgrad_part_width(K) + 255) / 256));
+        // partial width of the instantiation that wrote them (the mixed launch runs K <= 16 in the K <= 32 class)
+        const int64_t pw = t.cls == 1 ? wgrad_part_width(32) : wgrad_part_width(K);
+        return push(t, (int)((pw + 255) / 256));
     }
     int flush_wgrad() {
+        if (W0.n) {
+            int kmax = 0;
+            for (int i = 0; i < W0.n; ++i) kmax = std::max(kmax, W0.t[i].K);
+            const int xw = kmax <= 32 ? 32 : kmax <= 128 ? 128 : 192;
+            const size_t lds = (size_t)2 * kWgChunk * (kBtLd + xw + 16) * sizeof(float);
+            if (int rc = allow_lds(k_linear128_wgrad_mixed, lds)) return rc;
+            hipLaunchKernelGGL(k_linear128_wgrad_mixed, dim3(w0blocks), dim3(512), lds, st, W0);
+            W0.n = 0;  w0blocks = 0;
+            if (int rc = launch_status("weight-gradient partials (layer 0)")) return rc;
+        }
         if (W.n == 0) return 0;
         // rows per block from the WHOLE group: ~256 blocks (one per CU) instead of ~256 per product, which for the nine
         // products of a backward pass was 1.6 k blocks writing 104 MB of 64-KB partials (now ~16 MB); never fewer rows
@@ -4253,6 +4303,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         // the bond / fragment-bond projections already ran beside the previous layer's atom level and the atom projection rides
         // with this layer's bond levels below; otherwise one grouped launch for the three
         const bool grouped = l > 0 && fuse_ns && !multi;
+        bool atoms_projected = false;
         const fn_act_epilogue no_act{nullptr, 0.f, 0, 0, 0, nullptr};
         LinTasks with_pair{};                      // rides with the bond + fragment-bond launch of this layer
         if (grouped && colaunch) {
@@ -4276,6 +4327,13 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
                              NodeScalarEpi{w.a_b, lay.s_dst, lay.s_src, 3 * d, 0, 2 * d, H}, 0, 0, kb};
             T.t[1] = LinTask{w.proj_fb_w, in_fbond, bt_fb, w.proj_fb_b, a.h_fb, e->EF, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
                              NodeScalarEpi{w.f_a_b, lay.s_dst_fb, lay.s_src_fb, 3 * d, 0, 2 * d, H}, 0, 0, kfb};
+            if (colaunch && ka > 20 && ka <= 168) {     // the atom features' projection needs nothing of the bond levels either: same launch
+                T.t[2] = T.t[1];  T.t[1] = T.t[0];      // its (longer) workgroups first
+                T.t[0] = LinTask{w.proj_a_w, in_atoms, bt_a, w.proj_a_b, a.h_a, e->N, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
+                                 NodeScalarEpi{w.a, lay.s_dst_a, lay.s_src_a, wide, 0, d + FN_D, H}, 0, 0, ka};
+                T.n = 3;
+                atoms_projected = true;
+            }
             FN_TRY(launch_linear128_small_group(T, S(st)));
         } else {
             FN_TRY(project(in_bond, kb, bt_b, w.proj_b_b, a.h_b, e->E, w.a_b, 3 * d, 2 * d, lay.s_dst, lay.s_src, st));
@@ -4300,7 +4358,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         }
 
         // L2 atom graph (+ self loops), edge term = <new_bond, a[:, d:d+128]>
-        if (!grouped) FN_TRY(project(in_atoms, ka, bt_a, w.proj_a_b, a.h_a, e->N, w.a, wide, d + FN_D, lay.s_dst_a, lay.s_src_a, st));
+        if (!grouped && !atoms_projected) FN_TRY(project(in_atoms, ka, bt_a, w.proj_a_b, a.h_a, e->N, w.a, wide, d + FN_D, lay.s_dst_a, lay.s_src_a, st));
         if (!fuse_rd) FN_TRY(fn_row_dots_sorted_f32(a.new_bond, w.a, wide, d, H, &e->atom, lay.s_sorted, st));
         fn_edge_term et_a{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
         if (colaunch && !last) {
@@ -4389,6 +4447,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
     ReduceQueue rq;
     rq.st = hs;                      // all parameter-gradient reductions run as one launch at the very end
     rq.defer_wgrad = !multi;         // ... and so do the K = 128 weight-gradient partial products
+    rq.defer_mixed = !multi && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;      // ... and layer 0's
 
     const bool colaunch = !multi && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;
     LinTasks dx_carry{};             // input-gradient products handed from layer l+1 to layer l's first attention launch
