@@ -1,0 +1,30 @@
+#!/bin/bash
+# Regenerates the per-round evidence set on a GPU box:  bash tools/final_artifacts.sh <tag>   (writes gpurun_out/<tag>/, copy into profiles/)
+set -u
+TAG=${1:-r02f}
+R=$(pwd)
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
+timeout 1200 python3 -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -1 $O/pytest_gpu.txt
+timeout 600 python3 bench.py > $O/bench.json 2> $O/bench.err; cut -c1-200 $O/bench.json
+for r in 2 4 8; do timeout 300 python3 bench.py --no-cpu-baseline --no-roofline --shard-of $r 2>/dev/null | tail -1; done > $O/strong_shards.json
+for v in gat2_lite gat2_edge; do timeout 300 python3 bench.py --no-cpu-baseline --no-roofline --model-version $v 2>/dev/null | tail -1; done > $O/variants.json
+timeout 600 python3 bench.py --forward-sweep 2>/dev/null > $O/forward_sweep.json
+timeout 900 python3 bench.py --forward-sweep --store 1048576 2>/dev/null > $O/store_sweep.json
+timeout 300 python3 tools/tox21_bench.py > $O/tox21.txt 2>&1
+timeout 300 python3 tools/pretrain_bench.py > $O/pretrain.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/pd /tmp/pd2 /tmp/pmc_fetch /tmp/pmc_write
+timeout 300 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/pd -o d -- python3 $R/bench.py --no-cpu-baseline --no-roofline > /dev/null 2>&1
+DB=$(ls /tmp/pd/*/*.db /tmp/pd/*.db 2>/dev/null | head -1)
+python3 $R/tools/rocpd_summary.py $DB > $O/kernel_trace_summary.md 2>&1
+python3 $R/tools/rocpd_summary.py $DB --json "rocprofv3 --kernel-trace -- python3 bench.py --no-cpu-baseline --no-roofline ($TAG, whole-step hipGraph replays; k_gat_fwd_pair / k_gat_bwd_dst_pair are layer 0's launches, the only ones of their kind without projection workgroups riding along)" > $O/in_graph_kernels.json 2>/dev/null
+python3 $R/tools/rocpd_sequence.py $DB > $O/step_sequence.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/pd2 -o d -- python3 $R/bench.py > $O/bench_under_rocprof.json 2>/dev/null
+DB2=$(ls /tmp/pd2/*/*.db /tmp/pd2/*.db 2>/dev/null | head -1)
+python3 $R/tools/rocpd_summary.py $DB2 > $O/bench_full_kernel_trace_summary.md 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch -o p -- python3 $R/bench.py --kernels-only > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write -o p -- python3 $R/bench.py --kernels-only > /dev/null 2>&1
+python3 $R/tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write > $O/pmc_per_launch.json 2>/dev/null
+ls -la $O
