@@ -180,19 +180,20 @@ def test_fused_forward_flags_a_batch_that_is_not_molecule_contiguous(fused):
         batch["_fragnet_plan"].check()
 
 
-@pytest.mark.parametrize("key,value", [(8, 0), (9, 1), (7, 0), (6, 1), (14, 0), (14, 2)])
+@pytest.mark.parametrize("key,value", [(8, 0), (9, 1), (7, 0), (6, 1), (14, 0), (14, 1), (14, 3), (15, 16)])
 def test_alternative_kernels_behind_tuning_keys_stay_parity_green(key, value):
     """The measured-and-rejected (or superseded) kernels stay selectable for A/B runs (include/fragnet_hip.h FN_TUNE_*):
     8 = 0 the LDS-staged grouped weight-gradient kernel, 9 = 1 the wave-independent projection kernel, 7 = 0 the separate
     row-dots launch, 6 = 1 the register-resident-W projection kernel, 14 = 0 the projection GEMMs as launches of their own instead
-    of riding with the attention launches (2: their workgroups first in those launches).  Each must reproduce the default path's outputs and
+    of riding with the attention launches (1 / 3: their workgroups last in / interleaved with those launches instead of first),
+    15 = 16 riding GEMM workgroups that walk several tiles each.  Each must reproduce the default path's outputs and
     gradients (same Philox stream) on a training step with dropout."""
     from fragnet_amd import _lib, data, model as M, synth
     torch.manual_seed(0)
     net = M.FragNetFineTune(n_classes=1, num_layer=3, drop_ratio=0.1, h1=32, h2=32, h3=32, h4=32, act="relu", fthead="FTHead3").to(DEV)
     net.train()
     batch = data.batch_to(data.collate_fn(synth.synth_molecules(96, seed=17, profile="esol")), DEV)
-    default = {6: 0, 7: 1, 8: 1, 9: 0, 14: 1}[key]
+    default = {6: 0, 7: 1, 8: 1, 9: 0, 14: 2, 15: -1}[key]
     try:
         o0, g0 = _encoder_run(net, batch, 999)
         _lib.call("fn_set_tuning", key, value)
