@@ -4114,8 +4114,13 @@ struct ReduceQueue {
         }
         W.K = FN_D;
         if (g_tune[FN_TUNE_WGRAD_DIRECT]) {
-            if (int rc = allow_lds(k_wgrad128_multi, kWdLdsBytes)) return rc;
-            hipLaunchKernelGGL(k_wgrad128_multi, dim3(wblocks), dim3(kWdThreads), kWdLdsBytes, st, W);
+            if (g_tune[FN_TUNE_WGRAD_DIRECT] == 2) {      // four row slices per workgroup (1024 threads)
+                if (int rc = allow_lds(k_wgrad128_multi<4>, wd_lds_bytes<4>())) return rc;
+                hipLaunchKernelGGL(k_wgrad128_multi<4>, dim3(wblocks), dim3(wd_threads<4>()), wd_lds_bytes<4>(), st, W);
+            } else {
+                if (int rc = allow_lds(k_wgrad128_multi<2>, wd_lds_bytes<2>())) return rc;
+                hipLaunchKernelGGL(k_wgrad128_multi<2>, dim3(wblocks), dim3(wd_threads<2>()), wd_lds_bytes<2>(), st, W);
+            }
         } else {
             constexpr int XW = 16 * 4 * 2, XLD = XW + 16;
             const size_t lds = (size_t)2 * kWgChunk * (kBtLd + XLD) * sizeof(float);

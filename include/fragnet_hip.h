@@ -68,7 +68,9 @@ int fn_abi_version(void);
 #define FN_TUNE_FUSE_ROWDOTS 7 /* 1 (default): inside fn_encoder_forward the bond-graph attention kernel also writes the atom graph's edge
                                 * term <new_bond, a[:, d:d+128]> from the row it holds in registers; 0: a separate row-dots launch */
 #define FN_TUNE_WGRAD_DIRECT 8 /* 1 (default): the grouped K = 128 weight-gradient partials run as k_wgrad128_multi (operands straight from
-                                * global memory in the MFMA layout, csrc/wgrad128.inc); 0: the LDS-staged k_linear128_wgrad_multi */
+                                * global memory in the MFMA layout, csrc/wgrad128.inc); 0: the LDS-staged k_linear128_wgrad_multi; 2: the direct kernel with
+                                * four row slices per 1024-thread workgroup (twice the waves per CU, same partials) -- measured equal (0.873-0.877
+                                * against 0.873-0.875 ms per step): the launch is co-limited by HBM streaming and MFMA issue, not by latency */
 #define FN_TUNE_PROJ_DIRECT 9  /* 1: the grouped 128 -> 128 projections / input-gradient products run as k_proj_direct (one wave per 32 x 64 tile,
                                 * weights straight from L1/L2 in the MFMA layout, no block-shared LDS tile: csrc/proj_direct.inc); 0 (default):
                                 * k_linear128_multi -- measured 1.007 against 1.020 ms per step on MI355X */

@@ -180,10 +180,10 @@ def test_fused_forward_flags_a_batch_that_is_not_molecule_contiguous(fused):
         batch["_fragnet_plan"].check()
 
 
-@pytest.mark.parametrize("key,value", [(8, 0), (9, 1), (7, 0), (6, 1), (14, 0), (14, 1), (14, 3), (15, 16)])
+@pytest.mark.parametrize("key,value", [(8, 0), (8, 2), (9, 1), (7, 0), (6, 1), (14, 0), (14, 1), (14, 3), (15, 16)])
 def test_alternative_kernels_behind_tuning_keys_stay_parity_green(key, value):
     """The measured-and-rejected (or superseded) kernels stay selectable for A/B runs (include/fragnet_hip.h FN_TUNE_*):
-    8 = 0 the LDS-staged grouped weight-gradient kernel, 9 = 1 the wave-independent projection kernel, 7 = 0 the separate
+    8 = 0 the LDS-staged grouped weight-gradient kernel (2: the direct one with four row slices per 1024-thread workgroup), 9 = 1 the wave-independent projection kernel, 7 = 0 the separate
     row-dots launch, 6 = 1 the register-resident-W projection kernel, 14 = 0 the projection GEMMs as launches of their own instead
     of riding with the attention launches (1 / 3: their workgroups last in / interleaved with those launches instead of first),
     15 = 16 riding GEMM workgroups that walk several tiles each.  Each must reproduce the default path's outputs and
