@@ -2230,6 +2230,7 @@ struct LinTasks {
     LinTask t[3];
     int n, K;
     int base, total;          // co-launched with an attention pass (below): the GEMM workgroups are blocks [base, base + total) of that launch
+    int prio;                 // 1: the riding workgroups raise their wave priority (FN_TUNE_COLAUNCH_PRIO)
 };
 template <int KQ, bool VEC, bool PF>
 __global__ __launch_bounds__(kLinThreads) void k_linear128_multi(LinTasks T) {
@@ -2261,6 +2262,7 @@ __global__ __launch_bounds__(kLinThreads) void k_linear128_layer0(LinTasks T) {
 // of MFMA work behind a launch floor of their own -- so the GEMM tiles ride along as extra workgroups of the attention launch
 // (one 64 x 64 tile each, the k_linear128_multi body) and the layer loses a kernel boundary per pass.
 __device__ __forceinline__ void lin_side_block(float* sBt, const LinTasks& T, int b) {
+    if (T.prio) __builtin_amdgcn_s_setprio(3);             // (experiment) issue priority over the attention waves of the same SIMD
     int ti = 0;
     while (ti + 1 < T.n && b >= T.t[ti + 1].first) ++ti;
     const LinTask& t = T.t[ti];
@@ -2738,7 +2740,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 namespace {
 unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
 int64_t g_mol_stamps_n = 0;
-int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 256, 2, -1};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
+int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 256, 2, -1, 0};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -3222,6 +3224,7 @@ static bool lin_side_prepare(LinTasks& T, int gat_blocks, int* gat_base, LinMix*
     T.K = FN_D;
     if (!live) return false;
     T.total = blocks;
+    T.prio = g_tune[FN_TUNE_COLAUNCH_PRIO] != 0;
     T.base = mode == 2 ? 0 : gat_blocks;          // 2: GEMM workgroups are dispatched first; 1: after the attention workgroups
     *gat_base = mode == 2 ? blocks : 0;
     *mx = LinMix{0, 0};

@@ -87,7 +87,8 @@ int fn_abi_version(void);
 #define FN_TUNE_COLAUNCH_SLOTS 15 /* workgroups the co-launched GEMM tasks get: 0 (default) = the slots the attention pass leaves free
                                   * (1024 - its workgroups, at least 256 = one per CU), each walking several 64 x 64 tiles;
                                   * > 0 = that many; -1 = one tile per workgroup */
-#define FN_TUNE_COUNT 16
+#define FN_TUNE_COLAUNCH_PRIO 16  /* 1: riding GEMM workgroups run at raised wave priority (s_setprio 3); 0 (default) */
+#define FN_TUNE_COUNT 17
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * molecules 64-bit words) is
  * set, every workgroup of the fused molecule kernels writes s_memtime stamps of its phases into it (tools/mol_phase_times.py).
