@@ -770,3 +770,34 @@ def test_graph_step_loss_and_gradients_match_the_oracle_at_b512():
         torch.testing.assert_close(got, want, atol=ATOL, rtol=2e-3, msg=lambda s: f"{name}: {s}")
         checked += 1
     assert checked >= 60            # every live parameter of 4 layers + head
+
+
+@pytest.mark.parametrize("n_layers,n_mols,p_cut", [(1, 12, 0.35), (2, 1, 0.35), (5, 9, 0.35), (3, 10, 0.0), (3, 7, 1.0)])
+def test_engine_edge_shapes_match_the_oracle(n_layers, n_mols, p_cut):
+    """Shapes at the edges of the engine's launch merging (projection GEMMs ride in the attention launches of the layer before /
+    after, include/fragnet_hip.h FN_TUNE_GEMM_COLAUNCH): one layer (nothing to ride with), two, five; a single molecule; molecules
+    that are one fragment each (p_cut 0: no fragment-bond graph rows, every fragment graph is the (0, 0) self edge) and molecules cut
+    at every acyclic bond.  Engine against the oracle: logits and every gradient, train mode without dropout."""
+    import numpy as np
+    from fragnet_amd import data, synth
+    from fragnet_amd.model import FragNetFineTune
+    from oracle import fragnet_ref as ref
+    rng = np.random.default_rng(4200 + 10 * n_layers + n_mols)
+    batch = data.collate_fn([synth.make_molecule(rng, 10.5, p_cut, 0) for _ in range(n_mols)])
+    cfg = dict(n_classes=1, num_layer=n_layers, num_heads=4, drop_ratio=0.0, h1=64, h2=64, h3=64, h4=32, act="relu", edge_features=17)
+    torch.manual_seed(n_layers)
+    gold = ref.FragNetFineTune(**cfg).train()
+    want = gold(batch)
+    torch.nn.functional.mse_loss(want.view(-1), batch["y"]).backward()
+    model = FragNetFineTune(**cfg)
+    model.load_state_dict(gold.state_dict())
+    model = model.to(DEV).train()
+    model.pretrain.use_engine = True
+    b = _to_dev(batch)
+    got = model(b)
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), atol=ATOL, rtol=1e-4)
+    torch.nn.functional.mse_loss(got.view(-1), b["y"]).backward()
+    for (n, p), (_, q) in zip(model.named_parameters(), gold.named_parameters()):
+        if q.grad is not None:
+            assert p.grad is not None, n
+            torch.testing.assert_close(p.grad.cpu(), q.grad, atol=ATOL, rtol=2e-3, msg=lambda m, n=n: f"{n}: {m}")
