@@ -71,6 +71,67 @@ __global__ __launch_bounds__(kThreads) void k_f32(const float* __restrict__ X, c
     }
 }
 
+// ---------------- (a') fp32 MFMA, both column halves per workgroup: the rows are loaded ONCE and stay in registers while the
+// operand tile is restaged for the second half (half the workgroups, each twice as long, one more barrier pair)
+__global__ __launch_bounds__(kThreads) void k_f32_both(const float* __restrict__ X, const float* __restrict__ Bt, const float* __restrict__ bias,
+                                                       float* __restrict__ Y, int M) {
+    extern __shared__ __attribute__((aligned(16))) float sB[];      // [128 k][64 columns of the current half]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
+    const int tile = blockIdx.x;
+    float4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int idx = tid + q * kThreads, k = idx >> 4, n4 = idx & 15;
+        v[q] = *reinterpret_cast<const float4*>(Bt + (size_t)k * 128 + n4 * 4);
+    }
+    int row = tile * kRows + w * 16 + i;
+    row = row < M ? row : M - 1;
+    float a[32];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const float4 x = *reinterpret_cast<const float4*>(X + (size_t)row * 128 + 16 * s + 4 * kq);
+        a[4 * s] = x.x; a[4 * s + 1] = x.y; a[4 * s + 2] = x.z; a[4 * s + 3] = x.w;
+    }
+#pragma unroll
+    for (int wc = 0; wc < 2; ++wc) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = tid + q * kThreads, k = idx >> 4, n4 = idx & 15;
+            *reinterpret_cast<float4*>(sB + k * 64 + n4 * 4) = v[q];
+        }
+        __syncthreads();
+        if (wc == 0) {      // the second half's tile is requested while the first half multiplies
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int idx = tid + q * kThreads, k = idx >> 4, n4 = idx & 15;
+                v[q] = *reinterpret_cast<const float4*>(Bt + (size_t)k * 128 + 64 + n4 * 4);
+            }
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int k = 16 * (s >> 2) + 4 * kq + (s & 3);
+            const float4 b = *reinterpret_cast<const float4*>(sB + k * 64 + 4 * i);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b.y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b.z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b.w, acc[3], 0, 0, 0);
+        }
+        const int col = 64 * wc + 4 * i;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int orow = tile * kRows + w * 16 + kq * 4 + r;
+            if (orow < M)
+                *reinterpret_cast<float4*>(Y + (size_t)orow * 128 + col) =
+                    make_float4(acc[0][r] + bv.x, acc[1][r] + bv.y, acc[2][r] + bv.z, acc[3][r] + bv.w);
+        }
+        if (wc == 0) __syncthreads();       // everyone is done reading the first tile
+    }
+}
+
 // ---------------- (b) three bf16 terms per operand ----------------
 // Bs: [2 column halves][3 terms][4 k-steps of 32][4 column tiles][64 lanes][8 bf16]; lane (i, kb) of tile t holds Bt[32 s + 8 kb + c][64 wc + 4 i + t]
 constexpr int kBsHalf = 3 * 4 * 4 * 64 * 8;     // bf16 elements per column half (48 KB)
@@ -219,6 +280,9 @@ int main() {
     hipLaunchKernelGGL(k_f32, dim3(gridR), dim3(kThreads), lds_f32, 0, dX, dB, dbias, dY, R);
     CK(hipDeviceSynchronize());  report("fp32 MFMA");
     CK(hipMemset(dY, 0, (size_t)R * 512));
+    hipLaunchKernelGGL(k_f32_both, dim3(gridR / 2), dim3(kThreads), lds_f32, 0, dX, dB, dbias, dY, R);
+    CK(hipDeviceSynchronize());  report("fp32 MFMA, both halves");
+    CK(hipMemset(dY, 0, (size_t)R * 512));
     hipLaunchKernelGGL(k_b6<6>, dim3(gridR), dim3(kThreads), lds_b6, 0, dX, dBs, dbias, dY, R);
     CK(hipDeviceSynchronize());  report("3 x 3 bf16 terms, 6 products");
     CK(hipMemset(dY, 0, (size_t)R * 512));
@@ -230,7 +294,9 @@ int main() {
         const float t0 = time_us([&]() { hipLaunchKernelGGL(k_f32, dim3(grid), dim3(kThreads), lds_f32, 0, dX, dB, dbias, dY, M); }, 100);
         const float t6 = time_us([&]() { hipLaunchKernelGGL(k_b6<6>, dim3(grid), dim3(kThreads), lds_b6, 0, dX, dBs, dbias, dY, M); }, 100);
         const float t3 = time_us([&]() { hipLaunchKernelGGL(k_b6<3>, dim3(grid), dim3(kThreads), lds_b6, 0, dX, dBs, dbias, dY, M); }, 100);
-        printf("M=%7d workgroups=%5d   fp32 MFMA %7.2f us   six bf16 products %7.2f us   three %7.2f us\n", M, grid, t0, t6, t3);
+        const float tb = time_us([&]() { hipLaunchKernelGGL(k_f32_both, dim3(grid / 2), dim3(kThreads), lds_f32, 0, dX, dB, dbias, dY, M); }, 100);
+        printf("M=%7d workgroups=%5d   fp32 MFMA %7.2f us   six bf16 products %7.2f us   three %7.2f us   fp32, both halves per workgroup %7.2f us\n",
+               M, grid, t0, t6, t3, tb);
     }
     return 0;
 }
