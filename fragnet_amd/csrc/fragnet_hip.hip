@@ -2553,6 +2553,27 @@ __global__ __launch_bounds__(512) void k_linear128_wgrad_mixed(WgradTasks T) {
     else wgrad_body<6, 2>(smem, t.dY, t.X, t.K, t.M, t.rpb, t.part, bid);
 }
 
+// every weight-gradient partial product of a backward pass in ONE launch: blocks [0, n128) run the direct K = 128 kernel
+// (csrc/wgrad128.inc, two row slices), the others layer 0's products; the launch's LDS size is the larger of the two needs.
+// Neither group waits for the other, and the short layer-0 workgroups fill the CUs the long K = 128 ones leave towards the end.
+__global__ __launch_bounds__(512) void k_wgrad_all(const WgradTasks W, const WgradTasks W0, int n128) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < n128) {
+        int ti = 0;
+        while (ti + 1 < W.n && (int)blockIdx.x >= W.t[ti + 1].first) ++ti;
+        wgrad128_block<2>(W.t[ti], (int)blockIdx.x - W.t[ti].first, smem);
+        return;
+    }
+    const int b = (int)blockIdx.x - n128;
+    int ti = 0;
+    while (ti + 1 < W0.n && b >= W0.t[ti + 1].first) ++ti;
+    const WgradTask& t = W0.t[ti];
+    const int bid = b - t.first;
+    if (t.K <= 32) wgrad_body<1, 2>(smem, t.dY, t.X, t.K, t.M, t.rpb, t.part, bid);
+    else if (t.K <= 128) wgrad_body<4, 2>(smem, t.dY, t.X, t.K, t.M, t.rpb, t.part, bid);
+    else wgrad_body<6, 2>(smem, t.dY, t.X, t.K, t.M, t.rpb, t.part, bid);
+}
+
 // sums the native-layout partials over blocks and scatters them to dW [128][K] / db [128]
 template <int CTW, int NH>
 __device__ __forceinline__ void wgrad_reduce_body(int vb, float* sm, const float* __restrict__ part, int n_rows, int K,
@@ -4088,11 +4109,37 @@ struct ReduceQueue {
         return push(t, (int)((pw + 255) / 256));
     }
     int flush_wgrad() {
+        size_t lds0 = 0;
         if (W0.n) {
             int kmax = 0;
             for (int i = 0; i < W0.n; ++i) kmax = std::max(kmax, W0.t[i].K);
             const int xw = kmax <= 32 ? 32 : kmax <= 128 ? 128 : 192;
-            const size_t lds = (size_t)2 * kWgChunk * (kBtLd + xw + 16) * sizeof(float);
+            lds0 = (size_t)2 * kWgChunk * (kBtLd + xw + 16) * sizeof(float);
+        }
+        if (W0.n && W.n && g_tune[FN_TUNE_WGRAD_DIRECT] == 1 && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0) {
+            // both groups in one launch (k_wgrad_all): block counts of the K = 128 group as below
+            int64_t total = 0;
+            for (int i = 0; i < W.n; ++i) total += W.t[i].M;
+            const int64_t target = g_tune[FN_TUNE_WGRAD_BLOCKS] > 0 ? g_tune[FN_TUNE_WGRAD_BLOCKS] : 256;
+            const int group_rpb = (int)(((total + target - 1) / target + kWgChunk - 1) / kWgChunk * kWgChunk);
+            wblocks = 0;
+            for (int i = 0; i < W.n; ++i) {
+                WgradTask& t = W.t[i];
+                t.rpb = std::max(group_rpb, wgrad_rows_per_block(t.M));
+                t.first = wblocks;
+                const int grid = (int)((t.M + t.rpb - 1) / t.rpb);
+                T.t[w_reduce[i]].n0 = grid;
+                wblocks += grid;
+            }
+            W.K = FN_D;
+            const size_t lds = std::max(lds0, (size_t)wd_lds_bytes<2>());
+            if (int rc = allow_lds(k_wgrad_all, lds)) return rc;
+            hipLaunchKernelGGL(k_wgrad_all, dim3(wblocks + w0blocks), dim3(512), lds, st, W, W0, wblocks);
+            W.n = 0;  wblocks = 0;  W0.n = 0;  w0blocks = 0;
+            return launch_status("weight-gradient partials (all products)");
+        }
+        if (W0.n) {
+            const size_t lds = lds0;
             if (int rc = allow_lds(k_linear128_wgrad_mixed, lds)) return rc;
             hipLaunchKernelGGL(k_linear128_wgrad_mixed, dim3(w0blocks), dim3(512), lds, st, W0);
             W0.n = 0;  w0blocks = 0;
