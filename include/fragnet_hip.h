@@ -82,11 +82,13 @@ int fn_abi_version(void);
 #define FN_TUNE_GEMM_COLAUNCH 14 /* inside fn_encoder_*: the 128 -> 128 projections (forward) and input-gradient products (backward) that do
                                  * not depend on an attention pass ride along as extra workgroups of that pass's launch (the atom projection
                                  * beside the bond + fragment-bond levels, the next layer's bond / fragment-bond projections beside the atom
-                                 * level; mirrored in the backward).  2 (default): GEMM workgroups first in the launch, 1: after the attention
-                                 * workgroups, 0: separate grouped launches */
-#define FN_TUNE_COLAUNCH_SLOTS 15 /* workgroups the co-launched GEMM tasks get: 0 (default) = the slots the attention pass leaves free
-                                  * (1024 - its workgroups, at least 256 = one per CU), each walking several 64 x 64 tiles;
-                                  * > 0 = that many; -1 = one tile per workgroup */
+                                 * level; mirrored in the backward), layer 0's three raw-feature projections share a launch and all weight-gradient
+                                 * partial products of a backward pass are one launch.  2 (default): GEMM workgroups first in the launch,
+                                 * 1: after the attention workgroups, 3: interleaved with them in units of 8, 4 / 5: first in the single-level
+                                 * launches and last in the two-level ones / the reverse (all measured), 0: separate launches */
+#define FN_TUNE_COLAUNCH_SLOTS 15 /* workgroups the co-launched GEMM tasks get: -1 (default) = one 64 x 64 tile per workgroup; 0 = the slots
+                                  * the attention pass leaves free (1024 - its workgroups, at least 256 = one per CU), each walking
+                                  * several tiles; > 0 = that many */
 #define FN_TUNE_COLAUNCH_PRIO 16  /* 1: riding GEMM workgroups run at raised wave priority (s_setprio 3); 0 (default) */
 #define FN_TUNE_COUNT 17
 int fn_set_tuning(int key, int value);
