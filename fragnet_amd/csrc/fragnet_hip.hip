@@ -1233,9 +1233,10 @@ __device__ __forceinline__ void row_dots_sorted_bwd_body(const RowDotsBwdArgs& T
             for (int u = 0; u < 4; ++u) {
                 const int64_t e = (gi + u) * kRows + hw;
                 if (gi + u >= g1 || e >= pl.m_real) continue;
+                fma4(q[0], gs[u].x, v[u]);  fma4(q[1], gs[u].y, v[u]);  fma4(q[2], gs[u].z, v[u]);  fma4(q[3], gs[u].w, v[u]);
+                if (!g_feat) continue;          // parameter partials only: the rows' term rides in a GEMM epilogue (RowAdd)
                 float4 acc = ad[u];
                 fma4(acc, gs[u].x, a[0]);  fma4(acc, gs[u].y, a[1]);  fma4(acc, gs[u].z, a[2]);  fma4(acc, gs[u].w, a[3]);
-                fma4(q[0], gs[u].x, v[u]);  fma4(q[1], gs[u].y, v[u]);  fma4(q[2], gs[u].z, v[u]);  fma4(q[3], gs[u].w, v[u]);
                 st4(g_feat + e * FN_D + lane * 4, acc);
             }
         }
@@ -2036,10 +2037,18 @@ struct NodeScalarEpi {             // optional fused epilogue: s_dst/s_src[row, 
 // VEC (K == 4*KQ, KQ % 4 == 0): lane (i, kq) owns the k's {16 s + 4 kq + c}: one wave-instruction then reads 64
 // contiguous bytes of each of its 16 rows (a blocked split, k = kq*KQ + .., made every lane touch its own 128-byte
 // line and re-fetched each line eight times through a thrashing L1).  The B rows in LDS are indexed to match.
-template <int KQ, bool VEC, bool PF>
+// optional epilogue term of an input-gradient product (RA instances): Y[row, :] += sum_h z[row, h] * a[h * lda + :], h < 4 -- the
+// backward of the atom graph's edge term <new_bond[e], a[h, mid block]> lands on the bond rows without a pass of its own
+struct RowAdd {
+    const float* z;           // [M][4]: dL/d(edge term) of row e, the four heads together; null: no term
+    const float* a;           // a[h * lda + column]
+    int lda;
+};
+template <int KQ, bool VEC, bool PF, bool RA = false>
 __device__ __forceinline__ void linear128_body(float* sBt, const float* __restrict__ X, int K, const float* __restrict__ Bt,
                                                const float* __restrict__ bias, float* __restrict__ Y, int64_t M,
-                                               const fn_act_epilogue& mk, const NodeScalarEpi& ns, int bid, int nblk) {
+                                               const fn_act_epilogue& mk, const NodeScalarEpi& ns, int bid, int nblk,
+                                               const RowAdd& ra = RowAdd{nullptr, nullptr, 0}) {
     // A block is 4 waves = 64 rows x 64 COLUMNS (column half wc = bid & 1) and walks the row tiles bid>>1, += nblk>>1.
     // sBt: the [4*KQ][kLinLd] operand tile of this column half, staged ONCE; after that the block never synchronises
     // again: A rows live in registers (PF: the next tile's rows are requested before this tile's MFMA chain), and
@@ -2114,6 +2123,11 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
         a_src = ld4(ns.att + ns_head * ns.att_w + ns.src_off + col % ns_d);
     }
     const float ik = mk.p < 1.f ? 1.f / (1.f - mk.p) : 0.f;
+    float4 ra_a[4];
+    if (RA) {
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) ra_a[hh] = ra.z ? ld4(ra.a + hh * ra.lda + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __syncthreads();
 
     // MFMA tile t of a wave covers the columns {4 i + t}: one 16-byte LDS read per step feeds all four tiles
@@ -2178,6 +2192,12 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
                         o.z *= keep_scale(rnd.z, mk.p, ik); o.w *= keep_scale(rnd.w, mk.p, ik);
                     }
                 }
+                if (RA) {
+                    if (ra.z) {          // after the gate: the term is a gradient w.r.t. the pre-activation row itself
+                        const float4 z = ld4(ra.z + (r0 + r) * 4);
+                        fma4(o, z.x, ra_a[0]);  fma4(o, z.y, ra_a[1]);  fma4(o, z.z, ra_a[2]);  fma4(o, z.w, ra_a[3]);
+                    }
+                }
                 st4(Y + (r0 + r) * 128 + col, o);
             }
             __builtin_amdgcn_sched_barrier(0);               // one row at a time: four interleaved Philox chains cost 60 VGPRs
@@ -2225,6 +2245,7 @@ struct LinTask {
     NodeScalarEpi ns;
     int first, nblk;
     int K;                    // 0: the group's K (LinTasks::K); else this task's own reduction length (layer 0: 17 bond / 6 connection features)
+    RowAdd ra;                // riding input-gradient products only (lin_side_block)
 };
 struct LinTasks {
     LinTask t[3];
@@ -2239,6 +2260,15 @@ __global__ __launch_bounds__(kLinThreads) void k_linear128_multi(LinTasks T) {
     while (ti + 1 < T.n && (int)blockIdx.x >= T.t[ti + 1].first) ++ti;
     const LinTask& t = T.t[ti];
     linear128_body<KQ, VEC, PF>(sBt, t.X, t.K ? t.K : T.K, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, (int)blockIdx.x - t.first, t.nblk);
+}
+
+// the grouped launch when a task carries a RowAdd term and cannot ride in an attention launch
+__global__ __launch_bounds__(kLinThreads) void k_linear128_multi_ra(LinTasks T) {
+    extern __shared__ __attribute__((aligned(16))) float sBt[];
+    int ti = 0;
+    while (ti + 1 < T.n && (int)blockIdx.x >= T.t[ti + 1].first) ++ti;
+    const LinTask& t = T.t[ti];
+    linear128_body<32, true, false, true>(sBt, t.X, 128, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, (int)blockIdx.x - t.first, t.nblk, t.ra);
 }
 
 // layer 0: all three projections read raw features only (K = 17 bond, 6 connection, 167 atom features at the reference's sizes), so
@@ -2266,7 +2296,7 @@ __device__ __forceinline__ void lin_side_block(float* sBt, const LinTasks& T, in
     int ti = 0;
     while (ti + 1 < T.n && b >= T.t[ti + 1].first) ++ti;
     const LinTask& t = T.t[ti];
-    linear128_body<32, true, false>(sBt, t.X, 128, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, b - t.first, t.nblk);
+    linear128_body<32, true, false, true>(sBt, t.X, 128, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, b - t.first, t.nblk, t.ra);
 }
 // Which workgroup is which: the dispatcher fills a CU with CONSECUTIVE workgroups of its XCD (measured: with all GEMM workgroups
 // first or last in the launch the two kinds ended up on different CUs and the launch took as long as both alone), so the roles
@@ -2324,6 +2354,34 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst_pair_lin(GatBwdDstArgs 
     if (lin_side_role(T, gat_base, mx, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
     if (g < A.nblk) gat_bwd_dst_body<H, KLA, RB>(A, sP, g, A.nblk);
     else if (g < A.nblk + B.nblk) gat_bwd_dst_body<H, KLB, RB>(B, sP, g - A.nblk, B.nblk);
+}
+
+// ---- the backward's two chains side by side.  Gradient flows atom level -> bond levels only (through the edge term), so the
+// atom chain of layer l (destination pass, source pass, input-gradient product) never waits for the bond chain of layer l:
+//   k_gat_bwd_src_pair_dst : source pass of the bond + fragment-bond levels of layer l+1  ||  destination pass of the atom level of layer l
+//   k_gat_bwd_src_lin_rd   : bond / fragment-bond input-gradient products of layer l+1 (the bond one adds the atom graph's
+//                            edge-term gradient of layer l in its epilogue, RowAdd)  ||  source pass of the atom level of layer l
+//                            ||  the edge term's parameter-gradient partials of layer l
+// (the third launch of a layer is k_gat_bwd_dst_pair_lin: bond levels' destination pass || atom input-gradient product).
+template <int H, int RB>
+__global__ __launch_bounds__(RB * 32) void k_gat_bwd_src_pair_dst(GatBwdSrcArgs A, GatBwdSrcArgs B, GatBwdDstArgs D) {
+    __shared__ float sA[RB][2 * FN_D];
+    __shared__ float sP[RB][8][kWfLd];
+    const int b = (int)blockIdx.x;
+    if (b < A.nblk) gat_bwd_src_body<H, RB>(A, sA, b, A.nblk);
+    else if (b < A.nblk + B.nblk) gat_bwd_src_body<H, RB>(B, sA, b - A.nblk, B.nblk);
+    else gat_bwd_dst_body<H, 0, RB>(D, sP, b - A.nblk - B.nblk, D.nblk);
+}
+template <int H, int RB>
+__global__ __launch_bounds__(RB * 32, 4) void k_gat_bwd_src_lin_rd(GatBwdSrcArgs A, LinTasks T, RowDotsBwdArgs R) {
+    static_assert(RB * 32 == kBlock && RB == kRows, "all three bodies run 256 threads");
+    extern __shared__ __attribute__((aligned(16))) float sBt[];
+    __shared__ float sA[RB][2 * FN_D];
+    const int b = (int)blockIdx.x;
+    if (b < T.total) { lin_side_block(sBt, T, b);  return; }               // GEMM workgroups first (FN_TUNE_GEMM_COLAUNCH = 2)
+    const int g = b - T.total;
+    if (g < A.nblk) gat_bwd_src_body<H, RB>(A, sA, g, A.nblk);
+    else row_dots_sorted_bwd_body(R, reinterpret_cast<float(*)[FN_D]>(&sA[0][0]), g - A.nblk, R.nblk);
 }
 
 // Bt[k][n] = W[n][k]  (W is nn.Linear.weight [128, K])
@@ -2761,7 +2819,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 namespace {
 unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
 int64_t g_mol_stamps_n = 0;
-int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 256, 2, -1, 0};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
+int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 256, 2, -1, 0, 1};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -2825,6 +2883,7 @@ bool proj128_ok(const LinTasks& T) {
     if (!g_tune[FN_TUNE_PROJ]) return false;
     for (int i = 0; i < T.n; ++i) {
         const LinTask& s = T.t[i];
+        if (s.ra.z) return false;
         if (!s.Wn || (((uintptr_t)s.Wn | (uintptr_t)s.X | (uintptr_t)s.Y) & 15)) return false;
         if (s.mk.y && !s.mk.relu) return false;
         if (s.mk.y && ((uintptr_t)s.mk.y & 15)) return false;
@@ -2854,6 +2913,7 @@ bool proj_direct_ok(const LinTasks& T) {
     if (!g_tune[FN_TUNE_PROJ_DIRECT]) return false;
     for (int i = 0; i < T.n; ++i) {
         const LinTask& s = T.t[i];
+        if (s.ra.z) return false;
         if (s.M > (1 << 23) || (((uintptr_t)s.X | (uintptr_t)s.Bt | (uintptr_t)s.Y | (uintptr_t)s.bias | (uintptr_t)s.mk.y) & 15)) return false;
     }
     return true;
@@ -2879,6 +2939,18 @@ int launch_linear128_group(LinTasks& T, hipStream_t st) {
     T.n = live;
     T.K = 128;
     if (!live) return 0;
+    bool any_ra = false;
+    for (int i = 0; i < T.n; ++i) any_ra |= T.t[i].ra.z != nullptr;
+    if (any_ra) {                          // a RowAdd term must not get lost: the kernel variant that applies it (one tile per workgroup)
+        blocks = 0;
+        for (int i = 0; i < T.n; ++i) {
+            T.t[i].first = blocks;
+            T.t[i].nblk = lin_blocks((T.t[i].M + kLinRows - 1) / kLinRows, 1);
+            blocks += T.t[i].nblk;
+        }
+        hipLaunchKernelGGL(k_linear128_multi_ra, dim3(blocks), dim3(kLinThreads), lds, st, T);
+        return launch_status("grouped projection GEMM (+ row term)");
+    }
     if (iters > 1) {
         if (int rc = allow_lds(k_linear128_multi<KQ, true, true>, lds)) return rc;
         hipLaunchKernelGGL((k_linear128_multi<KQ, true, true>), dim3(blocks), dim3(kLinThreads), lds, st, T);
@@ -4182,6 +4254,35 @@ struct ReduceQueue {
     }
 };
 
+// ---- the two-chain launches of the backward (k_gat_bwd_src_pair_dst, k_gat_bwd_src_lin_rd); both fall back to plain launches
+// in dependency order when a part is empty or has no kernel
+static int launch_gat_bwd_src_pair_dst(const GatBwdSrcArgs& A, const GatBwdSrcArgs& B, const GatBwdDstArgs& D, int heads, hipStream_t st) {
+    if (A.nblk + B.nblk == 0) return launch_gat_bwd_dst(D, heads, st);
+    if (D.nblk == 0 || edge_class(&D.et) != 0) {
+        if (int rc = launch_gat_bwd_src_pair(A, B, heads, st)) return rc;
+        return launch_gat_bwd_dst(D, heads, st);
+    }
+    FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src_pair_dst<HH, kBwdRows>), dim3(A.nblk + B.nblk + D.nblk), dim3(kBwdRows * 32), 0, st, A, B, D));
+    return launch_status("bond levels' source pass + atom level's destination pass");
+}
+// R.g_feat == nullptr: the rows' term rides in T's bond product (RowAdd); R.nblk == 0: no edge term at all
+static int launch_gat_bwd_src_lin_rd(const GatBwdSrcArgs& A, LinTasks& T, const RowDotsBwdArgs& R, int heads, hipStream_t st) {
+    int gb = 0, grid = 0;
+    LinMix mx{};
+    if (A.nblk == 0 || !lin_side_prepare(T, A.nblk + R.nblk, &gb, &mx, &grid, false)) {
+        if (T.n) if (int rc = launch_linear128_group(T, st)) return rc;
+        if (R.nblk == 0) return launch_gat_bwd_src(A, heads, st);
+        if (A.nblk == 0) {
+            hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(R.nblk), dim3(kBlock), 0, st, R);
+            return launch_status("edge-term backward");
+        }
+        FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src_rd<HH, kBwdRows>), dim3(A.nblk + R.nblk), dim3(kBlock), 0, st, A, R));
+        return launch_status("fn_gat_bwd_src_f32 + edge-term backward");
+    }
+    FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src_lin_rd<HH, kBwdRows>), dim3(T.total + A.nblk + R.nblk), dim3(kBlock), kLinSideLds, st, A, T, R));
+    return launch_status("bond input-gradient products + atom level's source pass + edge-term partials");
+}
+
 // source pass of a level + backward of its edge term <feat[e], att[:, mid block]> as ONE launch (k_gat_bwd_src_rd); they
 // share nothing but their input dz.  *n_rd = blocks of the edge-term part (0: the level has no real edges).
 int bwd_src_and_edge_term(const float* g_out, const float* h, const float* pz_src, const float* g_s_dst, const float* att, int att_w,
@@ -4505,6 +4606,12 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
     rq.defer_mixed = !multi && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;      // ... and layer 0's
 
     const bool colaunch = !multi && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;
+    // two chains side by side (k_gat_bwd_src_pair_dst / k_gat_bwd_src_lin_rd): the bond levels' source pass of layer l+1 is held back
+    // and launched with the atom level's destination pass of layer l; the atom graph's edge-term gradient reaches the bond rows in
+    // the epilogue of the bond input-gradient product (RowAdd: every bond is edge e of the atom graph, in order)
+    const bool pipeline = colaunch && H == 4 && g_tune[FN_TUNE_BWD_PIPELINE] != 0 && e->atom.m_real == e->E && e->E > 0;
+    GatBwdSrcArgs pend_sb{}, pend_sfb{};
+    bool pend = false, carry_has_rd = false;
     LinTasks dx_carry{};             // input-gradient products handed from layer l+1 to layer l's first attention launch
     // gradients w.r.t. the current layer's post-activation outputs (null = zero)
     bool pre_atoms = false, pre_bond = false, pre_fbond = false;   // g_pre_* already hold layer l's pre-activation grads
@@ -4534,12 +4641,15 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         LinTasks dxT{}, dxA{};
         LinTasks dx_now = dx_carry;          // products of layer l+1 that this layer's atom level launches
         dx_carry = LinTasks{};
+        const bool now_has_rd = carry_has_rd;        // ... whose bond product adds this layer's edge-term gradient (RowAdd)
+        carry_has_rd = false;
         // Wt: the transposed copy the forward prologue left in the workspace (k_proj128 wants the weight n-major)
         auto input_grad = [&](const float* gh, const float* W, const float* Wt, float* gy, int64_t rows, const fn_act_epilogue& mk, fn_stream_t sq,
-                              int where) -> int {
+                              int where, const RowAdd* ra = nullptr) -> int {
             if (multi) return fn_linear128_f32(gh, FN_D, W, nullptr, gy, rows, &mk, sq);
             LinTasks& dst = !colaunch ? dxT : (where == 0 ? dxA : dx_carry);
             dst.t[dst.n++] = LinTask{Wt, gh, W, nullptr, gy, rows, mk, NodeScalarEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0}, 0, 0};
+            if (ra) dst.t[dst.n - 1].ra = *ra;
             return 0;
         };
         const float* bt_b = lay.bt + (size_t)(3 * l) * 192 * FN_D;
@@ -4610,12 +4720,32 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             {
                 GatBwdDstArgs da{};
                 FN_TRY(prep_gat_bwd_dst(bw.g_pre_atoms, a.h_a, a.p_atom, &et_a, &e->atom, 0.2f, nullptr, sa.dz, sa.pz, sa.g_s_dst, nullptr, &n_e, H, &da));
-                FN_TRY(launch_gat_bwd_dst_lin(da, dx_now, H, hs));          // + layer l+1's bond / fragment-bond input-gradient products
-                dx_now = LinTasks{};
+                if (pipeline) {          // + the source pass of layer l+1's bond levels, held back for this launch
+                    FN_TRY(launch_gat_bwd_src_pair_dst(pend_sb, pend_sfb, da, H, hs));
+                    pend = false;  pend_sb = GatBwdSrcArgs{};  pend_sfb = GatBwdSrcArgs{};
+                } else {
+                    FN_TRY(launch_gat_bwd_dst_lin(da, dx_now, H, hs));      // + layer l+1's bond / fragment-bond input-gradient products
+                    dx_now = LinTasks{};
+                }
             }
             int gr = 0;
-            FN_TRY(bwd_src_and_edge_term(bw.g_pre_atoms, a.h_a, sa.pz, sa.g_s_dst, w.a, wide, 0, d + FN_D, &e->atom, sa.g_h, sa.part_a, &n_a,
-                                         sa.dz, a.new_bond, d, bw.g_pre_bond, sa.part_rd, have_bond, &gr, H, hs));
+            if (pipeline && dx_now.n && now_has_rd) {
+                // layer l+1's bond / fragment-bond products (the bond one adds THIS layer's edge-term gradient to the rows it writes),
+                // this level's source pass and the edge term's parameter partials: one launch
+                GatBwdSrcArgs sA{};
+                FN_TRY(prep_gat_bwd_src(bw.g_pre_atoms, a.h_a, sa.pz, sa.g_s_dst, w.a, wide, 0, d + FN_D, &e->atom, sa.g_h, sa.part_a, &n_a, H, &sA));
+                gr = row_grid(e->atom.m_real, g_tune[FN_TUNE_RD_BLOCKS] > 0 ? g_tune[FN_TUNE_RD_BLOCKS] : kRowDotsBwdBlocks);
+                const RowDotsBwdArgs R{sa.dz, a.new_bond, w.a, wide, d, H, e->atom, nullptr, sa.part_rd, nullptr, 1, gr};
+                FN_TRY(launch_gat_bwd_src_lin_rd(sA, dx_now, R, H, hs));
+                dx_now = LinTasks{};
+            } else {
+                if (dx_now.n) {          // (pipeline without a RowAdd carrier: the products first, the edge term accumulates into their rows)
+                    FN_TRY(launch_linear128_group(dx_now, hs));
+                    dx_now = LinTasks{};
+                }
+                FN_TRY(bwd_src_and_edge_term(bw.g_pre_atoms, a.h_a, sa.pz, sa.g_s_dst, w.a, wide, 0, d + FN_D, &e->atom, sa.g_h, sa.part_a, &n_a,
+                                             sa.dz, a.new_bond, d, bw.g_pre_bond, sa.part_rd, have_bond, &gr, H, hs));
+            }
             if (gr) have_bond = true;
             FN_TRY(rq.finalize(sa.part_a, n_a, nullptr, 0, et_a, w.a, wide, 0, d + FN_D, g.a, nullptr, nullptr, H));
             if (gr) FN_TRY(rq.colsum(sa.part_rd, gr, H * FN_D, g.a, wide, d));
@@ -4627,7 +4757,12 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
                 nxt_atoms = true;
             }
         }
-        if (dx_now.n) {          // no atom level ran in this layer: the carried products still have to
+        if (pend) {              // no atom level ran in this layer: the held-back source pass and the carried products still have to
+            FN_TRY(launch_gat_bwd_src_pair(pend_sb, pend_sfb, H, hs));
+            pend = false;  pend_sb = GatBwdSrcArgs{};  pend_sfb = GatBwdSrcArgs{};
+        }
+        if (dx_now.n) {
+            for (int i = 0; i < dx_now.n; ++i) dx_now.t[i].ra = RowAdd{nullptr, nullptr, 0};     // no destination pass wrote the term's input
             FN_TRY(launch_linear128_group(dx_now, hs));
             dx_now = LinTasks{};
         }
@@ -4657,7 +4792,8 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             } else {
                 FN_TRY(launch_gat_bwd_dst_pair_lin(db, dfb, dxA, H, hs));        // + this layer's atom input-gradient product
                 dxA = LinTasks{};
-                FN_TRY(launch_gat_bwd_src_pair(sbA, sfbA, H, hs));
+                if (pipeline && l > 0) { pend_sb = sbA;  pend_sfb = sfbA;  pend = true; }     // rides with layer l-1's atom destination pass
+                else FN_TRY(launch_gat_bwd_src_pair(sbA, sfbA, H, hs));
             }
             if (have_fbond) {
                 if (l) {     // dL/d(pre-activation fbond output of layer l-1), gated by that layer's dropout mask and ReLU
@@ -4674,7 +4810,13 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
                 FN_TRY(rq.wgrad(sb.g_h, in_bond, kb, e->E, sb.wg_ws, g.proj_b_w, g.proj_b_b, S(st_leaf)));
                 if (l) {
                     const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_bond), p, 1, e->seed, rng.y[l - 1][2], e->offset_dev};
-                    FN_TRY(input_grad(sb.g_h, w.proj_b_w, bt_b, bw.g_pre_bond, e->E, mk, st, 1));
+                    if (pipeline && nxt_atoms) {      // layer l-1's atom level will run: its edge-term gradient rides in this product's epilogue
+                        const RowAdd ra{bw.atom[l - 1].dz, e->w[l - 1].a + d, wide};
+                        FN_TRY(input_grad(sb.g_h, w.proj_b_w, bt_b, bw.g_pre_bond, e->E, mk, st, 1, &ra));
+                        carry_has_rd = true;
+                    } else {
+                        FN_TRY(input_grad(sb.g_h, w.proj_b_w, bt_b, bw.g_pre_bond, e->E, mk, st, 1));
+                    }
                     nxt_bond = true;
                 }
             }
@@ -4685,6 +4827,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         gy_atoms = gy_bond = gy_fbond = nullptr;
         gy_frags = nullptr;        // a layer's x_frags input is dead in the reference (overwritten at gat2.py:234)
     }
+    if (pend) FN_TRY(launch_gat_bwd_src_pair(pend_sb, pend_sfb, H, hs));
     // join: the caller's stream continues only after both side streams have drained
     if (leaf_forked) FN_TRY(order_after(S(st_leaf), hs));
     if (fb_forked) FN_TRY(order_after(S(st_fb), hs));

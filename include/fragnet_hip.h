@@ -90,7 +90,11 @@ int fn_abi_version(void);
                                   * the attention pass leaves free (1024 - its workgroups, at least 256 = one per CU), each walking
                                   * several tiles; > 0 = that many */
 #define FN_TUNE_COLAUNCH_PRIO 16  /* 1: riding GEMM workgroups run at raised wave priority (s_setprio 3); 0 (default) */
-#define FN_TUNE_COUNT 17
+#define FN_TUNE_BWD_PIPELINE 17   /* 1 (default): fn_encoder_backward runs the atom chain of layer l beside the bond chain of layer l+1
+                                  * (three launches per layer: k_gat_bwd_src_pair_dst, k_gat_bwd_src_lin_rd, k_gat_bwd_dst_pair_lin; the
+                                  * atom graph's edge-term gradient lands on the bond rows in the epilogue of the bond input-gradient
+                                  * product); 0: four launches per layer in series.  Needs 4 heads and FN_TUNE_GEMM_COLAUNCH != 0 */
+#define FN_TUNE_COUNT 18
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * molecules 64-bit words) is
  * set, every workgroup of the fused molecule kernels writes s_memtime stamps of its phases into it (tools/mol_phase_times.py).

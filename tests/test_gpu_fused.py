@@ -180,7 +180,7 @@ def test_fused_forward_flags_a_batch_that_is_not_molecule_contiguous(fused):
         batch["_fragnet_plan"].check()
 
 
-@pytest.mark.parametrize("key,value", [(8, 0), (8, 2), (9, 1), (7, 0), (6, 1), (14, 0), (14, 1), (14, 3), (15, 16)])
+@pytest.mark.parametrize("key,value", [(8, 0), (8, 2), (17, 0), (9, 1), (7, 0), (6, 1), (14, 0), (14, 1), (14, 3), (15, 16)])
 def test_alternative_kernels_behind_tuning_keys_stay_parity_green(key, value):
     """The measured-and-rejected (or superseded) kernels stay selectable for A/B runs (include/fragnet_hip.h FN_TUNE_*):
     8 = 0 the LDS-staged grouped weight-gradient kernel (2: the direct one with four row slices per 1024-thread workgroup), 9 = 1 the wave-independent projection kernel, 7 = 0 the separate
@@ -193,7 +193,7 @@ def test_alternative_kernels_behind_tuning_keys_stay_parity_green(key, value):
     net = M.FragNetFineTune(n_classes=1, num_layer=3, drop_ratio=0.1, h1=32, h2=32, h3=32, h4=32, act="relu", fthead="FTHead3").to(DEV)
     net.train()
     batch = data.batch_to(data.collate_fn(synth.synth_molecules(96, seed=17, profile="esol")), DEV)
-    default = {6: 0, 7: 1, 8: 1, 9: 0, 14: 2, 15: -1}[key]
+    default = {6: 0, 7: 1, 8: 1, 9: 0, 14: 2, 15: -1, 17: 1}[key]
     try:
         o0, g0 = _encoder_run(net, batch, 999)
         _lib.call("fn_set_tuning", key, value)
