@@ -186,7 +186,8 @@ def test_alternative_kernels_behind_tuning_keys_stay_parity_green(key, value):
     8 = 0 the LDS-staged grouped weight-gradient kernel (2: the direct one with four row slices per 1024-thread workgroup), 9 = 1 the wave-independent projection kernel, 7 = 0 the separate
     row-dots launch, 6 = 1 the register-resident-W projection kernel, 14 = 0 the projection GEMMs as launches of their own instead
     of riding with the attention launches (1 / 3: their workgroups last in / interleaved with those launches instead of first),
-    15 = 16 riding GEMM workgroups that walk several tiles each.  Each must reproduce the default path's outputs and
+    15 = 16 riding GEMM workgroups that walk several tiles each, 17 = 0 the backward's four launches per layer in series instead of
+    the atom chain beside the bond chain.  Each must reproduce the default path's outputs and
     gradients (same Philox stream) on a training step with dropout."""
     from fragnet_amd import _lib, data, model as M, synth
     torch.manual_seed(0)
