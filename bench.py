@@ -3,14 +3,18 @@
 of 512 molecules per GPU (BASELINE.json configs[1]; `e1pt4.yaml` model: 4 layers, 4 heads, emb 128,
 FTHead3 128/1024/1024/512, drop 0.1, fp32), synthetic data already resident in HBM.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: this process starts the N ranks itself, as child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+    python bench.py --gpus 1 --spawn                        (one child, 1-rank RCCL group: the N>1 step sequence on one GPU)
 
 A step = graph plan build + zero grads + forward + MSE loss + backward + (N>1: one flat-bucket
 gradient all-reduce over RCCL) + Adam step, on a batch the model has not seen in the previous step
-(a pool of pre-collated batches, seeds 1000+i).  `--scaling weak` (default): every rank owns 512 molecules per step;
-`--scaling strong`: the GLOBAL batch is 512 molecules (what SURVEY.md §8d quotes the metric on), split over the ranks
-by parallel.shard_indices (rank r owns molecules r::N of the same 512).  At N = 1 the two are the same run.
+(a pool of pre-collated batches, seeds 1000+i).  N > 1 (`--scaling both`, the default): the headline is STRONG scaling --
+the GLOBAL batch is 512 molecules (what SURVEY.md §8d quotes the metric on), split over the ranks by
+parallel.shard_indices (rank r owns molecules r::N of the same 512) -- and the same line carries `weak` (every rank owns 512
+molecules per step), `overlap_on` (two-graph step, the head's gradient exchange beside the encoder backward),
+`allreduce_alone` (the flat-buffer all-reduce by itself), `nccl_ranks` and the fastest rank's step time; `--scaling weak` /
+`strong` measure only that one.  At N = 1 the two are the same run.
 
 Default mode "graph": the batch is staged into fixed-capacity buffers (one kernel; the few % of padding are
 disconnected dummy rows, see fragnet_amd/graphstep.py) and plan + forward + loss + backward + gradient gather
@@ -316,22 +320,86 @@ def forward_sweep_store(rank, world, dev, args):
         torch.distributed.destroy_process_group()
 
 
-def main():
+def spawn_ranks(n, argv, child_cmd=None, poll_s=0.2):
+    """Parent of an N-rank run started as plain `python bench.py --gpus N` (no RANK in the environment): starts N CHILD
+    processes -- never exec, and before this process has imported torch.cuda or touched a GPU -- one per GPU, with the torchrun
+    environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT = a free port), relays rank 0's
+    stdout and prints rank 0's last JSON line as ITS OWN last stdout line.  Returns the exit code: 0 only if every child
+    exited 0; the first failing child ends the others (by PID).  `child_cmd` (a list; tests) replaces `python bench.py ...`.
+    Reference precedent for the data-parallel launch: train/finetune/finetune_gat2_pl.py:230-248 (Fabric starts the ranks)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = list(child_cmd) if child_cmd else [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), FRAGNET_BENCH_CHILD="1")
+        # rank 0's stdout is the result channel; the other ranks' stdout joins stderr (their stderr passes through)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    import threading
+    lines = []
+
+    def pump():
+        for ln in procs[0].stdout:
+            lines.append(ln.rstrip("\n"))
+
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in list(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"[bench parent] rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in live:
+                    procs[q].terminate()                 # exact PIDs of our own children
+        if live:
+            time.sleep(poll_s)
+    th.join(timeout=10)
+    result = None
+    for ln in lines:
+        if ln.startswith("{") and ln.endswith("}"):
+            result = ln
+        else:
+            print(ln, flush=True)                        # anything else rank 0 printed, in order
+    if result is not None:
+        print(result, flush=True)                        # the JSON line is the LAST line of stdout
+    elif rc == 0:
+        print("[bench parent] rank 0 printed no JSON line", file=sys.stderr, flush=True)
+        rc = 1
+    return rc
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-collated batches cycled through")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: 512 molecules per rank and step; strong: 512 molecules per step in total, sharded over the ranks")
+    ap.add_argument("--scaling", choices=("weak", "strong", "both"), default="both",
+                    help="N>1 only.  both (default): the headline is the GLOBAL batch of 512 sharded over the ranks (strong, what SURVEY.md "
+                         "8d quotes the metric on) and the line carries a `weak` sub-object (512 molecules per rank); weak / strong: "
+                         "only that one")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks as child processes even for --gpus 1 (one child, 1-rank RCCL group, the N>1 step sequence)")
+    ap.add_argument("--child-cmd", default=None, help=argparse.SUPPRESS)      # tests: JSON list replacing the child command line
     ap.add_argument("--shard-of", type=int, default=0, metavar="R",
                     help="dev measurement on ONE GPU: time what rank 0 of an R-GPU strong-scaling job does per step (its 512/R-molecule "
                          "shard, no collective); the line is marked config.emulated_shard_of and is not a contract line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch-by-launch step instead of the whole-step hipGraph")
-    ap.add_argument("--overlap", choices=("on", "off"), default="off",
-                    help="on: two-graph step with the head's gradient all-reduce (async) beside the encoder backward")
+    ap.add_argument("--overlap", choices=("on", "off", "both"), default=None,
+                    help="on: two-graph step with the head's gradient all-reduce (async) beside the encoder backward; N>1 default: "
+                         "both (headline off, `overlap_on` sub-object)")
     ap.add_argument("--margin", type=float, default=0.02, help="capacity head-room of the static shapes over the pool")
     ap.add_argument("--eager-head", action="store_true", help="(--eager) do not HIP-graph-capture the prediction head")
     ap.add_argument("--kernels-only", action="store_true", help="only time the bond-level scatter kernels (dev loop)")
@@ -348,18 +416,146 @@ def main():
     ap.add_argument("--library-head", action="store_true", help="A/B: head layers as library GEMMs + element-wise kernels instead of fn_dense_*")
     ap.add_argument("--tune", action="append", default=None, help="A/B: KEY=VALUE for fn_set_tuning (include/fragnet_hip.h FN_TUNE_*)")
     ap.add_argument("--scatter-blocks", type=int, default=None, help="A/B: resident workgroups of the scatter kernels (FN_TUNE_FWD_BLOCKS)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+class StepRun:
+    """One configuration of the training step (scaling x overlap): its own model, optimiser, batch pool and captured graph."""
+
+    def __init__(self, args, rank, world, dev, scaling, overlap, force_distributed=False):
+        import fragnet_amd
+        from fragnet_amd import parallel
+        from fragnet_amd.model import FragNetFineTune
+        from fragnet_amd.plan import PLAN_KEY
+        self.args, self.rank, self.world, self.dev, self.scaling, self.overlap = args, rank, world, dev, scaling, overlap
+        if args.shard_of > 1 and world == 1:
+            pool = make_pool(args.pool, 0, dev, PER_GPU_BATCH, args.shard_of, "strong")
+        else:
+            pool = make_pool(args.pool, rank, dev, PER_GPU_BATCH, world, scaling)
+        self.pool = pool
+        self.local_batch = int(pool[0]["y"].shape[0])
+        self.global_batch = PER_GPU_BATCH if scaling == "strong" else PER_GPU_BATCH * world
+        if args.model_version == "gat2_edge":      # gat2_edge.py:46 wants 8 connection features, the featuriser writes 6
+            for b in pool:
+                b["cnx_attr"] = torch.nn.functional.pad(b["cnx_attr"], (0, 8 - b["cnx_attr"].shape[1]))
+        torch.manual_seed(0)
+        model = self.model = FragNetFineTune(**MODEL_CFG, variant=args.model_version).to(dev)
+        model.train()
+        model.pretrain.rng.rank = rank
+
+        def fwd_bwd(batch):
+            batch.pop(PLAN_KEY, None)                      # every step pays for its own graph plan
+            loss = torch.nn.functional.mse_loss(model(batch).view(-1), batch["y"])
+            loss.backward()
+            return loss
+
+        opt = self.opt = parallel.FlatAdam.for_live_parameters(model, lambda: fwd_bwd(pool[0]), lr=1e-4)
+        self.gstep, self.capture_note, self.graphed_head = None, None, False
+        eager = args.eager
+        if not eager:
+            from fragnet_amd import graphstep
+            try:
+                shapes = graphstep.StaticShapes.from_batches(pool, margin=args.margin, heads=MODEL_CFG["num_heads"])
+                self.gstep = graphstep.GraphedTrainStep(model, opt, shapes, pool[0], loss="regr", overlap=overlap,
+                                                        force_distributed=force_distributed)
+                torch.cuda.synchronize()
+            except Exception as exc:      # never lose the measurement to a capture problem: run the same step eagerly
+                self.gstep, self.capture_note = None, f"hipGraph capture failed ({type(exc).__name__}: {exc}); eager step"
+                print(f"[bench rank {rank}] {self.capture_note}", file=sys.stderr, flush=True)
+            if world > 1:                 # all ranks take the same path
+                ok = torch.tensor([int(self.gstep is not None)], device=dev)
+                torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+                if not int(ok.item()) and self.gstep is not None:
+                    self.gstep, self.capture_note = None, "another rank could not capture the step; eager step"
+        self.eager = self.gstep is None
+        if self.eager:
+            if force_distributed:
+                opt.force_collective = True
+            self.graphed_head = fragnet_amd.graph_capture_head(model, self.local_batch) if not args.eager_head else False
+
+            def step(i):
+                opt.zero_grad()
+                loss = fwd_bwd(pool[i % len(pool)])
+                opt.step()                                   # one cat + (N>1: one all-reduce) + one fused Adam
+                return loss
+        else:
+            gstep = self.gstep
+
+            def step(i):
+                return gstep(pool[i % len(pool)])            # stage (1 kernel) + graph replay + (all-reduce) + Adam
+        self.step = step
+
+    def timed(self, steps, warmup):
+        """W untimed steps, barrier + synchronize, EXACTLY K steps, synchronize + barrier; seconds of this rank, the max and the
+        min over ranks, the last loss."""
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        for i in range(warmup):
+            self.step(i)
+        if dist_on:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = self.step(warmup + i)
+        torch.cuda.synchronize()
+        if dist_on:
+            torch.distributed.barrier()
+        mine = time.perf_counter() - t0
+        hi = torch.tensor([mine], dtype=torch.float64, device=self.dev)
+        lo = hi.clone()
+        if dist_on:
+            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        return float(hi.item()), float(lo.item()), float(loss.item())
+
+    def mode(self):
+        if self.eager:
+            return "eager launches, head " + ("hipGraph-captured" if self.graphed_head else "eager")
+        if self.gstep.split:
+            return ("two hipGraphs over static shapes (stage+plan+fwd+mse+head bwd | encoder bwd); the head's gradient "
+                    "all-reduce runs beside the second")
+        return "whole-step hipGraph over static shapes (stage+plan+fwd+mse+bwd+grad gather in the graph)"
+
+    def release(self):
+        self.gstep = self.step = self.model = self.opt = self.pool = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def allreduce_alone(opt, dev, iters=20):
+    """The step's only collective by itself: blocking all-reduce (AVG) of the flat gradient buffer, back to back between
+    synchronisations; microseconds per call, max over ranks."""
+    for _ in range(3):
+        opt.all_reduce()
+    torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        opt.all_reduce()
+    torch.cuda.synchronize()
+    t = torch.tensor([(time.perf_counter() - t0) / iters * 1e6], dtype=torch.float64, device=dev)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(t.item())
+
+
+def main():
+    args = parse_args()
+    # ---- N > 1 (or --spawn) without a launcher: this process becomes the PARENT of the ranks.  Nothing above or below this
+    # point has initialised a GPU yet (torch is imported, torch.cuda is not initialised; device_count is not even asked).
+    if (args.gpus > 1 or args.spawn) and "RANK" not in os.environ:
+        child = json.loads(args.child_cmd) if args.child_cmd else None
+        argv = [a for a in sys.argv[1:] if a != "--spawn"]
+        sys.exit(spawn_ranks(args.gpus, argv, child))
 
     import fragnet_amd
     from fragnet_amd import parallel
-    from fragnet_amd.model import FragNetFineTune
     fragnet_amd.prefer_rocblas_for_dense_heads()
     if args.library_head:
         from fragnet_amd import ops
         ops.DENSE_HEAD = False
     if args.library_head and not args.no_gemm_tuning:
         fragnet_amd.tune_library_gemms()
-    from fragnet_amd.plan import PLAN_KEY
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
@@ -373,121 +569,105 @@ def main():
     if os.environ.get("FN_STREAMS"):
         from fragnet_amd import _lib
         _lib.call("fn_set_tuning", 2, int(os.environ["FN_STREAMS"]))
-    rank, local_rank, world = parallel.init_distributed()
+    spawned_single = os.environ.get("FRAGNET_BENCH_CHILD") == "1" and int(os.environ.get("WORLD_SIZE", "1")) == 1
+    rank, local_rank, world = parallel.init_distributed(force=spawned_single)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    dist_on = world > 1 or spawned_single            # the N>1 step sequence: graph replay -> RCCL all-reduce -> Adam outside the graph
 
     if args.forward_sweep:
         (forward_sweep_store if args.store > 0 else forward_sweep)(rank, world, dev, args)
         return
-    if args.shard_of > 1 and world == 1:
-        pool = make_pool(args.pool, 0, dev, PER_GPU_BATCH, args.shard_of, "strong")
-    else:
-        pool = make_pool(1, rank, dev, args.kbatch) if args.kernels_only else make_pool(args.pool, rank, dev, PER_GPU_BATCH, world, args.scaling)
-    local_batch = int(pool[0]["y"].shape[0])
-    global_batch = PER_GPU_BATCH if args.scaling == "strong" else PER_GPU_BATCH * world
-    if args.model_version == "gat2_edge":      # gat2_edge.py:46 wants 8 connection features, the featuriser writes 6
-        for b in pool:
-            b["cnx_attr"] = torch.nn.functional.pad(b["cnx_attr"], (0, 8 - b["cnx_attr"].shape[1]))
-    torch.manual_seed(0)
-    model = FragNetFineTune(**MODEL_CFG, variant=args.model_version).to(dev)
     if args.kernels_only:
-        print(json.dumps(kernel_roofline(pool[0], model)))
+        from fragnet_amd.model import FragNetFineTune
+        torch.manual_seed(0)
+        model = FragNetFineTune(**MODEL_CFG, variant=args.model_version).to(dev)
+        print(json.dumps(kernel_roofline(make_pool(1, rank, dev, args.kbatch)[0], model)))
         return
-    model.train()
-    model.pretrain.rng.rank = rank
 
-    def fwd_bwd(batch):
-        batch.pop(PLAN_KEY, None)                      # every step pays for its own graph plan
-        loss = torch.nn.functional.mse_loss(model(batch).view(-1), batch["y"])
-        loss.backward()
-        return loss
-
-    opt = parallel.FlatAdam.for_live_parameters(model, lambda: fwd_bwd(pool[0]), lr=1e-4)
-    bucket = opt
-    gstep, capture_note = None, None
-    if not args.eager:
-        from fragnet_amd import graphstep
+    # headline configuration: one GPU = the 512-molecule batch; N > 1 = the global batch of 512 sharded over the ranks
+    # (SURVEY.md 8d quotes the metric on a global batch of 512) unless --scaling weak
+    head_scaling = "weak" if (world == 1 or args.scaling == "weak") else "strong"
+    overlap_sel = args.overlap if args.overlap is not None else ("both" if dist_on else "off")
+    head_overlap = overlap_sel == "on"
+    run = StepRun(args, rank, world, dev, head_scaling, head_overlap, force_distributed=spawned_single)
+    elapsed, fastest, final_loss = run.timed(args.steps, args.warmup)
+    extras = {}
+    sub_steps, sub_warm = max(5, min(args.steps, 20)), max(2, min(args.warmup, 5))
+    if dist_on:
+        extras["allreduce_alone"] = {"bytes": run.opt.nbytes, "us_per_call": round(allreduce_alone(run.opt, dev), 1),
+                                     "what": "blocking all-reduce (AVG) of the flat gradient buffer, 20 back-to-back calls, max over ranks"}
         try:
-            shapes = graphstep.StaticShapes.from_batches(pool, margin=args.margin, heads=MODEL_CFG["num_heads"])
-            gstep = graphstep.GraphedTrainStep(model, opt, shapes, pool[0], loss="regr",
-                                               overlap=args.overlap == "on")
-            torch.cuda.synchronize()
-        except Exception as exc:      # never lose the measurement to a capture problem: run the same step eagerly
-            gstep, capture_note = None, f"hipGraph capture failed ({type(exc).__name__}: {exc}); eager step"
-            print(f"[bench rank {rank}] {capture_note}", file=sys.stderr, flush=True)
-        if world > 1:                 # all ranks take the same path
-            ok = torch.tensor([int(gstep is not None)], device=dev)
-            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
-            if not int(ok.item()) and gstep is not None:
-                gstep, capture_note = None, "another rank could not capture the step; eager step"
-    if gstep is None:
-        args.eager = True
-        graphed_head = fragnet_amd.graph_capture_head(model, local_batch) if not args.eager_head else False
+            import torch.cuda.nccl as _nccl
+            ver = ".".join(str(v) for v in _nccl.version())
+        except Exception:      # noqa: BLE001 -- version string only
+            ver = "?"
+        extras["nccl_ranks"] = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
+                                "library_version": ver, "devices": torch.cuda.device_count()}
+    head = {"local_batch": run.local_batch, "global_batch": run.global_batch, "mode": run.mode(), "capture_note": run.capture_note,
+            "cap": None if run.gstep is None else run.gstep.shapes.cap, "replays": None if run.gstep is None else run.gstep.replays,
+            "fallbacks": None if run.gstep is None else run.gstep.fallbacks, "nbytes": run.opt.nbytes, "eager": run.eager,
+            "pool0": run.pool[0]}
 
-        def step(i):
-            opt.zero_grad()
-            loss = fwd_bwd(pool[i % len(pool)])
-            opt.step()                                   # one cat + (N>1: one all-reduce) + one fused Adam
-            return loss
-    else:
-        def step(i):
-            return gstep(pool[i % len(pool)])            # stage (1 kernel) + graph replay + (all-reduce) + Adam
+    def sub_run(scaling, overlap):
+        r = StepRun(args, rank, world, dev, scaling, overlap, force_distributed=spawned_single)
+        hi, lo, _ = r.timed(sub_steps, sub_warm)
+        out = {"value": round(r.global_batch * sub_steps / hi, 1), "unit": "molecules/s", "scaling": scaling, "overlap": "on" if overlap else "off",
+               "per_gpu_batch": r.local_batch, "global_batch": r.global_batch, "steps": sub_steps, "warmup": sub_warm,
+               "ms_per_step": round(hi / sub_steps * 1e3, 3), "ms_per_step_fastest_rank": round(lo / sub_steps * 1e3, 3), "mode": r.mode()}
+        r.release()
+        return out
 
-    for i in range(args.warmup):
-        step(i)
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(t.item())
-    final_loss = float(loss.item())
+    if dist_on and not args.eager and args.shard_of <= 1:
+        if overlap_sel == "both":
+            extras["overlap_on"] = sub_run(head_scaling, True)
+        if world > 1 and args.scaling == "both":
+            extras["weak"] = sub_run("weak", False)
+            if overlap_sel == "both":
+                extras["weak"]["overlap_on"] = sub_run("weak", True)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        value = global_batch * args.steps / elapsed
+        value = head["global_batch"] * args.steps / elapsed
         if args.shard_of > 1 and world == 1:      # dev line: one rank's shard of a strong-scaling job, measured alone
-            value = local_batch * args.steps / elapsed
-        sb = step_bytes(pool[0])
+            value = head["local_batch"] * args.steps / elapsed
+        sb = step_bytes(head["pool0"])
         line = {
-            "metric": "molecules/sec fwd+bwd (full training step), ESOL-shape batch=512 " + ("per GPU" if args.scaling == "weak" else "global"),
+            "metric": "molecules/sec fwd+bwd (full training step), ESOL-shape batch=512 " + ("per GPU" if head_scaling == "weak" else "global"),
             "value": round(value, 1), "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": head_scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"model_version": args.model_version,
                        "workload": "ESOL finetune batch=512 fp32 (BASELINE configs[1]): FragNetFineTune 4 layers x 4 heads, "
                                    "emb 128, FTHead3 128/1024/1024/512, drop 0.1; synthetic ESOL-shape molecules (synth.py)",
-                       "per_gpu_batch": local_batch, "global_batch": global_batch, "parallelism": f"dp{world}",
+                       "per_gpu_batch": head["local_batch"], "global_batch": head["global_batch"], "parallelism": f"dp{world}",
                        **({"emulated_shard_of": args.shard_of, "note": "NOT a contract line: rank 0's shard of a strong-scaling job on "
                            "one GPU, no collective; value = this shard's molecules/s"} if args.shard_of > 1 and world == 1 else {}),
-                       "mode": "eager launches, head " + ("hipGraph-captured" if graphed_head else "eager") if args.eager else
-                               ("two hipGraphs over static shapes (stage+plan+fwd+mse+head bwd | encoder bwd); the head's gradient "
-                                "all-reduce runs beside the second" if gstep.split else
-                                "whole-step hipGraph over static shapes (stage+plan+fwd+mse+bwd+grad gather in the graph)"),
-                       "capture_note": capture_note,
-                       "static_capacity": None if gstep is None else gstep.shapes.cap,
-                       "graph_replays": None if gstep is None else gstep.replays,
-                       "eager_fallbacks": None if gstep is None else gstep.fallbacks,
-                       "step": "plan+zero_grad+fwd+mse+bwd" + ("+allreduce(flat %.1f MB)" % (bucket.nbytes / 1e6) if world > 1 else "") + "+adam",
-                       "atoms": int(pool[0]["x_atoms"].shape[0]), "bond_graph_edges": int(pool[0]["edge_index_bonds_graph"].shape[1])},
+                       **({"spawned": "one child process, 1-rank RCCL group, N>1 step sequence (all-reduce + Adam outside the graph)"}
+                          if spawned_single else {}),
+                       "mode": head["mode"], "overlap": "on" if head_overlap else "off",
+                       "capture_note": head["capture_note"],
+                       "static_capacity": head["cap"],
+                       "graph_replays": head["replays"],
+                       "eager_fallbacks": head["fallbacks"],
+                       "step": "plan+zero_grad+fwd+mse+bwd" + ("+allreduce(flat %.1f MB)" % (head["nbytes"] / 1e6) if dist_on else "") + "+adam",
+                       "atoms": int(head["pool0"]["x_atoms"].shape[0]), "bond_graph_edges": int(head["pool0"]["edge_index_bonds_graph"].shape[1])},
             "final_loss": round(final_loss, 6),
-            "step_algorithmic_GB": round(sb / 1e9, 4),
-            "step_achieved_GBps": round(sb / (ms * 1e-3) / 1e9, 1),
-            "step_frac_of_hbm_peak": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "ms_per_step_fastest_rank": round(fastest / args.steps * 1e3, 3),
+            "step_algorithmic_GB": round(sb * (world if head_scaling == "strong" else 1) / 1e9, 4),
         }
+        # whole job: bytes all ranks moved per step / the step time (strong: rank 0's shard x world approximates the global batch)
+        job_bytes = sb * world
+        line["step_achieved_GBps"] = round(job_bytes / (ms * 1e-3) / 1e9, 1)
+        line["step_frac_of_hbm_peak"] = round(job_bytes / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 4)
+        line.update(extras)
         if not args.no_roofline:
-            kr = kernel_roofline(pool[0], model)
+            # the roofline object is quoted on the metric's configuration: a full 512-molecule batch (a rank of a strong-scaling
+            # job holds only its shard)
+            roof_batch = head["pool0"] if head["local_batch"] == PER_GPU_BATCH else make_pool(1, 0, dev, PER_GPU_BATCH)[0]
+            kr = kernel_roofline(roof_batch, run.model)
             passes = ("k_gat_fwd", "k_gat_bwd(dst+src)")
             dom = max(passes, key=lambda k: kr[k]["us_per_launch"])
             traffic, traffic_source = None, None
@@ -514,7 +694,7 @@ def main():
                 gj = json.load(open(ig))
                 ks = gj.get("kernels", {})
                 # inside the step the bond and fragment-bond levels share a launch (k_gat_*_pair): bytes of both levels
-                fb_n, fb_m = int(pool[0]["node_features_fbonds"].shape[0]), int(pool[0]["edge_index_fbonds"].shape[1])
+                fb_n, fb_m = int(head["pool0"]["node_features_fbonds"].shape[0]), int(head["pool0"]["edge_index_fbonds"].shape[1])
                 f2, b2 = level_bytes(fb_n, fb_m)
                 nb, mb = kr["k_gat_fwd"]["n"], kr["k_gat_fwd"]["m"]
                 f1, b1 = level_bytes(nb, mb)
@@ -529,14 +709,14 @@ def main():
             # extra evidence (not part of the contract): the same kernels on a 2048-molecule batch, where a launch
             # is long enough for the per-launch fixed cost (~4 us) not to dominate
             big = make_pool(1, rank, dev, 2048)[0]
-            kb = kernel_roofline(big, model, iters=20)
+            kb = kernel_roofline(big, run.model, iters=20)
             line["roofline"]["at_batch_2048"] = {k: {"us_per_launch": v["us_per_launch"], "GBps": v["GBps"],
                                                      "frac": round(v["GBps"] / HBM_PEAK_GBPS, 4)} for k, v in kb.items()}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -10,6 +10,7 @@
 //     per-block partial-sum rows any backward kernel writes is bounded by FN_MAX_PART.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <functional>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -4126,7 +4127,12 @@ struct ReduceQueue {
     int w_reduce[kMaxWgradTasks] = {};      // index in T of each grouped product's reduction
     bool defer_wgrad = false;
     hipStream_t st = nullptr;
+    // launches whatever the caller still holds back that the queued tasks read (the pipelined backward's pending source pass):
+    // a flush in the middle of a pass -- more than kMaxReduceTasks / kMaxWgradTasks queued, i.e. six or more layers -- would
+    // otherwise reduce partials and multiply rows that no kernel has written yet
+    std::function<int()> before_flush;
     int flush() {
+        if (before_flush) { if (int rc = before_flush()) return rc; }
         if (int rc = flush_wgrad()) return rc;
         if (T.n == 0) return 0;
         hipLaunchKernelGGL(k_reduce_tasks, dim3(blocks), dim3(1024), 0, st, T);
@@ -4612,6 +4618,13 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
     const bool pipeline = colaunch && H == 4 && g_tune[FN_TUNE_BWD_PIPELINE] != 0 && e->atom.m_real == e->E && e->E > 0;
     GatBwdSrcArgs pend_sb{}, pend_sfb{};
     bool pend = false, carry_has_rd = false;
+    rq.before_flush = [&]() -> int {
+        if (!pend) return 0;
+        pend = false;
+        const int rc = launch_gat_bwd_src_pair(pend_sb, pend_sfb, H, hs);
+        pend_sb = GatBwdSrcArgs{};  pend_sfb = GatBwdSrcArgs{};
+        return rc;
+    };
     LinTasks dx_carry{};             // input-gradient products handed from layer l+1 to layer l's first attention launch
     // gradients w.r.t. the current layer's post-activation outputs (null = zero)
     bool pre_atoms = false, pre_bond = false, pre_fbond = false;   // g_pre_* already hold layer l's pre-activation grads

@@ -19,12 +19,13 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend: Optional[str] = None) -> tuple:
-    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract). Returns (rank, local_rank, world)."""
+def init_distributed(backend: Optional[str] = None, force: bool = False) -> tuple:
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract). Returns (rank, local_rank, world).
+    ``force``: create the process group even for WORLD_SIZE = 1 (a 1-rank RCCL group runs the N>1 step sequence on one GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:

@@ -772,12 +772,15 @@ def test_graph_step_loss_and_gradients_match_the_oracle_at_b512():
     assert checked >= 60            # every live parameter of 4 layers + head
 
 
-@pytest.mark.parametrize("n_layers,n_mols,p_cut", [(1, 12, 0.35), (2, 1, 0.35), (5, 9, 0.35), (3, 10, 0.0), (3, 7, 1.0)])
+@pytest.mark.parametrize("n_layers,n_mols,p_cut", [(1, 12, 0.35), (2, 1, 0.35), (5, 9, 0.35), (3, 10, 0.0), (3, 7, 1.0),
+                                                   (6, 6, 0.35), (8, 5, 0.35)])
 def test_engine_edge_shapes_match_the_oracle(n_layers, n_mols, p_cut):
     """Shapes at the edges of the engine's launch merging (projection GEMMs ride in the attention launches of the layer before /
     after, include/fragnet_hip.h FN_TUNE_GEMM_COLAUNCH): one layer (nothing to ride with), two, five; a single molecule; molecules
     that are one fragment each (p_cut 0: no fragment-bond graph rows, every fragment graph is the (0, 0) self edge) and molecules cut
-    at every acyclic bond.  Engine against the oracle: logits and every gradient, train mode without dropout."""
+    at every acyclic bond; six and eight layers (FN_MAX_LAYERS): the queue of deferred parameter-gradient tasks overflows in the
+    middle of the backward pass and must not reduce partials of a pass that is still held back.  Engine against the oracle: logits
+    and every gradient, train mode without dropout."""
     import numpy as np
     from fragnet_amd import data, synth
     from fragnet_amd.model import FragNetFineTune
