@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfragnet_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 FN_D = 128
 FN_MAX_TASKS = 16
 FN_MAX_EDGE_K = 8
@@ -92,6 +92,10 @@ SIGNATURES = {
                        C.POINTER(ActEpilogue), C.c_int, vp],
     "fn_gat_bwd_dst_f32": [vp, vp, vp, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp, vp, vp, ip, C.c_int, vp],
     "fn_gat_bwd_src_f32": [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(GatPlan), vp, vp, ip, C.c_int, vp],
+    "fn_mol_extents": [C.POINTER(SegPlan), C.POINTER(SegPlan), C.POINTER(GatPlan), C.POINTER(GatPlan), C.POINTER(GatPlan),
+                       C.POINTER(GatPlan), i64, vp, vp],
+    "fn_gat_bwd_mol_f32": [vp, vp, vp, C.POINTER(EdgeTerm), vp, C.c_int, C.c_int, C.c_int, C.POINTER(GatPlan), f32, vp, i64,
+                           C.c_int, C.c_int, vp, vp, vp, vp, vp, ip, vp, vp, C.c_int, vp],
     "fn_gat_bwd_finalize_f32": [vp, C.c_int, vp, C.c_int, C.POINTER(EdgeTerm), vp, C.c_int, C.c_int, C.c_int, vp, vp, vp,
                                 C.c_int, vp],
     "fn_attn_by_src_f32": [vp, C.POINTER(GatPlan), vp, C.c_int, vp],

@@ -14,12 +14,13 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = [os.path.join(HERE, "csrc", "fragnet_hip.hip")]
-INCLUDED = sorted(glob.glob(os.path.join(HERE, "csrc", "*.inc")))          # #include'd into the one translation unit
+SOURCES = sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")))           # one translation unit each, compiled in parallel
+INCLUDED = sorted(glob.glob(os.path.join(HERE, "csrc", "*.inc")) + glob.glob(os.path.join(HERE, "csrc", "*.h")))
 HEADERS = [os.path.join(ROOT, "include", "fragnet_hip.h")]
+OBJ_DIR = os.path.join(HERE, "lib", "obj")
 OUT = os.path.join(HERE, "lib", "libfragnet_hip.so")
 STAMP = OUT + ".sha256"
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
 def _hipcc() -> str:
@@ -49,13 +50,29 @@ def stale() -> bool:
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [_hipcc(), *FLAGS, "-I", os.path.join(ROOT, "include"), *SOURCES, "-o", OUT]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    inc = ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc")]
+    # every translation unit to an object (in parallel: the big one takes ~60 s, the others seconds), then one link
+    jobs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
+        cmd = [_hipcc(), *FLAGS, *inc, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        jobs.append((obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    errors = []
+    for obj, proc in jobs:
+        out, err = proc.communicate()
+        if proc.returncode != 0:
+            errors.append(f"{obj}:\n{out}\n{err}")
+    if errors:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(errors))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *[obj for obj, _ in jobs], "-o", OUT]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
+        raise RuntimeError(f"hipcc (link) failed:\n{res.stdout}\n{res.stderr}")
     with open(STAMP, "w") as f:
         f.write(source_digest() + "\n")
     return OUT

@@ -1,0 +1,165 @@
+// Internal declarations shared by the translation units of libfragnet_hip.so (not part of the C-ABI: nothing here is exported).
+//  * device helpers every kernel file uses (vector loads, DPP reductions inside a head's lanes, Philox);
+//  * the per-molecule extents table (MolExt) the molecule-resident kernels are driven by;
+//  * host-side hooks into the error string / tuning table that live in fragnet_hip.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fragnet_hip.h"
+
+#define FNI_HIDDEN __attribute__((visibility("hidden")))
+
+namespace fni {
+FNI_HIDDEN int fail(int code, const char* what);        // sets fn_last_error(), returns code
+FNI_HIDDEN int launch_status(const char* where);        // hipGetLastError() -> 0 / error code + message
+FNI_HIDDEN int tune(int key);                           // fn_set_tuning table
+FNI_HIDDEN unsigned long long* stamps(int64_t* n_u64);  // fn_debug_set_stamps buffer (null: none)
+
+// extents of one molecule in the index spaces of a collated batch (dataset/data.py:877-948 concatenates molecules, so every
+// one of these is a contiguous range); filled by k_mol_extents from the molecule CSRs and the level plans
+struct MolExt {
+    int a0, na;            // atoms
+    int b0, nb;            // directed bonds = bond-graph nodes = atom-graph edges
+    int f0, nf;            // fragments
+    int c0, nc;            // fragment connections = fragment-bond-graph nodes = fragment-graph edges
+    int eb0, meb;          // bond-graph edges: level-local destination-sorted positions
+    int ea0, mea;          // atom-graph items (edges + self loops)
+    int ef0, mef;          // fragment-bond-graph edges
+    int ec0, mec;          // fragment-graph items
+};
+static_assert(sizeof(MolExt) == 64, "MolExt is sixteen int32 (include/fragnet_hip.h documents it as int32 [n_mols][16])");
+}  // namespace fni
+
+namespace {
+
+constexpr int kWfLd = FN_MAX_EDGE_K + 1;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ void fma4(float4& acc, float s, float4 v) {
+    acc.x = fmaf(s, v.x, acc.x); acc.y = fmaf(s, v.y, acc.y);
+    acc.z = fmaf(s, v.z, acc.z); acc.w = fmaf(s, v.w, acc.w);
+}
+
+// XCD-aware work split.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has
+// its own 4 MiB L2), so logical block ids are remapped to give every XCD one CONTIGUOUS range of rows: the
+// source rows a destination gathers belong to the same molecule, i.e. to neighbouring rows, and then stay
+// in that XCD's L2 instead of being fetched by all eight.  Bijective for any grid size; speed only.
+__device__ __forceinline__ int xcd_block(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+// [begin, end) of the row groups (RB rows each) owned by this block: contiguous chunks, XCD-swizzled
+__device__ __forceinline__ void block_groups(int64_t n_rows, int rb, int64_t& begin, int64_t& end) {
+    const int64_t groups = (n_rows + rb - 1) / rb;
+    const int64_t per = (groups + gridDim.x - 1) / gridDim.x;
+    begin = (int64_t)xcd_block(blockIdx.x, gridDim.x) * per;
+    end = begin + per < groups ? begin + per : groups;
+}
+
+__device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t seed) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t m0 = (uint64_t)0xD2511F53u * c0, m1 = (uint64_t)0xCD9E8D57u * c2;       // one v_mad_u64_u32 each
+        const uint32_t hi0 = (uint32_t)(m0 >> 32), lo0 = (uint32_t)m0, hi1 = (uint32_t)(m1 >> 32), lo1 = (uint32_t)m1;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+__device__ __forceinline__ float keep_scale(uint32_t bits, float p, float inv_keep) {
+    const float u = (float)(bits >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? inv_keep : 0.f;
+}
+
+template <int W> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = W / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+template <int W> __device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int off = W / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+
+// ---- reductions over the LPH lanes of one head group.  DPP row operations (one VALU op each) instead of
+// ds_bpermute: row_half_mirror pairs lane i with 7-i inside each 8 lanes, quad_perm covers xor 1 / xor 2.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141; // lane i <- lane 7-i  (within 8)
+constexpr int kDppMirror = 0x140;     // lane i <- lane 15-i (within 16)
+
+template <int W> __device__ __forceinline__ float head_sum(float v) {
+    static_assert(W == 4 || W == 8 || W == 16 || W == 32, "head group width");
+    if (W == 32) v += __shfl_xor(v, 16);
+    if (W >= 16) v += dpp_mov<kDppMirror>(v);
+    if (W >= 8) v += dpp_mov<kDppHalfMirror>(v);
+    v += dpp_mov<kDppXor2>(v);
+    v += dpp_mov<kDppXor1>(v);
+    return v;
+}
+template <int W> __device__ __forceinline__ float head_max(float v) {
+    if (W == 32) v = fmaxf(v, __shfl_xor(v, 16));
+    if (W >= 16) v = fmaxf(v, dpp_mov<kDppMirror>(v));
+    if (W >= 8) v = fmaxf(v, dpp_mov<kDppHalfMirror>(v));
+    v = fmaxf(v, dpp_mov<kDppXor2>(v));
+    v = fmaxf(v, dpp_mov<kDppXor1>(v));
+    return v;
+}
+
+
+struct __attribute__((packed, aligned(4))) i32x2u { int x, y; };       // 4-byte aligned pairs: one dwordx2 load
+struct __attribute__((packed, aligned(4))) f32x2u { float x, y; };
+struct __attribute__((packed, aligned(4))) f32x4u { float x, y, z, w; };
+__device__ __forceinline__ i32x2u ldp(const int32_t* p) { return *reinterpret_cast<const i32x2u*>(p); }
+__device__ __forceinline__ f32x2u ldp(const float* p) { return *reinterpret_cast<const f32x2u*>(p); }
+__device__ __forceinline__ void stp(float* p, float a, float b) { f32x2u v; v.x = a; v.y = b; *reinterpret_cast<f32x2u*>(p) = v; }
+
+
+__device__ __forceinline__ float4 ld4_off(const float* base, uint32_t byte_off) {      // scalar base + 32-bit offset
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float ld1_off(const float* base, uint32_t byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+
+}  // namespace
+
+// ---- molecule-resident single-pass backward of the attention levels (csrc/mol_bwd.hip)
+namespace fni {
+enum { LV_BOND = 0, LV_ATOM = 1, LV_FBOND = 2, LV_FRAG = 3 };      // which extents of MolExt a level's rows / edges are
+struct MolBwdLevel {
+    const float *g_out, *h, *p_sorted, *att;    // dL/d(out) [n,128], projected rows [n,128], signed probabilities [H,m], attention vector
+    int att_w, dst_off, src_off, which;
+    fn_edge_term et;                            // mode 0: dz goes to g_s_orig; mode 2: partials of sum dz (x, 1) go to part_e
+    fn_gat_plan pl;
+    float slope;
+    int mols_per_unit;                          // consecutive molecules a workgroup takes at a time (small levels: several)
+    float *g_h;                                 // [n,128]
+    float *g_s_orig;                            // mode 0: [m_real, H] dL/d(edge term) in ORIGINAL edge order (nullable)
+    float *part_a;                              // column-major [256][FN_MAX_PART] partials of dL/da_dst | dL/da_src
+    float *part_e;                              // mode 2: [n_blk][H * (K + 1)]
+    float *scr_z;                               // [H, m]  edge state of units that do not fit the LDS tile
+    float *scr_gsd;                             // [n, H]  ditto, per-node scalars
+    int first_blk, n_blk, n_fast, n_units;      // filled by launch_mol_bwd: n_blk = partial rows written (n_fast fast + the slow workgroups)
+};
+constexpr int kMolBwdMaxLevels = 3;
+// one launch for up to three independent levels; returns 0 / error code.  ext: MolExt[n_mols] (device); counts_dev: nullable
+// device count of the real molecules (rows behind them are padding: their outputs are zeroed); status: nullable, bit 2 = a unit
+// was not closed under the level's edges (the batch is not molecule-contiguous)
+FNI_HIDDEN int launch_mol_bwd(MolBwdLevel* lv, int n_lv, const MolExt* ext, int64_t n_mols, int64_t rows_hint, const int32_t* counts_dev,
+                              int32_t* status, int heads, hipStream_t st);
+FNI_HIDDEN bool mol_bwd_supported(int heads);
+}  // namespace fni

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "fragnet_hip.h"
+#include "fn_internal.h"
 
 namespace {
 
@@ -63,60 +64,6 @@ inline int flat_grid(int64_t work, int cap) {
     if (g < 1) g = 1;
     if (g > cap) g = cap;
     return (int)g;
-}
-
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-__device__ __forceinline__ void fma4(float4& acc, float s, float4 v) {
-    acc.x = fmaf(s, v.x, acc.x); acc.y = fmaf(s, v.y, acc.y);
-    acc.z = fmaf(s, v.z, acc.z); acc.w = fmaf(s, v.w, acc.w);
-}
-
-// XCD-aware work split.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has
-// its own 4 MiB L2), so logical block ids are remapped to give every XCD one CONTIGUOUS range of rows: the
-// source rows a destination gathers belong to the same molecule, i.e. to neighbouring rows, and then stay
-// in that XCD's L2 instead of being fetched by all eight.  Bijective for any grid size; speed only.
-__device__ __forceinline__ int xcd_block(int b, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, x = b & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-}
-// [begin, end) of the row groups (RB rows each) owned by this block: contiguous chunks, XCD-swizzled
-__device__ __forceinline__ void block_groups(int64_t n_rows, int rb, int64_t& begin, int64_t& end) {
-    const int64_t groups = (n_rows + rb - 1) / rb;
-    const int64_t per = (groups + gridDim.x - 1) / gridDim.x;
-    begin = (int64_t)xcd_block(blockIdx.x, gridDim.x) * per;
-    end = begin + per < groups ? begin + per : groups;
-}
-
-__device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t seed) {
-    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t m0 = (uint64_t)0xD2511F53u * c0, m1 = (uint64_t)0xCD9E8D57u * c2;       // one v_mad_u64_u32 each
-        const uint32_t hi0 = (uint32_t)(m0 >> 32), lo0 = (uint32_t)m0, hi1 = (uint32_t)(m1 >> 32), lo1 = (uint32_t)m1;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return make_uint4(c0, c1, c2, c3);
-}
-
-__device__ __forceinline__ float keep_scale(uint32_t bits, float p, float inv_keep) {
-    const float u = (float)(bits >> 8) * (1.0f / 16777216.0f);
-    return u >= p ? inv_keep : 0.f;
-}
-
-template <int W> __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int off = W / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-template <int W> __device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-    for (int off = W / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
 }
 
 // =====================================================================================
@@ -309,36 +256,6 @@ __global__ void k_plan_aux_src(PlanTasks P, const int32_t* __restrict__ perm_all
 // =====================================================================================
 // Attention level
 // =====================================================================================
-constexpr int kWfLd = FN_MAX_EDGE_K + 1;
-
-// ---- reductions over the LPH lanes of one head group.  DPP row operations (one VALU op each) instead of
-// ds_bpermute: row_half_mirror pairs lane i with 7-i inside each 8 lanes, quad_perm covers xor 1 / xor 2.
-template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
-constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
-constexpr int kDppHalfMirror = 0x141; // lane i <- lane 7-i  (within 8)
-constexpr int kDppMirror = 0x140;     // lane i <- lane 15-i (within 16)
-
-template <int W> __device__ __forceinline__ float head_sum(float v) {
-    static_assert(W == 4 || W == 8 || W == 16 || W == 32, "head group width");
-    if (W == 32) v += __shfl_xor(v, 16);
-    if (W >= 16) v += dpp_mov<kDppMirror>(v);
-    if (W >= 8) v += dpp_mov<kDppHalfMirror>(v);
-    v += dpp_mov<kDppXor2>(v);
-    v += dpp_mov<kDppXor1>(v);
-    return v;
-}
-template <int W> __device__ __forceinline__ float head_max(float v) {
-    if (W == 32) v = fmaxf(v, __shfl_xor(v, 16));
-    if (W >= 16) v = fmaxf(v, dpp_mov<kDppMirror>(v));
-    if (W >= 8) v = fmaxf(v, dpp_mov<kDppHalfMirror>(v));
-    v = fmaxf(v, dpp_mov<kDppXor2>(v));
-    v = fmaxf(v, dpp_mov<kDppXor1>(v));
-    return v;
-}
-
 // folded edge-embedding weights: Wf[h][k] = sum_c att[h, mid+c] * embW[c,k],  Wf[h][K] = sum_c att[h, mid+c] * embb[c]
 __device__ __forceinline__ void fold_edge_embed(const fn_edge_term& et, const float* att, int att_w, int H,
                                                 float (*sWf)[kWfLd]) {
@@ -369,13 +286,6 @@ __device__ __forceinline__ float edge_term_at(int pos, int head, int64_t m, cons
     for (int k = 0; k < et.K; ++k) e = fmaf(et.x_sorted[(size_t)k * m + pos], sWf[head][k], e);
     return e;
 }
-
-struct __attribute__((packed, aligned(4))) i32x2u { int x, y; };       // 4-byte aligned pairs: one dwordx2 load
-struct __attribute__((packed, aligned(4))) f32x2u { float x, y; };
-struct __attribute__((packed, aligned(4))) f32x4u { float x, y, z, w; };
-__device__ __forceinline__ i32x2u ldp(const int32_t* p) { return *reinterpret_cast<const i32x2u*>(p); }
-__device__ __forceinline__ f32x2u ldp(const float* p) { return *reinterpret_cast<const f32x2u*>(p); }
-__device__ __forceinline__ void stp(float* p, float a, float b) { f32x2u v; v.x = a; v.y = b; *reinterpret_cast<f32x2u*>(p) = v; }
 
 template <int H>
 __global__ __launch_bounds__(kBlock) void k_node_scalars(const float* __restrict__ h, const float* __restrict__ att,
@@ -419,13 +329,6 @@ template <int NE> struct FwdRawT {                            // sized to the lo
     i32x2u sp;
     f32x2u e[NE];
 };
-__device__ __forceinline__ float4 ld4_off(const float* base, uint32_t byte_off) {      // scalar base + 32-bit offset
-    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-__device__ __forceinline__ float ld1_off(const float* base, uint32_t byte_off) {
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-
 // The hot loop is STRAIGHT-LINE: every load is unconditional (addresses clamped into the arrays, results masked
 // afterwards).  A load inside a divergent branch whose value is used inside that branch makes the compiler wait
 // for vmcnt(0) right there -- which serialised the row gathers, the two source-scalar gathers and the prefetches
@@ -2385,6 +2288,17 @@ __global__ __launch_bounds__(RB * 32, 4) void k_gat_bwd_src_lin_rd(GatBwdSrcArgs
     else row_dots_sorted_bwd_body(R, reinterpret_cast<float(*)[FN_D]>(&sA[0][0]), g - A.nblk, R.nblk);
 }
 
+// input-gradient products (one 64 x 64 tile per workgroup, RowAdd epilogue where a task carries one) || the parameter-gradient
+// partials (and, g_feat != null, the rows' term) of an attention level's edge term: the launch between two molecule-resident
+// backward passes (csrc/mol_bwd.hip), which leave no attention pass for the products to ride with
+__global__ __launch_bounds__(kBlock, 4) void k_lin_rd(LinTasks T, RowDotsBwdArgs R) {
+    extern __shared__ __attribute__((aligned(16))) float sBt[];
+    __shared__ float sR[kRows][FN_D];
+    const int b = (int)blockIdx.x;
+    if (b < T.total) { lin_side_block(sBt, T, b);  return; }
+    row_dots_sorted_bwd_body(R, sR, b - T.total, R.nblk);
+}
+
 // Bt[k][n] = W[n][k]  (W is nn.Linear.weight [128, K])
 __global__ void k_transpose_w(const float* __restrict__ W, int K, float* __restrict__ Bt) {
     __shared__ float tile[32][33];
@@ -2820,7 +2734,15 @@ bool bad_edge_term(const fn_edge_term* et) {
 namespace {
 unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
 int64_t g_mol_stamps_n = 0;
-int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 256, 2, -1, 0, 1};   // FN_TUNE_FWD_BLOCKS, FN_TUNE_GEMM_SLOTS, FN_TUNE_STREAMS, FN_TUNE_WGRAD_BLOCKS, FN_TUNE_FUSED
+int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 256, 2, -1, 0, 1, 0, 0};   // in the order of the FN_TUNE_* keys
+}  // namespace
+namespace fni {      // hooks for the other translation units (fn_internal.h)
+int fail(int code, const char* what) { return ::fail(code, what); }
+int launch_status(const char* where) { return ::launch_status(where); }
+int tune(int key) { return key >= 0 && key < FN_TUNE_COUNT ? g_tune[key] : 0; }
+unsigned long long* stamps(int64_t* n_u64) { *n_u64 = g_mol_stamps_n;  return g_mol_stamps; }
+}  // namespace fni
+namespace {
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -3447,6 +3369,37 @@ int fn_gat_bwd_src_f32(const float* g_out, const float* h, const float* pz_src,
     return launch_gat_bwd_src(A, heads, S(stream));
 }
 
+namespace {
+__global__ void k_mol_extents(MolExtArgs A) { mol_extents_body(A, (int)blockIdx.x); }
+}
+int fn_mol_extents(const fn_seg_plan* mol_atoms, const fn_seg_plan* mol_frags, const fn_gat_plan* bond, const fn_gat_plan* atom,
+                   const fn_gat_plan* fbond, const fn_gat_plan* frag, int64_t n_mols, int32_t* ext, fn_stream_t stream) {
+    if (!mol_atoms || !mol_frags || !bond || !atom || !frag || !ext || n_mols < 0) return fail(FN_EINVAL, "fn_mol_extents: bad argument");
+    if (mol_atoms->n_seg != n_mols || mol_frags->n_seg != n_mols) return fail(FN_EINVAL, "fn_mol_extents: the molecule CSRs must have n_mols segments");
+    if (n_mols == 0) return 0;
+    const MolExtArgs A{mol_atoms->rowptr, mol_frags->rowptr, mol_atoms->pos_base, mol_frags->pos_base, *bond, *atom,
+                       fbond ? *fbond : fn_gat_plan{}, *frag, (int)n_mols, reinterpret_cast<MolExt*>(ext)};
+    hipLaunchKernelGGL(k_mol_extents, dim3((unsigned)((n_mols + 255) / 256)), dim3(256), 0, S(stream), A);
+    return launch_status("fn_mol_extents");
+}
+
+int fn_gat_bwd_mol_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et, const float* att,
+                       int att_w, int dst_off, int src_off, const fn_gat_plan* plan, float slope, const int32_t* mol_ext,
+                       int64_t n_mols, int which, int mols_per_unit, const int32_t* counts_dev, float* g_h, float* g_s_orig,
+                       float* part_a, float* part_e, int* n_part, float* scratch, int32_t* status, int heads, fn_stream_t stream) {
+    if (!plan || !mol_ext || !n_part || bad_edge_term(et) || which < 0 || which > 3 || !scratch) return fail(FN_EINVAL, "fn_gat_bwd_mol_f32: bad argument");
+    fni::MolBwdLevel L{};
+    L.g_out = g_out;  L.h = h;  L.p_sorted = p_sorted;  L.att = att;  L.att_w = att_w;  L.dst_off = dst_off;  L.src_off = src_off;
+    L.which = which;  L.et = *et;  L.pl = *plan;  L.slope = slope;  L.mols_per_unit = mols_per_unit;
+    L.g_h = g_h;  L.g_s_orig = g_s_orig;  L.part_a = part_a;  L.part_e = part_e;
+    L.scr_z = scratch;  L.scr_gsd = scratch + (size_t)heads * plan->m;
+    int64_t rows = 0;       // size class: mean rows per molecule of this level
+    rows = plan->n;
+    if (int rc = fni::launch_mol_bwd(&L, 1, reinterpret_cast<const fni::MolExt*>(mol_ext), n_mols, rows, counts_dev, status, heads, S(stream))) return rc;
+    *n_part = L.n_blk;
+    return 0;
+}
+
 int fn_gat_bwd_finalize_f32(const float* part_a, int n_part_a, const float* part_e, int n_part_e, const fn_edge_term* et,
                             const float* att, int att_w, int dst_off, int src_off, float* g_att, float* g_embW,
                             float* g_embb, int heads, fn_stream_t stream) {
@@ -4007,9 +3960,15 @@ EncLayout enc_layout(const fn_encoder* e, float* ws) {
 }
 
 // the molecule-resident fused kernels apply when the caller handed over the molecule CSRs (and the tuning switch is on)
+bool have_mol(const fn_encoder* e) {       // the caller handed over the molecule CSRs: every level is block-diagonal per molecule
+    return e->n_mols > 0 && e->mol_atoms.rowptr && e->mol_frags.rowptr && e->mol_atoms.n_seg == e->n_mols && e->mol_frags.n_seg == e->n_mols;
+}
 bool mol_fused(const fn_encoder* e) {
-    return g_tune[FN_TUNE_FUSED] != 0 && e->heads == 4 && e->n_mols > 0 && e->mol_atoms.rowptr && e->mol_frags.rowptr &&
-           e->mol_atoms.n_seg == e->n_mols && e->mol_frags.n_seg == e->n_mols && g_tune[FN_TUNE_STREAMS] == 0;
+    return g_tune[FN_TUNE_FUSED] != 0 && e->heads == 4 && have_mol(e) && g_tune[FN_TUNE_STREAMS] == 0;
+}
+// the backward of every attention level as one pass of the molecule-resident kernel (csrc/mol_bwd.hip)
+bool mol_bwd_on(const fn_encoder* e) {
+    return g_tune[FN_TUNE_BWD_MOL] != 0 && have_mol(e) && fni::mol_bwd_supported(e->heads) && g_tune[FN_TUNE_STREAMS] == 0;
 }
 
 // Backward scratch.  Nothing is reused across levels or layers: the kernels that only produce parameter gradients
@@ -4308,6 +4267,242 @@ int bwd_src_and_edge_term(const float* g_out, const float* h, const float* pz_sr
     return launch_status("source pass + edge-term backward");
 }
 
+// GEMM tiles + edge-term blocks as one launch (k_lin_rd); falls back to separate launches when a part is empty or misaligned
+static int launch_lin_rd(LinTasks& T, const RowDotsBwdArgs& R, hipStream_t st) {
+    int blocks = 0, live = 0;
+    bool aligned = true;
+    for (int i = 0; i < T.n; ++i) {
+        if (T.t[i].M <= 0) continue;
+        LinTask t = T.t[i];
+        if (((uintptr_t)t.X | (uintptr_t)t.Bt | (uintptr_t)t.Y | (uintptr_t)t.bias | (uintptr_t)t.mk.y) & 15) aligned = false;
+        t.first = blocks;
+        t.nblk = lin_blocks((t.M + kLinRows - 1) / kLinRows, 1);
+        blocks += t.nblk;
+        T.t[live++] = t;
+    }
+    T.n = live;  T.K = FN_D;  T.total = blocks;  T.base = 0;  T.prio = 0;
+    if (!live || !aligned || R.nblk == 0) {
+        if (live) if (int rc = launch_linear128_group(T, st)) return rc;
+        if (R.nblk) {
+            hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(R.nblk), dim3(kBlock), 0, st, R);
+            return launch_status("edge-term backward");
+        }
+        return 0;
+    }
+    hipLaunchKernelGGL(k_lin_rd, dim3(blocks + R.nblk), dim3(kBlock), kLinSideLds, st, T, R);
+    return launch_status("input-gradient products + edge-term backward");
+}
+
+// ---- fn_encoder_backward with every attention level as ONE pass of the molecule-resident kernel (csrc/mol_bwd.hip).
+// Gradient flows atom level -> bond levels only (through the edge term <new_bond[e], a[:, mid]>), so the atom chain of layer l
+// and the bond chain of layer l+1 run side by side, two launches per layer:
+//   L1  k_mol_bwd  { bond level (l+1), atom level (l), fragment-bond level (l+1) }           three independent levels
+//   L2  k_lin_rd   { dX of the atom projection (l), of the bond projection (l+1) + the atom graph's edge-term gradient of layer l
+//                    on the rows it writes (RowAdd), of the fragment-bond projection (l+1) }  ||  the edge term's parameter partials
+// and every weight-gradient partial product / parameter-gradient reduction is queued for the two launches at the very end.
+// A task is queued only after the launch that produces its operands has been enqueued, so a flush in the middle of the
+// pass (six or more layers) reads finished buffers.
+int encoder_backward_mol(const fn_encoder* e, const EncLayout& lay, const BwdLayout& bw, const RngPlan& rng, const float* out_atoms,
+                         const float* out_frags, const float* out_bond, const float* out_fbond, const float* g_atoms, const float* g_frags,
+                         const float* g_bond, const float* g_fbond, const fn_layer_weights* grads, hipStream_t hs) {
+    const int H = e->heads, d = FN_D / H, wide = 2 * d + FN_D, NL = e->n_layers;
+    const float p = e->training ? e->drop_p : 0.f;
+    const bool lite = e->variant == 1, edge = e->variant == 2, no_fb = lite || edge;
+    const fni::MolExt* ext = reinterpret_cast<const fni::MolExt*>(lay.mol_ext);
+    ReduceQueue rq;
+    rq.st = hs;
+    rq.defer_wgrad = true;
+    rq.defer_mixed = g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;
+    auto mol_launch = [&](fni::MolBwdLevel* lv, int n) -> int {
+        return n ? fni::launch_mol_bwd(lv, n, ext, e->n_mols, e->E, e->counts_dev, e->status, H, hs) : 0;
+    };
+    auto level = [&](int which, const float* g_out, const float* h, const float* p_sorted, const float* att, int att_w, int src_off,
+                     const fn_edge_term& et, const fn_gat_plan& pl, const LevelScratch& sc, float* g_s_orig, int per_unit) {
+        fni::MolBwdLevel L{};
+        L.g_out = g_out;  L.h = h;  L.p_sorted = p_sorted;  L.att = att;  L.att_w = att_w;  L.dst_off = 0;  L.src_off = src_off;
+        L.which = which;  L.et = et;  L.pl = pl;  L.slope = 0.2f;  L.mols_per_unit = per_unit;
+        L.g_h = sc.g_h;  L.g_s_orig = g_s_orig;  L.part_a = sc.part_a;  L.part_e = sc.part_e;  L.scr_z = sc.pz;  L.scr_gsd = sc.g_s_dst;
+        return L;
+    };
+    const int kPerBond = 1, kPerAtom = 2, kPerFbond = 8, kPerFrag = 16;
+
+    bool have_atoms = g_atoms != nullptr, have_frags = g_frags != nullptr, have_bond = g_bond != nullptr, have_fbond = g_fbond != nullptr;
+    {   // backward of relu(dropout(.)) of the last layer's outputs (y > 0 already encodes the mask): one launch
+        GateTasks G{};
+        auto add = [&](const float* g, const float* y, float* o, int64_t numel) {
+            if (!g) return;
+            GateTask& t = G.t[G.n++];
+            t.g = g;  t.y = y;  t.o = o;  t.n4 = (numel + 3) / 4;  t.first = G.blocks;  t.nblk = flat_grid(t.n4, 512);
+            G.blocks += t.nblk;
+        };
+        add(g_atoms, out_atoms, bw.g_pre_atoms, e->N * FN_D);
+        add(g_frags, out_frags, bw.g_pre_frags, e->F * FN_D);
+        add(g_bond, out_bond, bw.g_pre_bond, e->E * FN_D);
+        add(g_fbond, out_fbond, bw.g_pre_fbond, e->EF * FN_D);
+        if (G.blocks) {
+            G.scale = p > 0.f ? (p < 1.f ? 1.f / (1.f - p) : 0.f) : 1.f;
+            hipLaunchKernelGGL(k_gate_many, dim3(G.blocks), dim3(kBlock), 0, hs, G);
+            FN_TRY(launch_status("fn_encoder_backward: activation backward"));
+        }
+    }
+
+    bool pend_b = false, pend_fb = false;        // bond / fragment-bond level of layer l+1: gradients ready, pass not launched yet
+    for (int l = NL - 1; l >= 0; --l) {
+        const fn_layer_weights& w = e->w[l];
+        const fn_layer_weights& g = grads[l];
+        const LayerActs& a = lay.L[l];
+        const bool last = l + 1 == NL;
+        const float* in_atoms = l ? lay.L[l - 1].y_atoms : (lay.in_atoms0 ? lay.in_atoms0 : e->x_atoms);
+        const int ka = l ? FN_D : e->k_atom0;
+        const LevelScratch &sa = bw.atom[l], &sf = bw.frag;
+
+        // ---- L4b fragment graph (only the last layer's output is ever read) and L3 atom -> fragment sum
+        if (last && have_frags) {
+            const float* g_frags_h = bw.g_frags;
+            if (lite) {
+                g_frags_h = bw.g_pre_frags;
+            } else if (edge) {       // gat2_edge: the edge term's parameters are the cnx_attr Linear (emb_fb_*) and f's middle block
+                fn_edge_term et_f{2, e->k_fattr, FN_D, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
+                LevelScratch sc = sf;  sc.g_h = bw.g_frags;
+                fni::MolBwdLevel F = level(fni::LV_FRAG, bw.g_pre_frags, a.frags, a.p_frag, w.f, wide, d + FN_D, et_f, e->frag, sc, nullptr, kPerFrag);
+                FN_TRY(mol_launch(&F, 1));
+                FN_TRY(rq.finalize(sf.part_a, F.n_blk, sf.part_e, F.n_blk, et_f, w.f, wide, 0, d + FN_D, g.f, g.emb_fb_w, g.emb_fb_b, H));
+            } else {
+                fn_edge_term et_f{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+                LevelScratch sc = sf;  sc.g_h = bw.g_frags;
+                fni::MolBwdLevel F = level(fni::LV_FRAG, bw.g_pre_frags, a.frags, a.p_frag, w.f, wide, d + FN_D, et_f, e->frag, sc, sf.dz, kPerFrag);
+                FN_TRY(mol_launch(&F, 1));
+                FN_TRY(rq.finalize(sf.part_a, F.n_blk, nullptr, 0, et_f, w.f, wide, 0, d + FN_D, g.f, nullptr, nullptr, H));
+                // edge term <new_fbond, f[:, d:d+128]>: dL/dnew_fbond (accumulates into g_pre_fbond) and dL/df's middle block
+                const int gr = e->frag.m_real > 0 ? row_grid(e->frag.m_real, g_tune[FN_TUNE_RD_BLOCKS] > 0 ? g_tune[FN_TUNE_RD_BLOCKS] : kRowDotsBwdBlocks) : 0;
+                if (gr) {
+                    const RowDotsBwdArgs T{sf.dz, a.new_fbond, w.f, wide, d, H, e->frag, bw.g_pre_fbond, sf.part_rd,
+                                           have_fbond ? (const float*)bw.g_pre_fbond : nullptr, 1, gr};
+                    hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(gr), dim3(kBlock), 0, hs, T);
+                    FN_TRY(launch_status("fragment graph: edge-term backward"));
+                    FN_TRY(rq.colsum(sf.part_rd, gr, H * FN_D, g.f, wide, d));
+                    have_fbond = true;
+                }
+            }
+            hipLaunchKernelGGL(k_gather_rows4, dim3(flat_grid(e->N * 32, kGridCap)), dim3(kBlock), 0, hs, g_frags_h, e->a2f.index,
+                               bw.g_pre_atoms, e->N, (int64_t)32, have_atoms ? (const float*)bw.g_pre_atoms : (const float*)nullptr);
+            FN_TRY(launch_status("fn_encoder_backward: gather(a2f)"));
+            have_atoms = true;
+        }
+
+        // ---- L1: the atom level of this layer beside the bond / fragment-bond levels of layer l+1
+        fni::MolBwdLevel lv[3];
+        int nl = 0, iA = -1, iB = -1, iFB = -1;
+        const fn_edge_term et_a{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+        if (pend_b) {
+            const fn_layer_weights& wn = e->w[l + 1];
+            const fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, wn.emb_b_w, wn.emb_b_b};
+            iB = nl;
+            lv[nl++] = level(fni::LV_BOND, bw.g_pre_bond, lay.L[l + 1].h_b, lay.L[l + 1].p_bond, wn.a_b, 3 * d, 2 * d, et_b, e->bond, bw.bond[l + 1], nullptr, kPerBond);
+        }
+        if (have_atoms) {
+            iA = nl;
+            lv[nl++] = level(fni::LV_ATOM, bw.g_pre_atoms, a.h_a, a.p_atom, w.a, wide, d + FN_D, et_a, e->atom, sa, sa.dz, kPerAtom);
+        }
+        if (pend_fb) {
+            const fn_layer_weights& wn = e->w[l + 1];
+            const fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, wn.emb_fb_w, wn.emb_fb_b};
+            iFB = nl;
+            lv[nl++] = level(fni::LV_FBOND, bw.g_pre_fbond, lay.L[l + 1].h_fb, lay.L[l + 1].p_fbond, wn.f_a_b, 3 * d, 2 * d, et_fb, e->fbond, bw.fbond[l + 1], nullptr, kPerFbond);
+        }
+        FN_TRY(mol_launch(lv, nl));
+
+        // ---- L2: input-gradient products of what L1 produced (+ the atom graph's edge term), and the deferred parameter work
+        LinTasks T{};
+        const fn_act_epilogue no_ns_mk{nullptr, 0.f, 0, 0, 0, nullptr};
+        (void)no_ns_mk;
+        auto product = [&](const float* gh, const float* W, const float* Wt, float* gy, int64_t rows, const fn_act_epilogue& mk, const RowAdd* ra) {
+            LinTask& t = T.t[T.n++];
+            t = LinTask{Wt, gh, W, nullptr, gy, rows, mk, NodeScalarEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0}, 0, 0};
+            if (ra) t.ra = *ra;
+        };
+        bool nxt_bond = false, nxt_fbond = false, nxt_atoms = false;
+        const bool rd_rows_ride = iA >= 0 && iB >= 0 && e->atom.m_real == e->E && e->E > 0;      // the bond product of layer l+1 carries the rows' term
+        if (iB >= 0) {       // layer l+1's bond level: parameter work + dL/d(pre-activation bond output of layer l)
+            const fn_layer_weights& wn = e->w[l + 1];
+            const fn_layer_weights& gn = grads[l + 1];
+            const LevelScratch& sb = bw.bond[l + 1];
+            const fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, wn.emb_b_w, wn.emb_b_b};
+            FN_TRY(rq.finalize(sb.part_a, lv[iB].n_blk, sb.part_e, lv[iB].n_blk, et_b, wn.a_b, 3 * d, 0, 2 * d, gn.a_b, gn.emb_b_w, gn.emb_b_b, H));
+            FN_TRY(rq.wgrad(sb.g_h, a.y_bond, FN_D, e->E, sb.wg_ws, gn.proj_b_w, gn.proj_b_b, hs));
+            const fn_act_epilogue mk{const_cast<float*>(a.y_bond), p, 1, e->seed, rng.y[l][2], e->offset_dev};
+            const RowAdd ra{sa.dz, w.a + d, wide};
+            product(sb.g_h, wn.proj_b_w, lay.bt + (size_t)(3 * (l + 1)) * 192 * FN_D, bw.g_pre_bond, e->E, mk, rd_rows_ride ? &ra : nullptr);
+            nxt_bond = true;
+        }
+        if (iFB >= 0) {
+            const fn_layer_weights& wn = e->w[l + 1];
+            const fn_layer_weights& gn = grads[l + 1];
+            const LevelScratch& sfb = bw.fbond[l + 1];
+            const fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, wn.emb_fb_w, wn.emb_fb_b};
+            FN_TRY(rq.finalize(sfb.part_a, lv[iFB].n_blk, sfb.part_e, lv[iFB].n_blk, et_fb, wn.f_a_b, 3 * d, 0, 2 * d, gn.f_a_b, gn.emb_fb_w, gn.emb_fb_b, H));
+            FN_TRY(rq.wgrad(sfb.g_h, a.y_fbond, FN_D, e->EF, sfb.wg_ws, gn.proj_fb_w, gn.proj_fb_b, hs));
+            const fn_act_epilogue mk{const_cast<float*>(a.y_fbond), p, 1, e->seed, rng.y[l][3], e->offset_dev};
+            product(sfb.g_h, wn.proj_fb_w, lay.bt + (size_t)(3 * (l + 1) + 2) * 192 * FN_D, bw.g_pre_fbond, e->EF, mk, nullptr);
+            nxt_fbond = true;
+        }
+        RowDotsBwdArgs R{};
+        if (iA >= 0) {
+            FN_TRY(rq.finalize(sa.part_a, lv[iA].n_blk, nullptr, 0, et_a, w.a, wide, 0, d + FN_D, g.a, nullptr, nullptr, H));
+            FN_TRY(rq.wgrad(sa.g_h, in_atoms, ka, e->N, sa.wg_ws, g.proj_a_w, g.proj_a_b, hs));
+            if (l) {
+                const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_atoms), p, 1, e->seed, rng.y[l - 1][0], e->offset_dev};
+                product(sa.g_h, w.proj_a_w, lay.bt + (size_t)(3 * l + 1) * 192 * FN_D, bw.g_pre_atoms, e->N, mk, nullptr);
+                nxt_atoms = true;
+            }
+            // the edge term <new_bond[e], a[:, d:d+128]> of the atom graph: parameter partials always; the rows' term (dL/dnew_bond)
+            // rides in the bond product above, or -- no product to ride in (top layer) -- is written / accumulated here
+            const int gr = e->atom.m_real > 0 ? row_grid(e->atom.m_real, g_tune[FN_TUNE_RD_BLOCKS] > 0 ? g_tune[FN_TUNE_RD_BLOCKS] : kRowDotsBwdBlocks) : 0;
+            if (gr) {
+                const bool have_b_now = iB >= 0 || (last && have_bond);
+                R = RowDotsBwdArgs{sa.dz, a.new_bond, w.a, wide, d, H, e->atom, rd_rows_ride ? nullptr : bw.g_pre_bond, sa.part_rd,
+                                   (!rd_rows_ride && have_b_now) ? (const float*)bw.g_pre_bond : nullptr, 1, gr};
+                FN_TRY(rq.colsum(sa.part_rd, gr, H * FN_D, g.a, wide, d));
+                nxt_bond = true;
+            }
+        }
+        if (R.nblk && !rd_rows_ride && iB >= 0) {
+            // (atom graph whose edges are not the bonds in order: the product first, the rows' term accumulates behind it)
+            FN_TRY(launch_linear128_group(T, hs));
+            T = LinTasks{};
+        }
+        FN_TRY(launch_lin_rd(T, R, hs));
+
+        // ---- what the next iteration's L1 finds
+        if (last) { nxt_bond = nxt_bond || have_bond;  nxt_fbond = nxt_fbond || have_fbond; }
+        pend_b = nxt_bond;
+        pend_fb = nxt_fbond && !no_fb;
+        have_atoms = nxt_atoms;
+        have_bond = have_fbond = have_frags = false;
+        // layer l's bond levels run in iteration l-1 (or behind the loop); their operands of THIS layer are named there via l+1
+    }
+    {   // the bond / fragment-bond levels of layer 0
+        fni::MolBwdLevel lv[2];
+        int nl = 0, iB = -1, iFB = -1;
+        const fn_layer_weights& w0 = e->w[0];
+        const fn_layer_weights& g0 = grads[0];
+        const fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w0.emb_b_w, w0.emb_b_b};
+        const fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w0.emb_fb_w, w0.emb_fb_b};
+        if (pend_b) { iB = nl;  lv[nl++] = level(fni::LV_BOND, bw.g_pre_bond, lay.L[0].h_b, lay.L[0].p_bond, w0.a_b, 3 * d, 2 * d, et_b, e->bond, bw.bond[0], nullptr, kPerBond); }
+        if (pend_fb) { iFB = nl;  lv[nl++] = level(fni::LV_FBOND, bw.g_pre_fbond, lay.L[0].h_fb, lay.L[0].p_fbond, w0.f_a_b, 3 * d, 2 * d, et_fb, e->fbond, bw.fbond[0], nullptr, kPerFbond); }
+        FN_TRY(mol_launch(lv, nl));
+        if (iB >= 0) {
+            FN_TRY(rq.finalize(bw.bond[0].part_a, lv[iB].n_blk, bw.bond[0].part_e, lv[iB].n_blk, et_b, w0.a_b, 3 * d, 0, 2 * d, g0.a_b, g0.emb_b_w, g0.emb_b_b, H));
+            FN_TRY(rq.wgrad(bw.bond[0].g_h, e->bond_nodes, e->k_bond0, e->E, bw.bond[0].wg_ws, g0.proj_b_w, g0.proj_b_b, hs));
+        }
+        if (iFB >= 0) {
+            FN_TRY(rq.finalize(bw.fbond[0].part_a, lv[iFB].n_blk, bw.fbond[0].part_e, lv[iFB].n_blk, et_fb, w0.f_a_b, 3 * d, 0, 2 * d, g0.f_a_b, g0.emb_fb_w, g0.emb_fb_b, H));
+            FN_TRY(rq.wgrad(bw.fbond[0].g_h, e->fbond_nodes, e->k_fbond0, e->EF, bw.fbond[0].wg_ws, g0.proj_fb_w, g0.proj_fb_b, hs));
+        }
+    }
+    return rq.flush();
+}
+
 int enc_check(const fn_encoder* e) {
     if (!e) return fail(FN_EINVAL, "fn_encoder: null descriptor");
     if (e->n_layers < 1 || e->n_layers > FN_MAX_LAYERS) return fail(FN_EINVAL, "fn_encoder: n_layers out of range");
@@ -4383,11 +4578,13 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
             A.sx[1] = e->fattr_raw;  A.so[1] = const_cast<float*>(e->fattr_sorted);  A.sK[1] = e->k_fattr;  A.spl[1] = fattr_plan;
             A.n_s[1] = flat_grid(fattr_plan.m * e->k_fattr, 512);
         }
-        if (fused) {
+        if (fused || mol_bwd_on(e)) {
             A.mx = MolExtArgs{e->mol_atoms.rowptr, e->mol_frags.rowptr, e->mol_atoms.pos_base, e->mol_frags.pos_base,
                               e->bond, e->atom, no_fb ? fn_gat_plan{} : e->fbond, e->frag, (int)e->n_mols,
                               reinterpret_cast<MolExt*>(lay.mol_ext)};
             A.n_x = (int)((e->n_mols + 255) / 256);
+        }
+        if (fused) {
             for (int l = 0; l < e->n_layers; ++l) {
                 A.fold.att[2 * l] = e->w[l].a_b;  A.fold.embW[2 * l] = e->w[l].emb_b_w;  A.fold.embb[2 * l] = e->w[l].emb_b_b;  A.fold.Ke[2 * l] = 1;
                 A.fold.att[2 * l + 1] = e->w[l].f_a_b;  A.fold.embW[2 * l + 1] = e->w[l].emb_fb_w;  A.fold.embb[2 * l + 1] = e->w[l].emb_fb_b;
@@ -4594,6 +4791,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
     const BwdLayout bw = bwd_layout(e, scratch);
     if (bw.total > scratch_floats) return fail(FN_EINVAL, "fn_encoder_backward: scratch too small");
     const RngPlan rng = rng_plan(e);
+    if (mol_bwd_on(e)) return encoder_backward_mol(e, lay, bw, rng, out_atoms, out_frags, out_bond, out_fbond, g_atoms, g_frags, g_bond, g_fbond, grads, S(st));
     const int H = e->heads, d = FN_D / H;
     const float p = e->training ? e->drop_p : 0.f;
     const int wide = 2 * d + FN_D;

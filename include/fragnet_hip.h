@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FN_ABI_VERSION 6
+#define FN_ABI_VERSION 7
 #define FN_D 128              /* feature width of every node table on the path (emb_dim) */
 #define FN_MAX_TASKS 16       /* CSR builds fused into one fn_plan_build call */
 #define FN_MAX_EDGE_K 8       /* widest raw edge attribute folded in-kernel (6 for fragment bonds) */
@@ -94,7 +94,17 @@ int fn_abi_version(void);
                                   * (three launches per layer: k_gat_bwd_src_pair_dst, k_gat_bwd_src_lin_rd, k_gat_bwd_dst_pair_lin; the
                                   * atom graph's edge-term gradient lands on the bond rows in the epilogue of the bond input-gradient
                                   * product); 0: four launches per layer in series.  Needs 4 heads and FN_TUNE_GEMM_COLAUNCH != 0 */
-#define FN_TUNE_COUNT 18
+#define FN_TUNE_BWD_MOL 18        /* 1: fn_encoder_backward runs every attention level's backward as ONE pass of the molecule-resident
+                                  * kernel (csrc/mol_bwd.hip: a workgroup owns whole molecules, stages their gradient rows in LDS
+                                  * once, never sends (p, dz) through memory; two launches per layer) when the batch carries
+                                  * molecule CSRs (fn_encoder.n_mols) and heads == 4.  0 (default): destination pass + source pass.
+                                  * Measured (MI355X, ESOL batch 512, bond level): 39 us against 28.7 us for the two passes -- every
+                                  * workgroup carries one molecule through load -> three barrier-separated passes, and the largest
+                                  * molecule (2 x the mean) sets the launch time; DESIGN.md has the phase timings */
+#define FN_TUNE_BWD_MOL_FORCE_SLOW 19 /* test / dev hook of the molecule-resident backward: 1 = every unit takes the path for molecules
+                                  * that do not fit the LDS tile (rows and edge state in global memory); 2 = the large size class
+                                  * (1024-thread workgroups, 192 rows); 3, 4 = smaller LDS images */
+#define FN_TUNE_COUNT 20
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * molecules 64-bit words) is
  * set, every workgroup of the fused molecule kernels writes s_memtime stamps of its phases into it (tools/mol_phase_times.py).
@@ -199,6 +209,15 @@ typedef struct fn_gat_plan {          /* slices of the fn_plan_build outputs for
     int64_t m_real;           /* edges with an explicit attribute     */
 } fn_gat_plan;
 
+/* a plain CSR of fn_plan_build (segment sums, pooling, molecule membership) */
+typedef struct fn_seg_plan {
+    const int32_t* rowptr;    /* [n_seg+1] global positions */
+    const int32_t* perm;      /* [n_items] */
+    const int64_t* index;     /* [n_items] the original key (for the gather backward) */
+    int64_t n_seg, n_items;
+    int32_t pos_base, pad_;
+} fn_seg_plan;
+
 /* Optional fused epilogue of the forward kernel: y = relu?(dropout(out)) with the Philox stream of
  * fn_dropout_act_f32 (block index = element / 4), so the standalone backward kernel applies to it. */
 typedef struct fn_act_epilogue {
@@ -236,6 +255,28 @@ int fn_gat_bwd_src_f32(const float* g_out, const float* h, const float* pz_src,
                        const float* g_s_dst, const float* att, int att_w, int dst_off, int src_off,
                        const fn_gat_plan* plan, float* g_h, float* part_a, int* n_part_a,
                        int heads, fn_stream_t stream);
+
+/* Molecule extents of a collated batch.  collate_fn concatenates molecules (dataset/data.py:877-948), so the atoms, directed
+ * bonds, fragments, fragment connections and the edges of the four graphs of molecule i are contiguous ranges; ext [n_mols][16]
+ * int32 = {a0, na, b0, nb, f0, nf, c0, nc, eb0, meb, ea0, mea, ef0, mef, ec0, mec}: first index and count of its atoms / bonds /
+ * fragments / connections, then first destination-sorted position and count of its bond-graph edges, atom-graph items (edges +
+ * self loops), fragment-bond-graph edges and fragment-graph items.  mol_atoms / mol_frags: fn_plan_build segment CSRs keyed by
+ * `batch` / `frag_batch` (gat2.py:820-821); fbond may be NULL (gat2_lite / gat2_edge). */
+int fn_mol_extents(const fn_seg_plan* mol_atoms, const fn_seg_plan* mol_frags, const fn_gat_plan* bond, const fn_gat_plan* atom,
+                   const fn_gat_plan* fbond, const fn_gat_plan* frag, int64_t n_mols, int32_t* ext, fn_stream_t stream);
+
+/* Backward of one attention level in ONE pass (replaces fn_gat_bwd_dst_f32 + fn_gat_bwd_src_f32 for molecule-contiguous batches;
+ * autograd of gat2.py:146-169): a workgroup owns `mols_per_unit` consecutive molecules, stages their g_out rows and edge state
+ * in LDS once, and writes g_h [n,128], the edge-term gradient (mode 0: g_s_orig [m_real, H] in original edge order, nullable;
+ * mode 2: part_e [*n_part, H*(K+1)] partials of sum dz (x, 1)) and part_a (column-major [256][FN_MAX_PART], *n_part rows used),
+ * to be reduced by fn_gat_bwd_finalize_f32.  which: 0 bond graph, 1 atom graph, 2 fragment-bond graph, 3 fragment graph (the
+ * extents of mol_ext the level's rows / edges are).  scratch: [H*m + n*H] floats, used by molecules beyond the LDS tile only.
+ * counts_dev: nullable device int32 = number of real molecules (rows behind them get zero gradients).  status: nullable device
+ * word, bit 1 (value 2) is set when a molecule's edges leave its rows (the batch is not molecule-contiguous).  heads must be 4. */
+int fn_gat_bwd_mol_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et, const float* att,
+                       int att_w, int dst_off, int src_off, const fn_gat_plan* plan, float slope, const int32_t* mol_ext,
+                       int64_t n_mols, int which, int mols_per_unit, const int32_t* counts_dev, float* g_h, float* g_s_orig,
+                       float* part_a, float* part_e, int* n_part, float* scratch, int32_t* status, int heads, fn_stream_t stream);
 
 /* Reduces the partials into g_att [H, att_w] (dst/src blocks, and the edge block in mode 2) and,
  * in mode 2, g_embW [d_e,K], g_embb [d_e].  g_att must be zero-initialised by the caller. */
@@ -447,14 +488,6 @@ int fn_stage_padded(const fn_stage_field* fields, int n_fields, fn_stream_t stre
  * last (the fragment-graph output of inner layers is dead in the reference).
  * ------------------------------------------------------------------------------------------ */
 #define FN_MAX_LAYERS 8
-
-typedef struct fn_seg_plan {
-    const int32_t* rowptr;    /* [n_seg+1] global positions */
-    const int32_t* perm;      /* [n_items] */
-    const int64_t* index;     /* [n_items] the original key (for the gather backward) */
-    int64_t n_seg, n_items;
-    int32_t pos_base, pad_;
-} fn_seg_plan;
 
 typedef struct fn_layer_weights {          /* parameters of one FragNetLayerA, or their gradients */
     float *proj_b_w, *proj_b_b;            /* projection_b  [128,Kb], [128]  (gat2.py:88)  */
