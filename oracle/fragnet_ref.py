@@ -369,6 +369,39 @@ def pool_cat(x_atoms, x_frags, batch):
     return torch.cat((atoms, frags), 1)
 
 
+class InjectedDropout(nn.Module):
+    """Test hook: a drop-in for ``nn.Dropout`` that multiplies its input by SUPPLIED scaled keep masks (mask / (1 - p)) in
+    call order instead of drawing them, so that this restatement can be run with the masks another implementation drew
+    (tests/test_gpu_dropout_parity.py regenerates the HIP path's Philox masks).  ``None`` in the list = identity (a dropout whose
+    result the reference never reads, e.g. gat2.py:397 on x_frags)."""
+
+    def __init__(self, masks, p: float = 0.0):
+        super().__init__()
+        self.masks, self.cursor, self.p = list(masks), 0, p
+
+    def forward(self, x):
+        if self.cursor >= len(self.masks):
+            raise IndexError(f"InjectedDropout: call {self.cursor} has no mask ({len(self.masks)} supplied)")
+        m = self.masks[self.cursor]
+        self.cursor += 1
+        if m is None:
+            return x
+        if m.numel() != x.numel():
+            raise ValueError(f"InjectedDropout: call {self.cursor - 1} got a mask of {m.numel()} elements for an input of {x.numel()}")
+        return x * m.reshape(x.shape)
+
+
+def inject_dropout(model: nn.Module, masks) -> InjectedDropout:
+    """Replaces EVERY ``nn.Dropout`` of ``model`` by one shared InjectedDropout, so the masks are consumed in the order the
+    forward pass calls dropout (gat2.py:396-397, then per layer :414-418, then the head :721-722 / :668-675)."""
+    inj = InjectedDropout(masks)
+    for mod in model.modules():
+        for name, child in list(mod.named_children()):
+            if isinstance(child, nn.Dropout):
+                setattr(mod, name, inj)
+    return inj
+
+
 class FragNetFineTune(nn.Module):
     def __init__(self, n_classes=1, atom_features=167, frag_features=167, edge_features=17, num_layer=4,
                  num_heads=4, drop_ratio=0.15, h1=256, h2=256, h3=256, h4=256, act="celu", emb_dim=128,

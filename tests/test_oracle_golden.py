@@ -183,3 +183,22 @@ def test_fthead5_oracle_matches_reference():
 def json_keys(z):
     import json
     return json.loads(str(z["pkeys"]))
+
+
+def test_injected_dropout_hook_follows_the_call_order_and_is_the_identity_with_unit_masks():
+    """oracle.inject_dropout (used by the GPU dropout-parity tests): every nn.Dropout of the model becomes one shared hook that
+    consumes supplied masks in call order -- 2 encoder inputs + 4 per layer + one per hidden layer of FTHead3; with identity
+    masks a train-mode forward equals the eval-mode forward."""
+    from fragnet_amd import data, synth
+    from oracle import fragnet_ref as ref
+    cfg = dict(n_classes=1, num_layer=2, num_heads=4, drop_ratio=0.3, h1=16, h2=16, h3=16, h4=8, act="relu", fthead="FTHead3")
+    batch = data.collate_fn(synth.synth_molecules(5, seed=3, profile="esol"))
+    torch.manual_seed(0)
+    model = ref.FragNetFineTune(**cfg)
+    want = model.eval()(batch)
+    inj = ref.inject_dropout(model, [None] * (2 + 4 * 2 + 4))
+    got = model.train()(batch)
+    assert inj.cursor == 14
+    torch.testing.assert_close(got, want)
+    with pytest.raises(IndexError):
+        model(batch)                       # the masks are used up
