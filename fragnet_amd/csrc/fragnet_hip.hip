@@ -3750,7 +3750,11 @@ int fn_dense_bwd_f32(const float* g_y, const float* X, const float* W, float* g_
     P.b.first_block = blocks;
     if (M_out < M) M_out = M;
     if (M_out > FN_DENSE_MAX_ROWS) return fail(FN_EINVAL, "fn_dense_bwd_f32: M_out > FN_DENSE_MAX_ROWS");
-    if (g_x && M_out > 0) {
+    if (g_x && M_out > 0 && M == 0) {                    // no input rows: the padding rows of g_x are all there is, and they are zero
+        hipLaunchKernelGGL(k_zero2_i32, dim3(flat_grid(M_out * K, kGridCap)), dim3(kBlock), 0, S(stream),
+                           reinterpret_cast<int32_t*>(g_x), M_out * K, static_cast<int32_t*>(nullptr), (int64_t)0);
+        if (int rc = launch_status("fn_dense_bwd_f32 (empty input)")) return rc;
+    } else if (g_x && M_out > 0) {
         DenseArgs& b = P.b;                              // gX [M,K] = gy W, gated by X > 0
         b.A = g_y;  b.Bsrc = W;  b.OUT = g_x;  b.Z = gate_scale > 0.f ? X : nullptr;  b.gate_scale = gate_scale;
         b.I = (int)M;  b.I_out = (int)M_out;  b.J = (int)K;  b.R = (int)N;  b.lda = (int)N;  b.ldb = (int)K;

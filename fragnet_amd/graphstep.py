@@ -324,6 +324,11 @@ class GraphedTrainStep:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.loss: Optional[torch.Tensor] = None
         self.replays = self.fallbacks = 0
+        # Philox bookkeeping of the captured step (set by _capture): the host offset the capture started from, the blocks one
+        # step draws, and whether the staging launch advances the device counters (single-graph step).  Invariant: between
+        # replays the device counter is ONE STEP BEHIND when _stage_bumps is set -- the staging launch in front of every
+        # replay moves it on -- so anything that replays without staging (or stages without replaying) must go through replay()
+        self._rng_base, self._per_step, self._stage_bumps = 0, 0, False
         from . import ops
         self._unit = ops.unit_grad(self.static.device)
         self.graph_b: Optional[torch.cuda.CUDAGraph] = None
@@ -480,7 +485,7 @@ class GraphedTrainStep:
         # never share Philox blocks
         host_after = self.rng.offset
         self.rng.offset = self._rng_base
-        behind = self._per_step if getattr(self, "_stage_bumps", False) else 0      # see _capture: the staging launch bumps the counter
+        behind = self._per_step if self._stage_bumps else 0      # see _capture: the staging launch bumps the counter
         if behind:
             self._counters[0:1] += behind
         if self.loss_kind == "pretrain":
@@ -508,6 +513,23 @@ class GraphedTrainStep:
             self._counters[0:1] += drawn - behind
         self.rng.offset = host_after
         return loss.detach()
+
+    def replay(self, batch: Dict[str, torch.Tensor]) -> bool:
+        """Stage ``batch`` and replay the captured graph(s) -- always as a pair: the staging launch zeroes the plan workspaces
+        and advances the Philox / step counters the graph reads.  No collective, no optimiser step outside the graph (tools
+        that time or profile the captured part use this instead of ``static.load`` + ``graph.replay``).  False: the batch does
+        not fit the capacities (nothing ran)."""
+        self._sync_adam_state()
+        if not self.static.load(batch):
+            return False
+        self.graph.replay()
+        if self.graph_b is not None:
+            self.graph_b.replay()
+        if self.adam_in_graph:
+            self.opt.steps += 1
+            self._dev_steps += 1
+        self.replays += 1
+        return True
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         """One optimiser step on ``batch``.  Returns the loss (a tensor that the next call overwrites)."""

@@ -672,7 +672,9 @@ class _MLPHead(torch.autograd.Function):
         C_out, K = W.shape
         P, slots = ctx.params, ctx.slots
         dense, need_x = ctx.dense, ctx.needs_input_grad[0]
-        scale = 1.0 / (1.0 - ctx.p) if 0.0 < ctx.p < 1.0 else (1.0 if ctx.p == 0.0 else 0.0)
+        # gate scale of the fused backward of relu(dropout(.)): the kernels read 0 as "no gate", so p >= 1 (every element dropped:
+        # the saved outputs are all 0 and the gate lets nothing through) passes a positive value, not 1 / (1 - p) = inf or 0
+        scale = 1.0 / (1.0 - ctx.p) if 0.0 < ctx.p < 1.0 else 1.0
         dW, db = grad_buffer(P[-2], slots[-2]), grad_buffer(P[-1], slots[-1])
 
         def input_grad(like, last, zeroed_by_kernel=False):

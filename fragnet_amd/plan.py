@@ -179,6 +179,8 @@ class GraphPlan:
             raise ValueError("edge_index and node_features_bonds disagree on the number of directed bonds")
         if fi.shape[1] != EF:
             raise ValueError("frag_index and node_features_fbonds disagree on the number of fragment edges")
+        # the two molecule-membership CSRs (mol_atoms, mol_frags) are read by the readout (ops.pool_cat: gat2.py:820-823) of
+        # every model, and drive the molecule-resident kernels when those are switched on
         specs = [
             dict(kind="gat", name="bond", dst=eib[0], src=eib[1], n=E, n_loops=0),
             dict(kind="gat", name="atom", dst=ei[1], src=ei[0], n=N, n_loops=N),

@@ -194,6 +194,54 @@ def test_graph_step_matches_eager_step():
 
 
 @gpu
+def test_graph_step_gradient_equals_eager_gradient_at_default_eps_and_is_bitwise_reproducible():
+    """the multi-step weight comparisons above use a well-conditioned Adam eps, which could hide a race or an
+    uninitialised read in the captured step.  So, with the DEFAULT optimiser settings and lr = 0 (weights fixed): (1) the flat
+    gradient a replay leaves equals the eager step's gradient of the same batch to rounding (the padded step sums a few
+    partial rows more); (2) replaying the same batch again, and replaying it in a SECOND, independently captured step (other
+    buffers, other memory contents), gives the same bits -- every reduction has a fixed order, no float atomics."""
+    dev = _dev()
+    batches = [data.batch_to(b, dev) for b in _batches(3, 48, seed=61)]
+    shapes = graphstep.StaticShapes.from_batches(batches, margin=0.05)
+    model_a, parallel, _ = _make(dev)
+    model_b, model_c = copy.deepcopy(model_a), copy.deepcopy(model_a)
+
+    def probe(model):
+        return lambda: torch.nn.functional.mse_loss(model(dict(batches[0])).view(-1), batches[0]["y"]).backward()
+    opt_a = parallel.FlatAdam.for_live_parameters(model_a, probe(model_a), lr=0.0)
+    opt_b = parallel.FlatAdam.for_live_parameters(model_b, probe(model_b), lr=0.0)
+    opt_c = parallel.FlatAdam.for_live_parameters(model_c, probe(model_c), lr=0.0)
+    step_b = graphstep.GraphedTrainStep(model_b, opt_b, shapes, dict(batches[0]), loss="regr")
+    junk = torch.full((64 << 20,), float("nan"), device=dev)      # the second capture allocates from dirtied memory
+    del junk
+    step_c = graphstep.GraphedTrainStep(model_c, opt_c, shapes, dict(batches[2]), loss="regr")
+    for k in (1, 2, 1):
+        b = batches[k]
+        opt_a.zero_grad()
+        torch.nn.functional.mse_loss(model_a(dict(b)).view(-1), b["y"]).backward()
+        opt_a.gather_grads()
+        step_b(dict(b))
+        g1 = opt_b.grad.detach().clone()
+        torch.testing.assert_close(g1, opt_a.grad, atol=2e-6, rtol=2e-5, msg=lambda m: m + _where_grad(model_a, opt_a, opt_b))
+        step_b(dict(batches[0]))                                    # something else in between
+        step_b(dict(b))
+        assert torch.equal(opt_b.grad, g1), "the same batch replayed twice gave different gradient bits"
+        step_c(dict(b))
+        assert torch.equal(opt_c.grad, g1), "two captures of the same step disagree bitwise"
+    assert torch.isfinite(opt_b.grad).all()
+
+
+def _where_grad(model, opt_a, opt_b):
+    names = {id(p): n for n, p in model.named_parameters()}
+    out = []
+    for p, off in zip(opt_a.params, opt_a.offsets):
+        d = (opt_a.grad[off: off + p.numel()] - opt_b.grad[off: off + p.numel()]).abs()
+        if float(d.max()) > 2e-6:
+            out.append(f"{names[id(p)]}{tuple(p.shape)}: max {float(d.max()):.2e}")
+    return "\n" + "\n".join(out)
+
+
+@gpu
 def test_graph_step_draws_fresh_dropout_masks():
     dev = _dev()
     batches = [data.batch_to(b, dev) for b in _batches(2, 48, seed=31)]

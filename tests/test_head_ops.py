@@ -273,3 +273,37 @@ def test_masked_bce_matches_the_torch_formula():
     want.backward()
     assert abs(float(loss) - float(want)) < 2e-6
     torch.testing.assert_close(out.grad, ref.grad.float(), atol=1e-8, rtol=1e-4)
+
+
+@gpu
+def test_dense_bwd_with_no_input_rows_zeroes_the_padding_rows_without_reading_null():
+    """M = 0 with g_x and M_out > 0: g_y / X may be NULL then; the input gradient's rows are all padding = 0,
+    dW and db are 0."""
+    from fragnet_amd import _lib
+    from fragnet_amd.plan import _stream_ptr
+    dev = _dev()
+    K, N, M_out = 64, 32, 24
+    w = torch.randn(N, K, device=dev)
+    gx = torch.full((M_out, K), 7.0, device=dev)
+    dW, db = torch.full((N, K), 7.0, device=dev), torch.full((N,), 7.0, device=dev)
+    _lib.call("fn_dense_bwd_f32", None, None, w.data_ptr(), gx.data_ptr(), 1.25, dW.data_ptr(), db.data_ptr(), 0, K, N, M_out, _stream_ptr(dev))
+    torch.cuda.synchronize()
+    assert float(gx.abs().max()) == 0.0 and float(dW.abs().max()) == 0.0 and float(db.abs().max()) == 0.0
+
+
+@gpu
+def test_fused_head_with_drop_probability_one_passes_no_gradient():
+    """p = 1 drops everything: outputs are the last bias, every gradient below the last layer is exactly 0 (the gate scale
+    must not be read as "no gate")."""
+    from fragnet_amd import ops
+    dev = _dev()
+    torch.manual_seed(0)
+    lins = [torch.nn.Linear(64, 32).to(dev), torch.nn.Linear(32, 32).to(dev), torch.nn.Linear(32, 2).to(dev)]
+    x = torch.randn(20, 64, device=dev, requires_grad=True)
+    out = ops.mlp_head(x, lins, 1.0, True, ops.PhiloxStream(seed=3))
+    torch.testing.assert_close(out, lins[-1].bias.detach().expand(20, 2))
+    out.sum().backward()
+    assert float(x.grad.abs().max()) == 0.0
+    for lin in lins[:-1]:
+        assert float(lin.weight.grad.abs().max()) == 0.0 and float(lin.bias.grad.abs().max()) == 0.0
+    torch.testing.assert_close(lins[-1].bias.grad, torch.full((2,), 20.0, device=dev))

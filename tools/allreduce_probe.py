@@ -39,12 +39,12 @@ def plain():
     step(dict(batches[0]))
 
 def blocking():
-    step.static.load(dict(batches[0])); step.graph.replay()
+    step.replay(dict(batches[0]))          # staging + replay as a pair (counters, plan workspaces)
     dist.all_reduce(opt.grad, op=dist.ReduceOp.AVG)
     opt.apply_gathered(reduced=True)
 
 def asynchronous():
-    step.static.load(dict(batches[0])); step.graph.replay()
+    step.replay(dict(batches[0]))          # staging + replay as a pair (counters, plan workspaces)
     w = dist.all_reduce(opt.grad, op=dist.ReduceOp.AVG, async_op=True)
     w.wait()
     opt.apply_gathered(reduced=True)

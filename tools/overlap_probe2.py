@@ -40,13 +40,11 @@ def timeit(fn, n=40):
 cur = torch.cuda.current_stream()
 
 def compute_only():
-    step.static.load(dict(batches[0]))
-    step.graph.replay(); step.graph_b.replay()
+    step.replay(dict(batches[0]))          # staging + both graphs as a pair
     opt.apply_gathered(reduced=True)
 
 def p1_after():
-    step.static.load(dict(batches[0]))
-    step.graph.replay(); step.graph_b.replay()
+    step.replay(dict(batches[0]))          # staging + both graphs as a pair
     side.wait_stream(cur)
     with torch.cuda.stream(side):
         fake_exchange(3)
