@@ -54,6 +54,14 @@ class LayerWeights(C.Structure):
     _fields_ = [(name, vp) for name in LAYER_FIELDS]
 
 
+class Tower(C.Structure):
+    _fields_ = [("x", vp), ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("w3", vp), ("b3", vp), ("h1", vp), ("h2", vp), ("out", vp),
+                ("M", i64), ("g_out", vp), ("g_x", vp), ("g_w1", vp), ("g_b1", vp), ("g_w2", vp), ("g_b2", vp), ("g_w3", vp), ("g_b3", vp)]
+
+
+FN_MAX_TOWERS = 4
+
+
 class StageField(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("n_real", i64), ("cap", i64), ("width", i32), ("kind", i32),
                 ("pad_hi", i64), ("pad_mod", i64)]
@@ -92,6 +100,9 @@ SIGNATURES = {
                        C.POINTER(ActEpilogue), C.c_int, vp],
     "fn_gat_bwd_dst_f32": [vp, vp, vp, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp, vp, vp, ip, C.c_int, vp],
     "fn_gat_bwd_src_f32": [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(GatPlan), vp, vp, ip, C.c_int, vp],
+    "fn_tower_fwd_f32": [C.POINTER(Tower), C.c_int, vp],
+    "fn_tower_bwd_ws": [C.POINTER(Tower), C.c_int],
+    "fn_tower_bwd_f32": [C.POINTER(Tower), C.c_int, vp, vp],
     "fn_mol_extents": [C.POINTER(SegPlan), C.POINTER(SegPlan), C.POINTER(GatPlan), C.POINTER(GatPlan), C.POINTER(GatPlan),
                        C.POINTER(GatPlan), i64, vp, vp],
     "fn_gat_bwd_mol_f32": [vp, vp, vp, C.POINTER(EdgeTerm), vp, C.c_int, C.c_int, C.c_int, C.POINTER(GatPlan), f32, vp, i64,

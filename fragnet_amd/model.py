@@ -465,6 +465,7 @@ class PretrainTask(nn.Module):
         self.L = L
         self.activation = nn.ReLU()
 
+    fused_towers = True          # False: the tall towers through ops.mlp_head (library GEMMs + element-wise launches; A/B and tests)
     need_bond_length = True      # False: skip the bond-length tower (graphstep / trainers: the reference's loss never reads it,
                                  # pretrain_utils.py:17-24 overwrites that term) and return None in its place
     _no_rng = ops.PhiloxStream(seed=0)
@@ -482,8 +483,12 @@ class PretrainTask(nn.Module):
         if self.need_bond_length:
             # pretrain_heads.py:67-76: reduce -> [lin(act(.))]*: the same stack with the reduce layer in front
             bl = self._tower([self.bl_reduce_layer] + list(self.bl_layers), ops.edge_concat(x_atoms, edge_attr, batch["edge_index"], plan))
-        ba = self._tower(self.ba_layers, x_atoms)
-        da = self._tower(self.da_layers, edge_attr)
+        if self.fused_towers and ops.tower_ok(x_atoms, list(self.ba_layers)) and ops.tower_ok(edge_attr, list(self.da_layers)):
+            # the two tall towers (every atom, every directed bond) as one launch each way (csrc/tower.hip)
+            ba, da = ops.towers([(x_atoms, list(self.ba_layers)), (edge_attr, list(self.da_layers))])
+        else:
+            ba = self._tower(self.ba_layers, x_atoms)
+            da = self._tower(self.da_layers, edge_attr)
         graph_rep = self._tower(self.FC_layers, pooled(x_atoms, x_frags, batch))
         return bl, ba, da, graph_rep
 

@@ -739,6 +739,79 @@ def mlp_head(x, linears, p: float, training: bool, rng: "PhiloxStream", live=Non
 
 
 # ======================================================================================
+# PretrainTask's tall towers: Linear(128 -> 64) -> ReLU -> Linear(64 -> 32) -> ReLU -> Linear(32 -> 1) on every atom / bond
+# ======================================================================================
+TOWER_SHAPES = ((64, 128), (32, 64), (1, 32))
+
+
+def tower_ok(x, linears) -> bool:
+    """The fused tower kernels take exactly the reference's `PretrainTask(128, 1)` shape (pretrain_heads.py:33-58) on GPU rows."""
+    return x.is_cuda and x.dim() == 2 and x.shape[1] == FN_D and len(linears) == 3 and \
+        all(tuple(lin.weight.shape) == shp and lin.bias is not None for lin, shp in zip(linears, TOWER_SHAPES))
+
+
+class _Towers(torch.autograd.Function):
+    """Up to FN_MAX_TOWERS towers as ONE launch each way (csrc/tower.hip): forward keeps h1 / h2, backward writes the input
+    gradients and reduces the weight-gradient partials straight into the parameters' gradient buffers (FlatAdam slots)."""
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        xs, params = [_f32c(x, "x") for x in args[:n]], args[n:]
+        dev = xs[0].device
+        tw = (_lib.Tower * n)()
+        keep, outs = [], []
+        for i, x in enumerate(xs):
+            M = x.shape[0]
+            w1, b1, w2, b2, w3, b3 = (_f32c(q, "tower parameter") for q in params[6 * i: 6 * i + 6])
+            h1 = torch.empty((M, 64), dtype=torch.float32, device=dev)
+            h2 = torch.empty((M, 32), dtype=torch.float32, device=dev)
+            out = torch.empty((M, 1), dtype=torch.float32, device=dev)
+            t = tw[i]
+            t.x, t.w1, t.b1, t.w2, t.b2, t.w3, t.b3 = (q.data_ptr() for q in (x, w1, b1, w2, b2, w3, b3))
+            t.h1, t.h2, t.out, t.M = h1.data_ptr(), h2.data_ptr(), out.data_ptr(), M
+            keep += [x, h1, h2, w1, b1, w2, b2, w3, b3]
+            outs.append(out)
+        _lib.call("fn_tower_fwd_f32", tw, n, _stream_ptr(dev))
+        ctx.n = n
+        ctx.params, ctx.slots = params, [grad_slot(q) for q in params]
+        ctx.save_for_backward(*keep)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n, saved = ctx.n, ctx.saved_tensors
+        dev = saved[0].device
+        tw = (_lib.Tower * n)()
+        gxs, grads, keep = [], [], []
+        for i in range(n):
+            x, h1, h2, w1, b1, w2, b2, w3, b3 = saved[9 * i: 9 * i + 9]
+            M = x.shape[0]
+            g = gs[i]
+            g = torch.zeros((M, 1), dtype=torch.float32, device=dev) if g is None else _f32c(g, "g")
+            gx = torch.empty_like(x) if ctx.needs_input_grad[1 + i] else None
+            pg = [grad_buffer(ctx.params[6 * i + k], ctx.slots[6 * i + k]) for k in range(6)]
+            t = tw[i]
+            t.x, t.w1, t.b1, t.w2, t.b2, t.w3, t.b3 = (q.data_ptr() for q in (x, w1, b1, w2, b2, w3, b3))
+            t.h1, t.h2, t.M, t.g_out, t.g_x = h1.data_ptr(), h2.data_ptr(), M, g.data_ptr(), _ptr(gx)
+            t.g_w1, t.g_b1, t.g_w2, t.g_b2, t.g_w3, t.g_b3 = (q.data_ptr() for q in pg)
+            gxs.append(gx)
+            grads += pg
+            keep.append(g)
+        ws = torch.empty(_lib.load().fn_tower_bwd_ws(tw, n), dtype=torch.float32, device=dev)
+        _lib.call("fn_tower_bwd_f32", tw, n, ws.data_ptr(), _stream_ptr(dev))
+        return (None, *gxs, *grads)
+
+
+def towers(pairs):
+    """``pairs`` = [(x [M,128], [Linear(128,64), Linear(64,32), Linear(32,1)]), ...] -> list of [M,1] outputs; every pair must pass
+    ``tower_ok``."""
+    if not 1 <= len(pairs) <= _lib.FN_MAX_TOWERS:
+        raise ValueError("towers: 1..FN_MAX_TOWERS towers per call")
+    params = [q for _, lins in pairs for lin in lins for q in (lin.weight, lin.bias)]
+    return list(_Towers.apply(len(pairs), *[x for x, _ in pairs], *params))
+
+
+# ======================================================================================
 # pretrain bond-length head input: cat(x[src], x[dst], e_attr)
 # ======================================================================================
 class _EdgeConcat(torch.autograd.Function):

@@ -481,6 +481,28 @@ typedef struct fn_stage_field {
 int fn_stage_padded(const fn_stage_field* fields, int n_fields, fn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * PretrainTask's tall towers (pretrain_heads.py:33-58, 77-88: `PretrainTask(128, 1)`, L = 2): Linear(128 -> 64) -> ReLU ->
+ * Linear(64 -> 32) -> ReLU -> Linear(32 -> 1) on every atom (bond angle) / every directed bond (dihedral).  One launch each way
+ * for up to FN_MAX_TOWERS towers (+ one reduction launch in the backward): the 41 KB of weights live in LDS, a workgroup walks
+ * 32-row tiles, the hidden rows never leave the CU in the forward except as the saved h1 / h2.
+ * fn_tower_bwd_f32: g_x [M,128] = dL/dx (nullable), g_w* / g_b* = parameter gradients (overwritten), ws = fn_tower_bwd_ws() floats.
+ * ------------------------------------------------------------------------------------------ */
+#define FN_MAX_TOWERS 4
+typedef struct fn_tower {
+    const float* x;                              /* [M,128] */
+    const float *w1, *b1, *w2, *b2, *w3, *b3;    /* [64,128], [64], [32,64], [32], [1,32], [1] */
+    float *h1, *h2;                              /* [M,64], [M,32]: relu outputs, written by the forward, read by the backward */
+    float* out;                                  /* [M,1] (forward) */
+    int64_t M;
+    const float* g_out;                          /* [M,1] (backward) */
+    float* g_x;
+    float *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3;
+} fn_tower;
+int fn_tower_fwd_f32(const fn_tower* towers, int n, fn_stream_t stream);
+int64_t fn_tower_bwd_ws(const fn_tower* towers, int n);
+int fn_tower_bwd_f32(const fn_tower* towers, int n, float* ws, fn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Encoder engine: the reference's FragNet.forward (gat2.py:381-442: L x FragNetLayerA + act(dropout(.))) and
  * its backward pass as one call each.  The host side only walks the layers and enqueues kernels on `stream`;
  * nothing is allocated, nothing synchronises.  `ws` keeps the activations the backward pass reads.

@@ -307,3 +307,60 @@ def test_fused_head_with_drop_probability_one_passes_no_gradient():
     for lin in lins[:-1]:
         assert float(lin.weight.grad.abs().max()) == 0.0 and float(lin.bias.grad.abs().max()) == 0.0
     torch.testing.assert_close(lins[-1].bias.grad, torch.full((2,), 20.0, device=dev))
+
+
+@gpu
+@pytest.mark.parametrize("rows", [(0, 5), (1, 31), (33, 64), (1000, 13337), (27001, 13872)])
+def test_fused_towers_match_torch(rows):
+    """ops.towers (csrc/tower.hip: PretrainTask's Linear(128->64)->ReLU->Linear(64->32)->ReLU->Linear(32->1) towers, two towers in
+    one launch each way) against plain torch: outputs, input gradients, all six parameter gradients per tower; ragged tile
+    tails, an empty tower, tall inputs (several tiles per workgroup in the backward)."""
+    from fragnet_amd import ops
+    dev = _dev()
+    torch.manual_seed(sum(rows))
+    mk = lambda: [torch.nn.Linear(128, 64).to(dev), torch.nn.Linear(64, 32).to(dev), torch.nn.Linear(32, 1).to(dev)]
+    ta, tb = mk(), mk()
+    xa = torch.randn(rows[0], 128, device=dev, requires_grad=True)
+    xb = torch.randn(rows[1], 128, device=dev, requires_grad=True)
+    assert ops.tower_ok(xa, ta) and ops.tower_ok(xb, tb)
+    oa, ob = ops.towers([(xa, ta), (xb, tb)])
+    ga, gb = torch.randn_like(oa), torch.randn_like(ob)
+    torch.autograd.backward([oa, ob], [ga, gb])
+    got = [xa.grad.clone(), xb.grad.clone()] + [q.grad.clone() for lin in ta + tb for q in (lin.weight, lin.bias)]
+    for q in [xa, xb] + [q for lin in ta + tb for q in (lin.weight, lin.bias)]:
+        q.grad = None
+    ref = lambda x, lins: lins[2](torch.relu(lins[1](torch.relu(lins[0](x)))))
+    ra, rb = ref(xa, ta), ref(xb, tb)
+    torch.testing.assert_close(oa, ra.detach(), atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(ob, rb.detach(), atol=2e-5, rtol=1e-5)
+    torch.autograd.backward([ra, rb], [ga, gb])
+    want = [xa.grad, xb.grad] + [q.grad for lin in ta + tb for q in (lin.weight, lin.bias)]
+    for i, (g, w) in enumerate(zip(got, want)):
+        scale = max(1.0, float(w.abs().max())) if w.numel() else 1.0
+        torch.testing.assert_close(g, w, atol=3e-5 * scale, rtol=1e-4, msg=lambda m, i=i: f"tensor {i}: {m}")
+
+
+@gpu
+def test_pretrain_task_fused_towers_equal_the_generic_path():
+    """FragNetPreTrain with the fused towers against the same model with `fused_towers = False` (ops.mlp_head on the tall inputs):
+    the four outputs and every gradient."""
+    from fragnet_amd import data, synth
+    from fragnet_amd.model import FragNetPreTrain
+    from fragnet_amd.train import pretrain_loss
+    dev = _dev()
+    b = data.batch_to(data.collate_fn_pt(synth.synth_molecules(24, seed=8, profile="esol", pretrain_targets=True)), dev)
+    torch.manual_seed(2)
+    model = FragNetPreTrain(num_layer=2, drop_ratio=0.0, edge_features=17).to(dev).train()
+    res = []
+    for fused in (True, False):
+        model.head.fused_towers = fused
+        for q in model.parameters():
+            q.grad = None
+        outs = model(dict(b))
+        pretrain_loss(outs, b).backward()
+        res.append(([o.detach().clone() for o in outs if o is not None], {n: q.grad.clone() for n, q in model.named_parameters() if q.grad is not None}))
+    for a, c in zip(*[r[0] for r in res]):
+        torch.testing.assert_close(a, c, atol=2e-5, rtol=1e-5)
+    assert res[0][1].keys() == res[1][1].keys()
+    for n in res[0][1]:
+        torch.testing.assert_close(res[0][1][n], res[1][1][n], atol=2e-5, rtol=1e-3, msg=lambda m, n=n: f"{n}: {m}")
