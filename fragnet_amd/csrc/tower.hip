@@ -274,28 +274,37 @@ __global__ __launch_bounds__(512, 2) void k_tower_bwd(const TowerTasks T) {
     else if (tid == 128) part[oDB3] = small;
 }
 
-// column sums of each tower's partial rows into its six parameter-gradient buffers (fixed order: bitwise reproducible)
+// column sums of each tower's partial rows into its six parameter-gradient buffers (fixed order: bitwise reproducible).
+// A block = 64 columns x 4 row groups: four loads in flight per thread, the groups combined through LDS in order.
+constexpr int kRedCols = 64;
+constexpr int kRedStrips = (kPartW + kRedCols - 1) / kRedCols;
 __global__ __launch_bounds__(256) void k_tower_reduce(const TowerTasks T) {
-    constexpr int kStrips = (kPartW + 255) / 256;
-    const int ti = (int)blockIdx.x / kStrips, strip = (int)blockIdx.x % kStrips;
+    __shared__ float red[4][kRedCols];
+    const int ti = (int)blockIdx.x / kRedStrips, strip = (int)blockIdx.x % kRedStrips;
     const fn_tower& t = T.t[ti];
-    const int c = strip * 256 + threadIdx.x;
-    if (c >= kPartW) return;
-    const float* p = T.part[ti] + c;
+    const int cl = threadIdx.x & (kRedCols - 1), rgp = threadIdx.x >> 6;
+    const int c = strip * kRedCols + cl;
     const int n = T.nblk[ti];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int r = 0;
-    for (; r + 3 < n; r += 4) {
-        a0 += p[(size_t)r * kPartW];  a1 += p[(size_t)(r + 1) * kPartW];  a2 += p[(size_t)(r + 2) * kPartW];  a3 += p[(size_t)(r + 3) * kPartW];
+    if (c < kPartW) {
+        const float* p = T.part[ti] + c;
+        int r = rgp;
+        for (; r + 12 < n; r += 16) {
+            a0 += p[(size_t)r * kPartW];  a1 += p[(size_t)(r + 4) * kPartW];  a2 += p[(size_t)(r + 8) * kPartW];  a3 += p[(size_t)(r + 12) * kPartW];
+        }
+        for (; r < n; r += 4) a0 += p[(size_t)r * kPartW];
     }
-    for (; r < n; ++r) a0 += p[(size_t)r * kPartW];
-    const float v = (a0 + a1) + (a2 + a3);
-    if (c < oDB1) t.g_w1[c] = v;
-    else if (c < oDW2) t.g_b1[c - oDB1] = v;
-    else if (c < oDB2) t.g_w2[c - oDW2] = v;
-    else if (c < oDW3) t.g_b2[c - oDB2] = v;
-    else if (c < oDB3) t.g_w3[c - oDW3] = v;
-    else t.g_b3[0] = v;
+    red[rgp][cl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rgp == 0 && c < kPartW) {
+        const float v = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        if (c < oDB1) t.g_w1[c] = v;
+        else if (c < oDW2) t.g_b1[c - oDB1] = v;
+        else if (c < oDB2) t.g_w2[c - oDW2] = v;
+        else if (c < oDW3) t.g_b2[c - oDB2] = v;
+        else if (c < oDB3) t.g_w3[c - oDW3] = v;
+        else t.g_b3[0] = v;
+    }
 }
 
 int set_lds(const void* kern, size_t bytes) {
@@ -370,7 +379,7 @@ int fn_tower_bwd_f32(const fn_tower* towers, int n, float* ws, fn_stream_t strea
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(k_tower_bwd, dim3(grid), dim3(512), kBwdLds * sizeof(float), st, T);
     if (int rc = fni::launch_status("fn_tower_bwd_f32")) return rc;
-    hipLaunchKernelGGL(k_tower_reduce, dim3(T.n * ((kPartW + 255) / 256)), dim3(256), 0, st, T);
+    hipLaunchKernelGGL(k_tower_reduce, dim3(T.n * kRedStrips), dim3(256), 0, st, T);
     return fni::launch_status("fn_tower_bwd_f32 (reduction)");
 }
 
