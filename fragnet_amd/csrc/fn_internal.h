@@ -135,6 +135,30 @@ __device__ __forceinline__ float ld1_off(const float* base, uint32_t byte_off) {
 }
 
 
+
+// ---- explicit address spaces.  Pointers read out of an argument block in memory are generic; dereferenced as such they become
+// flat_load / flat_store, which tick BOTH wait counters and so serialise with the LDS traffic.  Hot accesses cast to the global
+// (G()) or LDS address space.
+typedef float f32x4 __attribute__((ext_vector_type(4)));       // MFMA accumulator / 16-byte vector
+#define FN_LDS __attribute__((address_space(3)))
+#define FN_GLB __attribute__((address_space(1)))
+typedef FN_LDS float lds_f;
+typedef FN_LDS int lds_i;
+typedef FN_GLB float glb_f;
+typedef FN_GLB int glb_i;
+__device__ __forceinline__ const glb_f* G(const float* p) { return (const glb_f*)p; }
+__device__ __forceinline__ glb_f* G(float* p) { return (glb_f*)p; }
+__device__ __forceinline__ const glb_i* G(const int* p) { return (const glb_i*)p; }
+__device__ __forceinline__ float4 ld4(const glb_f* p) {
+    const f32x4 v = *reinterpret_cast<const FN_GLB f32x4*>(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4(glb_f* p, float4 v) { *reinterpret_cast<FN_GLB f32x4*>(p) = (f32x4){v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ float4 ld4s(const lds_f* p) {
+    const f32x4 v = *reinterpret_cast<const FN_LDS f32x4*>(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4s(lds_f* p, float4 v) { *reinterpret_cast<FN_LDS f32x4*>(p) = (f32x4){v.x, v.y, v.z, v.w}; }
 }  // namespace
 
 // ---- molecule-resident single-pass backward of the attention levels (csrc/mol_bwd.hip)

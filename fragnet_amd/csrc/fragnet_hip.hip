@@ -1918,7 +1918,6 @@ __global__ __launch_bounds__(256) void k_small_linear_bwd(const float* __restric
 //   input grad dX[M,128] = dY[M,128] * W[128,128]            (same kernel, Bt = W as stored, no bias)
 //   weight grad dW[128,K] = dY^T X, db = colsum(dY)           (split over row chunks, deterministic 2-stage sum)
 // =====================================================================================
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(4))) f32x4_u4 { float v[4]; };      // 16 bytes at a 4-byte-aligned address
 constexpr int kBtLd = 144;     // LDS leading dimension of the [K][128] operand: 144 % 32 == 16
 constexpr int kLinLd = 64;     // k_linear128's operand tile [K][64 columns], unpadded: a lane reads 4 consecutive columns (ds_read_b128) and the
@@ -2155,7 +2154,6 @@ struct LinTasks {
     LinTask t[3];
     int n, K;
     int base, total;          // co-launched with an attention pass (below): the GEMM workgroups are blocks [base, base + total) of that launch
-    int prio;                 // 1: the riding workgroups raise their wave priority (FN_TUNE_COLAUNCH_PRIO)
 };
 template <int KQ, bool VEC, bool PF>
 __global__ __launch_bounds__(kLinThreads) void k_linear128_multi(LinTasks T) {
@@ -2196,66 +2194,55 @@ __global__ __launch_bounds__(kLinThreads) void k_linear128_layer0(LinTasks T) {
 // of MFMA work behind a launch floor of their own -- so the GEMM tiles ride along as extra workgroups of the attention launch
 // (one 64 x 64 tile each, the k_linear128_multi body) and the layer loses a kernel boundary per pass.
 __device__ __forceinline__ void lin_side_block(float* sBt, const LinTasks& T, int b) {
-    if (T.prio) __builtin_amdgcn_s_setprio(3);             // (experiment) issue priority over the attention waves of the same SIMD
     int ti = 0;
     while (ti + 1 < T.n && b >= T.t[ti + 1].first) ++ti;
     const LinTask& t = T.t[ti];
     linear128_body<32, true, false, true>(sBt, t.X, 128, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, b - t.first, t.nblk, t.ra);
 }
-// Which workgroup is which: the dispatcher fills a CU with CONSECUTIVE workgroups of its XCD (measured: with all GEMM workgroups
-// first or last in the launch the two kinds ended up on different CUs and the launch took as long as both alone), so the roles
-// are interleaved in units of 8 workgroups (one per XCD): of the launch's `units` units, `gemm_units` spread evenly are GEMM
-// units.  Returns the role's own block index (>= 0) in *idx; an attention index keeps blockIdx % 8, i.e. its XCD.
-struct LinMix { int units, gemm_units; };       // units == 0: not interleaved (T.base / gat_base ranges)
-__device__ __forceinline__ bool lin_mix_role(const LinMix& mx, int* idx) {     // true: GEMM workgroup
-    const int u = (int)blockIdx.x >> 3, x = (int)blockIdx.x & 7;
-    const int before = (int)(((int64_t)u * mx.gemm_units) / mx.units), after = (int)(((int64_t)(u + 1) * mx.gemm_units) / mx.units);
-    const bool gemm = after > before;
-    *idx = (gemm ? before : u - before) * 8 + x;
-    return gemm;
-}
-__device__ __forceinline__ bool lin_side_role(const LinTasks& T, int gat_base, const LinMix& mx, int* idx) {
-    if (mx.units) return lin_mix_role(mx, idx);
+// Which workgroup is which: the GEMM workgroups are blocks [T.base, T.base + T.total) of the launch -- first, so that the
+// dispatcher starts them before the attention workgroups (measured best of first / last / interleaved: profiles/r02e_colaunch_ab.txt).
+// Returns the role's own block index in *idx.
+__device__ __forceinline__ bool lin_side_role(const LinTasks& T, int gat_base, int* idx) {
     const int b = (int)blockIdx.x - T.base;
     if ((unsigned)b < (unsigned)T.total) { *idx = b;  return true; }
     *idx = (int)blockIdx.x - gat_base;
     return false;
 }
-// gat_base: block id of the first attention workgroup (0 when the GEMM blocks come last, T.total when they come first).
+// gat_base: block id of the first attention workgroup (= T.total: the GEMM blocks come first).
 // __launch_bounds__(.., 4): four waves per SIMD as for the plain attention kernels -- without it the accumulators of the GEMM
 // branch go to AGPRs ON TOP of the attention branch's VGPRs and the launch drops to three (the two-level destination pass
 // with the 8-attribute edge class is at three either way and would spill, so it keeps the default).
 template <int H, int KL>
-__global__ __launch_bounds__(kBlock, 4) void k_gat_fwd_lin(GatFwdArgs A, LinTasks T, int gat_base, LinMix mx) {
+__global__ __launch_bounds__(kBlock, 4) void k_gat_fwd_lin(GatFwdArgs A, LinTasks T, int gat_base) {
     extern __shared__ __attribute__((aligned(16))) float sBt[];
     __shared__ float sWf[8][kWfLd];
     int g;
-    if (lin_side_role(T, gat_base, mx, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
+    if (lin_side_role(T, gat_base, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
     if (g < A.nblk) gat_fwd_body<H, KL>(A, sWf, g, A.nblk);
 }
 template <int H, int KLA, int KLB, bool RDA>
-__global__ __launch_bounds__(kBlock, 4) void k_gat_fwd_pair_lin(GatFwdArgs A, GatFwdArgs B, LinTasks T, int gat_base, LinMix mx) {
+__global__ __launch_bounds__(kBlock, 4) void k_gat_fwd_pair_lin(GatFwdArgs A, GatFwdArgs B, LinTasks T, int gat_base) {
     extern __shared__ __attribute__((aligned(16))) float sBt[];
     __shared__ float sWf[8][kWfLd];
     int g;
-    if (lin_side_role(T, gat_base, mx, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
+    if (lin_side_role(T, gat_base, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
     if (g < A.nblk) gat_fwd_body<H, KLA, RDA>(A, sWf, g, A.nblk);
     else if (g < A.nblk + B.nblk) gat_fwd_body<H, KLB>(B, sWf, g - A.nblk, B.nblk);
 }
 template <int H, int KL, int RB>
-__global__ __launch_bounds__(RB * 32, 4) void k_gat_bwd_dst_lin(GatBwdDstArgs A, LinTasks T, int gat_base, LinMix mx) {
+__global__ __launch_bounds__(RB * 32, 4) void k_gat_bwd_dst_lin(GatBwdDstArgs A, LinTasks T, int gat_base) {
     extern __shared__ __attribute__((aligned(16))) float sBt[];
     __shared__ float sP[RB][8][kWfLd];
     int g;
-    if (lin_side_role(T, gat_base, mx, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
+    if (lin_side_role(T, gat_base, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
     if (g < A.nblk) gat_bwd_dst_body<H, KL, RB>(A, sP, g, A.nblk);
 }
 template <int H, int KLA, int KLB, int RB>
-__global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst_pair_lin(GatBwdDstArgs A, GatBwdDstArgs B, LinTasks T, int gat_base, LinMix mx) {
+__global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst_pair_lin(GatBwdDstArgs A, GatBwdDstArgs B, LinTasks T, int gat_base) {
     extern __shared__ __attribute__((aligned(16))) float sBt[];
     __shared__ float sP[RB][8][kWfLd];
     int g;
-    if (lin_side_role(T, gat_base, mx, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
+    if (lin_side_role(T, gat_base, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
     if (g < A.nblk) gat_bwd_dst_body<H, KLA, RB>(A, sP, g, A.nblk);
     else if (g < A.nblk + B.nblk) gat_bwd_dst_body<H, KLB, RB>(B, sP, g - A.nblk, B.nblk);
 }
@@ -2331,10 +2318,35 @@ __global__ void k_transpose_many(TransposeMany tm, float* __restrict__ bt_base) 
     transpose_many_body(tm, bt_base, tile, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x);
 }
 
-#include "mol_fused.inc"
-#include "proj128.inc"
+// extents of every molecule in the index spaces of a collated batch (fn_internal.h: MolExt), from the molecule CSRs and the level plans
+using fni::MolExt;
+struct MolExtArgs {
+    const int32_t *mol_atoms, *mol_frags;       // molecule CSRs over atoms / fragments (global positions)
+    int32_t base_atoms, base_frags;
+    fn_gat_plan bond, atom, fbond, frag;
+    int n_mol;
+    MolExt* out;
+};
+__device__ __forceinline__ void mol_extents_body(const MolExtArgs& A, int vb) {
+    const int mol = vb * blockDim.x + threadIdx.x;
+    if (mol >= A.n_mol) return;
+    MolExt x;
+    const int a0 = A.mol_atoms[mol] - A.base_atoms, a1 = A.mol_atoms[mol + 1] - A.base_atoms;
+    const int f0 = A.mol_frags[mol] - A.base_frags, f1 = A.mol_frags[mol + 1] - A.base_frags;
+    // the by-source CSR of the atom graph counts, before atom a, the bonds leaving atoms < a (+ one loop item per atom)
+    const int la = A.atom.m > A.atom.m_real ? 1 : 0, lf = A.frag.m > A.frag.m_real ? 1 : 0;
+    const int b0 = A.atom.rowptr_s[a0] - A.atom.pos_base_s - la * a0, b1 = A.atom.rowptr_s[a1] - A.atom.pos_base_s - la * a1;
+    const int c0 = A.frag.rowptr_s[f0] - A.frag.pos_base_s - lf * f0, c1 = A.frag.rowptr_s[f1] - A.frag.pos_base_s - lf * f1;
+    x.a0 = a0;  x.na = a1 - a0;  x.b0 = b0;  x.nb = b1 - b0;  x.f0 = f0;  x.nf = f1 - f0;  x.c0 = c0;  x.nc = c1 - c0;
+    x.eb0 = A.bond.rowptr_d[b0] - A.bond.pos_base_d;   x.meb = A.bond.rowptr_d[b1] - A.bond.pos_base_d - x.eb0;
+    x.ea0 = A.atom.rowptr_d[a0] - A.atom.pos_base_d;   x.mea = A.atom.rowptr_d[a1] - A.atom.pos_base_d - x.ea0;
+    if (A.fbond.rowptr_d) {
+        x.ef0 = A.fbond.rowptr_d[c0] - A.fbond.pos_base_d;  x.mef = A.fbond.rowptr_d[c1] - A.fbond.pos_base_d - x.ef0;
+    } else { x.ef0 = 0;  x.mef = 0; }
+    x.ec0 = A.frag.rowptr_d[f0] - A.frag.pos_base_d;   x.mec = A.frag.rowptr_d[f1] - A.frag.pos_base_d - x.ec0;
+    A.out[mol] = x;
+}
 #include "dense_head.inc"
-#include "proj_direct.inc"
 
 // Everything the encoder's forward pass needs before its first projection, none of which depends on the other: W^T of
 // every projection, dropout of the atom features, and the permutation of the two raw edge-attribute tensors into
@@ -2346,8 +2358,7 @@ struct EncPrologue {
     const float* dx;  float* dy;  int64_t dnumel;  float p;  uint64_t seed, offset;  const uint64_t* offset_dev;  int n_d;
     const float* sx[2];  float* so[2];  int sK[2];  fn_gat_plan spl[2];  int n_s[2];
     float* zp;  int64_t zn;  int n_z;                               // buffer zeroed once per forward (edge-term scratch: loop positions stay 0)
-    MolExtArgs mx;  int n_x;                                        // molecule extents for the fused kernels (256 molecules per block)
-    MolFoldArgs fold;  int n_f;                                     // folded edge-embedding weights, one block per (layer, level)
+    MolExtArgs mx;  int n_x;                                        // molecule extents for the molecule-resident backward (256 molecules per block)
 };
 __global__ __launch_bounds__(256) void k_enc_prologue(EncPrologue A) {
     __shared__ float tile[32][33];
@@ -2376,9 +2387,7 @@ __global__ __launch_bounds__(256) void k_enc_prologue(EncPrologue A) {
         return;
     }
     b -= A.n_z;
-    if (b < A.n_x) { mol_extents_body(A.mx, b);  return; }
-    b -= A.n_x;
-    if (b < A.n_f) mol_fold_body(A.fold, b);
+    if (b < A.n_x) mol_extents_body(A.mx, b);
 }
 
 // Weight gradient: block = `rows_per_block` rows in chunks of 32 staged through double-buffered LDS.  Wave w owns
@@ -2779,72 +2788,7 @@ int launch_linear128(const float* X, int K, const float* Bt, const float* bias, 
     }
     return 0;
 }
-// grouped launch for K == 128 (every projection beyond layer 0 and every input-gradient product)
-int launch_proj128_group(const LinTasks& T, hipStream_t st) {
-    ProjTasks P{};
-    int blocks = 0;
-    for (int i = 0; i < T.n; ++i) {
-        const LinTask& s = T.t[i];
-        if (s.M <= 0) continue;
-        ProjTask& t = P.t[P.n++];
-        t.X = s.X;  t.Wn = s.Wn;  t.bias = s.bias;  t.Y = s.Y;  t.M = s.M;  t.ns = s.ns;
-        t.gate_y = s.mk.y;
-        t.gate_scale = s.mk.p > 0.f ? (s.mk.p < 1.f ? 1.f / (1.f - s.mk.p) : 0.f) : 1.f;
-        t.first_block = blocks;
-        t.n_blocks = (int)((s.M + kProjRows - 1) / kProjRows);
-        blocks += t.n_blocks;
-    }
-    if (!P.n) return 0;
-    P.total_blocks = blocks;
-    const int cap = g_tune[FN_TUNE_PROJ] > 1 ? g_tune[FN_TUNE_PROJ] : 768;     // persistent workgroups (three per CU by default)
-    const int grid = blocks < cap ? blocks : cap;
-    hipLaunchKernelGGL(k_proj128, dim3(grid), dim3(kProjThreads), (size_t)kProjRows * FN_D * sizeof(float), st, P);
-    return launch_status("grouped projection GEMM (register-resident W)");
-}
-// can the register-resident-W kernel take this group?  (needs the n-major weights, 16-byte alignment, and a relu gate if any)
-bool proj128_ok(const LinTasks& T) {
-    if (!g_tune[FN_TUNE_PROJ]) return false;
-    for (int i = 0; i < T.n; ++i) {
-        const LinTask& s = T.t[i];
-        if (s.ra.z) return false;
-        if (!s.Wn || (((uintptr_t)s.Wn | (uintptr_t)s.X | (uintptr_t)s.Y) & 15)) return false;
-        if (s.mk.y && !s.mk.relu) return false;
-        if (s.mk.y && ((uintptr_t)s.mk.y & 15)) return false;
-    }
-    return true;
-}
-
-// wave-independent form (csrc/proj_direct.inc): a block = 4 waves = 4 wave tiles of 32 rows x 64 columns
-int launch_proj_direct_group(LinTasks& T, hipStream_t st) {
-    int blocks = 0, live = 0;
-    for (int i = 0; i < T.n; ++i) {
-        if (T.t[i].M <= 0) continue;
-        LinTask t = T.t[i];
-        const int64_t tiles = 2 * ((t.M + 31) / 32);
-        t.first = blocks;
-        t.nblk = (int)((tiles + 3) / 4);
-        blocks += t.nblk;
-        T.t[live++] = t;
-    }
-    T.n = live;
-    T.K = 128;
-    if (!live) return 0;
-    hipLaunchKernelGGL(k_proj_direct, dim3(blocks), dim3(kPdThreads), 4 * kPdSlab * sizeof(float), st, T);
-    return launch_status("grouped projection GEMM (wave-independent)");
-}
-bool proj_direct_ok(const LinTasks& T) {
-    if (!g_tune[FN_TUNE_PROJ_DIRECT]) return false;
-    for (int i = 0; i < T.n; ++i) {
-        const LinTask& s = T.t[i];
-        if (s.ra.z) return false;
-        if (s.M > (1 << 23) || (((uintptr_t)s.X | (uintptr_t)s.Bt | (uintptr_t)s.Y | (uintptr_t)s.bias | (uintptr_t)s.mk.y) & 15)) return false;
-    }
-    return true;
-}
-
 int launch_linear128_group(LinTasks& T, hipStream_t st) {
-    if (proj128_ok(T)) return launch_proj128_group(T, st);
-    if (proj_direct_ok(T)) return launch_proj_direct_group(T, st);
     constexpr int KQ = 32;
     const size_t lds = (size_t)(4 * KQ * kLinLd) * sizeof(float);
     int64_t total = 0;
@@ -3205,34 +3149,23 @@ static_assert(kBlock == kLinThreads && kBwdRows * 32 == kLinThreads, "co-launche
 constexpr size_t kLinSideLds = (size_t)(4 * 32 * kLinLd) * sizeof(float);
 // lays the tasks' workgroups out (one 64 x 64 output tile each); false: cannot ride along (empty, co-launch off, misaligned, or the
 // register-resident / wave-independent GEMM variants are selected, which have their own launch shapes)
-static bool lin_side_prepare(LinTasks& T, int gat_blocks, int* gat_base, LinMix* mx, int* grid, bool pair) {
-    int mode = g_tune[FN_TUNE_GEMM_COLAUNCH];
-    if (mode == 4) mode = pair ? 1 : 2;           // 4 / 5: one order for the single-level launches, the other for the two-level ones
-    else if (mode == 5) mode = pair ? 2 : 1;
-    if (!mode || g_tune[FN_TUNE_PROJ] || g_tune[FN_TUNE_PROJ_DIRECT] || g_tune[FN_TUNE_GEMM_SLOTS] > 0) return false;
+static bool lin_side_prepare(LinTasks& T, int gat_blocks, int* gat_base, int* grid) {
+    if (!g_tune[FN_TUNE_GEMM_COLAUNCH] || g_tune[FN_TUNE_GEMM_SLOTS] > 0) return false;
     for (int i = 0; i < T.n; ++i) {
         const LinTask& t = T.t[i];
         if (t.M <= 0) continue;
         if (t.K && t.K != FN_D) return false;
         if (((uintptr_t)t.X | (uintptr_t)t.Bt | (uintptr_t)t.Y | (uintptr_t)t.bias | (uintptr_t)t.mk.y) & 15) return false;
     }
-    // The GEMM workgroups are meant to be RESIDENT BESIDE the attention workgroups (four 256-thread workgroups per CU), so that
-    // a SIMD interleaves one wave's MFMA chain with the attention waves' round trips: as many of them as the attention pass
-    // leaves slots (at least one per CU), each walking several 64 x 64 tiles.  One tile per workgroup (the stand-alone GEMM's
-    // shape) fills the chip with GEMM workgroups first and the two kinds then run one after the other.
-    int64_t total_tiles = 0;
-    for (int i = 0; i < T.n; ++i) total_tiles += T.t[i].M > 0 ? (T.t[i].M + kLinRows - 1) / kLinRows : 0;
-    int iters = 1;
-    if (g_tune[FN_TUNE_COLAUNCH_SLOTS] >= 0) {
-        const int64_t slots = g_tune[FN_TUNE_COLAUNCH_SLOTS] > 0 ? g_tune[FN_TUNE_COLAUNCH_SLOTS] : std::max<int64_t>(256, 1024 - gat_blocks);
-        iters = (int)std::max<int64_t>(1, (2 * total_tiles + slots - 1) / slots);
-    }
+    // one 64 x 64 tile per GEMM workgroup, all of them in front of the attention workgroups: the launch then takes what both
+    // parts take back to back minus one kernel boundary (interleaving the two kinds, GEMM workgroups last, persistent GEMM
+    // workgroups walking several tiles and raised wave priority all measured slower or equal: DESIGN.md section 4)
     int blocks = 0, live = 0;
     for (int i = 0; i < T.n; ++i) {
         if (T.t[i].M <= 0) continue;
         LinTask t = T.t[i];
         t.first = blocks;
-        t.nblk = lin_blocks((t.M + kLinRows - 1) / kLinRows, iters);
+        t.nblk = lin_blocks((t.M + kLinRows - 1) / kLinRows, 1);
         blocks += t.nblk;
         T.t[live++] = t;
     }
@@ -3240,44 +3173,35 @@ static bool lin_side_prepare(LinTasks& T, int gat_blocks, int* gat_base, LinMix*
     T.K = FN_D;
     if (!live) return false;
     T.total = blocks;
-    T.prio = g_tune[FN_TUNE_COLAUNCH_PRIO] != 0;
-    T.base = mode == 2 ? 0 : gat_blocks;          // 2: GEMM workgroups are dispatched first; 1: after the attention workgroups
-    *gat_base = mode == 2 ? blocks : 0;
-    *mx = LinMix{0, 0};
+    T.base = 0;
+    *gat_base = blocks;
     *grid = gat_blocks + blocks;
-    if (mode == 3) {                              // 3: interleaved in units of 8 workgroups
-        mx->gemm_units = (blocks + 7) / 8;
-        mx->units = mx->gemm_units + (gat_blocks + 7) / 8;
-        *grid = 8 * mx->units;
-    }
     return true;
 }
 static_assert(kLinSideLds <= 64 * 1024, "the co-launched GEMM tile fits the default dynamic LDS limit");
 
 static int launch_gat_fwd_lin(const GatFwdArgs& A, LinTasks& T, int heads, hipStream_t st) {
     int gb = 0, grid = 0;
-    LinMix mx{};
-    if (A.nblk == 0 || A.rd_out || edge_class(&A.et) != 0 || !lin_side_prepare(T, A.nblk, &gb, &mx, &grid, false)) {
+    if (A.nblk == 0 || A.rd_out || edge_class(&A.et) != 0 || !lin_side_prepare(T, A.nblk, &gb, &grid)) {
         if (int rc = launch_gat_fwd(A, heads, st)) return rc;
         return T.n ? launch_linear128_group(T, st) : 0;
     }
     FN_DISPATCH_H(heads, {
-        hipLaunchKernelGGL((k_gat_fwd_lin<HH, 0>), dim3(grid), dim3(kBlock), kLinSideLds, st, A, T, gb, mx);
+        hipLaunchKernelGGL((k_gat_fwd_lin<HH, 0>), dim3(grid), dim3(kBlock), kLinSideLds, st, A, T, gb);
     });
     return launch_status("attention forward + projections of the next level");
 }
 static int launch_gat_fwd_pair_lin(const GatFwdArgs& A, const GatFwdArgs& B, LinTasks& T, int heads, hipStream_t st) {
     const int ka = edge_class(&A.et), kb = edge_class(&B.et);
     int gb = 0, nwg = 0;
-    LinMix mx{};
-    if (A.nblk == 0 || B.nblk == 0 || ka != 1 || (kb != 1 && kb != FN_MAX_EDGE_K) || !lin_side_prepare(T, A.nblk + B.nblk, &gb, &mx, &nwg, true)) {
+    if (A.nblk == 0 || B.nblk == 0 || ka != 1 || (kb != 1 && kb != FN_MAX_EDGE_K) || !lin_side_prepare(T, A.nblk + B.nblk, &gb, &nwg)) {
         if (int rc = launch_gat_fwd_pair(A, B, heads, st)) return rc;
         return T.n ? launch_linear128_group(T, st) : 0;
     }
     const dim3 grid(nwg);
 #define FN_PAIR_LIN(KB, RD)                                                                                      \
     do {                                                                                                         \
-        hipLaunchKernelGGL((k_gat_fwd_pair_lin<HH, 1, KB, RD>), grid, dim3(kBlock), kLinSideLds, st, A, B, T, gb, mx); \
+        hipLaunchKernelGGL((k_gat_fwd_pair_lin<HH, 1, KB, RD>), grid, dim3(kBlock), kLinSideLds, st, A, B, T, gb); \
     } while (0)
     FN_DISPATCH_H(heads, {
         if (A.rd_out) { if (kb == 1) FN_PAIR_LIN(1, true); else FN_PAIR_LIN(FN_MAX_EDGE_K, true); }
@@ -3288,30 +3212,28 @@ static int launch_gat_fwd_pair_lin(const GatFwdArgs& A, const GatFwdArgs& B, Lin
 }
 static int launch_gat_bwd_dst_lin(const GatBwdDstArgs& A, LinTasks& T, int heads, hipStream_t st) {
     int gb = 0, grid = 0;
-    LinMix mx{};
-    if (A.nblk == 0 || edge_class(&A.et) != 0 || !lin_side_prepare(T, A.nblk, &gb, &mx, &grid, false)) {
+    if (A.nblk == 0 || edge_class(&A.et) != 0 || !lin_side_prepare(T, A.nblk, &gb, &grid)) {
         if (T.n) if (int rc = launch_linear128_group(T, st)) return rc;          // the products first: the level below reads them
         return launch_gat_bwd_dst(A, heads, st);
     }
     FN_DISPATCH_H(heads, {
-        hipLaunchKernelGGL((k_gat_bwd_dst_lin<HH, 0, kBwdRows>), dim3(grid), dim3(kBwdRows * 32), kLinSideLds, st, A, T, gb, mx);
+        hipLaunchKernelGGL((k_gat_bwd_dst_lin<HH, 0, kBwdRows>), dim3(grid), dim3(kBwdRows * 32), kLinSideLds, st, A, T, gb);
     });
     return launch_status("attention backward, destination pass + input-gradient products");
 }
 static int launch_gat_bwd_dst_pair_lin(const GatBwdDstArgs& A, const GatBwdDstArgs& B, LinTasks& T, int heads, hipStream_t st) {
     const int ka = edge_class(&A.et), kb = edge_class(&B.et);
     int gb = 0, nwg = 0;
-    LinMix mx{};
-    if (A.nblk == 0 || B.nblk == 0 || ka != 1 || (kb != 1 && kb != FN_MAX_EDGE_K) || !lin_side_prepare(T, A.nblk + B.nblk, &gb, &mx, &nwg, true)) {
+    if (A.nblk == 0 || B.nblk == 0 || ka != 1 || (kb != 1 && kb != FN_MAX_EDGE_K) || !lin_side_prepare(T, A.nblk + B.nblk, &gb, &nwg)) {
         if (int rc = launch_gat_bwd_dst_pair(A, B, heads, st)) return rc;
         return T.n ? launch_linear128_group(T, st) : 0;
     }
     const dim3 grid(nwg);
     FN_DISPATCH_H(heads, {
         if (kb == 1) {
-            hipLaunchKernelGGL((k_gat_bwd_dst_pair_lin<HH, 1, 1, kBwdRows>), grid, dim3(kBwdRows * 32), kLinSideLds, st, A, B, T, gb, mx);
+            hipLaunchKernelGGL((k_gat_bwd_dst_pair_lin<HH, 1, 1, kBwdRows>), grid, dim3(kBwdRows * 32), kLinSideLds, st, A, B, T, gb);
         } else {
-            hipLaunchKernelGGL((k_gat_bwd_dst_pair_lin<HH, 1, FN_MAX_EDGE_K, kBwdRows>), grid, dim3(kBwdRows * 32), kLinSideLds, st, A, B, T, gb, mx);
+            hipLaunchKernelGGL((k_gat_bwd_dst_pair_lin<HH, 1, FN_MAX_EDGE_K, kBwdRows>), grid, dim3(kBwdRows * 32), kLinSideLds, st, A, B, T, gb);
         }
     });
     return launch_status("attention backward, destination pass (two levels) + atom input-gradient product");
@@ -3920,9 +3842,7 @@ struct EncLayout {
     float* in_atoms0;        // dropout(x_atoms) when training with p > 0, else null (use x_atoms)
     // forward scratch
     float *atoms_new, *frags_new, *s_sorted, *s_dst, *s_src, *s_dst_a, *s_src_a, *s_dst_fb, *s_src_fb, *bt;
-    float* mol_ext;          // MolExt[n_mols] for the fused molecule kernels (null without molecule CSRs)
-    float* wf_tab;           // [n_layers][2][8][kWfLd] folded edge-embedding weights (bond, fbond) for the fused kernels
-    float* mol_args;         // MolFwdArgs of the fused forward kernel (its out-of-line level functions read it from memory)
+    float* mol_ext;          // MolExt[n_mols] for the molecule-resident backward (null without molecule CSRs)
     int64_t total;
 };
 
@@ -3957,18 +3877,12 @@ EncLayout enc_layout(const fn_encoder* e, float* ws) {
     o.s_src_fb = b.take(e->EF * H);
     o.bt = b.take((int64_t)3 * e->n_layers * 192 * FN_D);
     o.mol_ext = e->n_mols > 0 ? b.take(e->n_mols * (int64_t)(sizeof(MolExt) / sizeof(float))) : nullptr;
-    o.wf_tab = e->n_mols > 0 ? b.take((int64_t)e->n_layers * 2 * 8 * kWfLd) : nullptr;
-    o.mol_args = e->n_mols > 0 ? b.take((int64_t)((sizeof(MolFwdArgs) + 3) / 4)) : nullptr;
     o.total = b.used;
     return o;
 }
 
-// the molecule-resident fused kernels apply when the caller handed over the molecule CSRs (and the tuning switch is on)
 bool have_mol(const fn_encoder* e) {       // the caller handed over the molecule CSRs: every level is block-diagonal per molecule
     return e->n_mols > 0 && e->mol_atoms.rowptr && e->mol_frags.rowptr && e->mol_atoms.n_seg == e->n_mols && e->mol_frags.n_seg == e->n_mols;
-}
-bool mol_fused(const fn_encoder* e) {
-    return g_tune[FN_TUNE_FUSED] != 0 && e->heads == 4 && have_mol(e) && g_tune[FN_TUNE_STREAMS] == 0;
 }
 // the backward of every attention level as one pass of the molecule-resident kernel (csrc/mol_bwd.hip)
 bool mol_bwd_on(const fn_encoder* e) {
@@ -4205,13 +4119,8 @@ struct ReduceQueue {
         }
         W.K = FN_D;
         if (g_tune[FN_TUNE_WGRAD_DIRECT]) {
-            if (g_tune[FN_TUNE_WGRAD_DIRECT] == 2) {      // four row slices per workgroup (1024 threads)
-                if (int rc = allow_lds(k_wgrad128_multi<4>, wd_lds_bytes<4>())) return rc;
-                hipLaunchKernelGGL(k_wgrad128_multi<4>, dim3(wblocks), dim3(wd_threads<4>()), wd_lds_bytes<4>(), st, W);
-            } else {
-                if (int rc = allow_lds(k_wgrad128_multi<2>, wd_lds_bytes<2>())) return rc;
-                hipLaunchKernelGGL(k_wgrad128_multi<2>, dim3(wblocks), dim3(wd_threads<2>()), wd_lds_bytes<2>(), st, W);
-            }
+            if (int rc = allow_lds(k_wgrad128_multi<2>, wd_lds_bytes<2>())) return rc;
+            hipLaunchKernelGGL(k_wgrad128_multi<2>, dim3(wblocks), dim3(wd_threads<2>()), wd_lds_bytes<2>(), st, W);
         } else {
             constexpr int XW = 16 * 4 * 2, XLD = XW + 16;
             const size_t lds = (size_t)2 * kWgChunk * (kBtLd + XLD) * sizeof(float);
@@ -4237,8 +4146,7 @@ static int launch_gat_bwd_src_pair_dst(const GatBwdSrcArgs& A, const GatBwdSrcAr
 // R.g_feat == nullptr: the rows' term rides in T's bond product (RowAdd); R.nblk == 0: no edge term at all
 static int launch_gat_bwd_src_lin_rd(const GatBwdSrcArgs& A, LinTasks& T, const RowDotsBwdArgs& R, int heads, hipStream_t st) {
     int gb = 0, grid = 0;
-    LinMix mx{};
-    if (A.nblk == 0 || !lin_side_prepare(T, A.nblk + R.nblk, &gb, &mx, &grid, false)) {
+    if (A.nblk == 0 || !lin_side_prepare(T, A.nblk + R.nblk, &gb, &grid)) {
         if (T.n) if (int rc = launch_linear128_group(T, st)) return rc;
         if (R.nblk == 0) return launch_gat_bwd_src(A, heads, st);
         if (A.nblk == 0) {
@@ -4284,7 +4192,7 @@ static int launch_lin_rd(LinTasks& T, const RowDotsBwdArgs& R, hipStream_t st) {
         blocks += t.nblk;
         T.t[live++] = t;
     }
-    T.n = live;  T.K = FN_D;  T.total = blocks;  T.base = 0;  T.prio = 0;
+    T.n = live;  T.K = FN_D;  T.total = blocks;  T.base = 0;
     if (!live || !aligned || R.nblk == 0) {
         if (live) if (int rc = launch_linear128_group(T, st)) return rc;
         if (R.nblk) {
@@ -4544,11 +4452,10 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
     const bool multi = g_tune[FN_TUNE_STREAMS] != 0;
     const bool lite = e->variant == 1, edge = e->variant == 2;      // gat2_lite / gat2_edge: neither has a fragment-bond graph
     const bool no_fb = lite || edge;
-    const bool fused = mol_fused(e);
     // the atom graph's edge term <new_bond, a[:, d:d+128]> is produced by the bond-graph kernel's epilogue (one launch less per layer)
-    const bool fuse_rd = !fused && g_tune[FN_TUNE_FUSE_ROWDOTS] != 0 && e->atom.m > 0 && e->atom.m_real == e->E;
+    const bool fuse_rd = g_tune[FN_TUNE_FUSE_ROWDOTS] != 0 && e->atom.m > 0 && e->atom.m_real == e->E;
     // projections ride along with the attention launches they do not depend on (k_gat_*_lin); needs the node scalars in the GEMM epilogue
-    const bool colaunch = !fused && !multi && H >= 2 && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;
+    const bool colaunch = !multi && H >= 2 && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;
     const fn_act_epilogue no_act_l{nullptr, 0.f, 0, 0, 0, nullptr};
     if (multi) FN_TRY(aux_init());
     fn_stream_t st_fb = multi ? (fn_stream_t)g_aux.s[1] : st;       // the fragment-bond chain's stream
@@ -4582,63 +4489,21 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
             A.sx[1] = e->fattr_raw;  A.so[1] = const_cast<float*>(e->fattr_sorted);  A.sK[1] = e->k_fattr;  A.spl[1] = fattr_plan;
             A.n_s[1] = flat_grid(fattr_plan.m * e->k_fattr, 512);
         }
-        if (fused || mol_bwd_on(e)) {
+        if (mol_bwd_on(e)) {
             A.mx = MolExtArgs{e->mol_atoms.rowptr, e->mol_frags.rowptr, e->mol_atoms.pos_base, e->mol_frags.pos_base,
                               e->bond, e->atom, no_fb ? fn_gat_plan{} : e->fbond, e->frag, (int)e->n_mols,
                               reinterpret_cast<MolExt*>(lay.mol_ext)};
             A.n_x = (int)((e->n_mols + 255) / 256);
         }
-        if (fused) {
-            for (int l = 0; l < e->n_layers; ++l) {
-                A.fold.att[2 * l] = e->w[l].a_b;  A.fold.embW[2 * l] = e->w[l].emb_b_w;  A.fold.embb[2 * l] = e->w[l].emb_b_b;  A.fold.Ke[2 * l] = 1;
-                A.fold.att[2 * l + 1] = e->w[l].f_a_b;  A.fold.embW[2 * l + 1] = e->w[l].emb_fb_w;  A.fold.embb[2 * l + 1] = e->w[l].emb_fb_b;
-                A.fold.Ke[2 * l + 1] = no_fb ? 0 : e->k_fattr;
-            }
-            A.fold.att_w = 3 * d;  A.fold.mid_off = d;  A.fold.H = H;  A.fold.n = 2 * e->n_layers;  A.fold.out = lay.wf_tab;
-            A.n_f = 2 * e->n_layers;
-        }
         if (fuse_rd) {
             A.zp = lay.s_sorted;  A.zn = e->atom.m * H;  A.n_z = flat_grid(A.zn, 64);
         }
-        hipLaunchKernelGGL(k_enc_prologue, dim3(A.n_t + A.n_d + A.n_s[0] + A.n_s[1] + A.n_z + A.n_x + A.n_f), dim3(256), 0, S(st), A);
+        hipLaunchKernelGGL(k_enc_prologue, dim3(A.n_t + A.n_d + A.n_s[0] + A.n_s[1] + A.n_z + A.n_x), dim3(256), 0, S(st), A);
         FN_TRY(launch_status("fn_encoder_forward: prologue"));
     }
     FN_TRY(order_after(S(st), S(st_fb)));      // fork: the fragment-bond levels of ALL layers depend on nothing else
 
-    if (fused) {
-        // bond graph, atom graph and fragment-bond graph of EVERY layer: one launch, one workgroup per molecule (mol_fused.inc);
-        // only the last layer's atom -> fragment sum and fragment graph (a few rows per molecule) follow as per-level kernels
-        MolFwdArgs M{};
-        M.n_mol = (int)e->n_mols;  M.n_zero = e->counts_dev ? 64 : 0;  M.l0 = 0;  M.l1 = e->n_layers;
-        M.skew = g_tune[FN_TUNE_MOL_SKEW];
-        M.has_fbond = no_fb ? 0 : 1;  M.k_fattr = e->k_fattr;  M.drop_p = p;  M.seed = e->seed;  M.offset_dev = e->offset_dev;
-        M.counts_dev = e->counts_dev;  M.ext = reinterpret_cast<const MolExt*>(lay.mol_ext);
-        M.plan[MOL_BOND] = e->bond;  M.plan[MOL_ATOM] = e->atom;  M.plan[MOL_FBOND] = no_fb ? fn_gat_plan{} : e->fbond;
-        M.xattr[MOL_BOND] = e->cos_sorted;  M.xattr[MOL_ATOM] = nullptr;  M.xattr[MOL_FBOND] = e->fattr_sorted;
-        M.s_edge_g = lay.s_sorted;  M.status = e->status;  M.wf_tab = lay.wf_tab;
-        M.rows[MOL_BOND] = e->E;  M.rows[MOL_ATOM] = e->N;  M.rows[MOL_FBOND] = e->EF;
-        for (int l = 0; l < e->n_layers; ++l) {
-            const fn_layer_weights& w = e->w[l];
-            const LayerActs& a = lay.L[l];
-            const bool last = l + 1 == e->n_layers;
-            MolLayer& Y = M.L[l];
-            Y.lev[MOL_BOND] = MolLevel{l ? lay.L[l - 1].y_bond : e->bond_nodes, w.proj_b_w, w.proj_b_b, w.a_b, w.emb_b_w, w.emb_b_b, a.h_b, a.new_bond,
-                                       a.p_bond, last ? out_bond : a.y_bond, lay.s_dst, lay.s_src, rng.y[l][2], l ? FN_D : e->k_bond0, 3 * d, 2 * d, d, 1, 0};
-            Y.lev[MOL_ATOM] = MolLevel{l ? lay.L[l - 1].y_atoms : in_atoms, w.proj_a_w, w.proj_a_b, w.a, nullptr, nullptr, a.h_a, last ? lay.atoms_new : nullptr,
-                                       a.p_atom, last ? out_atoms : a.y_atoms, lay.s_dst_a, lay.s_src_a, rng.y[l][0], l ? FN_D : e->k_atom0, wide, d + FN_D, d, 0, 0};
-            if (!no_fb)
-                Y.lev[MOL_FBOND] = MolLevel{l ? lay.L[l - 1].y_fbond : e->fbond_nodes, w.proj_fb_w, w.proj_fb_b, w.f_a_b, w.emb_fb_w, w.emb_fb_b, a.h_fb, a.new_fbond,
-                                            a.p_fbond, last ? out_fbond : a.y_fbond, lay.s_dst_fb, lay.s_src_fb, rng.y[l][3], l ? FN_D : e->k_fbond0, 3 * d, 2 * d, d, e->k_fattr, 0};
-            Y.a_mid = w.a + d;
-        }
-        M.stamps = g_mol_stamps_n >= (int64_t)M.n_mol * kMolStampsPerMol ? g_mol_stamps : nullptr;
-        const size_t lds = kMolFwdLds(4);
-        FN_TRY(allow_lds(k_mol_fwd<4>, lds));
-        hipLaunchKernelGGL(k_mol_fwd<4>, dim3(M.n_mol + M.n_zero), dim3(kMolThreads), lds, S(st), M);
-        FN_TRY(launch_status("fn_encoder_forward: fused molecule kernel"));
-    }
-
-    for (int l = fused ? e->n_layers - 1 : 0; l < e->n_layers; ++l) {
+    for (int l = 0; l < e->n_layers; ++l) {
         const fn_layer_weights& w = e->w[l];
         const LayerActs& a = lay.L[l];
         const bool last = l + 1 == e->n_layers;
@@ -4653,7 +4518,6 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         // act(dropout(.)) of the four layer outputs rides in the producing kernels' epilogues
         const fn_act_epilogue ep_atoms{y_atoms, p, 1, e->seed, rng.y[l][0], e->offset_dev}, ep_frags{y_frags, p, 1, e->seed, rng.y[l][1], e->offset_dev};
         const fn_act_epilogue ep_bond{y_bond, p, 1, e->seed, rng.y[l][2], e->offset_dev}, ep_fbond{y_fbond, p, 1, e->seed, rng.y[l][3], e->offset_dev};
-        if (!fused) {
         // L1 bond graph
         const bool fuse_ns = H >= 2;         // a head's columns fit one wave's 64-column half for H >= 2
         auto project = [&](const float* x, int k, const float* bt, const float* bias, float* hout, int64_t rows,
@@ -4740,7 +4604,6 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         } else {
         FN_TRY(fn_gat_fwd_f32(a.h_a, lay.s_dst_a, lay.s_src_a, w.a, wide, &et_a, &e->atom, 0.2f, lay.atoms_new, a.p_atom, nullptr, &ep_atoms, H, st));
         }
-        }   // !fused
 
         // L3 atom -> fragment sum.  Like L4b below it is only ever read in the last layer (the next layer recomputes its own
         // sum from its own atoms before first use, gat2.py:234), so inner layers skip it too.

@@ -54,9 +54,6 @@ __device__ __forceinline__ void lv_extent(const MolExt& x, int which, int& r0, i
     else { r0 = x.f0;  nr = x.nf;  e0 = x.ec0;  me = x.mec; }
 }
 
-#define FN_LDS __attribute__((address_space(3)))
-#define FN_GLB __attribute__((address_space(1)))
-
 // LDS-DMA (global_load_lds_*): the wave's 64 lanes write 64 x SIZE consecutive bytes at the wave-uniform LDS address; the
 // global source address is per lane.  No VGPR destination: the tile costs no registers while it is in flight.
 template <int SIZE>

@@ -57,23 +57,16 @@ int fn_abi_version(void);
 #define FN_TUNE_STREAMS 2      /* 1: the encoder forks parameter-gradient work and the fragment-bond chain onto side streams;
                                 * 0 (default): one stream -- forked hipGraph replays measured slower on ROCm 7.2 */
 #define FN_TUNE_WGRAD_BLOCKS 3 /* target workgroup count of the grouped weight-gradient launch of a backward pass (default 256: one per CU; 512 wrote twice the partials and measured 1 % slower per step) */
-#define FN_TUNE_FUSED 4        /* 1: fn_encoder_forward runs the molecule-resident fused layer kernel (csrc/mol_fused.inc) when the
-                                * descriptor carries the molecule CSRs (mol_atoms / mol_frags) and heads == 4; 0 (default): per-level
-                                * kernels -- measured on MI355X the fused kernel only matches them at 512 molecules */
-#define FN_TUNE_MOL_SKEW 5     /* fused kernels: workgroups with bit (value - 1) of their index set run the fragment-bond level FIRST in
-                                * every layer, so that the two workgroups of a CU are in different phases (MFMA vs. VALU); 0 = off */
-#define FN_TUNE_PROJ 6         /* > 0: the 128 -> 128 projections and their input-gradient products inside fn_encoder_* run as k_proj128
-                                * (W pieces register-resident, X staged in LDS, persistent workgroups; value > 1 = workgroup cap);
-                                * 0 (default): k_linear128 -- measured 1-4 % faster per step on MI355X */
+#define FN_TUNE_RETIRED_4 4     /* (retired in round 3, no effect: the molecule-resident fused FORWARD of round 2 -- measured equal at 512
+                                * molecules, slower elsewhere; source kept out of the build under tools/probe/retired/mol_fused.inc) */
+#define FN_TUNE_RETIRED_5 5     /* (retired: phase skew of that kernel) */
+#define FN_TUNE_RETIRED_6 6     /* (retired: register-resident-weights projection kernel k_proj128, 1-4 % slower per step) */
 #define FN_TUNE_FUSE_ROWDOTS 7 /* 1 (default): inside fn_encoder_forward the bond-graph attention kernel also writes the atom graph's edge
                                 * term <new_bond, a[:, d:d+128]> from the row it holds in registers; 0: a separate row-dots launch */
 #define FN_TUNE_WGRAD_DIRECT 8 /* 1 (default): the grouped K = 128 weight-gradient partials run as k_wgrad128_multi (operands straight from
-                                * global memory in the MFMA layout, csrc/wgrad128.inc); 0: the LDS-staged k_linear128_wgrad_multi; 2: the direct kernel with
-                                * four row slices per 1024-thread workgroup (twice the waves per CU, same partials) -- measured equal (0.873-0.877
-                                * against 0.873-0.875 ms per step): the launch is co-limited by HBM streaming and MFMA issue, not by latency */
-#define FN_TUNE_PROJ_DIRECT 9  /* 1: the grouped 128 -> 128 projections / input-gradient products run as k_proj_direct (one wave per 32 x 64 tile,
-                                * weights straight from L1/L2 in the MFMA layout, no block-shared LDS tile: csrc/proj_direct.inc); 0 (default):
-                                * k_linear128_multi -- measured 1.007 against 1.020 ms per step on MI355X */
+                                * global memory in the MFMA layout, csrc/wgrad128.inc); 0: the LDS-staged k_linear128_wgrad_multi (also
+                                * what layer 0's narrow products use) */
+#define FN_TUNE_RETIRED_9 9     /* (retired: wave-independent projection kernel k_proj_direct, 1 % slower per step) */
 #define FN_TUNE_FWD_BLOCKS_EVAL 10
 #define FN_TUNE_DST_BLOCKS 11  /* target workgroup count of the backward destination pass (default 1536: three rows per half-wave at ESOL batch
                                 * 512; never more than three rows, see prep_gat_bwd_dst) */
@@ -83,13 +76,11 @@ int fn_abi_version(void);
                                  * not depend on an attention pass ride along as extra workgroups of that pass's launch (the atom projection
                                  * beside the bond + fragment-bond levels, the next layer's bond / fragment-bond projections beside the atom
                                  * level; mirrored in the backward), layer 0's three raw-feature projections share a launch and all weight-gradient
-                                 * partial products of a backward pass are one launch.  2 (default): GEMM workgroups first in the launch,
-                                 * 1: after the attention workgroups, 3: interleaved with them in units of 8, 4 / 5: first in the single-level
-                                 * launches and last in the two-level ones / the reverse (all measured), 0: separate launches */
-#define FN_TUNE_COLAUNCH_SLOTS 15 /* workgroups the co-launched GEMM tasks get: -1 (default) = one 64 x 64 tile per workgroup; 0 = the slots
-                                  * the attention pass leaves free (1024 - its workgroups, at least 256 = one per CU), each walking
-                                  * several tiles; > 0 = that many */
-#define FN_TUNE_COLAUNCH_PRIO 16  /* 1: riding GEMM workgroups run at raised wave priority (s_setprio 3); 0 (default) */
+                                 * partial products of a backward pass are one launch.  != 0 (default 2): on, the GEMM workgroups first in the
+                                 * launch (after / interleaved with the attention workgroups measured slower and were removed in round 3:
+                                 * profiles/r02e_colaunch_ab.txt); 0: separate launches */
+#define FN_TUNE_RETIRED_15 15    /* (retired: persistent riding GEMM workgroups walking several tiles, slower) */
+#define FN_TUNE_RETIRED_16 16    /* (retired: raised wave priority of the riding workgroups, no effect) */
 #define FN_TUNE_BWD_PIPELINE 17   /* 1 (default): fn_encoder_backward runs the atom chain of layer l beside the bond chain of layer l+1
                                   * (three launches per layer: k_gat_bwd_src_pair_dst, k_gat_bwd_src_lin_rd, k_gat_bwd_dst_pair_lin; the
                                   * atom graph's edge-term gradient lands on the bond rows in the epilogue of the bond input-gradient
@@ -106,10 +97,11 @@ int fn_abi_version(void);
                                   * (1024-thread workgroups, 192 rows); 3, 4 = smaller LDS images */
 #define FN_TUNE_COUNT 20
 int fn_set_tuning(int key, int value);
-/* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * molecules 64-bit words) is
- * set, every workgroup of the fused molecule kernels writes s_memtime stamps of its phases into it (tools/mol_phase_times.py).
- * NULL switches it off (the default: the kernels then pay one uniform branch per phase). */
-#define FN_MOL_STAMPS 128
+/* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * workgroups 64-bit words) is
+ * set, every workgroup of the molecule-resident backward (FN_TUNE_BWD_MOL) writes s_memtime stamps of its phases into it
+ * (tools/molbwd_check.py --stamps; words 14 / 15 = wall_clock64 at start / end).  NULL switches it off (the default: the kernel
+ * then pays one uniform branch per phase). */
+#define FN_MOL_STAMPS 16
 int fn_debug_set_stamps(void* buf, int64_t n_u64);
 const char* fn_last_error(void);
 
@@ -547,9 +539,9 @@ typedef struct fn_encoder {
     float* ws;
     int64_t ws_floats;                     /* >= fn_encoder_ws_floats() */
     /* Molecule CSRs (optional; n_mols = 0: absent).  collate_fn concatenates molecules, so the atoms / bonds / fragments /
-     * connections / graph edges of molecule i are contiguous ranges (dataset/data.py:877-948).  When they are given (and
-     * heads == 4) the encoder runs as molecule-resident fused kernels: one workgroup carries one molecule through all
-     * levels of all layers with its rows in LDS.  A batch that violates the contiguity sets bit 1 of *status. */
+     * connections / graph edges of molecule i are contiguous ranges (dataset/data.py:877-948).  They drive the molecule-resident
+     * single-pass backward (FN_TUNE_BWD_MOL, csrc/mol_bwd.hip; heads == 4).  A batch that violates the contiguity sets bit 1 of
+     * *status. */
     fn_seg_plan mol_atoms, mol_frags;      /* atoms / fragments keyed by molecule (batch, frag_batch: gat2.py:820-821) */
     int64_t n_mols;
     const int32_t* counts_dev;             /* nullable device [1]: number of REAL molecules (the first ones) when the batch is
