@@ -570,10 +570,12 @@ def main():
         from fragnet_amd import _lib
         _lib.call("fn_set_tuning", 2, int(os.environ["FN_STREAMS"]))
     spawned_single = os.environ.get("FRAGNET_BENCH_CHILD") == "1" and int(os.environ.get("WORLD_SIZE", "1")) == 1
-    rank, local_rank, world = parallel.init_distributed(force=spawned_single)
+    # FRAGNET_BENCH_BACKEND=gloo (tests): the N > 1 code path with several ranks on ONE GPU -- RCCL refuses two ranks per device,
+    # gloo moves the CUDA buffers through the host; ranks then share device LOCAL_RANK % device_count
+    rank, local_rank, world = parallel.init_distributed(backend=os.environ.get("FRAGNET_BENCH_BACKEND") or None, force=spawned_single)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     dist_on = world > 1 or spawned_single            # the N>1 step sequence: graph replay -> RCCL all-reduce -> Adam outside the graph
 
