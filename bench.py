@@ -566,9 +566,6 @@ def main():
     if args.scatter_blocks is not None:
         from fragnet_amd import _lib
         _lib.call("fn_set_tuning", 0, args.scatter_blocks)
-    if os.environ.get("FN_STREAMS"):
-        from fragnet_amd import _lib
-        _lib.call("fn_set_tuning", 2, int(os.environ["FN_STREAMS"]))
     spawned_single = os.environ.get("FRAGNET_BENCH_CHILD") == "1" and int(os.environ.get("WORLD_SIZE", "1")) == 1
     # FRAGNET_BENCH_BACKEND=gloo (tests): the N > 1 code path with several ranks on ONE GPU -- RCCL refuses two ranks per device,
     # gloo moves the CUDA buffers through the host; ranks then share device LOCAL_RANK % device_count
@@ -693,8 +690,12 @@ def main():
                                 "all": kr}
             ig = os.path.join(ROOT, "profiles", "in_graph_kernels.json")       # tools/rocpd_summary.py --json of the replayed step
             if os.path.exists(ig):
+                from fragnet_amd import build
                 gj = json.load(open(ig))
-                ks = gj.get("kernels", {})
+                # the trace is of another run: it only describes THIS library if it was built from the same sources
+                ks = gj.get("kernels", {}) if gj.get("source_digest") == build.source_digest() else {}
+                if not ks:
+                    gj["source"] = gj.get("source", "?") + " -- STALE: traced with other kernel sources than this library, figures dropped"
                 # inside the step the bond and fragment-bond levels share a launch (k_gat_*_pair): bytes of both levels
                 fb_n, fb_m = int(head["pool0"]["node_features_fbonds"].shape[0]), int(head["pool0"]["edge_index_fbonds"].shape[1])
                 f2, b2 = level_bytes(fb_n, fb_m)

@@ -3886,7 +3886,7 @@ bool have_mol(const fn_encoder* e) {       // the caller handed over the molecul
 }
 // the backward of every attention level as one pass of the molecule-resident kernel (csrc/mol_bwd.hip)
 bool mol_bwd_on(const fn_encoder* e) {
-    return g_tune[FN_TUNE_BWD_MOL] != 0 && have_mol(e) && fni::mol_bwd_supported(e->heads) && g_tune[FN_TUNE_STREAMS] == 0;
+    return g_tune[FN_TUNE_BWD_MOL] != 0 && have_mol(e) && fni::mol_bwd_supported(e->heads);
 }
 
 // Backward scratch.  Nothing is reused across levels or layers: the kernels that only produce parameter gradients
@@ -3949,40 +3949,6 @@ RngPlan rng_plan(const fn_encoder* e) {
     }
     r.total = off - e->offset;
     return r;
-}
-
-// Auxiliary streams.  The main dependency chain of a step is ~100 kernels of 5-20 us, each waiting for its
-// predecessor; everything that nobody downstream waits for -- parameter-gradient reductions and weight-gradient
-// GEMMs ("leaf" work) and the whole fragment-bond chain, which only meets the others at the last fragment level --
-// can be forked onto two side streams with event dependencies and joined before the call returns.  Works the same
-// launched eagerly or while the caller's stream is being captured into a hipGraph (the forks become graph branches).
-// OFF by default (FN_TUNE_STREAMS): measured on MI355X / ROCm 7.2 the forked hipGraph replays SLOWER than the linear
-// one (1.84 vs 1.69 ms per step, ~14 cross-branch dependencies), and two big kernel chains side by side gain only
-// 11 % over running them back to back (tools/concurrency_probe.py); launched eagerly it is worth ~5 %.
-struct AuxStreams {
-    hipStream_t s[2] = {nullptr, nullptr};       // 0: leaf work, 1: fragment-bond chain
-    hipEvent_t ev[64];
-    int cursor = 0;
-    bool ready = false;
-};
-AuxStreams g_aux;
-int aux_init() {
-    if (g_aux.ready) return 0;
-    for (auto& st : g_aux.s)
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return fail(FN_EINVAL, "auxiliary stream creation failed"); }
-    for (auto& ev : g_aux.ev)
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return fail(FN_EINVAL, "event creation failed"); }
-    g_aux.ready = true;
-    return 0;
-}
-// everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on
-int order_after(hipStream_t from, hipStream_t to) {
-    if (from == to) return 0;
-    hipEvent_t ev = g_aux.ev[g_aux.cursor++ & 63];
-    hipError_t e = hipEventRecord(ev, from);
-    if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail((int)e, "stream dependency (event record / wait) failed"); }
-    return 0;
 }
 
 // weight-gradient partials only (the reduction is deferred); *grid = partial rows written, *cls = kernel class
@@ -4449,16 +4415,13 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
     const int H = e->heads, d = FN_D / H;
     const float p = e->training ? e->drop_p : 0.f;
     const int wide = 2 * d + FN_D;             // width of a / f
-    const bool multi = g_tune[FN_TUNE_STREAMS] != 0;
     const bool lite = e->variant == 1, edge = e->variant == 2;      // gat2_lite / gat2_edge: neither has a fragment-bond graph
     const bool no_fb = lite || edge;
     // the atom graph's edge term <new_bond, a[:, d:d+128]> is produced by the bond-graph kernel's epilogue (one launch less per layer)
     const bool fuse_rd = g_tune[FN_TUNE_FUSE_ROWDOTS] != 0 && e->atom.m > 0 && e->atom.m_real == e->E;
     // projections ride along with the attention launches they do not depend on (k_gat_*_lin); needs the node scalars in the GEMM epilogue
-    const bool colaunch = !multi && H >= 2 && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;
+    const bool colaunch = H >= 2 && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;
     const fn_act_epilogue no_act_l{nullptr, 0.f, 0, 0, 0, nullptr};
-    if (multi) FN_TRY(aux_init());
-    fn_stream_t st_fb = multi ? (fn_stream_t)g_aux.s[1] : st;       // the fragment-bond chain's stream
 
     const float* in_atoms = lay.in_atoms0 ? lay.in_atoms0 : e->x_atoms;
     const float* in_bond = e->bond_nodes;
@@ -4501,7 +4464,6 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         hipLaunchKernelGGL(k_enc_prologue, dim3(A.n_t + A.n_d + A.n_s[0] + A.n_s[1] + A.n_z + A.n_x), dim3(256), 0, S(st), A);
         FN_TRY(launch_status("fn_encoder_forward: prologue"));
     }
-    FN_TRY(order_after(S(st), S(st_fb)));      // fork: the fragment-bond levels of ALL layers depend on nothing else
 
     for (int l = 0; l < e->n_layers; ++l) {
         const fn_layer_weights& w = e->w[l];
@@ -4529,7 +4491,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         // layers >= 1: the three projections (K = 128) depend only on the previous layer.  With co-launching (FN_TUNE_GEMM_COLAUNCH)
         // the bond / fragment-bond projections already ran beside the previous layer's atom level and the atom projection rides
         // with this layer's bond levels below; otherwise one grouped launch for the three
-        const bool grouped = l > 0 && fuse_ns && !multi;
+        const bool grouped = l > 0 && fuse_ns;
         bool atoms_projected = false;
         const fn_act_epilogue no_act{nullptr, 0.f, 0, 0, 0, nullptr};
         LinTasks with_pair{};                      // rides with the bond + fragment-bond launch of this layer
@@ -4547,7 +4509,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
             T.t[2] = LinTask{w.proj_fb_w, in_fbond, bt_fb, w.proj_fb_b, a.h_fb, e->EF, no_act,
                              NodeScalarEpi{w.f_a_b, lay.s_dst_fb, lay.s_src_fb, 3 * d, 0, 2 * d, H}, 0, 0};
             FN_TRY(launch_linear128_group(T, S(st)));
-        } else if (l == 0 && fuse_ns && !multi && !no_fb && kb <= 20 && kfb <= 20) {
+        } else if (l == 0 && fuse_ns && !no_fb && kb <= 20 && kfb <= 20) {
             LinTasks T{};                               // layer 0: both edge-feature projections have K <= 20 -> one launch
             T.n = 2;
             T.t[0] = LinTask{w.proj_b_w, in_bond, bt_b, w.proj_b_b, a.h_b, e->E, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
@@ -4564,7 +4526,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
             FN_TRY(launch_linear128_small_group(T, S(st)));
         } else {
             FN_TRY(project(in_bond, kb, bt_b, w.proj_b_b, a.h_b, e->E, w.a_b, 3 * d, 2 * d, lay.s_dst, lay.s_src, st));
-            if (!no_fb) FN_TRY(project(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, w.f_a_b, 3 * d, 2 * d, lay.s_dst_fb, lay.s_src_fb, st_fb));
+            if (!no_fb) FN_TRY(project(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, w.f_a_b, 3 * d, 2 * d, lay.s_dst_fb, lay.s_src_fb, st));
         }
         fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
         fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
@@ -4575,10 +4537,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         if (fuse_rd) {
             gb.rd_A = w.a + d;  gb.rd_lda = wide;  gb.rd_J = H;  gb.rd_out = lay.s_sorted;  gb.rd_pos = e->atom.inv_d;  gb.rd_m = e->atom.m;
         }
-        if (multi) {
-            FN_TRY(launch_gat_fwd(gb, H, S(st)));
-            FN_TRY(launch_gat_fwd(gfb, H, S(st_fb)));
-        } else if (with_pair.n) {
+        if (with_pair.n) {
             FN_TRY(launch_gat_fwd_pair_lin(gb, gfb, with_pair, H, S(st)));
         } else {
             FN_TRY(launch_gat_fwd_pair(gb, gfb, H, S(st)));
@@ -4615,14 +4574,12 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         // overwrites x_frags with its own atom->fragment sum before first use (gat2.py:234), so inner
         // layers skip this level entirely (the reference computes it and throws it away).
         if (last && lite) {      // gat2_lite: the encoder's fragment output is act(dropout(.)) of the plain fragment sums
-            FN_TRY(order_after(S(st_fb), S(st)));
             FN_TRY(fn_dropout_act_f32(a.frags, y_frags, e->F * FN_D, p, e->seed, rng.y[l][1], e->offset_dev, 1, st));
         } else if (last && edge) {   // gat2_edge (gat2_edge.py:148-172): edge term = <Linear(8 -> 128)(cnx_attr), f[:, d:d+128]>, folded in-kernel
             FN_TRY(fn_node_scalars_f32(a.frags, w.f, wide, 0, d + FN_D, lay.s_dst, lay.s_src, e->F, H, st));
             fn_edge_term et_f{2, e->k_fattr, FN_D, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
             FN_TRY(fn_gat_fwd_f32(a.frags, lay.s_dst, lay.s_src, w.f, wide, &et_f, &e->frag, 0.2f, nullptr, a.p_frag, nullptr, &ep_frags, H, st));
         } else if (last) {
-            FN_TRY(order_after(S(st_fb), S(st)));            // join: the fragment graph's edge term reads new_fbond
             if (tail_fused) {                                // atom -> fragment sum + node scalars + edge term: one launch
                 FragTailArgs T{};
                 T.src = lay.atoms_new;  T.rowptr = e->a2f.rowptr;  T.perm = e->a2f.perm;  T.pos_base = e->a2f.pos_base;  T.out = a.frags;
@@ -4663,20 +4620,13 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
     const float p = e->training ? e->drop_p : 0.f;
     const int wide = 2 * d + FN_D;
     hipStream_t hs = S(st);
-    const bool multi = g_tune[FN_TUNE_STREAMS] != 0;
     const bool lite = e->variant == 1, edge = e->variant == 2;
-    if (multi) FN_TRY(aux_init());
-    // leaf: kernels nobody downstream waits for (parameter-gradient reductions, weight-gradient GEMMs);
-    // fb: the fragment-bond chain, which after the last layer's fragment level never meets the others again
-    fn_stream_t st_leaf = multi ? (fn_stream_t)g_aux.s[0] : st;
-    fn_stream_t st_fb = multi ? (fn_stream_t)g_aux.s[1] : st;
-    bool fb_forked = false, leaf_forked = false;
     ReduceQueue rq;
     rq.st = hs;                      // all parameter-gradient reductions run as one launch at the very end
-    rq.defer_wgrad = !multi;         // ... and so do the K = 128 weight-gradient partial products
-    rq.defer_mixed = !multi && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;      // ... and layer 0's
+    rq.defer_wgrad = true;           // ... and so do the K = 128 weight-gradient partial products
+    rq.defer_mixed = g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;      // ... and layer 0's
 
-    const bool colaunch = !multi && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;
+    const bool colaunch = g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;
     // two chains side by side (k_gat_bwd_src_pair_dst / k_gat_bwd_src_lin_rd): the bond levels' source pass of layer l+1 is held back
     // and launched with the atom level's destination pass of layer l; the atom graph's edge-term gradient reaches the bond rows in
     // the epilogue of the bond input-gradient product (RowAdd: every bond is edge e of the atom graph, in order)
@@ -4724,7 +4674,6 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         // Wt: the transposed copy the forward prologue left in the workspace (k_proj128 wants the weight n-major)
         auto input_grad = [&](const float* gh, const float* W, const float* Wt, float* gy, int64_t rows, const fn_act_epilogue& mk, fn_stream_t sq,
                               int where, const RowAdd* ra = nullptr) -> int {
-            if (multi) return fn_linear128_f32(gh, FN_D, W, nullptr, gy, rows, &mk, sq);
             LinTasks& dst = !colaunch ? dxT : (where == 0 ? dxA : dx_carry);
             dst.t[dst.n++] = LinTask{Wt, gh, W, nullptr, gy, rows, mk, NodeScalarEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0}, 0, 0};
             if (ra) dst.t[dst.n - 1].ra = *ra;
@@ -4827,8 +4776,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
             if (gr) have_bond = true;
             FN_TRY(rq.finalize(sa.part_a, n_a, nullptr, 0, et_a, w.a, wide, 0, d + FN_D, g.a, nullptr, nullptr, H));
             if (gr) FN_TRY(rq.colsum(sa.part_rd, gr, H * FN_D, g.a, wide, d));
-            if (multi) { FN_TRY(order_after(hs, S(st_leaf)));  leaf_forked = true; }
-            FN_TRY(rq.wgrad(sa.g_h, in_atoms, ka, e->N, sa.wg_ws, g.proj_a_w, g.proj_a_b, S(st_leaf)));
+            FN_TRY(rq.wgrad(sa.g_h, in_atoms, ka, e->N, sa.wg_ws, g.proj_a_w, g.proj_a_b, hs));
             if (l) {
                 const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_atoms), p, 1, e->seed, rng.y[l - 1][0], e->offset_dev};
                 FN_TRY(input_grad(sa.g_h, w.proj_a_w, bt_a, bw.g_pre_atoms, e->N, mk, st, 0));
@@ -4861,31 +4809,22 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
                 FN_TRY(prep_gat_bwd_dst(bw.g_pre_fbond, a.h_fb, a.p_fbond, &et_fb, &e->fbond, 0.2f, nullptr, nullptr, sfb.pz, sfb.g_s_dst, sfb.part_e, &n_e_fb, H, &dfb));
                 FN_TRY(prep_gat_bwd_src(bw.g_pre_fbond, a.h_fb, sfb.pz, sfb.g_s_dst, w.f_a_b, 3 * d, 0, 2 * d, &e->fbond, sfb.g_h, sfb.part_a, &n_a_fb, H, &sfbA));
             }
-            if (multi) {
-                if (have_fbond && !fb_forked) { FN_TRY(order_after(hs, S(st_fb)));  fb_forked = true; }
-                FN_TRY(launch_gat_bwd_dst(db, H, hs));
-                FN_TRY(launch_gat_bwd_src(sbA, H, hs));
-                FN_TRY(launch_gat_bwd_dst(dfb, H, S(st_fb)));
-                FN_TRY(launch_gat_bwd_src(sfbA, H, S(st_fb)));
-            } else {
-                FN_TRY(launch_gat_bwd_dst_pair_lin(db, dfb, dxA, H, hs));        // + this layer's atom input-gradient product
-                dxA = LinTasks{};
-                if (pipeline && l > 0) { pend_sb = sbA;  pend_sfb = sfbA;  pend = true; }     // rides with layer l-1's atom destination pass
-                else FN_TRY(launch_gat_bwd_src_pair(sbA, sfbA, H, hs));
-            }
+            FN_TRY(launch_gat_bwd_dst_pair_lin(db, dfb, dxA, H, hs));        // + this layer's atom input-gradient product
+            dxA = LinTasks{};
+            if (pipeline && l > 0) { pend_sb = sbA;  pend_sfb = sfbA;  pend = true; }     // rides with layer l-1's atom destination pass
+            else FN_TRY(launch_gat_bwd_src_pair(sbA, sfbA, H, hs));
             if (have_fbond) {
                 if (l) {     // dL/d(pre-activation fbond output of layer l-1), gated by that layer's dropout mask and ReLU
                     const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_fbond), p, 1, e->seed, rng.y[l - 1][3], e->offset_dev};
-                    FN_TRY(input_grad(sfb.g_h, w.proj_fb_w, bt_fb, bw.g_pre_fbond, e->EF, mk, st_fb, 1));
+                    FN_TRY(input_grad(sfb.g_h, w.proj_fb_w, bt_fb, bw.g_pre_fbond, e->EF, mk, st, 1));
                     nxt_fbond = true;
                 }
                 FN_TRY(rq.finalize(sfb.part_a, n_a_fb, sfb.part_e, n_e_fb, et_fb, w.f_a_b, 3 * d, 0, 2 * d, g.f_a_b, g.emb_fb_w, g.emb_fb_b, H));
-                FN_TRY(rq.wgrad(sfb.g_h, in_fbond, kfb, e->EF, sfb.wg_ws, g.proj_fb_w, g.proj_fb_b, S(st_fb)));
+                FN_TRY(rq.wgrad(sfb.g_h, in_fbond, kfb, e->EF, sfb.wg_ws, g.proj_fb_w, g.proj_fb_b, hs));
             }
             if (have_bond) {
                 FN_TRY(rq.finalize(sb.part_a, n_a_b, sb.part_e, n_e_b, et_b, w.a_b, 3 * d, 0, 2 * d, g.a_b, g.emb_b_w, g.emb_b_b, H));
-                if (multi) { FN_TRY(order_after(hs, S(st_leaf)));  leaf_forked = true; }
-                FN_TRY(rq.wgrad(sb.g_h, in_bond, kb, e->E, sb.wg_ws, g.proj_b_w, g.proj_b_b, S(st_leaf)));
+                    FN_TRY(rq.wgrad(sb.g_h, in_bond, kb, e->E, sb.wg_ws, g.proj_b_w, g.proj_b_b, hs));
                 if (l) {
                     const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_bond), p, 1, e->seed, rng.y[l - 1][2], e->offset_dev};
                     if (pipeline && nxt_atoms) {      // layer l-1's atom level will run: its edge-term gradient rides in this product's epilogue
@@ -4906,9 +4845,6 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         gy_frags = nullptr;        // a layer's x_frags input is dead in the reference (overwritten at gat2.py:234)
     }
     if (pend) FN_TRY(launch_gat_bwd_src_pair(pend_sb, pend_sfb, H, hs));
-    // join: the caller's stream continues only after both side streams have drained
-    if (leaf_forked) FN_TRY(order_after(S(st_leaf), hs));
-    if (fb_forked) FN_TRY(order_after(S(st_fb), hs));
     return rq.flush();
 }
 

@@ -54,8 +54,8 @@ int fn_abi_version(void);
 #define FN_TUNE_GEMM_SLOTS 1   /* > 0: cap on the workgroups of a projection GEMM launch (1024 = 256 CUs x 4 resident); a launch with
                                 * more 64x64 output tiles then walks several row tiles per workgroup, prefetching the next tile's
                                 * rows.  Default 0 = one tile per workgroup (faster at every measured size) */
-#define FN_TUNE_STREAMS 2      /* 1: the encoder forks parameter-gradient work and the fragment-bond chain onto side streams;
-                                * 0 (default): one stream -- forked hipGraph replays measured slower on ROCm 7.2 */
+#define FN_TUNE_RETIRED_2 2     /* (retired in round 3, no effect: parameter-gradient work and the fragment-bond chain forked onto side streams --
+                                * a forked hipGraph replays SLOWER than the serial one on ROCm 7.2, 1.84 vs 1.69 ms per step) */
 #define FN_TUNE_WGRAD_BLOCKS 3 /* target workgroup count of the grouped weight-gradient launch of a backward pass (default 256: one per CU; 512 wrote twice the partials and measured 1 % slower per step) */
 #define FN_TUNE_RETIRED_4 4     /* (retired in round 3, no effect: the molecule-resident fused FORWARD of round 2 -- measured equal at 512
                                 * molecules, slower elsewhere; source kept out of the build under tools/probe/retired/mol_fused.inc) */

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the per-round evidence set on a GPU box:  bash tools/final_artifacts.sh <tag>   (writes gpurun_out/<tag>/, copy into profiles/)
 set -u
-TAG=${1:-r02f}
+TAG=${1:-r03}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -14,6 +14,10 @@ timeout 600 python3 bench.py --forward-sweep 2>/dev/null > $O/forward_sweep.json
 timeout 900 python3 bench.py --forward-sweep --store 1048576 2>/dev/null > $O/store_sweep.json
 timeout 300 python3 tools/tox21_bench.py > $O/tox21.txt 2>&1
 timeout 300 python3 tools/pretrain_bench.py > $O/pretrain.txt 2>&1
+timeout 300 python3 bench.py --gpus 1 --spawn --no-cpu-baseline --no-roofline > $O/bench_spawn_1rank.json 2> $O/bench_spawn_1rank.err
+FRAGNET_BENCH_BACKEND=gloo timeout 300 python3 bench.py --gpus 2 --overlap off --no-cpu-baseline --no-roofline --steps 10 > $O/bench_2ranks_gloo_one_gpu.json 2> /dev/null
+timeout 300 python3 tools/molbwd_check.py --stamps > $O/molbwd_check.txt 2>&1
+timeout 300 python3 tools/molbwd_check.py --batch 2048 --levels bond,atom --stamps > $O/molbwd_check_b2048.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pd /tmp/pd2 /tmp/pmc_fetch /tmp/pmc_write
 timeout 300 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/pd -o d -- python3 $R/bench.py --no-cpu-baseline --no-roofline > /dev/null 2>&1
@@ -21,6 +25,11 @@ DB=$(ls /tmp/pd/*/*.db /tmp/pd/*.db 2>/dev/null | head -1)
 python3 $R/tools/rocpd_summary.py $DB > $O/kernel_trace_summary.md 2>&1
 python3 $R/tools/rocpd_summary.py $DB --json "rocprofv3 --kernel-trace -- python3 bench.py --no-cpu-baseline --no-roofline ($TAG, whole-step hipGraph replays; k_gat_fwd_pair / k_gat_bwd_dst_pair are layer 0's launches, the only ones of their kind without projection workgroups riding along)" > $O/in_graph_kernels.json 2>/dev/null
 python3 $R/tools/rocpd_sequence.py $DB > $O/step_sequence.txt 2>&1
+rm -rf /tmp/pdp
+timeout 300 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/pdp -o d -- python3 $R/tools/pretrain_bench.py > /dev/null 2>&1
+DBP=$(ls /tmp/pdp/*/*.db /tmp/pdp/*.db 2>/dev/null | head -1)
+python3 $R/tools/rocpd_sequence.py $DBP > $O/pretrain_step_sequence.txt 2>&1
+python3 $R/tools/rocpd_summary.py $DBP > $O/pretrain_kernel_trace_summary.md 2>&1
 timeout 600 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/pd2 -o d -- python3 $R/bench.py > $O/bench_under_rocprof.json 2>/dev/null
 DB2=$(ls /tmp/pd2/*/*.db /tmp/pd2/*.db 2>/dev/null | head -1)
 python3 $R/tools/rocpd_summary.py $DB2 > $O/bench_full_kernel_trace_summary.md 2>&1

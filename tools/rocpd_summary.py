@@ -46,7 +46,11 @@ def main():
     total = sum(sum(v) for v in per.values())
     t0, t1 = min(r[1] for r in rows), max(r[2] for r in rows)
     if len(sys.argv) > 2 and sys.argv[2] == "--json":
-        print(json.dumps({"source": sys.argv[3] if len(sys.argv) > 3 else sys.argv[1],
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from fragnet_amd import build              # the digest of the sources the traced library was built from: bench.py drops
+        print(json.dumps({"source": sys.argv[3] if len(sys.argv) > 3 else sys.argv[1],          # these figures when it differs
+                          "source_digest": build.source_digest(),
                           "kernels": {k: {"calls": len(v), "avg_us": round(sum(v) / len(v) / 1e3, 2)} for k, v in sorted(per.items())}}, indent=1))
         return
     print(f"# {sys.argv[1]}\n")
