@@ -214,6 +214,37 @@ def kernel_roofline(batch, model, iters=50):
         us = a.elapsed_time(b) * 1000.0 / iters
         res[name] = {"us_per_launch": round(us, 2), "algorithmic_bytes": nbytes, "GBps": round(nbytes / us / 1e3, 1),
                      "n": n, "m": m}
+    # the single-pass alternative (csrc/mol_bwd.hip, off by default): same inputs, same bytes model -- reported beside the two passes
+    try:
+        from fragnet_amd._lib import SegPlan
+        seg = lambda q: SegPlan(q.rowptr.data_ptr(), q.perm.data_ptr(), q.index.data_ptr(), q.n_seg, q.n_items, q.pos_base, 0)
+        L = plan.levels
+        ext = torch.zeros(plan.n_mols, 16, dtype=torch.int32, device=dev)
+        _lib.call("fn_mol_extents", C.byref(seg(plan.segs["mol_atoms"])), C.byref(seg(plan.segs["mol_frags"])), C.byref(L["bond"].c),
+                  C.byref(L["atom"].c), C.byref(L["fbond"].c), C.byref(L["frag"].c), plan.n_mols, ext.data_ptr(), st)
+        g_h2, scratch = torch.empty(n, 128, **f32), torch.empty(H * m + n * H, **f32)
+        status, n_p = torch.zeros(1, dtype=torch.int32, device=dev), C.c_int(0)
+
+        def bwd_mol():
+            _lib.call("fn_gat_bwd_mol_f32", gout.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), C.byref(et), att.data_ptr(), 96, 0, 64,
+                      C.byref(lv.c), 0.2, ext.data_ptr(), plan.n_mols, 0, 1, None, g_h2.data_ptr(), None, part_a.data_ptr(),
+                      part_e.data_ptr(), C.byref(n_p), scratch.data_ptr(), status.data_ptr(), H, st)
+        extra = (("k_mol_bwd(single pass, FN_TUNE_BWD_MOL; not the default)", bwd_mol, bwd_b),)
+    except Exception as exc:      # noqa: BLE001 -- an A/B figure must never cost the measurement
+        extra = ()
+        res["k_mol_bwd_error"] = f"{type(exc).__name__}: {exc}"
+    for name, fn, nbytes in extra:
+        for _ in range(5):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) * 1000.0 / iters
+        res[name] = {"us_per_launch": round(us, 2), "algorithmic_bytes": nbytes, "GBps": round(nbytes / us / 1e3, 1), "n": n, "m": m}
     us_bwd = res["k_gat_bwd_dst"]["us_per_launch"] + res["k_gat_bwd_src"]["us_per_launch"]
     res["k_gat_bwd(dst+src)"] = {"us_per_launch": round(us_bwd, 2), "algorithmic_bytes": bwd_b, "GBps": round(bwd_b / us_bwd / 1e3, 1),
                                  "n": n, "m": m}

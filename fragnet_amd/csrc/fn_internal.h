@@ -159,6 +159,18 @@ __device__ __forceinline__ float4 ld4s(const lds_f* p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void st4s(lds_f* p, float4 v) { *reinterpret_cast<FN_LDS f32x4*>(p) = (f32x4){v.x, v.y, v.z, v.w}; }
+
+// LDS-DMA (global_load_lds_*): the wave's 64 lanes write 64 x SIZE consecutive bytes at the wave-uniform LDS address; the
+// global source address is per lane.  No VGPR destination: the tile costs no registers while it is in flight.
+template <int SIZE>
+__device__ __forceinline__ void dma_to_lds(const void* gsrc, void* lds_wave_base) {
+    static_assert(SIZE == 4 || SIZE == 16, "dword or dwordx4 pieces");
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (SIZE == 16) __builtin_amdgcn_global_load_lds((const FN_GLB void*)gsrc, (FN_LDS void*)lds_wave_base, 16, 0, 0);
+    else __builtin_amdgcn_global_load_lds((const FN_GLB void*)gsrc, (FN_LDS void*)lds_wave_base, 4, 0, 0);
+#endif
+}
+
 }  // namespace
 
 // ---- molecule-resident single-pass backward of the attention levels (csrc/mol_bwd.hip)

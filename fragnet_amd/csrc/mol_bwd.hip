@@ -54,17 +54,6 @@ __device__ __forceinline__ void lv_extent(const MolExt& x, int which, int& r0, i
     else { r0 = x.f0;  nr = x.nf;  e0 = x.ec0;  me = x.mec; }
 }
 
-// LDS-DMA (global_load_lds_*): the wave's 64 lanes write 64 x SIZE consecutive bytes at the wave-uniform LDS address; the
-// global source address is per lane.  No VGPR destination: the tile costs no registers while it is in flight.
-template <int SIZE>
-__device__ __forceinline__ void dma_to_lds(const void* gsrc, void* lds_wave_base) {
-    static_assert(SIZE == 4 || SIZE == 16, "dword or dwordx4 pieces");
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (SIZE == 16) __builtin_amdgcn_global_load_lds((const FN_GLB void*)gsrc, (FN_LDS void*)lds_wave_base, 16, 0, 0);
-    else __builtin_amdgcn_global_load_lds((const FN_GLB void*)gsrc, (FN_LDS void*)lds_wave_base, 4, 0, 0);
-#endif
-}
-
 template <int H, int NT, int RPH, int RT, int MCAP>
 struct Cfg {
     static constexpr int NHW = NT / 32;            // half-waves = rows in flight
