@@ -147,9 +147,10 @@ def cpu_baseline(budget_s=28.0):
         step(batch)
         times.append(time.perf_counter() - t0)
     med = statistics.median(times)
-    return {"value": round(PER_GPU_BATCH / med, 2), "unit": "molecules/s", "cores": all_cores, "kind": "port",
-            "sample": f"{len(times)} all-core training step(s) of one ESOL-shape batch of {PER_GPU_BATCH} (median {med:.2f} s/step; "
-                      f"the first doubles as warm-up) + 2 warm-up / 5 timed steps of a 32-molecule batch at 1 and {all_cores} threads; "
+    return {"value": round(PER_GPU_BATCH / med, 2), "unit": "molecules/s", "cores": all_cores, "kind": "port", "timed_steps": len(times),
+            "sample": f"n = {len(times)} all-core training step(s) of one ESOL-shape batch of {PER_GPU_BATCH} (median {med:.2f} s/step; the leg is "
+                      f"bounded to ~{budget_s:.0f} s, so BASELINE.md's 2 warm-up + 5 timed steps do not fit at ~8 s per step: the first step "
+                      f"doubles as warm-up) + 2 warm-up / 5 timed steps of a 32-molecule batch at 1 and {all_cores} threads; "
                       f"oracle/fragnet_ref.py, torch {torch.__version__} CPU",
             "batch_32": b32, "cpu_model": _cpu_model(), "host_cpus": os.cpu_count()}
 
