@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import engine, ops
+from ._lib import FN_D
 from .plan import LIVE_MOLS_KEY, plan_for
 
 _ACTS = {
@@ -54,6 +55,16 @@ def _plan_from_indices(N, E, F_, EF, edge_index, frag_index, a2f, eib, eifb):
 
 def _two_layer(width: int) -> nn.Sequential:
     return nn.Sequential(nn.Linear(width, 2 * width), nn.ReLU(), nn.Linear(2 * width, width))
+
+
+def _project(x, lin: nn.Linear):
+    """``lin(x)`` for the 128-wide node projections (gat2.py:138,186,241): the hand-written fp32-MFMA kernel with its own
+    backward (ops.linear128) wherever it applies -- GPU rows, 128 outputs, K <= 168, an input gradient only for K == 128 --
+    so that the per-level path (return_attentions, masks, per-op tests) issues no library GEMM either."""
+    w = lin.weight
+    if x.is_cuda and lin.bias is not None and w.shape[0] == FN_D and w.shape[1] <= 168 and (w.shape[1] == FN_D or not x.requires_grad):
+        return ops.linear128(x, w, lin.bias)
+    return F.linear(x, w, lin.bias)
 
 
 class FragNetLayerA(nn.Module):
@@ -118,7 +129,7 @@ class FragNetLayerA(nn.Module):
         L = plan.levels
 
         # L1 bond graph (gat2.py:137-169): affine-in-cos edge term folded in-kernel
-        r = ops.gat_level(F.linear(bond_nodes, self.projection_b.weight, self.projection_b.bias), self.a_b, L["bond"], H,
+        r = ops.gat_level(_project(bond_nodes, self.projection_b), self.a_b, L["bond"], H,
                           x_sorted=plan.sorted_attr("bond", bond_cos), embW=self.edge_attr_bond_embed.weight,
                           embb=self.edge_attr_bond_embed.bias,
                           want_probs=want)
@@ -129,7 +140,7 @@ class FragNetLayerA(nn.Module):
 
         # L2 atom graph with self loops (gat2.py:179-224): edge term = <new_bond[e], a[:, d:d+128]>, 0 on loops
         s_edge = ops.row_dots_sorted(new_bond, self.a, d, L["atom"])
-        r = ops.gat_level(F.linear(x_atoms, self.projection_a.weight, self.projection_a.bias), self.a, L["atom"], H,
+        r = ops.gat_level(_project(x_atoms, self.projection_a), self.a, L["atom"], H,
                           s_sorted=s_edge, want_probs=want)
         atoms_new, p_atom = (r[0], r[2]) if want else (r, None)
         if self.atom_mask_individual is not None:
@@ -145,7 +156,7 @@ class FragNetLayerA(nn.Module):
             return atoms_new, frags, new_bond, None
 
         # L4a fragment-bond graph (gat2.py:239-272)
-        r = ops.gat_level(F.linear(fbond_nodes, self.projection_fb.weight, self.projection_fb.bias), self.f_a_b,
+        r = ops.gat_level(_project(fbond_nodes, self.projection_fb), self.f_a_b,
                           L["fbond"], H, x_sorted=plan.sorted_attr("fbond", fbond_attr), embW=self.edge_attr_fbond_embed.weight,
                           embb=self.edge_attr_fbond_embed.bias, want_probs=want)
         new_fbond, p_fbond = (r[0], r[2]) if want else (r, None)
@@ -224,12 +235,12 @@ class FragNetLayerEdge(nn.Module):
         H, d = self.num_heads, self.edge_out // self.num_heads
         want = self.return_attentions
         L = plan.levels
-        r = ops.gat_level(F.linear(bond_nodes, self.projection_b.weight, self.projection_b.bias), self.a_b, L["bond"], H,
+        r = ops.gat_level(_project(bond_nodes, self.projection_b), self.a_b, L["bond"], H,
                           x_sorted=plan.sorted_attr("bond", bond_cos), embW=self.edge_attr_bond_embed.weight,
                           embb=self.edge_attr_bond_embed.bias, want_probs=want)                      # L1 :74-103
         new_bond, p_bond = (r[0], r[2]) if want else (r, None)
         s_edge = ops.row_dots_sorted(new_bond, self.a, d, L["atom"])                                  # L2 :108-141
-        r = ops.gat_level(F.linear(x_atoms, self.projection_a.weight, self.projection_a.bias), self.a, L["atom"], H,
+        r = ops.gat_level(_project(x_atoms, self.projection_a), self.a, L["atom"], H,
                           s_sorted=s_edge, want_probs=want)
         atoms_new, p_atom = (r[0], r[2]) if want else (r, None)
         frags = ops.segment_sum(atoms_new, plan.segs["a2f"], plan)                                    # L3 :142
