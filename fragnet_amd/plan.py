@@ -1,5 +1,5 @@
 """Per-batch graph plan: every destination-sorted CSR the four levels, the atom->fragment sum and
-the pooling need, built by ONE fn_plan_build call (6 small kernels) and reused by all layers,
+the pooling need, built by ONE fn_plan_build call (5 small kernels) and reused by all layers,
 forward and backward.
 
 Which row of each index tensor is the destination follows the reference's unpacking:
@@ -87,7 +87,8 @@ class GraphPlan:
         ti, ts = tot_items.value, tot_segs.value
         # one int32 arena: rowptr | perm | aux_a | aux_b | aux_c | workspace(cursor, tmp, status, block sums)
         ta = max(ti, 1)                 # keep every region non-empty so its pointer is never null
-        arena = torch.empty(ts + 1 + 4 * ta + (ts + ti + 4 + 2 * (ts // 2048 + 1) + 2), dtype=torch.int32, device=device)
+        ws_zeroed = ts + ti + 4 + 2 * (ts // 2048 + 1) + 2                  # FN_PLAN_WS_ZEROED; FN_PLAN_WS = that + ti (never zeroed)
+        arena = torch.empty(ts + 1 + 4 * ta + ws_zeroed + ti, dtype=torch.int32, device=device)
         self._arena = arena
         self.rowptr = arena[: ts + 1]
         self.perm = arena[ts + 1: ts + 1 + ta]
@@ -97,7 +98,7 @@ class GraphPlan:
         ws = arena[ts + 1 + 4 * ta:]
         self._status = ws[ts + ti: ts + ti + 1]
         # regions fn_plan_build needs zeroed: a captured step has its staging launch do it (graphstep, PREZEROED context)
-        self.zero_regions = [(self.rowptr.data_ptr(), ts + 1), (ws.data_ptr(), int(ws.numel()))]
+        self.zero_regions = [(self.rowptr.data_ptr(), ts + 1), (ws.data_ptr(), ws_zeroed)]
         self.prezeroed = bool(_PREZEROED)
         if self.prezeroed:
             _BUILT.append(self)

@@ -143,7 +143,8 @@ int fn_plan_layout(fn_csr_task* tasks, int n_tasks, int64_t* total_items, int64_
 
 /* ws_i32 must hold FN_PLAN_WS(total_segs, total_items) int32.  ws_i32[total_segs + total_items] is a
  * status word: non-zero after the call completes if any key was outside [0, n_seg). */
-#define FN_PLAN_WS(total_segs, total_items) ((total_segs) + (total_items) + 4 + 2 * ((total_segs) / 2048 + 1) + 2)
+#define FN_PLAN_WS(total_segs, total_items) ((total_segs) + 2 * (total_items) + 4 + 2 * ((total_segs) / 2048 + 1) + 2)
+#define FN_PLAN_WS_ZEROED(total_segs, total_items) ((total_segs) + (total_items) + 4 + 2 * ((total_segs) / 2048 + 1) + 2)   /* the leading part that must be zero (FN_PLAN_PREZEROED) */
 int fn_plan_build(const fn_csr_task* tasks, int n_tasks,
                   int32_t* rowptr_all /*[total_segs+1]*/, int32_t* perm_all /*[total_items]*/,
                   int32_t* aux_a /*[total_items]*/, int32_t* aux_b /*[total_items]*/, int32_t* aux_c /*[total_items]*/,
