@@ -708,7 +708,7 @@ def main():
                 parts = ("k_gat_fwd",) if dom == "k_gat_fwd" else ("k_gat_bwd_dst", "k_gat_bwd_src")
                 if all(k in pj for k in parts):
                     traffic = sum(pj[k]["hbm_bytes_per_launch"] for k in parts)
-                    traffic_source = ("profiles/pmc_per_launch.json (" + pj.get("_collected", "round 1, profiles/r01g; kernels unchanged since") +
+                    traffic_source = ("profiles/pmc_per_launch.json (" + pj.get("_collected", "round 2; the two-pass kernels are unchanged since") +
                                       "): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --kernels-only`, NOT this run")
             line["roofline"] = {"bound": "hbm", "kernel": dom + "<4> @ bond-graph level", "achieved": kr[dom]["GBps"],
                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(kr[dom]["GBps"] / HBM_PEAK_GBPS, 4),

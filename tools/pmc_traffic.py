@@ -14,7 +14,7 @@ import csv
 import json
 import sys
 
-KERNELS = ("k_gat_fwd", "k_gat_bwd_dst", "k_gat_bwd_src")
+KERNELS = ("k_gat_fwd", "k_gat_bwd_dst", "k_gat_bwd_src", "k_mol_bwd")      # k_mol_bwd: the single-pass alternative (off by default)
 
 
 def per_kernel(path, counter):
@@ -37,6 +37,7 @@ def main():
             f, w = fetch[k] * 1024 * 2, write[k] * 1024
             out[k] = {"hbm_bytes_per_launch": int(f + w), "fetch_bytes_corrected_x2": int(f), "write_bytes": int(w),
                       "raw_FETCH_SIZE_KiB": round(fetch[k], 1), "raw_WRITE_SIZE_KiB": round(write[k], 1)}
+    out["_collected"] = "round 3, tools/final_artifacts.sh"
     out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --kernels-only` (bond-graph level, "
                     "B=512 ESOL shape), averaged over the launches of each kernel; FETCH_SIZE doubled per MI355X_MICROARCH.md "
                     "section HBM; tools/pmc_traffic.py")
