@@ -1,20 +1,27 @@
 // Molecule-resident single-pass backward of an attention level (autograd of reference model/gat/gat2.py:146-169,
 // 196-224, 250-272, 286-316: scatter_softmax + weighted scatter_add of one level).
+// STATUS: parity-green, measured SLOWER than the two passes it was built to replace (39-42 us against 28 us, bond level at
+// ESOL batch 512) and therefore off by default (FN_TUNE_BWD_MOL); DESIGN.md section 4c and profiles/r03_molbwd_phases.md have the
+// phase timings and the reasons.
 //
 // The graphs of a collated batch are block-diagonal per molecule (dataset/data.py:877-948), so a workgroup that owns whole
-// molecules owns every edge that touches their rows.  It stages the molecule's GRADIENT rows g[t] (coalesced, once) and the
-// per-edge state (probabilities, both CSR orders) in LDS, keeps the projected rows h[s] of the rows it owns in registers,
-// and then needs no further global read:
-//   pass A  (source-owner half-waves)  dp_e = <h[s], g[t_e]> per head  and  acc_s = sum_e p_e g[t_e]   -- ONE LDS gather per edge
-//   pass B  (one thread per (t, head))  c_t = sum_e p_e dp_e,  dz_e = p_e (dp_e - c_t) LeakyReLU'_e,  g_s_dst[t] = sum dz_e
-//   pass C  (source-owner half-waves)  g_s_src[s] = sum_e dz_e,  g_h[s] = acc_s + g_s_dst[s] a_dst + g_s_src[s] a_src  -> global
-//   edge outputs: dz in original edge order (mode 0) or the workgroup's partial of sum_e dz_e (x_e, 1) (mode 2)
-// g and h are read once, (p, dz) never leave the CU, g_h / dz are written once.  The two-pass kernels this replaces
-// (k_gat_bwd_dst + k_gat_bwd_src, fragnet_hip.hip) read g and h twice and exchange (p, dz) through HBM.
+// molecules owns every edge that touches their rows.  It stages the molecule's GRADIENT rows g[t] in LDS by LDS-DMA (coalesced,
+// once, no registers; 64-row tile rounds for molecules beyond the tile) together with the per-edge state (probabilities, both
+// CSR orders packed into one word per edge, raw attribute or original edge id), keeps the projected rows h[s] of the rows it
+// owns in registers, and then needs no further global read:
+//   pass A  (source-owner half-waves)    dp_e = <h[s], g[t_e]> per head  and  acc_s = sum_e p_e g[t_e]  -- ONE LDS row read per edge
+//   pass B  (half-wave per destination row, lane j of a head owns in-edges 2j, 2j+1, DPP sums)
+//                                       c_t = sum_e p_e dp_e,  dz_e = p_e (dp_e - c_t) LeakyReLU'_e,  g_s_dst[t] = sum dz_e,
+//                                       and the edge outputs: dz in original edge order (mode 0) or the lane's share of
+//                                       sum_e dz_e (x_e, 1) (mode 2)
+//   pass C  (source-owner half-waves)    g_s_src[s] = sum_e dz_e,  g_h[s] = acc_s + g_s_dst[s] a_dst + g_s_src[s] a_src -> global,
+//                                       dL/da partial columns
+// g and h are read once, (p, dz) never leave the CU, g_h / dz are written once.  The two-pass kernels (k_gat_bwd_dst +
+// k_gat_bwd_src, fragnet_hip.hip) read g and h twice and exchange (p, dz) through HBM.
 //
-// Units that do not fit the LDS tile (rows > R or edges > M of the launch's size class) run the same three passes with
-// their rows gathered from global memory and the edge state in a caller-provided scratch -- correct, slower, rare.
-// Rows behind the last real molecule of a padded batch (fn_stage_padded) are zeroed by extra workgroups.
+// Units that do not fit the size class of the launch (rows > R or edges > M) run the same three passes with their rows
+// gathered from global memory and the edge state in a caller-provided scratch, in extra workgroups of the launch -- correct,
+// slow, rare.  Rows behind the last real molecule of a padded batch (fn_stage_padded) are zeroed by extra workgroups.
 // Everything is fixed-order: no float atomics, bitwise reproducible.
 #include <algorithm>
 #include <stdio.h>
