@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfragnet_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 FN_D = 128
 FN_MAX_TASKS = 16
 FN_MAX_EDGE_K = 8
@@ -84,7 +84,8 @@ class Encoder(C.Structure):
                 ("x_atoms", vp), ("bond_nodes", vp), ("fbond_nodes", vp), ("cos_sorted", vp), ("fattr_sorted", vp),
                 ("cos_raw", vp), ("fattr_raw", vp),
                 ("w", LayerWeights * FN_MAX_LAYERS), ("ws", vp), ("ws_floats", i64),
-                ("mol_atoms", SegPlan), ("mol_frags", SegPlan), ("n_mols", i64), ("counts_dev", vp), ("status", vp)]
+                ("mol_atoms", SegPlan), ("mol_frags", SegPlan), ("n_mols", i64), ("counts_dev", vp), ("status", vp),
+                ("mol_contiguous", i32), ("pad3_", i32), ("pooled", vp), ("g_pooled", vp)]
 
 
 # name -> argtypes; every function returns int (0 ok / <0 argument error / >0 hipError_t) unless noted.
@@ -118,6 +119,7 @@ SIGNATURES = {
     "fn_linear128_f32": [vp, C.c_int, vp, vp, vp, i64, C.POINTER(ActEpilogue), vp],
     "fn_linear128_wgrad_ws": [i64, C.c_int],
     "fn_linear128_wgrad_f32": [vp, vp, C.c_int, i64, vp, vp, vp, vp],
+    "fn_encoder_fused_tail": [C.POINTER(Encoder)],
     "fn_encoder_ws_floats": [C.POINTER(Encoder)],
     "fn_encoder_bwd_ws_floats": [C.POINTER(Encoder)],
     "fn_encoder_rng_blocks": [C.POINTER(Encoder)],

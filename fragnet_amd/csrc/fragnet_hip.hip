@@ -353,13 +353,13 @@ struct GatFwdArgs {
     int64_t rd_m;
     int rd_lda, rd_J;
 };
+// rows [blk0, te) of the level, taken interleaved by the block's half-waves (row = blk0 + i * kRows + hw, i < rows_per_hw);
+// sWf: the folded edge-embedding weights (KL != 0), already in LDS
 template <int H, int KL, bool RD = false>
-__device__ __forceinline__ void gat_fwd_body(const GatFwdArgs& A, float (*sWf)[kWfLd], int bid, int nblk) {
+__device__ __forceinline__ void gat_fwd_rows(const GatFwdArgs& A, float (*sWf)[kWfLd], int blk0, int te, int rows_per_hw) {
     const float* __restrict__ h = A.h;
     const float* __restrict__ s_dst = A.s_dst;
     const float* __restrict__ s_src = A.s_src;
-    const float* __restrict__ att = A.att;
-    const int att_w = A.att_w, rows_per_hw = A.rows_per_hw;
     const fn_edge_term& et = A.et;
     const fn_gat_plan& pl = A.pl;
     const float slope = A.slope;
@@ -369,7 +369,6 @@ __device__ __forceinline__ void gat_fwd_body(const GatFwdArgs& A, float (*sWf)[k
     const fn_act_epilogue& ep = A.ep;
     constexpr int LPH = 32 / H;
     constexpr int NE = KL ? KL : 1;                       // 8-byte edge loads per lane and row
-    fold_edge_embed(et, att, att_w, H, sWf);
     const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH;
     const int m = (int)pl.m, n = (int)pl.n;
     const int K = KL ? et.K : 0;
@@ -377,11 +376,7 @@ __device__ __forceinline__ void gat_fwd_body(const GatFwdArgs& A, float (*sWf)[k
 #pragma unroll
     for (int k = 0; k < NE; ++k) wf[k] = (KL && k < K) ? sWf[head][k] : 0.f;
     const float wbias = KL ? sWf[head][K] : 0.f;
-    // a block owns kRows * R consecutive rows; its half-waves take them INTERLEAVED (row = base + i * kRows + hw), so
-    // that at any moment the block works on kRows neighbouring rows whose source rows overlap (L1 reuse across waves)
-    const int blk0 = xcd_block(bid, nblk) * kRows * rows_per_hw;
     const int tb = blk0 + (int)(threadIdx.x >> 5);
-    const int te = blk0 + kRows * rows_per_hw < n ? blk0 + kRows * rows_per_hw : n;
     const bool pairs = m >= 2;                            // paired edge loads need two edges in the level
     const float* e_sorted = KL ? nullptr : et.s_sorted + (size_t)head * m;
 
@@ -435,7 +430,9 @@ __device__ __forceinline__ void gat_fwd_body(const GatFwdArgs& A, float (*sWf)[k
         const int beg = cur.beg, deg = cur.deg;
         const bool fast = pairs && deg >= 0 && deg <= 2 * LPH;
         const bool has0 = fast && 2 * j < deg, has1 = fast && 2 * j + 1 < deg;
-        const int src0 = ed.src0, src1 = has1 ? ed.src1 : ed.src0;
+        // a lane without an edge gathers the destination row itself (weight 0): always a row this launch may read -- the
+        // molecule-resident callers (mol_tail.inc) have only their own molecule's rows written, and 0 * stale NaN is NaN
+        const int src0 = has0 ? ed.src0 : (t < n ? t : n - 1), src1 = has1 ? ed.src1 : src0;
         // one round trip: next row's edge data, the row after's extent, this row's source rows and source scalars
         issue_edges(nxt, raw);
         const FwdExtent nn = load_extent(t + 2 * kRows);
@@ -544,6 +541,15 @@ __device__ __forceinline__ void gat_fwd_body(const GatFwdArgs& A, float (*sWf)[k
     }
 }
 
+// a block owns kRows * R consecutive rows; its half-waves take them INTERLEAVED (row = base + i * kRows + hw), so
+// that at any moment the block works on kRows neighbouring rows whose source rows overlap (L1 reuse across waves)
+template <int H, int KL, bool RD = false>
+__device__ __forceinline__ void gat_fwd_body(const GatFwdArgs& A, float (*sWf)[kWfLd], int bid, int nblk) {
+    fold_edge_embed(A.et, A.att, A.att_w, H, sWf);
+    const int blk0 = xcd_block(bid, nblk) * kRows * A.rows_per_hw, n = (int)A.pl.n;
+    gat_fwd_rows<H, KL, RD>(A, sWf, blk0, blk0 + kRows * A.rows_per_hw < n ? blk0 + kRows * A.rows_per_hw : n, A.rows_per_hw);
+}
+
 template <int H, int KL>
 __global__ __launch_bounds__(kBlock) void k_gat_fwd(GatFwdArgs A) {
     __shared__ float sWf[8][kWfLd];
@@ -581,8 +587,9 @@ struct GatBwdDstArgs {
     float *dz_sorted, *g_s_orig, *pz_src, *g_s_dst, *part_e;
     int rows_per_hw, nblk;
 };
+// rows [blk0, te) interleaved over the block's RB half-waves; bid: the block's slot in part_e (KL != 0)
 template <int H, int KL, int RB>
-__device__ __forceinline__ void gat_bwd_dst_body(const GatBwdDstArgs& A, float (*sP)[8][kWfLd], int bid, int nblk) {
+__device__ __forceinline__ void gat_bwd_dst_rows(const GatBwdDstArgs& A, float (*sP)[8][kWfLd], int blk0, int te, int rows_per_hw, int bid) {
     const float* __restrict__ g_out = A.g_out;
     const float* __restrict__ h = A.h;
     const float* __restrict__ p_sorted = A.p_sorted;
@@ -594,7 +601,6 @@ __device__ __forceinline__ void gat_bwd_dst_body(const GatBwdDstArgs& A, float (
     float* __restrict__ pz_src = A.pz_src;
     float* __restrict__ g_s_dst = A.g_s_dst;
     float* __restrict__ part_e = A.part_e;
-    const int rows_per_hw = A.rows_per_hw;
     constexpr int LPH = 32 / H;
     constexpr int NE = KL ? KL : 1;
     const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH, hw = threadIdx.x >> 5;
@@ -607,9 +613,7 @@ __device__ __forceinline__ void gat_bwd_dst_body(const GatBwdDstArgs& A, float (
     for (int k = 0; k <= NE; ++k) pw[k] = 0.f;
     const float* p_head = p_sorted + (size_t)head * m;
     float* pz_head = pz_src + (size_t)head * m * 2;
-    const int blk0 = xcd_block(bid, nblk) * RB * rows_per_hw;      // rows interleaved over the half-waves
     const int tb = blk0 + hw;
-    const int te = blk0 + RB * rows_per_hw < n ? blk0 + RB * rows_per_hw : n;
 
     auto load_extent = [&](int t, int& beg, int& deg) {
         const int tc = t < n ? t : n - 1;
@@ -644,7 +648,8 @@ __device__ __forceinline__ void gat_bwd_dst_body(const GatBwdDstArgs& A, float (
         const bool fast = pairs && deg >= 0 && deg <= 2 * LPH;
         const bool has0 = fast && 2 * j < deg, has1 = fast && 2 * j + 1 < deg;
         const bool shifted = beg + 2 * j != cur.pos;              // only the very last edge of the level
-        const int src0 = shifted ? cur.sp.y : cur.sp.x, src1 = has1 ? cur.sp.y : src0;
+        // (a lane without an edge gathers the destination row itself, see gat_fwd_rows)
+        const int src0 = has0 ? (shifted ? cur.sp.y : cur.sp.x) : (t < n ? t : n - 1), src1 = has1 ? cur.sp.y : src0;
         const float ps0 = has0 ? (shifted ? cur.pp.y : cur.pp.x) : 0.f, ps1 = has1 ? cur.pp.y : 0.f;
         const int sq0 = shifted ? cur.sq.y : cur.sq.x, sq1 = cur.sq.y;
         const int eq0 = shifted ? cur.eq.y : cur.eq.x, eq1 = cur.eq.y;
@@ -786,6 +791,11 @@ struct SrcRaw {
 };
 
 template <int H, int KL, int RB>
+__device__ __forceinline__ void gat_bwd_dst_body(const GatBwdDstArgs& A, float (*sP)[8][kWfLd], int bid, int nblk) {
+    const int blk0 = xcd_block(bid, nblk) * RB * A.rows_per_hw, n = (int)A.pl.n;      // rows interleaved over the half-waves
+    gat_bwd_dst_rows<H, KL, RB>(A, sP, blk0, blk0 + RB * A.rows_per_hw < n ? blk0 + RB * A.rows_per_hw : n, A.rows_per_hw, bid);
+}
+template <int H, int KL, int RB>
 __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(GatBwdDstArgs A) {
     __shared__ float sP[RB][8][kWfLd];
     gat_bwd_dst_body<H, KL, RB>(A, sP, (int)blockIdx.x, (int)gridDim.x);
@@ -804,14 +814,15 @@ struct GatBwdSrcArgs {
     float *g_h, *part_a;
     int rows_per_hw, nblk;
 };
+// source rows [blk0, se) interleaved over the block's RB half-waves; bid: the block's slot (row) in part_a
 template <int H, int RB>
-__device__ __forceinline__ void gat_bwd_src_body(const GatBwdSrcArgs& A, float (*sA)[2 * FN_D], int bid, int nblk) {
+__device__ __forceinline__ void gat_bwd_src_rows(const GatBwdSrcArgs& A, float (*sA)[2 * FN_D], int blk0, int se, int rows_per_hw, int bid) {
     const float* __restrict__ g_out = A.g_out;
     const float* __restrict__ h = A.h;
     const float* __restrict__ pz_src = A.pz_src;
     const float* __restrict__ g_s_dst = A.g_s_dst;
     const float* __restrict__ att = A.att;
-    const int att_w = A.att_w, dst_off = A.dst_off, src_off = A.src_off, rows_per_hw = A.rows_per_hw;
+    const int att_w = A.att_w, dst_off = A.dst_off, src_off = A.src_off;
     const fn_gat_plan& pl = A.pl;
     float* __restrict__ g_h = A.g_h;
     float* __restrict__ part_a = A.part_a;
@@ -823,9 +834,7 @@ __device__ __forceinline__ void gat_bwd_src_body(const GatBwdSrcArgs& A, float (
     const float4 as = ld4(att + head * att_w + src_off + j * 4);
     const float* pz_head = pz_src + (size_t)head * m * 2;
     float4 qd = make_float4(0.f, 0.f, 0.f, 0.f), qs = qd;
-    const int blk0 = xcd_block(bid, nblk) * RB * rows_per_hw;      // rows interleaved over the half-waves
     const int sb = blk0 + hw;
-    const int se = blk0 + RB * rows_per_hw < n ? blk0 + RB * rows_per_hw : n;
 
     auto load_extent = [&](int s, int& beg, int& deg, float& gsd) {
         const int sc = s < n ? s : n - 1;
@@ -856,7 +865,7 @@ __device__ __forceinline__ void gat_bwd_src_body(const GatBwdSrcArgs& A, float (
         const bool fast = pairs && deg >= 0 && deg <= 2 * LPH;
         const bool has0 = fast && 2 * j < deg, has1 = fast && 2 * j + 1 < deg;
         const bool shifted = beg + 2 * j != cur.pos;              // only the very last edge of the level
-        const int t0 = shifted ? cur.tp.y : cur.tp.x, t1 = has1 ? cur.tp.y : t0;
+        const int t0 = has0 ? (shifted ? cur.tp.y : cur.tp.x) : (s < n ? s : n - 1), t1 = has1 ? cur.tp.y : t0;      // (no edge: the row itself)
         const float p0 = has0 ? (shifted ? cur.v.z : cur.v.x) : 0.f, z0 = has0 ? (shifted ? cur.v.w : cur.v.y) : 0.f;
         const float p1 = has1 ? cur.v.z : 0.f, z1 = has1 ? cur.v.w : 0.f;
         issue_edges(beg_n, raw);
@@ -930,6 +939,11 @@ __device__ __forceinline__ void gat_bwd_src_body(const GatBwdSrcArgs& A, float (
     }
 }
 
+template <int H, int RB>
+__device__ __forceinline__ void gat_bwd_src_body(const GatBwdSrcArgs& A, float (*sA)[2 * FN_D], int bid, int nblk) {
+    const int blk0 = xcd_block(bid, nblk) * RB * A.rows_per_hw, n = (int)A.pl.n;      // rows interleaved over the half-waves
+    gat_bwd_src_rows<H, RB>(A, sA, blk0, blk0 + RB * A.rows_per_hw < n ? blk0 + RB * A.rows_per_hw : n, A.rows_per_hw, bid);
+}
 template <int H, int RB>
 __global__ __launch_bounds__(RB * 32) void k_gat_bwd_src(GatBwdSrcArgs A) {
     __shared__ float sA[RB][2 * FN_D];
@@ -1094,7 +1108,8 @@ struct RowDotsBwdArgs {
     const float* addend;
     int g_is_orig, nblk;
 };
-__device__ __forceinline__ void row_dots_sorted_bwd_body(const RowDotsBwdArgs& T, float (*sR)[FN_D], int vb, int nb) {
+// edges [e0, e1) in original order, taken interleaved by the block's half-waves; vb: the block's slot (row) in T.part
+__device__ __forceinline__ void row_dots_sorted_bwd_range(const RowDotsBwdArgs& T, float (*sR)[FN_D], int64_t e0, int64_t e1, int vb) {
     const float* __restrict__ g_s_sorted = T.g_s_sorted;
     const float* __restrict__ feat = T.feat;
     const float* __restrict__ A = T.A;
@@ -1113,29 +1128,23 @@ __device__ __forceinline__ void row_dots_sorted_bwd_body(const RowDotsBwdArgs& T
     // rows are walked in original edge order (sequential feat / g_feat rows).  The per-head gradient comes either in
     // original order, edge-major [m_real][J] (written that way by the destination pass: one 16-byte read), or in
     // destination-sorted head-major order [J][m] through the inverse permutation (autograd path)
-    int64_t g0, g1;
-    {   // block_groups() for a virtual block index (the kernel may share its launch with another body)
-        const int64_t groups = (pl.m_real + kRows - 1) / kRows, per = (groups + nb - 1) / nb;
-        g0 = (int64_t)xcd_block(vb, nb) * per;
-        g1 = g0 + per < groups ? g0 + per : groups;
-    }
     if (g_is_orig && J == 4) {
         // engine path: 4 heads, gradient in original edge order.  Four rows per trip, every load issued before the
         // first use (a single-row loop is one dependent round trip per row: 15 us for 28 k rows)
-        for (int64_t gi = g0; gi < g1; gi += 4) {
+        for (int64_t base = e0; base < e1; base += 4 * kRows) {
             float4 v[4], ad[4], gs[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                int64_t e = (gi + u) * kRows + hw;
-                e = (gi + u < g1 && e < pl.m_real) ? e : pl.m_real - 1;
+                int64_t e = base + u * kRows + hw;
+                e = e < e1 ? e : e1 - 1;
                 v[u] = ld4(feat + e * FN_D + lane * 4);
                 gs[u] = ld4(g_s_sorted + e * 4);
                 ad[u] = addend ? ld4(addend + e * FN_D + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int64_t e = (gi + u) * kRows + hw;
-                if (gi + u >= g1 || e >= pl.m_real) continue;
+                const int64_t e = base + u * kRows + hw;
+                if (e >= e1) continue;
                 fma4(q[0], gs[u].x, v[u]);  fma4(q[1], gs[u].y, v[u]);  fma4(q[2], gs[u].z, v[u]);  fma4(q[3], gs[u].w, v[u]);
                 if (!g_feat) continue;          // parameter partials only: the rows' term rides in a GEMM epilogue (RowAdd)
                 float4 acc = ad[u];
@@ -1144,9 +1153,7 @@ __device__ __forceinline__ void row_dots_sorted_bwd_body(const RowDotsBwdArgs& T
             }
         }
     } else
-    for (int64_t gi = g0; gi < g1; ++gi) {
-        const int64_t e = gi * kRows + hw;
-        if (e >= pl.m_real) continue;
+    for (int64_t e = e0 + hw; e < e1; e += kRows) {
         const size_t pos = g_is_orig ? 0 : (size_t)pl.inv_d[e];
         const float4 v = ld4(feat + e * FN_D + lane * 4);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1175,6 +1182,13 @@ __device__ __forceinline__ void row_dots_sorted_bwd_body(const RowDotsBwdArgs& T
             __syncthreads();
         }
     }
+}
+__device__ __forceinline__ void row_dots_sorted_bwd_body(const RowDotsBwdArgs& T, float (*sR)[FN_D], int vb, int nb) {
+    // block_groups() for a virtual block index (the kernel may share its launch with another body)
+    const int64_t groups = (T.pl.m_real + kRows - 1) / kRows, per = (groups + nb - 1) / nb;
+    const int64_t g0 = (int64_t)xcd_block(vb, nb) * per, g1 = g0 + per < groups ? g0 + per : groups;
+    const int64_t e1 = g1 * kRows < T.pl.m_real ? g1 * kRows : T.pl.m_real;
+    row_dots_sorted_bwd_range(T, sR, g0 * kRows < e1 ? g0 * kRows : e1, e1, vb);
 }
 __global__ __launch_bounds__(kBlock) void k_row_dots_sorted_bwd(RowDotsBwdArgs T) {
     __shared__ float sR[kRows][FN_D];
@@ -2346,6 +2360,7 @@ __device__ __forceinline__ void mol_extents_body(const MolExtArgs& A, int vb) {
     A.out[mol] = x;
 }
 #include "dense_head.inc"
+#include "mol_tail.inc"
 
 // Everything the encoder's forward pass needs before its first projection, none of which depends on the other: W^T of
 // every projection, dropout of the atom features, and the permutation of the two raw edge-attribute tensors into
@@ -2742,7 +2757,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 namespace {
 unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
 int64_t g_mol_stamps_n = 0;
-int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 256, 2, -1, 0, 1, 0, 0};   // in the order of the FN_TUNE_* keys
+int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 256, 2, -1, 0, 1, 0, 0, 1};   // in the order of the FN_TUNE_* keys
 }  // namespace
 namespace fni {      // hooks for the other translation units (fn_internal.h)
 int fail(int code, const char* what) { return ::fail(code, what); }
@@ -3888,6 +3903,13 @@ bool have_mol(const fn_encoder* e) {       // the caller handed over the molecul
 bool mol_bwd_on(const fn_encoder* e) {
     return g_tune[FN_TUNE_BWD_MOL] != 0 && have_mol(e) && fni::mol_bwd_supported(e->heads);
 }
+// the last layer's fragment tail (fragment sums -> fragment graph -> readout, and its backward) as one molecule-resident launch
+// each way (csrc/mol_tail.inc): needs the caller's word that the batch has collate_fn's molecule-contiguous layout
+bool tail_mol_on(const fn_encoder* e) {
+    return g_tune[FN_TUNE_MOL_TAIL] != 0 && e->mol_contiguous != 0 && have_mol(e) && !mol_bwd_on(e) && e->variant == 0 &&
+           (e->heads == 2 || e->heads == 4 || e->heads == 8) && e->F > 0 && e->EF > 0 && e->frag.m > 1 && e->n_mols <= FN_MAX_PART &&
+           !((uintptr_t)e->ws & 15);
+}
 
 // Backward scratch.  Nothing is reused across levels or layers: the kernels that only produce parameter gradients
 // (finalize, weight-gradient GEMMs, column sums) run on an auxiliary stream behind the main dependency chain, so a
@@ -4397,9 +4419,56 @@ int enc_check(const fn_encoder* e) {
     return 0;
 }
 
+int launch_tail_fwd(const fn_encoder* e, const EncLayout& lay, const LayerActs& a, const fn_layer_weights& w,
+                    const fn_act_epilogue& ep_frags, const float* y_atoms, hipStream_t st) {
+    const int H = e->heads, d = FN_D / H, wide = 2 * d + FN_D;
+    TailFwdArgs T{};
+    T.ext = reinterpret_cast<const MolExt*>(lay.mol_ext);  T.n_mols = (int)e->n_mols;  T.counts_dev = e->counts_dev;
+    T.atoms_new = lay.atoms_new;  T.a2f_rowptr = e->a2f.rowptr;  T.a2f_perm = e->a2f.perm;  T.a2f_base = e->a2f.pos_base;
+    T.frags = a.frags;  T.att = w.f;  T.att_w = wide;  T.dst_off = 0;  T.src_off = d + FN_D;  T.mid_off = d;
+    T.s_dst = lay.s_dst;  T.s_src = lay.s_src;  T.feat = a.new_fbond;  T.s_sorted = lay.s_sorted;
+    const fn_edge_term et_f{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
+    FN_TRY(prep_gat_fwd(a.frags, lay.s_dst, lay.s_src, w.f, wide, &et_f, &e->frag, 0.2f, nullptr, a.p_frag, nullptr, &ep_frags, H, &T.G));
+    T.y_atoms = y_atoms;  T.pooled = e->pooled;
+    if (((uintptr_t)y_atoms | (uintptr_t)ep_frags.y | (uintptr_t)e->pooled) & 15) return fail(FN_EINVAL, "fragment tail: outputs must be 16-byte aligned");
+    const dim3 grid((unsigned)e->n_mols);
+    if (H == 2) hipLaunchKernelGGL((k_tail_fwd<2>), grid, dim3(kBlock), 0, st, T);
+    else if (H == 4) hipLaunchKernelGGL((k_tail_fwd<4>), grid, dim3(kBlock), 0, st, T);
+    else hipLaunchKernelGGL((k_tail_fwd<8>), grid, dim3(kBlock), 0, st, T);
+    return launch_status("fragment tail, molecule-resident (sums + fragment graph + readout)");
+}
+
+// partial rows written: one per molecule (*n_part), for rq.finalize (part_a) and rq.colsum (part_rd)
+int launch_tail_bwd(const fn_encoder* e, const LayerActs& a, const fn_layer_weights& w, const BwdLayout& bw, const float* y_atoms,
+                    const float* y_frags, const float* g_atoms, const float* g_frags, float gate_scale, bool accumulate_fbond,
+                    int* n_part, hipStream_t st) {
+    const int H = e->heads, d = FN_D / H, wide = 2 * d + FN_D;
+    const LevelScratch& sf = bw.frag;
+    TailBwdArgs T{};
+    T.ext = reinterpret_cast<const MolExt*>(enc_layout(e, e->ws).mol_ext);  T.n_mols = (int)e->n_mols;  T.counts_dev = e->counts_dev;
+    T.g_atoms = g_atoms;  T.g_frags = g_frags;  T.g_pooled = e->g_pooled;  T.y_atoms = y_atoms;  T.y_frags = y_frags;  T.scale = gate_scale;
+    T.g_pre_atoms = bw.g_pre_atoms;  T.g_pre_frags = bw.g_pre_frags;  T.a2f_index = e->a2f.index;
+    const fn_edge_term et_f{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+    int n_e = 0, n_a = 0;
+    FN_TRY(prep_gat_bwd_dst(bw.g_pre_frags, a.frags, a.p_frag, &et_f, &e->frag, 0.2f, nullptr, sf.dz, sf.pz, sf.g_s_dst, nullptr, &n_e, H, &T.D));
+    FN_TRY(prep_gat_bwd_src(bw.g_pre_frags, a.frags, sf.pz, sf.g_s_dst, w.f, wide, 0, d + FN_D, &e->frag, bw.g_frags, sf.part_a, &n_a, H, &T.S));
+    T.R = RowDotsBwdArgs{sf.dz, a.new_fbond, w.f, wide, d, H, e->frag, bw.g_pre_fbond, sf.part_rd,
+                         accumulate_fbond ? (const float*)bw.g_pre_fbond : (const float*)nullptr, 1, 0};
+    if (((uintptr_t)y_atoms | (uintptr_t)y_frags | (uintptr_t)g_atoms | (uintptr_t)g_frags | (uintptr_t)e->g_pooled) & 15)
+        return fail(FN_EINVAL, "fragment tail backward: gradients must be 16-byte aligned");
+    const dim3 grid((unsigned)e->n_mols);
+    if (H == 2) hipLaunchKernelGGL((k_tail_bwd<2>), grid, dim3(kBlock), 0, st, T);
+    else if (H == 4) hipLaunchKernelGGL((k_tail_bwd<4>), grid, dim3(kBlock), 0, st, T);
+    else hipLaunchKernelGGL((k_tail_bwd<8>), grid, dim3(kBlock), 0, st, T);
+    *n_part = (int)e->n_mols;
+    return launch_status("fragment tail backward, molecule-resident (gates + fragment graph + scatter to atoms)");
+}
+
 }  // namespace
 
 extern "C" {
+
+int fn_encoder_fused_tail(const fn_encoder* e) { return e && tail_mol_on(e) ? 1 : 0; }
 
 int64_t fn_encoder_ws_floats(const fn_encoder* e) { return e ? enc_layout(e, nullptr).total : 0; }
 int64_t fn_encoder_bwd_ws_floats(const fn_encoder* e) { return e ? bwd_layout(e, nullptr).total : 0; }
@@ -4409,6 +4478,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
                        fn_stream_t st) {
     FN_TRY(enc_check(e));
     if (!out_atoms || !out_frags || !out_bond || !out_fbond) return fail(FN_EINVAL, "fn_encoder_forward: null output");
+    if (e->pooled && !tail_mol_on(e)) return fail(FN_EINVAL, "fn_encoder_forward: the readout is only produced by the fused fragment tail (fn_encoder_fused_tail)");
     const EncLayout lay = enc_layout(e, e->ws);
     if (lay.total > e->ws_floats) return fail(FN_EINVAL, "fn_encoder_forward: workspace too small");
     const RngPlan rng = rng_plan(e);
@@ -4452,7 +4522,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
             A.sx[1] = e->fattr_raw;  A.so[1] = const_cast<float*>(e->fattr_sorted);  A.sK[1] = e->k_fattr;  A.spl[1] = fattr_plan;
             A.n_s[1] = flat_grid(fattr_plan.m * e->k_fattr, 512);
         }
-        if (mol_bwd_on(e)) {
+        if (mol_bwd_on(e) || tail_mol_on(e)) {
             A.mx = MolExtArgs{e->mol_atoms.rowptr, e->mol_frags.rowptr, e->mol_atoms.pos_base, e->mol_frags.pos_base,
                               e->bond, e->atom, no_fb ? fn_gat_plan{} : e->fbond, e->frag, (int)e->n_mols,
                               reinterpret_cast<MolExt*>(lay.mol_ext)};
@@ -4566,9 +4636,10 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
 
         // L3 atom -> fragment sum.  Like L4b below it is only ever read in the last layer (the next layer recomputes its own
         // sum from its own atoms before first use, gat2.py:234), so inner layers skip it too.
-        const bool tail_fused = last && !lite && !edge && H > 1 && e->F > 0 && e->N >= 4 * e->F && e->frag.m > 0 &&
+        const bool tail_mol = last && tail_mol_on(e);      // sums + fragment graph + readout: one molecule-resident launch
+        const bool tail_fused = !tail_mol && last && !lite && !edge && H > 1 && e->F > 0 && e->N >= 4 * e->F && e->frag.m > 0 &&
                                 !(((uintptr_t)lay.atoms_new | (uintptr_t)a.frags) & 15);
-        if (last && !tail_fused) FN_TRY(fn_segment_sum_f32(lay.atoms_new, FN_D, e->a2f.rowptr, e->a2f.perm, e->a2f.pos_base, a.frags, e->F, FN_D, e->N, st));
+        if (last && !tail_fused && !tail_mol) FN_TRY(fn_segment_sum_f32(lay.atoms_new, FN_D, e->a2f.rowptr, e->a2f.perm, e->a2f.pos_base, a.frags, e->F, FN_D, e->N, st));
 
         // L4b fragment graph on the raw fragment sums.  Only the last layer's result is ever read: the next layer
         // overwrites x_frags with its own atom->fragment sum before first use (gat2.py:234), so inner
@@ -4579,6 +4650,8 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
             FN_TRY(fn_node_scalars_f32(a.frags, w.f, wide, 0, d + FN_D, lay.s_dst, lay.s_src, e->F, H, st));
             fn_edge_term et_f{2, e->k_fattr, FN_D, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
             FN_TRY(fn_gat_fwd_f32(a.frags, lay.s_dst, lay.s_src, w.f, wide, &et_f, &e->frag, 0.2f, nullptr, a.p_frag, nullptr, &ep_frags, H, st));
+        } else if (last && tail_mol) {
+            FN_TRY(launch_tail_fwd(e, lay, a, w, ep_frags, y_atoms, S(st)));
         } else if (last) {
             if (tail_fused) {                                // atom -> fragment sum + node scalars + edge term: one launch
                 FragTailArgs T{};
@@ -4615,6 +4688,7 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
     const BwdLayout bw = bwd_layout(e, scratch);
     if (bw.total > scratch_floats) return fail(FN_EINVAL, "fn_encoder_backward: scratch too small");
     const RngPlan rng = rng_plan(e);
+    if (e->g_pooled && !tail_mol_on(e)) return fail(FN_EINVAL, "fn_encoder_backward: dL/d(readout) is only taken by the fused fragment tail (fn_encoder_fused_tail)");
     if (mol_bwd_on(e)) return encoder_backward_mol(e, lay, bw, rng, out_atoms, out_frags, out_bond, out_fbond, g_atoms, g_frags, g_bond, g_fbond, grads, S(st));
     const int H = e->heads, d = FN_D / H;
     const float p = e->training ? e->drop_p : 0.f;
@@ -4688,6 +4762,10 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         // (mask and ReLU gate fused into their epilogue), flagged by pre_* below.
         bool have_atoms = gy_atoms != nullptr || pre_atoms, have_frags = gy_frags != nullptr;
         bool have_bond = gy_bond != nullptr || pre_bond, have_fbond = gy_fbond != nullptr || pre_fbond;
+        // last layer, molecule-resident tail (csrc/mol_tail.inc): the atoms' and fragments' gates, the fragment graph's two passes,
+        // its edge term's backward and the scatter to the atoms are ONE launch below; the readout's gradient enters there
+        const bool tail_mol = last && tail_mol_on(e) && (gy_frags != nullptr || e->g_pooled != nullptr);
+        const float gate_scale = p > 0.f ? (p < 1.f ? 1.f / (1.f - p) : 0.f) : 1.f;
         {   // backward of relu(dropout(.)) of up to four layer outputs in one launch; y > 0 already encodes the mask
             GateTasks G{};
             auto add = [&](const float* g, const float* y, float* o, int64_t numel) {
@@ -4696,12 +4774,14 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
                 t.g = g;  t.y = y;  t.o = o;  t.n4 = (numel + 3) / 4;  t.first = G.blocks;  t.nblk = flat_grid(t.n4, 512);
                 G.blocks += t.nblk;
             };
-            add(gy_atoms, y_atoms, bw.g_pre_atoms, e->N * FN_D);
-            add(gy_frags, y_frags, bw.g_pre_frags, e->F * FN_D);
+            if (!tail_mol) {
+                add(gy_atoms, y_atoms, bw.g_pre_atoms, e->N * FN_D);
+                add(gy_frags, y_frags, bw.g_pre_frags, e->F * FN_D);
+            }
             add(gy_bond, y_bond, bw.g_pre_bond, e->E * FN_D);
             add(gy_fbond, y_fbond, bw.g_pre_fbond, e->EF * FN_D);
             if (G.blocks) {
-                G.scale = p > 0.f ? (p < 1.f ? 1.f / (1.f - p) : 0.f) : 1.f;
+                G.scale = gate_scale;
                 hipLaunchKernelGGL(k_gate_many, dim3(G.blocks), dim3(kBlock), 0, S(st), G);
                 FN_TRY(launch_status("fn_encoder_backward: activation backward"));
             }
@@ -4711,7 +4791,14 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         // ---- L4b fragment graph (only where its output is consumed: the last layer, reference fact SURVEY §0.8)
         bool have_g_frags_h = false;
         const float* g_frags_h = bw.g_frags;      // dL/d(fragment sums), scattered back to the atoms below
-        if (have_frags && lite) {
+        if (tail_mol) {
+            int n_part = 0;
+            FN_TRY(launch_tail_bwd(e, a, w, bw, y_atoms, y_frags, gy_atoms, gy_frags, gate_scale, have_fbond, &n_part, hs));
+            const fn_edge_term et_f{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+            FN_TRY(rq.finalize(bw.frag.part_a, n_part, nullptr, 0, et_f, w.f, wide, 0, d + FN_D, g.f, nullptr, nullptr, H));
+            FN_TRY(rq.colsum(bw.frag.part_rd, n_part, H * FN_D, g.f, wide, d));
+            have_atoms = have_fbond = true;        // g_pre_atoms and g_pre_fbond are complete (scatter to the atoms included)
+        } else if (have_frags && lite) {
             g_frags_h = bw.g_pre_frags;            // no fragment graph in between
             have_g_frags_h = true;
         } else if (have_frags && edge) {   // gat2_edge: the edge term's parameters are the cnx_attr Linear (emb_fb_*) and f's middle block

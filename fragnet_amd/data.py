@@ -22,6 +22,8 @@ from typing import Dict, List, Sequence
 
 import torch
 
+from .plan import CollatedBatch
+
 _F32_EXACT = 1 << 24
 
 
@@ -52,7 +54,7 @@ def _collate_common(data_list: List) -> Dict[str, torch.Tensor]:
     cat1 = lambda name: torch.cat([getattr(d, name) for d in data_list], dim=1)
 
     mol_id = torch.arange(len(data_list), dtype=torch.long)
-    out = {
+    out = CollatedBatch({
         "x_atoms": cat0("x_atoms"),
         "edge_index": cat1("edge_index").to(torch.long) + _offsets(n_atoms, e),
         "frag_index": cat1("frag_index").to(torch.long) + _offsets(n_frags, ef),
@@ -68,7 +70,7 @@ def _collate_common(data_list: List) -> Dict[str, torch.Tensor]:
         "node_features_fbonds": cat0("node_feautures_fbondg"),
         "edge_index_fbonds": cat1("edge_index_fbondg").to(torch.long) + _offsets(n_fbnodes, efb),
         "edge_attr_fbonds": cat0("edge_attr_fbondg"),
-    }
+    })
     return out
 
 
@@ -101,7 +103,8 @@ def batch_to(batch: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]:
     """``batch[k] = batch[k].to(device)`` for every key -- reference train/utils.py:335-336.  A batch collated from a
     store without its bond-graph index (dataset.FlatMolStore.without_bond_graph_index) gets ``edge_index_bonds_graph``
     rebuilt from ``edge_index`` once it is on the GPU (ops.bond_graph)."""
-    out = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    out = type(batch)() if isinstance(batch, CollatedBatch) else {}      # the layout promise travels with the batch
+    out.update({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()})
     if "edge_index_bonds_graph" not in out and "edge_index" in out and out["edge_index"].is_cuda:
         from . import ops
         out["edge_index_bonds_graph"] = ops.bond_graph(out["edge_index"], out["batch"], int(out["y"].shape[0]))

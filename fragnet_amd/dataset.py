@@ -13,6 +13,8 @@ from typing import Dict, List, Optional, Sequence
 
 import torch
 
+from .plan import CollatedBatch
+
 # field -> (ragged axis, index space that offsets its VALUES or None)
 _ROW_FIELDS = {           # concatenated along dim 0
     "x_atoms": "atom", "edge_attr": "edge", "cnx_attr": "fedge", "x_frags": "frag", "atom_id_frag_id": "atom",
@@ -121,7 +123,7 @@ class FlatMolStore:
             rows[space], length[space], seg[space] = _ragged_rows(self.off[space], idx)
         base = {s: torch.cumsum(length[s], 0) - length[s] for s in ("atom", "frag", "edge", "fedge")}
         t = self.t
-        out = {
+        out = CollatedBatch({
             "x_atoms": t["x_atoms"][rows["atom"]],
             "edge_index": t["edge_index"][:, rows["edge"]] + base["atom"][seg["edge"]],
             "frag_index": t["frag_index"][:, rows["fedge"]] + base["frag"][seg["fedge"]],
@@ -137,7 +139,7 @@ class FlatMolStore:
             "node_features_fbonds": t["node_feautures_fbondg"][rows["fedge"]],
             "edge_index_fbonds": None,           # filled below too
             "edge_attr_fbonds": None,
-        }
+        })
         if "edge_index_bonds" in t:
             out["edge_index_bonds_graph"] = t["edge_index_bonds"][:, rows["bedge"]] + base["edge"][seg["bedge"]]
         elif dev.type == "cuda":          # topology rebuilt on the device; a CPU store leaves it to data.batch_to(batch, gpu)

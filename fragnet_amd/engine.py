@@ -77,6 +77,7 @@ def _describe(plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fat
         counts = getattr(plan, "real_mols", None)
         e.counts_dev = None if counts is None else counts.data_ptr()
         e.status = plan._status.data_ptr()
+        e.mol_contiguous = int(bool(getattr(plan, "mol_contiguous", False)))       # CollatedBatch: collate_fn's layout
     return e
 
 
@@ -94,7 +95,14 @@ class _EncoderFn(torch.autograd.Function):
         ws = torch.empty(lib.fn_encoder_ws_floats(C.byref(e)), dtype=torch.float32, device=dev)
         e.ws, e.ws_floats = ws.data_ptr(), ws.numel()
         outs = [torch.empty((n, FN_D), dtype=torch.float32, device=dev) for n in (e.N, e.F, e.E, e.EF)]
+        # molecule-contiguous batches: the last layer's fragment tail is one molecule-resident launch that also writes the
+        # readout cat(scatter_add(x_atoms, batch), scatter_add(x_frags, frag_batch)) (gat2.py:820-823) -- a fifth output
+        pooled = None
+        if lib.fn_encoder_fused_tail(C.byref(e)):
+            pooled = torch.empty((e.n_mols, 2 * FN_D), dtype=torch.float32, device=dev)
+            e.pooled = pooled.data_ptr()
         _lib.check(lib.fn_encoder_forward(C.byref(e), *(o.data_ptr() for o in outs), _stream_ptr(dev)), "fn_encoder_forward")
+        e.pooled = None
         plan.pending.pop("bond", None)
         plan.pending.pop("frag" if variant == 2 else "fbond", None)
         e.cos_raw = e.fattr_raw = None           # the backward pass reads the sorted copies only
@@ -104,10 +112,13 @@ class _EncoderFn(torch.autograd.Function):
         ctx.variant = int(variant)
         ctx.save_for_backward(*params, *outs)
         ctx.set_materialize_grads(False)
-        return tuple(outs)
+        if pooled is None:                   # placeholder: the caller pools with ops.pool_cat
+            pooled = torch.empty(0, dtype=torch.float32, device=dev)
+            ctx.mark_non_differentiable(pooled)
+        return tuple(outs) + (pooled,)
 
     @staticmethod
-    def backward(ctx, g_atoms, g_frags, g_bond, g_fbond):
+    def backward(ctx, g_atoms, g_frags, g_bond, g_fbond, g_pooled):
         n_layers = ctx.n_layers
         saved = ctx.saved_tensors
         params, outs = saved[: n_layers * NP], saved[n_layers * NP:]
@@ -115,6 +126,8 @@ class _EncoderFn(torch.autograd.Function):
         dev = outs[0].device
         lib = _lib.load()
         gs = [None if g is None else _f32(g, "grad") for g in (g_atoms, g_frags, g_bond, g_fbond)]
+        g_pooled = None if g_pooled is None else _f32(g_pooled, "grad")
+        e.g_pooled = None if g_pooled is None else g_pooled.data_ptr()       # only a fused-tail forward has a differentiable readout
         grads = [ops.grad_buffer(p, slot) for p, slot in zip(ctx.param_objs, ctx.slots)]      # FlatAdam slots where they exist
         gw = (LayerWeights * n_layers)()
         for l in range(n_layers):
@@ -124,9 +137,10 @@ class _EncoderFn(torch.autograd.Function):
         _lib.check(lib.fn_encoder_backward(C.byref(e), *(o.data_ptr() for o in outs),
                                            *(None if g is None else g.data_ptr() for g in gs), gw, scratch.data_ptr(),
                                            scratch.numel(), _stream_ptr(dev)), "fn_encoder_backward")
+        e.g_pooled = None
         out = []
-        have_frags = gs[1] is not None
-        any_grad = any(g is not None for g in gs)
+        have_frags = gs[1] is not None or g_pooled is not None
+        any_grad = have_frags or any(g is not None for g in gs)
         for l in range(n_layers):
             for k in range(NP):
                 live = any_grad and not (k == F_IDX and not (l == n_layers - 1 and have_frags))
@@ -140,9 +154,18 @@ class _EncoderFn(torch.autograd.Function):
 
 def encoder_forward(layers, plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, heads: int,
                     drop_p: float, training: bool, rng, variant: int = 0) -> tuple:
-    """Runs all ``layers`` (FragNetLayerA modules) + the inter-layer act(dropout(.)); returns the four outputs."""
+    """Runs all ``layers`` (FragNetLayerA modules) + the inter-layer act(dropout(.)); returns the four outputs and, fifth,
+    the readout [n_mols, 256] when the fused fragment tail produced it (an empty tensor otherwise)."""
     params = [p for layer in layers for p in layer_param_list(layer)]
     n_layers = len(layers)
+    # the C side takes widths from the batch and pointers from the parameters: a model built for other feature widths would
+    # read and write past its layer-0 weights.  Fail the way the reference's nn.Linear does.
+    for name, x, k in (("projection_b", bond_nodes, 0), ("projection_a", x_atoms, 2)) + \
+            ((("projection_fb", fbond_nodes, 4),) if variant == 0 else ()):
+        w = params[k]
+        if w.dim() != 2 or x.dim() != 2 or w.shape[1] != x.shape[1] or w.shape[0] != FN_D:
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({x.shape[0]}x{x.shape[-1]} and {w.shape[-1]}x{w.shape[0]}): "
+                               f"layer 0 {name} expects {w.shape[-1]} input features, the batch has {x.shape[-1]}")
     p_eff = float(drop_p) if training else 0.0
     if p_eff > 0.0:
         # reserve the Philox offsets the engine will consume (fn_encoder_rng_blocks): x_atoms + 4 tensors per layer

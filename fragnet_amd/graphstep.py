@@ -31,7 +31,7 @@ from typing import Callable, Dict, Iterable, Optional
 import torch
 
 from . import _lib
-from .plan import LIVE_MOLS_KEY, PLAN_KEY, REAL_MOLS_KEY, prezeroed_plans
+from .plan import LIVE_MOLS_KEY, PLAN_KEY, REAL_MOLS_KEY, CollatedBatch, prezeroed_plans
 
 # field -> (index space of the ragged axis, layout, index space its VALUES point into)
 FIELDS = {
@@ -197,7 +197,10 @@ class StaticBatch:
         if dev.type != "cuda":
             raise _lib.FragnetHipError("StaticBatch stages batches on the GPU (fn_stage_padded); there is no CPU path")
         self.shapes, self.device = shapes, dev
-        self.t: Dict[str, torch.Tensor] = {}
+        # the padded batch keeps the example's layout promise for its real molecules (the fused kernels treat the padding
+        # molecules, whose items point round-robin at the reserved slots, separately: REAL_MOLS_KEY)
+        self.collated = isinstance(example, CollatedBatch)
+        self.t: Dict[str, torch.Tensor] = CollatedBatch() if self.collated else {}
         self._desc = []
         for name, (space, layout, target) in FIELDS.items():
             if name not in example:
@@ -258,6 +261,8 @@ class StaticBatch:
         counts = batch_counts(batch)
         if not self.shapes.fits(counts):
             return False
+        if self.collated and not isinstance(batch, CollatedBatch):
+            return False        # no layout promise: the caller's eager step takes the general kernels
         keep = []
         for i, (name, space, kind, width, hi, mod) in enumerate(self._desc):
             src = batch[name]

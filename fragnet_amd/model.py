@@ -310,7 +310,9 @@ class FragNet(nn.Module):
                                           batch["node_features_fbonds"], plan.sorted_attr("bond", batch["edge_attr_bonds"], defer=True),
                                           plan.sorted_attr("fbond", batch["edge_attr_fbonds"], defer=True), self.layers[0].num_heads,
                                           p, train, self.rng, variant=1 if lite else 0)
-            return (outs[0], outs[1], outs[2], None) if lite else outs
+            if outs[4].numel():      # the fused fragment tail also produced the readout: pooled() below hands it out
+                outs[0]._fragnet_readout = (outs[1], outs[4])
+            return (outs[0], outs[1], outs[2], None) if lite else outs[:4]
         x_atoms = ops.dropout_act(batch["x_atoms"], p, train, False, self.rng)
         # batch["x_frags"] is dead in the reference too: every layer overwrites it with the atom->fragment
         # sum before first use (gat2.py:234); its dropout mask is drawn and discarded there (gat2.py:397).
@@ -413,7 +415,11 @@ class FTHead2(_PredictorStack):
 
 
 def pooled(x_atoms, x_frags, batch):
-    """cat(sum of atoms per molecule, sum of fragments per molecule) -- gat2.py:820-823."""
+    """cat(sum of atoms per molecule, sum of fragments per molecule) -- gat2.py:820-823.  For the encoder's own outputs on a
+    molecule-contiguous batch the engine has already produced it (inside the fused fragment tail, csrc/mol_tail.inc)."""
+    ready = getattr(x_atoms, "_fragnet_readout", None)
+    if ready is not None and ready[0] is x_frags:
+        return ready[1]
     return ops.pool_cat(x_atoms, x_frags, plan_for(batch))
 
 

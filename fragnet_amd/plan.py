@@ -196,6 +196,7 @@ class GraphPlan:
                       dict(kind="seg", name="edge_dst", key=ei[1], n_seg=N)]
         plan = cls(specs, dev)
         plan.n_mols = n_mols
+        plan.mol_contiguous = bool(getattr(batch, "mol_contiguous", False))      # CollatedBatch: collate_fn's layout
         plan.real_mols = batch.get(REAL_MOLS_KEY)      # int32 [1] on the device when the batch is padded to static shapes
         return plan
 
@@ -224,6 +225,16 @@ class prezeroed_plans:
         _PREZEROED = self._old
         self.plans = list(_BUILT)
         _BUILT.clear()
+
+
+class CollatedBatch(dict):
+    """A batch dict in collate_fn's layout (reference dataset/data.py:877-948): molecules are concatenated, so the atoms,
+    directed bonds, fragments, fragment connections and the edges of the four graphs of molecule i are contiguous index ranges.
+    data.collate_fn(_pt), FlatMolStore.collate, data.batch_to and StaticBatch return it; same keys and values as the plain
+    dict.  The encoder engine runs its molecule-resident kernels (csrc/mol_tail.inc) only for such batches: a hand-built plain
+    dict makes no promise about its layout and takes the general per-level kernels."""
+
+    mol_contiguous = True
 
 
 PLAN_KEY = "_fragnet_plan"

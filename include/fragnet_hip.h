@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FN_ABI_VERSION 7
+#define FN_ABI_VERSION 8
 #define FN_D 128              /* feature width of every node table on the path (emb_dim) */
 #define FN_MAX_TASKS 16       /* CSR builds fused into one fn_plan_build call */
 #define FN_MAX_EDGE_K 8       /* widest raw edge attribute folded in-kernel (6 for fragment bonds) */
@@ -95,7 +95,10 @@ int fn_abi_version(void);
 #define FN_TUNE_BWD_MOL_FORCE_SLOW 19 /* test / dev hook of the molecule-resident backward: 1 = every unit takes the path for molecules
                                   * that do not fit the LDS tile (rows and edge state in global memory); 2 = the large size class
                                   * (1024-thread workgroups, 192 rows); 3, 4 = smaller LDS images */
-#define FN_TUNE_COUNT 20
+#define FN_TUNE_MOL_TAIL 20           /* 1 (default): batches marked molecule-contiguous (fn_encoder.mol_contiguous) run the last layer's
+                                       * fragment tail -- fragment sums, fragment graph, readout and their backward -- as one
+                                       * molecule-resident launch each way (csrc/mol_tail.inc); 0: the separate launches */
+#define FN_TUNE_COUNT 21
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * workgroups 64-bit words) is
  * set, every workgroup of the molecule-resident backward (FN_TUNE_BWD_MOL) writes s_memtime stamps of its phases into it
@@ -549,7 +552,18 @@ typedef struct fn_encoder {
                                             * padded to static shapes (fn_stage_padded, FN_STAGE_COUNT); outputs of padding rows
                                             * are zero */
     int32_t* status;                       /* nullable device word, bits OR-ed in on malformed batches */
+    /* Fused fragment tail (csrc/mol_tail.inc).  mol_contiguous: the caller's word that the batch has collate_fn's layout
+     * (molecules concatenated: every index range of a molecule is contiguous and the molecule CSRs above are given).  Then the
+     * last layer's atom -> fragment sum, fragment-graph attention and -- when `pooled` is set -- the readout
+     * cat(scatter_add(out_atoms, batch), scatter_add(out_frags, frag_batch)) [n_mols, 256] (gat2.py:820-823) run as ONE
+     * molecule-resident launch, and their backward (with dL/d(pooled) in `g_pooled`, nullable, added to g_atoms / g_frags) as
+     * one more.  fn_encoder_fused_tail() says whether a descriptor takes that path; `pooled` / `g_pooled` must be NULL if not. */
+    int32_t mol_contiguous, pad3_;
+    float* pooled;
+    const float* g_pooled;
 } fn_encoder;
+
+int fn_encoder_fused_tail(const fn_encoder* e);      /* 1: fn_encoder_forward / _backward run the fused fragment tail */
 
 int64_t fn_encoder_ws_floats(const fn_encoder* e);
 int64_t fn_encoder_bwd_ws_floats(const fn_encoder* e);
