@@ -4424,12 +4424,12 @@ int launch_tail_fwd(const fn_encoder* e, const EncLayout& lay, const LayerActs& 
     const int H = e->heads, d = FN_D / H, wide = 2 * d + FN_D;
     TailFwdArgs T{};
     T.ext = reinterpret_cast<const MolExt*>(lay.mol_ext);  T.n_mols = (int)e->n_mols;  T.counts_dev = e->counts_dev;
-    T.atoms_new = lay.atoms_new;  T.a2f_rowptr = e->a2f.rowptr;  T.a2f_perm = e->a2f.perm;  T.a2f_base = e->a2f.pos_base;
+    T.atoms_new = lay.atoms_new;  T.a2f_rowptr = e->a2f.rowptr;  T.a2f_perm = e->a2f.perm;  T.a2f_base = e->a2f.pos_base;  T.a2f_items = (int)e->a2f.n_items;
     T.frags = a.frags;  T.att = w.f;  T.att_w = wide;  T.dst_off = 0;  T.src_off = d + FN_D;  T.mid_off = d;
     T.s_dst = lay.s_dst;  T.s_src = lay.s_src;  T.feat = a.new_fbond;  T.s_sorted = lay.s_sorted;
     const fn_edge_term et_f{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
     FN_TRY(prep_gat_fwd(a.frags, lay.s_dst, lay.s_src, w.f, wide, &et_f, &e->frag, 0.2f, nullptr, a.p_frag, nullptr, &ep_frags, H, &T.G));
-    T.y_atoms = y_atoms;  T.pooled = e->pooled;
+    T.y_atoms = y_atoms;  T.pooled = e->pooled;  T.force_global = g_tune[FN_TUNE_MOL_TAIL] == 2;
     if (((uintptr_t)y_atoms | (uintptr_t)ep_frags.y | (uintptr_t)e->pooled) & 15) return fail(FN_EINVAL, "fragment tail: outputs must be 16-byte aligned");
     const dim3 grid((unsigned)e->n_mols);
     if (H == 2) hipLaunchKernelGGL((k_tail_fwd<2>), grid, dim3(kBlock), 0, st, T);
@@ -4447,7 +4447,7 @@ int launch_tail_bwd(const fn_encoder* e, const LayerActs& a, const fn_layer_weig
     TailBwdArgs T{};
     T.ext = reinterpret_cast<const MolExt*>(enc_layout(e, e->ws).mol_ext);  T.n_mols = (int)e->n_mols;  T.counts_dev = e->counts_dev;
     T.g_atoms = g_atoms;  T.g_frags = g_frags;  T.g_pooled = e->g_pooled;  T.y_atoms = y_atoms;  T.y_frags = y_frags;  T.scale = gate_scale;
-    T.g_pre_atoms = bw.g_pre_atoms;  T.g_pre_frags = bw.g_pre_frags;  T.a2f_index = e->a2f.index;
+    T.g_pre_atoms = bw.g_pre_atoms;  T.g_pre_frags = bw.g_pre_frags;  T.a2f_index = e->a2f.index;  T.n_atoms = e->N;  T.force_global = g_tune[FN_TUNE_MOL_TAIL] == 2;
     const fn_edge_term et_f{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
     int n_e = 0, n_a = 0;
     FN_TRY(prep_gat_bwd_dst(bw.g_pre_frags, a.frags, a.p_frag, &et_f, &e->frag, 0.2f, nullptr, sf.dz, sf.pz, sf.g_s_dst, nullptr, &n_e, H, &T.D));

@@ -97,7 +97,8 @@ int fn_abi_version(void);
                                   * (1024-thread workgroups, 192 rows); 3, 4 = smaller LDS images */
 #define FN_TUNE_MOL_TAIL 20           /* 1 (default): batches marked molecule-contiguous (fn_encoder.mol_contiguous) run the last layer's
                                        * fragment tail -- fragment sums, fragment graph, readout and their backward -- as one
-                                       * molecule-resident launch each way (csrc/mol_tail.inc); 0: the separate launches */
+                                       * molecule-resident launch each way (csrc/mol_tail.inc); 0: the separate launches;
+                                       * 2 (test hook): fused, every molecule on the global-memory path of oversize molecules */
 #define FN_TUNE_COUNT 21
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * workgroups 64-bit words) is

@@ -47,11 +47,12 @@ def test_fused_tail_matches_reference_golden(case):
     assert _fused(model, b) and not _fused(model, data.batch_to(dict(batch), DEV))
 
 
+@pytest.mark.parametrize("path", [1, 2], ids=["lds", "global"])
 @pytest.mark.parametrize("heads,drop", [(4, 0.1), (2, 0.0), (8, 0.1)])
-def test_fused_tail_equals_the_separate_launches(heads, drop):
+def test_fused_tail_equals_the_separate_launches(heads, drop, path):
     """Same weights, same Philox stream: a CollatedBatch (fused tail) and the same tensors as a plain dict (k_frag_tail, k_gat_fwd,
     k_pool_cat; five launches backward) agree to summation-order round-off -- logits and every gradient, with single-fragment,
-    fully cut and salt molecules in the batch."""
+    fully cut and salt molecules in the batch; both the LDS path and the global-memory path of oversize molecules."""
     from fragnet_amd import data, synth
     from fragnet_amd.model import FragNetFineTune
     mols = synth.synth_molecules(70, seed=41, profile="esol", p_salt=0.2) + [synth.notebook_molecule()]
@@ -61,13 +62,18 @@ def test_fused_tail_equals_the_separate_launches(heads, drop):
     model = FragNetFineTune(n_classes=1, num_layer=2, num_heads=heads, drop_ratio=drop, h1=64, h2=64, h3=64, h4=32, act="relu",
                             fthead="FTHead3").to(DEV).train()
     res = []
-    for b in (coll, plain):
-        model.zero_grad(set_to_none=True)
-        model.pretrain.rng.offset = 77
-        out = model(b)
-        torch.nn.functional.mse_loss(out.view(-1), b["y"]).backward()
-        res.append((out.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
-    assert _fused(model, coll) and not _fused(model, plain)
+    from fragnet_amd import _lib
+    try:
+        _lib.call("fn_set_tuning", 20, path)        # 2: every molecule on the global-memory path of oversize molecules
+        for b in (coll, plain):
+            model.zero_grad(set_to_none=True)
+            model.pretrain.rng.offset = 77
+            out = model(b)
+            torch.nn.functional.mse_loss(out.view(-1), b["y"]).backward()
+            res.append((out.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+        assert _fused(model, coll) and not _fused(model, plain)
+    finally:
+        _lib.call("fn_set_tuning", 20, 1)
     torch.testing.assert_close(res[0][0], res[1][0], atol=1e-5, rtol=1e-5)
     assert set(res[0][1]) == set(res[1][1])
     for n, g in res[1][1].items():
@@ -147,7 +153,7 @@ def _poison():
     del xs
 
 
-@pytest.mark.parametrize("tail", [1, 0], ids=["fused_tail", "separate_launches"])
+@pytest.mark.parametrize("tail", [1, 2, 0], ids=["fused_tail_lds", "fused_tail_global", "separate_launches"])
 @pytest.mark.parametrize("kind,layers", [("ft", 1), ("ft", 2), ("ft", 4), ("pt", 1), ("pt", 2), ("pt", 4)])
 def test_training_step_reads_nothing_it_did_not_write(kind, layers, tail):
     """Workspaces come from torch.empty.  With the allocator's free memory poisoned with NaN before the forward and before the
