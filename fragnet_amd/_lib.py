@@ -27,6 +27,16 @@ class CsrTask(C.Structure):
                 ("item_base", i64), ("seg_base", i64), ("role", i32), ("partner", i32)]
 
 
+FN_MAX_SPACES = 8
+
+
+class MolLayout(C.Structure):
+    _fields_ = [("offsets", vp), ("n_spaces", i32), ("pad_", i32), ("n_mols", i64),
+                ("node_space", i32 * FN_MAX_TASKS), ("item_space", i32 * FN_MAX_TASKS), ("counts_dev", vp),
+                ("cap", i64 * FN_MAX_SPACES), ("pad_mod", i64 * FN_MAX_SPACES), ("max_per_mol", i64 * FN_MAX_SPACES),
+                ("pad_hint", i64 * FN_MAX_SPACES)]
+
+
 class EdgeTerm(C.Structure):
     _fields_ = [("mode", i32), ("K", i32), ("d_e", i32), ("mid_off", i32),
                 ("s_sorted", vp), ("x_sorted", vp), ("embW", vp), ("embb", vp)]
@@ -68,7 +78,7 @@ class StageField(C.Structure):
 
 
 FN_MAX_STAGE_FIELDS = 40
-STAGE_ROWS, STAGE_IDS, STAGE_COLS, STAGE_MASK, STAGE_COUNT, STAGE_BUMP, STAGE_ZERO = 0, 1, 2, 3, 4, 5, 6
+STAGE_ROWS, STAGE_IDS, STAGE_COLS, STAGE_MASK, STAGE_COUNT, STAGE_BUMP, STAGE_ZERO, STAGE_OFFSETS = 0, 1, 2, 3, 4, 5, 6, 7
 PLAN_PREZEROED = 1
 
 
@@ -96,6 +106,7 @@ SIGNATURES = {
     "fn_debug_set_stamps": [vp, i64],
     "fn_plan_layout": [C.POINTER(CsrTask), C.c_int, C.POINTER(i64), C.POINTER(i64)],
     "fn_plan_build": [C.POINTER(CsrTask), C.c_int, vp, vp, vp, vp, vp, vp, i32, vp],
+    "fn_plan_build_mol": [C.POINTER(CsrTask), C.c_int, C.POINTER(MolLayout), vp, vp, vp, vp, vp, vp, i32, vp],
     "fn_node_scalars_f32": [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, i64, C.c_int, vp],
     "fn_gat_fwd_f32": [vp, vp, vp, vp, C.c_int, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp,
                        C.POINTER(ActEpilogue), C.c_int, vp],

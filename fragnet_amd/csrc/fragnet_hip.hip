@@ -2917,6 +2917,13 @@ __global__ void k_stage_padded(StageFields F) {
         if (t0 == 0) *static_cast<int32_t*>(f.dst) = (int32_t)f.n_real;
     } else if (f.kind == FN_STAGE_BUMP) {
         if (t0 == 0) *static_cast<int64_t*>(f.dst) += f.n_real;
+    } else if (f.kind == FN_STAGE_OFFSETS) {
+        const int32_t* src = static_cast<const int32_t*>(f.src);
+        int32_t* dst = static_cast<int32_t*>(f.dst);
+        for (int64_t i = t0; i < f.width * (f.cap + 1); i += stride) {
+            const int64_t s = i / (f.cap + 1), m = i % (f.cap + 1);
+            dst[i] = src[s * (f.n_real + 1) + (m < f.n_real ? m : f.n_real)];
+        }
     } else if (f.kind == FN_STAGE_ZERO) {
         int32_t* dst = static_cast<int32_t*>(f.dst);
         for (int64_t i = t0; i < f.cap; i += stride) dst[i] = 0;
@@ -2926,7 +2933,7 @@ __global__ void k_stage_padded(StageFields F) {
         const int rows = f.kind == FN_STAGE_COLS ? 2 : 1;
         for (int64_t i = t0; i < rows * f.cap; i += stride) {
             const int64_t r = i >= f.cap ? 1 : 0, c = i - r * f.cap;
-            dst[i] = c < f.n_real ? src[r * f.n_real + c] : f.pad_hi - c % f.pad_mod;
+            dst[i] = c < f.n_real ? src[r * f.n_real + c] : f.pad_hi - (c - f.n_real) % f.pad_mod;
         }
     }
 }
@@ -3806,6 +3813,12 @@ int fn_stage_padded(const fn_stage_field* fields, int n_fields, fn_stream_t stre
             if (f.cap < 0 || (f.cap > 0 && !f.dst)) return fail(FN_EINVAL, "fn_stage_padded: bad zero field");
             F.f[i] = f;
             most = f.cap > most ? f.cap : most;
+            continue;
+        }
+        if (f.kind == FN_STAGE_OFFSETS) {
+            if (f.n_real < 0 || f.cap < f.n_real || f.width < 1 || !f.dst || !f.src) return fail(FN_EINVAL, "fn_stage_padded: bad offsets field");
+            F.f[i] = f;
+            most = std::max<int64_t>(most, f.width * (f.cap + 1));
             continue;
         }
         if (f.kind == FN_STAGE_COUNT) {

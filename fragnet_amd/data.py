@@ -22,7 +22,7 @@ from typing import Dict, List, Sequence
 
 import torch
 
-from .plan import CollatedBatch
+from .plan import CollatedBatch, mol_offsets
 
 _F32_EXACT = 1 << 24
 
@@ -71,6 +71,11 @@ def _collate_common(data_list: List) -> Dict[str, torch.Tensor]:
         "edge_index_fbonds": cat1("edge_index_fbondg").to(torch.long) + _offsets(n_fbnodes, efb),
         "edge_attr_fbonds": cat0("edge_attr_fbondg"),
     })
+    # the cumulative counts as a table (plan.CollatedBatch): the one-launch graph-plan builder is driven by it
+    per_mol = {"atom": n_atoms, "edge": e, "bedge": eb, "frag": n_frags, "fedge": ef, "fbedge": efb}
+    out.offsets = mol_offsets({k: torch.as_tensor(v, dtype=torch.long) for k, v in per_mol.items()})
+    out.max_per_mol = {k: max(v) for k, v in per_mol.items()}
+    out.max_per_mol["mol"] = 1
     return out
 
 
@@ -103,8 +108,11 @@ def batch_to(batch: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]:
     """``batch[k] = batch[k].to(device)`` for every key -- reference train/utils.py:335-336.  A batch collated from a
     store without its bond-graph index (dataset.FlatMolStore.without_bond_graph_index) gets ``edge_index_bonds_graph``
     rebuilt from ``edge_index`` once it is on the GPU (ops.bond_graph)."""
-    out = type(batch)() if isinstance(batch, CollatedBatch) else {}      # the layout promise travels with the batch
-    out.update({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()})
+    out = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    if isinstance(batch, CollatedBatch):         # the layout promise (and the offsets table) travels with the batch
+        out = batch.like(out)
+        if out.offsets is not None:
+            out.offsets = out.offsets.to(device)
     if "edge_index_bonds_graph" not in out and "edge_index" in out and out["edge_index"].is_cuda:
         from . import ops
         out["edge_index_bonds_graph"] = ops.bond_graph(out["edge_index"], out["batch"], int(out["y"].shape[0]))

@@ -13,7 +13,7 @@ from typing import Dict, List, Optional, Sequence
 
 import torch
 
-from .plan import CollatedBatch
+from .plan import CollatedBatch, mol_offsets
 
 # field -> (ragged axis, index space that offsets its VALUES or None)
 _ROW_FIELDS = {           # concatenated along dim 0
@@ -162,7 +162,20 @@ class FlatMolStore:
             out["bnd_angl"] = t["bnd_angl"][rows["atom"]]
             out["dh_angl"] = t["dh_angl"][rows["edge"]]
         out["y"] = self.y[idx]
+        # the per-molecule offsets of the batch (plan.CollatedBatch.offsets): cumulative lengths, already on the device;
+        # molecule extents are bounded by the store's own maxima (no device synchronisation here)
+        if all(s in length for s in ("atom", "edge", "bedge", "frag", "fedge", "fbedge")):
+            out.offsets = mol_offsets(length)
+            out.max_per_mol = self.max_per_mol()
         return out
+
+    def max_per_mol(self) -> Dict[str, int]:
+        """Largest extent of one molecule in every index space over the whole store (computed once)."""
+        if getattr(self, "_max_per_mol", None) is None:
+            m = {s: int((o[1:] - o[:-1]).max()) if o.numel() > 1 else 0 for s, o in self.off.items()}
+            m["mol"] = 1
+            self._max_per_mol = m
+        return self._max_per_mol
 
 
 class BatchSampler:

@@ -31,7 +31,7 @@ from typing import Callable, Dict, Iterable, Optional
 import torch
 
 from . import _lib
-from .plan import LIVE_MOLS_KEY, PLAN_KEY, REAL_MOLS_KEY, CollatedBatch, prezeroed_plans
+from .plan import LIVE_MOLS_KEY, PLAN_KEY, REAL_MOLS_KEY, SPACES, CollatedBatch, prezeroed_plans
 
 # field -> (index space of the ragged axis, layout, index space its VALUES point into)
 FIELDS = {
@@ -80,8 +80,12 @@ def _up(x: int, q: int = 64) -> int:
 class StaticShapes:
     """Capacities per index space + the number of trailing slots of each node space reserved for padding."""
 
-    def __init__(self, cap: Dict[str, int], slack: Dict[str, int], heads: int = 4):
+    def __init__(self, cap: Dict[str, int], slack: Dict[str, int], heads: int = 4, lower: Optional[Dict[str, int]] = None,
+                 max_per_mol: Optional[Dict[str, int]] = None):
         self.cap, self.slack, self.heads = dict(cap), dict(slack), heads
+        self.lower = dict(lower) if lower else {sp: 0 for sp in cap}       # fewest real items a batch is expected to bring
+        # largest molecule the one-launch plan builder's LDS tile is sized for (None: batches carry no such bound)
+        self.max_per_mol = dict(max_per_mol) if max_per_mol else None
 
     @classmethod
     def from_counts(cls, counts: Iterable[Dict[str, int]], margin: float = 0.03, heads: int = 4) -> "StaticShapes":
@@ -99,13 +103,20 @@ class StaticShapes:
             cap[node] = _up(int(math.ceil(mx[node] * (1.0 + grow))) + slack[node], 8)
             if node == "mol":       # the batch size is exact: every slot the rounding added is padding too (the head skips them)
                 slack[node] = cap[node] - mx[node]
-        return cls(cap, slack, heads)
+        return cls(cap, slack, heads, lower)
 
     @classmethod
     def from_batches(cls, batches, margin: float = 0.03, heads: int = 4) -> "StaticShapes":
-        return cls.from_counts([batch_counts(b) for b in batches], margin, heads)
+        batches = list(batches)
+        shapes = cls.from_counts([batch_counts(b) for b in batches], margin, heads)
+        bounds = [getattr(b, "max_per_mol", None) for b in batches]
+        if bounds and all(m is not None for m in bounds):       # CollatedBatches: room for molecules half as large again
+            shapes.max_per_mol = {sp: (1 if sp == "mol" else _up(int(1.5 * max(m[sp] for m in bounds)) + 8, 8)) for sp in SPACES}
+        return shapes
 
-    def fits(self, counts: Dict[str, int]) -> bool:
+    def fits(self, counts: Dict[str, int], max_per_mol: Optional[Dict[str, int]] = None) -> bool:
+        if self.max_per_mol is not None and max_per_mol is not None and any(max_per_mol[sp] > self.max_per_mol[sp] for sp in SPACES):
+            return False        # a molecule larger than the plan builder's tile was sized for
         for sp, n in counts.items():
             if n > self.cap[sp] - self.slack.get(sp, 0):
                 return False
@@ -116,8 +127,13 @@ class StaticShapes:
         return True
 
     def pad_rule(self, target: str):
-        """(pad_hi, pad_mod): padding position i of a field pointing into ``target`` holds pad_hi - i % pad_mod."""
+        """(pad_hi, pad_mod): padding position i of a field pointing into ``target`` holds pad_hi - (i - n_real) % pad_mod."""
         return self.cap[target] - 1, self.slack[target]
+
+    def pad_info(self) -> Dict[str, Dict[str, int]]:
+        """CollatedBatch.pad of a batch staged into these shapes (plan.GraphPlan.from_batch -> fn_plan_build_mol)."""
+        return {"cap": dict(self.cap), "mod": dict(self.slack),
+                "hint": {sp: self.cap[sp] - self.lower.get(sp, 0) for sp in self.cap}}
 
     def __repr__(self):
         return f"StaticShapes(cap={self.cap}, slack={self.slack})"
@@ -138,7 +154,7 @@ def pad_batch(batch: Dict[str, torch.Tensor], shapes: StaticShapes) -> Dict[str,
             dst[:n] = src
         else:
             hi, mod = shapes.pad_rule(target)
-            pad = hi - torch.arange(cap, device=src.device, dtype=torch.long) % mod
+            pad = hi - (torch.arange(cap, device=src.device, dtype=torch.long) - n) % mod
             if layout == "ids":
                 dst = pad.clone()
                 dst[:n] = src
@@ -150,6 +166,15 @@ def pad_batch(batch: Dict[str, torch.Tensor], shapes: StaticShapes) -> Dict[str,
         w = torch.zeros(shapes.cap[space], dtype=torch.float32, device=batch["y"].device)
         w[: counts[space]] = 1.0
         out[key] = w
+    if isinstance(batch, CollatedBatch) and batch.offsets is not None:      # the staged offsets table (FN_STAGE_OFFSETS)
+        out = batch.like(out)
+        B, cap = counts["mol"], shapes.cap["mol"]
+        off = batch.offsets.new_empty((len(SPACES), cap + 1))
+        off[:, : B + 1] = batch.offsets
+        off[:, B + 1:] = batch.offsets[:, B:]
+        out.offsets, out.pad = off, shapes.pad_info()
+        if shapes.max_per_mol is not None:
+            out.max_per_mol = shapes.max_per_mol
     return out
 
 
@@ -201,6 +226,11 @@ class StaticBatch:
         # molecules, whose items point round-robin at the reserved slots, separately: REAL_MOLS_KEY)
         self.collated = isinstance(example, CollatedBatch)
         self.t: Dict[str, torch.Tensor] = CollatedBatch() if self.collated else {}
+        # per-molecule offsets table of the staged batch: drives the one-launch plan builder (fn_plan_build_mol)
+        self.with_offsets = self.collated and example.offsets is not None and example.offsets.is_cuda and shapes.max_per_mol is not None
+        if self.with_offsets:
+            self.t.offsets = torch.zeros((len(SPACES), shapes.cap["mol"] + 1), dtype=torch.int32, device=dev)
+            self.t.max_per_mol, self.t.pad = dict(shapes.max_per_mol), shapes.pad_info()
         self._desc = []
         for name, (space, layout, target) in FIELDS.items():
             if name not in example:
@@ -234,6 +264,11 @@ class StaticBatch:
         c = self._fields[len(self._desc) + len(self._mask_spaces)]
         c.dst, c.cap, c.width, c.kind, c.pad_hi, c.pad_mod = self.t[REAL_MOLS_KEY].data_ptr(), 1, 1, _lib.STAGE_COUNT, 0, 1
         self.n_fields = len(self._desc) + len(self._mask_spaces) + 1
+        if self.with_offsets:
+            o = self._fields[self.n_fields]
+            o.dst, o.cap, o.width, o.kind, o.pad_hi, o.pad_mod = self.t.offsets.data_ptr(), shapes.cap["mol"], len(SPACES), _lib.STAGE_OFFSETS, 0, 1
+            self._off_field = self.n_fields
+            self.n_fields += 1
         # molecule rows behind capacity - slack are padding in every batch that fits: the prediction head skips them
         self.t[LIVE_MOLS_KEY] = shapes.cap["mol"] - shapes.slack["mol"]
         if self.n_fields > _lib.FN_MAX_STAGE_FIELDS:
@@ -259,10 +294,17 @@ class StaticBatch:
     def load(self, batch: Dict[str, torch.Tensor]) -> bool:
         """Stage ``batch`` (GPU tensors); False when it does not fit the capacities (nothing is written then)."""
         counts = batch_counts(batch)
-        if not self.shapes.fits(counts):
+        if not self.shapes.fits(counts, getattr(batch, "max_per_mol", None)):
             return False
         if self.collated and not isinstance(batch, CollatedBatch):
             return False        # no layout promise: the caller's eager step takes the general kernels
+        if self.with_offsets:
+            off = batch.offsets
+            if off is None or not off.is_cuda or batch.max_per_mol is None:
+                return False
+            off = off if off.is_contiguous() else off.contiguous()
+            o = self._fields[self._off_field]
+            o.src, o.n_real = off.data_ptr(), counts["mol"]
         keep = []
         for i, (name, space, kind, width, hi, mod) in enumerate(self._desc):
             src = batch[name]
@@ -280,6 +322,7 @@ class StaticBatch:
         c.src, c.n_real = None, counts["mol"]
         _lib.call("fn_stage_padded", self._fields, self.n_fields, torch.cuda.current_stream(self.device).cuda_stream)
         self.counts = counts
+        self._keep = (keep, batch.offsets if self.with_offsets else None)       # alive until the launch has run
         return True
 
 

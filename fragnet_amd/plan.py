@@ -51,8 +51,10 @@ class Level:
 
 
 class GraphPlan:
-    def __init__(self, specs: List[dict], device):
-        """specs: list of dicts(kind='gat'|'seg', name, ...) -- use GraphPlan.from_batch / .segments_only."""
+    def __init__(self, specs: List[dict], device, mol_layout: Optional[dict] = None):
+        """specs: list of dicts(kind='gat'|'seg', name, ...) -- use GraphPlan.from_batch / .segments_only.
+        ``mol_layout`` (molecule-contiguous batches): dict(offsets, n_mols, counts_dev, cap, mod, max_per_mol, hint) and specs that
+        carry ``nodes`` / ``items`` (index-space names) -> fn_plan_build_mol, one launch."""
         lib = _lib.load()
         self.device = device
         tasks = (CsrTask * _lib.FN_MAX_TASKS)()
@@ -102,11 +104,20 @@ class GraphPlan:
         self.prezeroed = bool(_PREZEROED)
         if self.prezeroed:
             _BUILT.append(self)
-        _lib.check(lib.fn_plan_build(tasks, nt, self.rowptr.data_ptr(), self.perm.data_ptr(), self.aux_a.data_ptr(),
-                                     self.aux_b.data_ptr(), self.aux_c.data_ptr(), ws.data_ptr(),
-                                     _lib.PLAN_PREZEROED if self.prezeroed else 0, _stream_ptr(device)),
-                   "fn_plan_build")
+        self.mol_built = False
+        if mol_layout is not None and self._build_mol(lib, tasks, nt, specs, mol_layout, ws, device):
+            self.mol_built = True
+            self.zero_regions = [(self._status.data_ptr(), 1)]      # the one-launch builder only needs a clean status word
+        else:
+            _lib.check(lib.fn_plan_build(tasks, nt, self.rowptr.data_ptr(), self.perm.data_ptr(), self.aux_a.data_ptr(),
+                                         self.aux_b.data_ptr(), self.aux_c.data_ptr(), ws.data_ptr(),
+                                         _lib.PLAN_PREZEROED if self.prezeroed else 0, _stream_ptr(device)),
+                       "fn_plan_build")
         self._keep = keep
+        # (name, role, item_base, seg_base, items, segments) per CSR task: which slices of the arena mean what (tests, tools)
+        self.task_meta = [(ent[1], int(tasks[ent[2] + q].role), int(tasks[ent[2] + q].item_base), int(tasks[ent[2] + q].seg_base),
+                           int(tasks[ent[2] + q].n_real + tasks[ent[2] + q].n_loops), int(tasks[ent[2] + q].n_seg))
+                          for ent in layout for q in range(2 if ent[0] == "gat" else 1)]
         self._sorted = {}
         self.pending = {}           # level name -> raw edge attribute whose sorted copy fn_encoder_forward still has to fill
         self.levels: Dict[str, Level] = {}
@@ -128,6 +139,46 @@ class GraphPlan:
                 self.segs[name] = Segments(self.rowptr[t.seg_base: t.seg_base + t.n_seg + 1],
                                            self.perm[t.item_base: t.item_base + t.n_real], int(t.item_base),
                                            int(t.n_seg), int(t.n_real), key)
+
+    def _build_mol(self, lib, tasks, nt, specs, layout, ws, device) -> bool:
+        """fn_plan_build_mol for a molecule-contiguous batch; False = not applicable (the general builder runs)."""
+        off = layout["offsets"]
+        if not MOL_PLAN or off is None or not off.is_cuda or off.dtype != torch.int32 or layout.get("max_per_mol") is None:
+            return False
+        n_mols = layout["n_mols"]
+        if off.shape != (len(SPACES), n_mols + 1) or not off.is_contiguous():
+            return False
+        ml = _lib.MolLayout()
+        ml.offsets, ml.n_spaces, ml.n_mols = off.data_ptr(), len(SPACES), n_mols
+        counts = layout.get("counts_dev")
+        ml.counts_dev = None if counts is None else counts.data_ptr()
+        ti = 0
+        for sp in specs:
+            if "nodes" not in sp:
+                return False
+            ns, it = SPACES.index(sp["nodes"]), SPACES.index(sp["items"])
+            for _ in range(2 if sp["kind"] == "gat" else 1):
+                ml.node_space[ti], ml.item_space[ti] = ns, it
+                ti += 1
+        words = 0
+        for s, name in enumerate(SPACES):
+            ml.cap[s] = layout["cap"][name]
+            ml.pad_mod[s] = max(1, layout["mod"].get(name, 1))
+            ml.max_per_mol[s] = layout["max_per_mol"][name]
+            ml.pad_hint[s] = layout["hint"].get(name, 0)
+        for i in range(nt):       # the LDS tile of csrc/mol_plan.hip: 2 (nodes + 1) + 1.5 items words per task
+            items = ml.max_per_mol[ml.item_space[i]] + (ml.max_per_mol[ml.node_space[i]] if tasks[i].n_loops else 0)
+            words += 2 * (max(ml.max_per_mol[ml.node_space[i]], 1) + 1) + (3 * max(items, 1) + 1) // 2 + 1
+            if items > 65535:
+                return False
+        if words * 4 > 64 * 1024:
+            return False             # a molecule too large for the tile: the general builder takes the batch
+        self._keep_layout = (off, counts)
+        _lib.check(lib.fn_plan_build_mol(tasks, nt, C.byref(ml), self.rowptr.data_ptr(), self.perm.data_ptr(), self.aux_a.data_ptr(),
+                                         self.aux_b.data_ptr(), self.aux_c.data_ptr(), ws.data_ptr(),
+                                         _lib.PLAN_PREZEROED if self.prezeroed else 0, _stream_ptr(device)),
+                   "fn_plan_build_mol")
+        return True
 
     def sorted_attr(self, name: str, x: torch.Tensor, defer: bool = False) -> torch.Tensor:
         """Raw edge attribute of level ``name`` permuted into destination-sorted order, once per batch
@@ -161,6 +212,8 @@ class GraphPlan:
         if st & 2:
             raise IndexError("graph plan: the batch is not molecule-contiguous (an edge joins nodes of different molecules, or "
                              "molecules are interleaved); the fused encoder needs collate_fn's layout (dataset/data.py:877-948)")
+        if st & 4:
+            raise IndexError("graph plan: a molecule is larger than CollatedBatch.max_per_mol says (fn_plan_build_mol's LDS tile)")
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -183,20 +236,27 @@ class GraphPlan:
         # the two molecule-membership CSRs (mol_atoms, mol_frags) are read by the readout (ops.pool_cat: gat2.py:820-823) of
         # every model, and drive the molecule-resident kernels when those are switched on
         specs = [
-            dict(kind="gat", name="bond", dst=eib[0], src=eib[1], n=E, n_loops=0),
-            dict(kind="gat", name="atom", dst=ei[1], src=ei[0], n=N, n_loops=N),
-            dict(kind="gat", name="fbond", dst=eifb[0], src=eifb[1], n=EF, n_loops=0),
-            dict(kind="gat", name="frag", dst=fi[1], src=fi[0], n=F, n_loops=0),
-            dict(kind="seg", name="a2f", key=batch["atom_to_frag_ids"], n_seg=F),
-            dict(kind="seg", name="mol_atoms", key=batch["batch"], n_seg=n_mols),
-            dict(kind="seg", name="mol_frags", key=batch["frag_batch"], n_seg=n_mols),
+            dict(kind="gat", name="bond", dst=eib[0], src=eib[1], n=E, n_loops=0, nodes="edge", items="bedge"),
+            dict(kind="gat", name="atom", dst=ei[1], src=ei[0], n=N, n_loops=N, nodes="atom", items="edge"),
+            dict(kind="gat", name="fbond", dst=eifb[0], src=eifb[1], n=EF, n_loops=0, nodes="fedge", items="fbedge"),
+            dict(kind="gat", name="frag", dst=fi[1], src=fi[0], n=F, n_loops=0, nodes="frag", items="fedge"),
+            dict(kind="seg", name="a2f", key=batch["atom_to_frag_ids"], n_seg=F, nodes="frag", items="atom"),
+            dict(kind="seg", name="mol_atoms", key=batch["batch"], n_seg=n_mols, nodes="mol", items="atom"),
+            dict(kind="seg", name="mol_frags", key=batch["frag_batch"], n_seg=n_mols, nodes="mol", items="frag"),
         ]
         if edge_ends:
-            specs += [dict(kind="seg", name="edge_src", key=ei[0], n_seg=N),
-                      dict(kind="seg", name="edge_dst", key=ei[1], n_seg=N)]
-        plan = cls(specs, dev)
+            specs += [dict(kind="seg", name="edge_src", key=ei[0], n_seg=N, nodes="atom", items="edge"),
+                      dict(kind="seg", name="edge_dst", key=ei[1], n_seg=N, nodes="atom", items="edge")]
+        contiguous = bool(getattr(batch, "mol_contiguous", False))               # CollatedBatch: collate_fn's layout
+        layout = None
+        if contiguous and getattr(batch, "offsets", None) is not None and getattr(batch, "max_per_mol", None) is not None:
+            cap = {"atom": N, "edge": E, "bedge": eib.shape[1], "frag": F, "fedge": EF, "fbedge": eifb.shape[1], "mol": n_mols}
+            pad = getattr(batch, "pad", None) or {}
+            layout = dict(offsets=batch.offsets, n_mols=n_mols, counts_dev=batch.get(REAL_MOLS_KEY), cap=cap,
+                          mod=pad.get("mod", {}), max_per_mol=batch.max_per_mol, hint=pad.get("hint", {}))
+        plan = cls(specs, dev, layout)
         plan.n_mols = n_mols
-        plan.mol_contiguous = bool(getattr(batch, "mol_contiguous", False))      # CollatedBatch: collate_fn's layout
+        plan.mol_contiguous = contiguous
         plan.real_mols = batch.get(REAL_MOLS_KEY)      # int32 [1] on the device when the batch is padded to static shapes
         return plan
 
@@ -206,6 +266,7 @@ class GraphPlan:
         return plan
 
 
+MOL_PLAN = True         # molecule-contiguous batches with offsets: fn_plan_build_mol (False: always the general builder; A/B, tests)
 _PREZEROED = False      # True only while graphstep captures its step: plans built then skip their zeroing launch
 _BUILT = []             # the plans built inside the current prezeroed_plans() context
 
@@ -227,14 +288,45 @@ class prezeroed_plans:
         _BUILT.clear()
 
 
+SPACES = ("atom", "edge", "bedge", "frag", "fedge", "fbedge", "mol")      # index spaces of a batch (graphstep.COUNT_FIELD)
+
+
 class CollatedBatch(dict):
     """A batch dict in collate_fn's layout (reference dataset/data.py:877-948): molecules are concatenated, so the atoms,
     directed bonds, fragments, fragment connections and the edges of the four graphs of molecule i are contiguous index ranges.
     data.collate_fn(_pt), FlatMolStore.collate, data.batch_to and StaticBatch return it; same keys and values as the plain
     dict.  The encoder engine runs its molecule-resident kernels (csrc/mol_tail.inc) only for such batches: a hand-built plain
-    dict makes no promise about its layout and takes the general per-level kernels."""
+    dict makes no promise about its layout and takes the general per-level kernels.
+
+    Attributes (not dict keys: the key set stays the reference's): ``offsets`` int32 [len(SPACES), B + 1], first index of
+    molecule i in each index space -- the collate's cumulative counts; with it (on the batch's device) the graph plan is built
+    by one molecule-resident launch (fn_plan_build_mol) instead of four grid-wide passes.  ``max_per_mol``: {space: largest
+    extent of one molecule} (python ints; sizes that kernel's LDS tile).  ``pad``: set by StaticBatch, the padding rule of a
+    static-shape batch {"cap": {space: n}, "mod": {space: n}, "hint": {space: n}}."""
 
     mol_contiguous = True
+    offsets = None
+    max_per_mol = None
+    pad = None
+
+    def like(self, items):
+        """A batch with the same layout attributes and the given items (moved / re-keyed tensors)."""
+        out = type(self)(items)
+        out.offsets, out.max_per_mol, out.pad = self.offsets, self.max_per_mol, self.pad
+        return out
+
+
+def mol_offsets(counts: Dict[str, "torch.Tensor"]) -> "torch.Tensor":
+    """int32 [len(SPACES), B + 1] from per-molecule counts (int64 tensors [B] per space except "mol")."""
+    B = counts["atom"].numel()
+    dev = counts["atom"].device
+    off = torch.zeros((len(SPACES), B + 1), dtype=torch.int32, device=dev)
+    for s, name in enumerate(SPACES):
+        if name == "mol":
+            off[s] = torch.arange(B + 1, dtype=torch.int32, device=dev)
+        else:
+            off[s, 1:] = torch.cumsum(counts[name], 0).to(torch.int32)
+    return off
 
 
 PLAN_KEY = "_fragnet_plan"

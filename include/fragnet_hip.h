@@ -153,6 +153,30 @@ int fn_plan_build(const fn_csr_task* tasks, int n_tasks,
                   int32_t* rowptr_all /*[total_segs+1]*/, int32_t* perm_all /*[total_items]*/,
                   int32_t* aux_a /*[total_items]*/, int32_t* aux_b /*[total_items]*/, int32_t* aux_c /*[total_items]*/,
                   int32_t* ws_i32, int32_t flags /*FN_PLAN_**/, fn_stream_t stream);
+
+/* The same plan for a MOLECULE-CONTIGUOUS batch in one launch (csrc/mol_plan.hip).  collate_fn concatenates molecules
+ * (dataset/data.py:877-948): every index space (atoms, directed bonds, bond-graph edges, fragments, fragment connections,
+ * fragment-bond-graph edges, molecules, ...) is a concatenation of per-molecule ranges and every key of molecule i is smaller
+ * than every key of molecule i + 1, so the stable sort of each CSR is the concatenation of per-molecule sorts: one workgroup per
+ * molecule sorts in LDS.  `offsets` (device, int32 [n_spaces][n_mols + 1]) = first index of molecule i in each space (the
+ * collate's cumulative counts); node_space / item_space name, per task, the spaces its segments and its items live in.
+ * Static-shape batches (fn_stage_padded): counts_dev = number of real molecules, offsets rows beyond it repeat the real
+ * totals, cap = array lengths, pad_mod = reserved slots per space; the padding tail (item c of a field pointing into space s
+ * holds cap[s] - 1 - (c - n_real) % pad_mod[s]) is written in closed form.  max_per_mol: upper bound of a molecule's extent in
+ * each space (sizes the LDS tile: <= 64 KB in total, else FN_EUNSUPPORTED); a larger molecule sets status bit 2 (value 4), a key
+ * outside its molecule's node range bit 1 (value 2).  pad_hint: upper bound of the padding items per space (grid sizing; 0: none).
+ * Same outputs, bit for bit, as fn_plan_build; ws_i32 only carries the status word (same place). */
+#define FN_MAX_SPACES 8
+typedef struct fn_mol_layout {
+    const int32_t* offsets;
+    int32_t n_spaces, pad_;
+    int64_t n_mols;
+    int32_t node_space[FN_MAX_TASKS], item_space[FN_MAX_TASKS];
+    const int32_t* counts_dev;             /* nullable */
+    int64_t cap[FN_MAX_SPACES], pad_mod[FN_MAX_SPACES], max_per_mol[FN_MAX_SPACES], pad_hint[FN_MAX_SPACES];
+} fn_mol_layout;
+int fn_plan_build_mol(const fn_csr_task* tasks, int n_tasks, const fn_mol_layout* layout, int32_t* rowptr_all, int32_t* perm_all,
+                      int32_t* aux_a, int32_t* aux_b, int32_t* aux_c, int32_t* ws_i32, int32_t flags, fn_stream_t stream);
 /* flags: the caller has already zeroed rowptr_all[0 .. total_segs] and the whole of ws_i32 on this stream (a captured step
  * lets the staging launch in front of the replay do it, FN_STAGE_ZERO): fn_plan_build skips its zeroing launch */
 #define FN_PLAN_PREZEROED 1
@@ -457,7 +481,8 @@ int fn_masked_mse_multi_f32(const fn_mse_task* tasks, int n_tasks /*<= 4*/, cons
  * every batch (the dict of dataset/data.py:931-948) is copied into fixed-capacity buffers and the tail of each
  * buffer is filled with PADDING that is itself a valid, disconnected piece of graph: zero feature rows, and index
  * values pointing at the last `pad_mod` slots of the target index space (pad value at position i =
- * pad_hi - i % pad_mod), so padding only ever talks to padding and in-degrees stay small.  One launch, all fields.
+ * pad_hi - (i - n_real) % pad_mod: the first padding item points at the last slot), so padding only ever talks to padding and
+ * in-degrees stay small.  One launch, all fields.
  * ------------------------------------------------------------------------------------------ */
 #define FN_MAX_STAGE_FIELDS 40
 #define FN_STAGE_ROWS 0 /* float32 [cap,width]  <- [n_real,width], zero rows after                         */
@@ -466,6 +491,8 @@ int fn_masked_mse_multi_f32(const fn_mse_task* tasks, int n_tasks /*<= 4*/, cons
 #define FN_STAGE_MASK 3 /* float32 [cap]        =  1 for i < n_real, 0 after (loss weights); src unused    */
 #define FN_STAGE_COUNT 4 /* int32 [1]           =  n_real (device-side copy of a count for the fused encoder)  */
 #define FN_STAGE_ZERO 6  /* int32 [cap]         =  0 (workspace of a captured fn_plan_build, see FN_PLAN_PREZEROED); src unused */
+#define FN_STAGE_OFFSETS 7 /* int32 [width][cap+1] <- [width][n_real+1]: per-molecule offsets of `width` index spaces (fn_mol_layout);
+                            *                       entries behind molecule n_real repeat the space's total */
 #define FN_STAGE_BUMP 5  /* int64 [1]          +=  n_real: a device-side counter of a captured step (Philox blocks, optimiser steps)
                           *                       advanced by the staging launch that precedes every replay instead of by a launch of its own */
 typedef struct fn_stage_field {

@@ -1,0 +1,95 @@
+"""fn_plan_build_mol (csrc/mol_plan.hip: the graph plan of a molecule-contiguous batch in one launch) against fn_plan_build
+(four grid-wide passes), bit for bit -- and thereby against the stable argsort that pins fn_plan_build
+(tests/test_gpu_parity.py::test_plan_matches_stable_argsort)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+
+
+def _plan_slices(plan):
+    """Every meaningful slice of the plan's arena, by task."""
+    out = {}
+    for name, role, ib, sb, items, segs in plan.task_meta:
+        tag = f"{name}/{role}"
+        out[tag + "/rowptr"] = plan.rowptr[sb: sb + segs + 1]
+        out[tag + "/perm"] = plan.perm[ib: ib + items]
+        if role != 0:                                     # by-destination (1) / by-source (2) order of a graph
+            out[tag + "/other"] = plan.aux_a[ib: ib + items]
+            out[tag + "/aux_b"] = plan.aux_b[ib: ib + items]          # inverse permutation / position in the destination order
+            if role == 1:
+                out[tag + "/spos"] = plan.aux_c[ib: ib + items]
+    return out
+
+
+def _both(batch, edge_ends=False):
+    from fragnet_amd import plan as P
+    res = []
+    for mol in (True, False):
+        P.MOL_PLAN = mol
+        try:
+            batch.pop(P.PLAN_KEY, None)
+            pl = P.GraphPlan.from_batch(batch, edge_ends=edge_ends)
+            torch.cuda.synchronize()
+            pl.check()
+            assert pl.mol_built == mol
+            res.append(_plan_slices(pl))
+        finally:
+            P.MOL_PLAN = True
+            batch.pop(P.PLAN_KEY, None)
+    assert res[0].keys() == res[1].keys()
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+
+
+@pytest.mark.parametrize("profile,n,pt", [("esol", 96, False), ("tox21", 40, False), ("esol", 33, True), ("synth40", 64, False), ("esol", 1, False)])
+def test_mol_plan_equals_the_general_plan(profile, n, pt):
+    from fragnet_amd import data, synth
+    mols = synth.synth_molecules(n, seed=3, profile=profile, pretrain_targets=pt, p_salt=0.2)
+    b = data.batch_to((data.collate_fn_pt if pt else data.collate_fn)(mols), DEV)
+    _both(b, edge_ends=pt)
+
+
+def test_mol_plan_from_the_gpu_collate():
+    from fragnet_amd import synth
+    from fragnet_amd.dataset import FlatMolStore
+    store = FlatMolStore.from_records(synth.synth_molecules(50, seed=8, profile="esol")).to(DEV)
+    b = store.collate(torch.tensor([7, 0, 22, 3, 3, 49, 11], device=DEV))
+    assert b.offsets is not None and b.offsets.is_cuda
+    _both(b)
+
+
+@pytest.mark.parametrize("n_real,margin", [(40, 0.1), (23, 0.3), (64, 0.02)])
+def test_mol_plan_on_a_padded_static_batch(n_real, margin):
+    """The staged batch (fn_stage_padded: padding items point at the reserved slots, offsets table padded with the totals,
+    real-molecule count on the device): the padding tail's closed forms against the general builder, and the staging kernel
+    against its torch reference (graphstep.pad_batch) under the (i - n_real) % pad_mod rule."""
+    from fragnet_amd import data, graphstep, synth
+    big = data.batch_to(data.collate_fn(synth.synth_molecules(64, seed=5, profile="esol")), DEV)
+    b = data.batch_to(data.collate_fn(synth.synth_molecules(n_real, seed=6, profile="esol")), DEV)
+    shapes = graphstep.StaticShapes.from_batches([big, b], margin=margin)
+    sb = graphstep.StaticBatch(shapes, b)
+    assert sb.with_offsets and sb.load(b)
+    ref = graphstep.pad_batch(b, shapes)
+    for k, v in ref.items():
+        assert torch.equal(sb.t[k], v), k
+    assert torch.equal(sb.t.offsets, ref.offsets)
+    _both(sb.t)
+
+
+def test_a_molecule_beyond_the_declared_bound_is_flagged():
+    from fragnet_amd import data, plan as P, synth
+    b = data.batch_to(data.collate_fn(synth.synth_molecules(12, seed=4, profile="esol")), DEV)
+    b.max_per_mol = dict(b.max_per_mol, bedge=b.max_per_mol["bedge"] - 1)
+    pl = P.GraphPlan.from_batch(b)
+    torch.cuda.synchronize()
+    assert pl.mol_built
+    with pytest.raises(IndexError, match="larger than"):
+        pl.check()
