@@ -2888,13 +2888,19 @@ inline int wgrad_rows_per_block(int64_t M) {
 }  // namespace
 
 namespace {
+// one block range per field, sized by the field (the grid used to be 1024 x fields: 25 k blocks for a batch whose ids, masks
+// and counters need a handful -- 8.7 us of block scheduling at any batch size)
 struct StageFields {
     fn_stage_field f[FN_MAX_STAGE_FIELDS];
+    int first[FN_MAX_STAGE_FIELDS + 1];
     int n;
 };
 __global__ void k_stage_padded(StageFields F) {
-    const fn_stage_field& f = F.f[blockIdx.y];
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int fi = 0;
+    while (fi + 1 < F.n && (int)blockIdx.x >= F.first[fi + 1]) ++fi;
+    const fn_stage_field& f = F.f[fi];
+    const int64_t stride = (int64_t)(F.first[fi + 1] - F.first[fi]) * blockDim.x;
+    const int64_t t0 = (int64_t)((int)blockIdx.x - F.first[fi]) * blockDim.x + threadIdx.x;
     if (f.kind == FN_STAGE_ROWS) {
         const float* src = static_cast<const float*>(f.src);
         float* dst = static_cast<float*>(f.dst);
@@ -3800,31 +3806,36 @@ int fn_stage_padded(const fn_stage_field* fields, int n_fields, fn_stream_t stre
     if (!fields || n_fields < 1 || n_fields > FN_MAX_STAGE_FIELDS) return fail(FN_EINVAL, "fn_stage_padded: bad field count");
     StageFields F;
     F.n = n_fields;
-    int64_t most = 0;
+    int blocks = 0;
+    // blocks of a field: one per 1024 work items (a work item = 16 bytes of an aligned row table), at least one, 1024 at the top
+    auto take = [&](int i, int64_t work) {
+        F.first[i] = blocks;
+        blocks += (int)std::min<int64_t>(std::max<int64_t>((work + 4 * kBlock - 1) / (4 * kBlock), 1), 1024);
+    };
     for (int i = 0; i < n_fields; ++i) {
         const fn_stage_field& f = fields[i];
         if (f.kind == FN_STAGE_BUMP) {
             if (!f.dst || ((uintptr_t)f.dst & 7)) return fail(FN_EINVAL, "fn_stage_padded: bad bump field");
             F.f[i] = f;
-            most = most > 1 ? most : 1;
+            take(i, 1);
             continue;
         }
         if (f.kind == FN_STAGE_ZERO) {
             if (f.cap < 0 || (f.cap > 0 && !f.dst)) return fail(FN_EINVAL, "fn_stage_padded: bad zero field");
             F.f[i] = f;
-            most = f.cap > most ? f.cap : most;
+            take(i, f.cap);
             continue;
         }
         if (f.kind == FN_STAGE_OFFSETS) {
             if (f.n_real < 0 || f.cap < f.n_real || f.width < 1 || !f.dst || !f.src) return fail(FN_EINVAL, "fn_stage_padded: bad offsets field");
             F.f[i] = f;
-            most = std::max<int64_t>(most, f.width * (f.cap + 1));
+            take(i, f.width * (f.cap + 1));
             continue;
         }
         if (f.kind == FN_STAGE_COUNT) {
             if (f.n_real < 0 || !f.dst) return fail(FN_EINVAL, "fn_stage_padded: bad count field");
             F.f[i] = f;
-            most = most > 1 ? most : 1;
+            take(i, 1);
             continue;
         }
         if (f.n_real < 0 || f.cap < f.n_real || f.width < 1 || f.kind < 0 || f.kind > FN_STAGE_MASK || (f.cap > 0 && !f.dst) ||
@@ -3832,11 +3843,10 @@ int fn_stage_padded(const fn_stage_field* fields, int n_fields, fn_stream_t stre
             ((f.kind == FN_STAGE_IDS || f.kind == FN_STAGE_COLS) && f.cap > f.n_real && f.pad_mod < 1))
             return fail(FN_EINVAL, "fn_stage_padded: bad field");
         F.f[i] = f;
-        const int64_t elems = f.cap * (f.kind == FN_STAGE_ROWS ? f.width : f.kind == FN_STAGE_COLS ? 2 : 1);
-        most = elems > most ? elems : most;
+        take(i, f.cap * (f.kind == FN_STAGE_ROWS ? (f.width + 3) / 4 : f.kind == FN_STAGE_COLS ? 2 : 1));
     }
-    if (most == 0) return 0;
-    hipLaunchKernelGGL(k_stage_padded, dim3(flat_grid(most, 1024), n_fields), dim3(kBlock), 0, S(stream), F);
+    F.first[n_fields] = blocks;
+    hipLaunchKernelGGL(k_stage_padded, dim3(blocks), dim3(kBlock), 0, S(stream), F);
     return launch_status("fn_stage_padded");
 }
 
