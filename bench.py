@@ -264,7 +264,7 @@ def forward_sweep(rank, world, dev, args):
         pool = [data.batch_to(data.collate_fn(synth.synth_molecules(B, seed=5000 + 31 * rank + i, profile="synth40")), dev)
                 for i in range(2)]
         with torch.no_grad():
-            for i in range(3):
+            for i in range(8):           # warm-up: the caching allocator grows into the new batch size over the first steps
                 pool[i % 2].pop(PLAN_KEY, None)
                 model(pool[i % 2])
             if world > 1:

@@ -9,6 +9,7 @@ Which row of each index tensor is the destination follows the reference's unpack
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -266,7 +267,7 @@ class GraphPlan:
         return plan
 
 
-MOL_PLAN = True         # molecule-contiguous batches with offsets: fn_plan_build_mol (False: always the general builder; A/B, tests)
+MOL_PLAN = os.environ.get("FRAGNET_MOL_PLAN", "1") != "0"      # molecule-contiguous batches with offsets: fn_plan_build_mol (False / FRAGNET_MOL_PLAN=0: always the general builder; A/B, tests)
 _PREZEROED = False      # True only while graphstep captures its step: plans built then skip their zeroing launch
 _BUILT = []             # the plans built inside the current prezeroed_plans() context
 

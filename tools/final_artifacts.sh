@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the per-round evidence set on a GPU box:  bash tools/final_artifacts.sh <tag>   (writes gpurun_out/<tag>/, copy into profiles/)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r03i}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p $O

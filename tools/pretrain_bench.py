@@ -9,6 +9,13 @@ from fragnet_amd import data, graphstep, parallel, synth, train
 from fragnet_amd.model import FragNetPreTrain
 
 dev = torch.device("cuda:0")
+
+
+def fresh(b):
+    """a copy of the batch dict (no cached plan) that keeps collate's layout promise (plan.CollatedBatch)"""
+    return b.like(b)
+
+
 fragnet_amd.prefer_rocblas_for_dense_heads()
 fragnet_amd.tune_library_gemms()
 B = 512
@@ -17,15 +24,15 @@ batches = [data.batch_to(data.collate_fn_pt(synth.synth_molecules(B, seed=60 + i
 shapes = graphstep.StaticShapes.from_batches(batches, margin=0.02)
 torch.manual_seed(5)
 model = FragNetPreTrain(num_layer=4, drop_ratio=0.2, edge_features=17).to(dev).train()
-opt = parallel.FlatAdam.for_live_parameters(model, lambda: train.pretrain_loss(model(dict(batches[0])), batches[0]).backward(), lr=1e-4)
-step = graphstep.GraphedTrainStep(model, opt, shapes, dict(batches[0]), loss="pretrain")
+opt = parallel.FlatAdam.for_live_parameters(model, lambda: train.pretrain_loss(model(fresh(batches[0])), batches[0]).backward(), lr=1e-4)
+step = graphstep.GraphedTrainStep(model, opt, shapes, fresh(batches[0]), loss="pretrain")
 for i in range(5):
-    step(dict(batches[i % 4]))
+    step(fresh(batches[i % 4]))
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 n = 30
 for i in range(n):
-    step(dict(batches[i % 4]))
+    step(fresh(batches[i % 4]))
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) * 1e3 / n
 print(f"pretrain step: {ms:.3f} ms, {B / ms * 1e3:.0f} molecules/s, replays {step.replays}, fallbacks {step.fallbacks}")
