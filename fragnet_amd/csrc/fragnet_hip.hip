@@ -2648,35 +2648,47 @@ __device__ __forceinline__ float colmajor_sum_128(const float* __restrict__ col,
 template <int CTW, int NH, bool PLAIN = false>
 __device__ __forceinline__ void wgrad_reduce_strip(int vb, float* sm, const float* __restrict__ part, int n_rows, int K,
                                                    float* __restrict__ dW, float* __restrict__ db) {
+    // a block sums a 1024-column strip of the partial rows: 256 float4 columns x 4 row groups (4 KiB contiguous per wave and
+    // row), four loads per thread in flight.  (Round 3: a strip used to be 256 columns x 16 row groups -- 65 blocks of 16
+    // waves per product that loaded two float4 each; a quarter of the waves now.)
     constexpr int XW = 16 * CTW * NH;
     constexpr int PW = 128 * XW + 128;
-    const int c4 = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int col0 = vb * 256 + c4 * 4;
+    const int c4 = threadIdx.x & 255, rg = threadIdx.x >> 8;
+    const int col0 = vb * 1024 + c4 * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (col0 < PW)
-        for (int r = rg; r < n_rows; r += 16) {
+    if (col0 < PW) {
+        float4 a1 = acc, a2 = acc, a3 = acc;
+        int r = rg;
+        for (; r + 12 < n_rows; r += 16) {
+            const float4 v0 = ld4(part + (size_t)r * PW + col0), v1 = ld4(part + (size_t)(r + 4) * PW + col0);
+            const float4 v2 = ld4(part + (size_t)(r + 8) * PW + col0), v3 = ld4(part + (size_t)(r + 12) * PW + col0);
+            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+            a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+            a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+        }
+        for (; r < n_rows; r += 4) {
             const float4 v = ld4(part + (size_t)r * PW + col0);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
-    st4(sm + rg * 256 + c4 * 4, acc);
+        acc.x = (acc.x + a1.x) + (a2.x + a3.x);  acc.y = (acc.y + a1.y) + (a2.y + a3.y);
+        acc.z = (acc.z + a1.z) + (a2.z + a3.z);  acc.w = (acc.w + a1.w) + (a2.w + a3.w);
+    }
+    st4(sm + rg * 1024 + c4 * 4, acc);
     __syncthreads();
-    if (threadIdx.x < 256) {
-        const int col = vb * 256 + threadIdx.x;
-        if (col < PW) {
-            float v = 0.f;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) v += sm[g * 256 + threadIdx.x];
-            if (col >= 128 * XW) {
-                db[col - 128 * XW] = v;
-            } else if (PLAIN) {                                                          // k_wgrad128_multi: partials are [o][k] already
-                dW[col] = v;
-            } else {
-                const int r = col & 3, lane = (col >> 2) & 63, tile = col >> 8;        // tile = (w*2+u)*CTW + cc
-                const int cc = tile % CTW, wu = tile / CTW, u = wu & 1, w = wu >> 1;
-                const int o = 32 * (w & 3) + 16 * u + 4 * (lane >> 4) + r;
-                const int xc = 16 * (CTW * (w >> 2) + cc) + (lane & 15);
-                if (xc < K) dW[(size_t)o * K + xc] = v;
-            }
+    const int col = vb * 1024 + threadIdx.x;
+    if (col < PW) {
+        const float v = (sm[threadIdx.x] + sm[1024 + threadIdx.x]) + (sm[2048 + threadIdx.x] + sm[3072 + threadIdx.x]);
+        if (col >= 128 * XW) {
+            db[col - 128 * XW] = v;
+        } else if (PLAIN) {                                                          // k_wgrad128_multi: partials are [o][k] already
+            dW[col] = v;
+        } else {
+            const int r = col & 3, lane = (col >> 2) & 63, tile = col >> 8;        // tile = (w*2+u)*CTW + cc
+            const int cc = tile % CTW, wu = tile / CTW, u = wu & 1, w = wu >> 1;
+            const int o = 32 * (w & 3) + 16 * u + 4 * (lane >> 4) + r;
+            const int xc = 16 * (CTW * (w >> 2) + cc) + (lane & 15);
+            if (xc < K) dW[(size_t)o * K + xc] = v;
         }
     }
 }
@@ -4072,7 +4084,7 @@ struct ReduceQueue {
         t.kind = RT_WGRAD;  t.p0 = ws;  t.n0 = grid;  t.K = K;  t.o0 = dW;  t.o1 = db;
         // partial width of the instantiation that wrote them (the mixed launch runs K <= 16 in the K <= 32 class)
         const int64_t pw = t.cls == 1 ? wgrad_part_width(32) : wgrad_part_width(K);
-        return push(t, (int)((pw + 255) / 256));
+        return push(t, (int)((pw + 1023) / 1024));
     }
     int flush_wgrad() {
         size_t lds0 = 0;

@@ -62,3 +62,32 @@ def test_every_last_node_has_an_incoming_edge():
         assert int(b["edge_index_fbonds"][0].max()) + 1 == b["node_features_fbonds"].shape[0]
         assert int(b["frag_index"][1].max()) + 1 == b["x_frags"].shape[0]
         assert int(b["atom_to_frag_ids"].max()) + 1 == b["x_frags"].shape[0]
+
+
+def test_collated_batch_carries_the_layout_promise_and_the_offsets_table(fixture):
+    """collate_fn's result is a dict with the reference's keys (above) whose TYPE says "molecules are concatenated" and whose
+    attributes hold the cumulative per-molecule counts; copies through dict() drop the promise, .like() / batch_to keep it."""
+    from fragnet_amd.plan import SPACES, CollatedBatch
+    recs = _records(fixture)
+    b = fdata.collate_fn(recs)
+    assert isinstance(b, CollatedBatch) and b.mol_contiguous
+    off = b.offsets
+    assert off.dtype == torch.int32 and tuple(off.shape) == (len(SPACES), len(recs) + 1)
+    sizes = {"atom": "x_atoms", "edge": "node_features_bonds", "bedge": "edge_attr_bonds", "frag": "x_frags",
+             "fedge": "node_features_fbonds", "fbedge": "edge_attr_fbonds", "mol": "y"}
+    for s, name in enumerate(SPACES):
+        assert int(off[s, 0]) == 0 and int(off[s, -1]) == b[sizes[name]].shape[0], name
+        assert bool((off[s, 1:] >= off[s, :-1]).all())
+        assert b.max_per_mol[name] == int((off[s, 1:] - off[s, :-1]).max()), name
+    # every atom of molecule i lies in its offsets range, every bond joins atoms of one molecule
+    mol_of_atom = b["batch"]
+    for i in range(len(recs)):
+        a0, a1 = int(off[0, i]), int(off[0, i + 1])
+        assert bool((mol_of_atom[a0:a1] == i).all())
+        e0, e1 = int(off[1, i]), int(off[1, i + 1])
+        ei = b["edge_index"][:, e0:e1]
+        assert ei.numel() == 0 or (int(ei.min()) >= a0 and int(ei.max()) < a1)
+    assert not isinstance(dict(b), CollatedBatch)
+    c = fdata.batch_to(b, "cpu")
+    assert isinstance(c, CollatedBatch) and torch.equal(c.offsets, off) and c.max_per_mol == b.max_per_mol
+    assert isinstance(b.like(dict(b)), CollatedBatch)

@@ -93,3 +93,31 @@ def test_a_molecule_beyond_the_declared_bound_is_flagged():
     assert pl.mol_built
     with pytest.raises(IndexError, match="larger than"):
         pl.check()
+
+
+def test_a_batch_with_a_huge_declared_molecule_takes_the_general_builder():
+    """max_per_mol sizes the LDS tile; beyond 64 KB the plan is built by fn_plan_build -- same arena."""
+    from fragnet_amd import data, plan as P, synth
+    b = data.batch_to(data.collate_fn(synth.synth_molecules(10, seed=4, profile="esol")), DEV)
+    ref = _plan_slices(P.GraphPlan.from_batch(b))
+    b.pop(P.PLAN_KEY, None)
+    b.max_per_mol = dict(b.max_per_mol, bedge=30000)
+    pl = P.GraphPlan.from_batch(b)
+    torch.cuda.synchronize()
+    assert not pl.mol_built
+    for k, v in _plan_slices(pl).items():
+        assert torch.equal(v, ref[k]), k
+
+
+def test_a_batch_that_breaks_the_layout_promise_is_flagged():
+    """A CollatedBatch whose bond joins atoms of two molecules (the promise is the caller's word, the kernel checks what it can)."""
+    from fragnet_amd import data, plan as P, synth
+    b = data.batch_to(data.collate_fn(synth.synth_molecules(6, seed=4, profile="esol")), DEV)
+    ei = b["edge_index"].clone()
+    ei[1, 0] = b["x_atoms"].shape[0] - 1          # first bond of molecule 0 now ends in the last molecule
+    b["edge_index"] = ei
+    pl = P.GraphPlan.from_batch(b)
+    torch.cuda.synchronize()
+    assert pl.mol_built
+    with pytest.raises(IndexError, match="not molecule-contiguous"):
+        pl.check()
