@@ -2625,6 +2625,10 @@ struct ReduceTask {
 constexpr int kMaxReduceTasks = 36;      // one launch for all 30 tasks of a 4-layer backward pass (5.5 KB of kernel arguments)
 struct ReduceTasks {
     ReduceTask t[kMaxReduceTasks];
+    int first[kMaxReduceTasks + 1];      // first block of every task, packed: a block finds its task by walking THIS array (three
+                                         // cache lines of the argument block) -- walking t[].first was one dependent scalar load
+                                         // per 152-byte struct, up to 30 in a row from the kernel-argument segment: 10 of the
+                                         // launch's 22 us before the first partial was read
     int n;
 };
 // "fat" bodies for the task-table kernel: a block reduces 8 columns of a column-major [cols][FN_MAX_PART] partial
@@ -2696,9 +2700,9 @@ __device__ __forceinline__ void wgrad_reduce_strip(int vb, float* sm, const floa
 __global__ __launch_bounds__(1024) void k_reduce_tasks(ReduceTasks T) {
     __shared__ float sm[16 * 256];
     int ti = 0;
-    while (ti + 1 < T.n && (int)blockIdx.x >= T.t[ti + 1].first) ++ti;
+    while (ti + 1 < T.n && (int)blockIdx.x >= T.first[ti + 1]) ++ti;
     const ReduceTask& t = T.t[ti];
-    const int vb = (int)blockIdx.x - t.first;
+    const int vb = (int)blockIdx.x - T.first[ti];
     if (t.kind == RT_FINALIZE) {
         if (vb < 2 * FN_D / 8) {
             const int col = vb * 8 + (threadIdx.x >> 7);
@@ -4042,6 +4046,7 @@ struct ReduceQueue {
     int push(ReduceTask t, int nblk) {
         if (T.n == kMaxReduceTasks) { if (int rc = flush()) return rc; }
         t.first = blocks;  t.nblk = nblk;
+        T.first[T.n] = blocks;
         T.t[T.n++] = t;
         blocks += nblk;
         return 0;
