@@ -2773,7 +2773,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 namespace {
 unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
 int64_t g_mol_stamps_n = 0;
-int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 256, 2, -1, 0, 1, 0, 0, 1};   // in the order of the FN_TUNE_* keys
+int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 256, 2, -1, 0, 1, 0, 0, 1, 23};   // in the order of the FN_TUNE_* keys
 }  // namespace
 namespace fni {      // hooks for the other translation units (fn_internal.h)
 int fail(int code, const char* what) { return ::fail(code, what); }
@@ -4080,7 +4080,13 @@ struct ReduceQueue {
             t.cls = g_tune[FN_TUNE_WGRAD_DIRECT] ? 4 : 2;
         } else if (defer_wgrad && defer_mixed && K <= 192) {      // layer 0's products: one launch for them too (flush_wgrad)
             if (W0.n == kMaxWgradTasks || T.n == kMaxReduceTasks) { if (int rc = flush()) return rc; }
-            const int rpb = wgrad_rows_per_block(M);
+            // rows per block: a multiple of the per-product rule (FN_TUNE_WGRAD0_ROWS).  Fewer, longer blocks = fewer partial
+            // rows to write and to reduce: at 1 x layer 0's atom product alone wrote 217 partials of 98 KB (21 MB, more than the
+            // nine K = 128 products together).  2 x for it, 3 x for the narrow ones: -6 us per step; 3 x / 4 x for the wide one
+            // or 1 x for it lose (the long blocks become the launch's tail / the partial traffic is back)
+            const int tv = g_tune[FN_TUNE_WGRAD0_ROWS] > 0 ? g_tune[FN_TUNE_WGRAD0_ROWS] : 23;
+            const int mult = std::max(1, K > FN_D ? tv / 10 : tv % 10);          // tens: the wide product (atoms), units: the narrow ones
+            const int rpb = wgrad_rows_per_block(M) * mult;
             grid = (int)((M + rpb - 1) / rpb);
             W0.t[W0.n++] = WgradTask{dY, X, ws, M, rpb, w0blocks, K};
             w0blocks += grid;

@@ -99,7 +99,10 @@ int fn_abi_version(void);
                                        * fragment tail -- fragment sums, fragment graph, readout and their backward -- as one
                                        * molecule-resident launch each way (csrc/mol_tail.inc); 0: the separate launches;
                                        * 2 (test hook): fused, every molecule on the global-memory path of oversize molecules */
-#define FN_TUNE_COUNT 21
+#define FN_TUNE_WGRAD0_ROWS 21        /* layer 0's weight-gradient products (K = 167 / 17 / 6): rows per block as a multiple of the
+                                       * per-product rule (M / 256 rounded up to 32); tens digit = the product with K > 128 (atoms),
+                                       * units digit = the narrow ones.  Default 23 */
+#define FN_TUNE_COUNT 22
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * workgroups 64-bit words) is
  * set, every workgroup of the molecule-resident backward (FN_TUNE_BWD_MOL) writes s_memtime stamps of its phases into it
