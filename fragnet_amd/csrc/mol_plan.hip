@@ -8,11 +8,12 @@
 // molecule in LDS and write the finished slices -- no global histogram, no scan, no atomics on global memory.
 //
 //   * molecule workgroups (one per molecule, 8 waves): two global round trips (the molecule's extents; the keys of every CSR
-//     task -> LDS), then LDS-only rounds in which groups of 4 / 2 / 1 waves take one task each (by-destination and by-source
-//     order of a graph are two tasks): counts per node (LDS atomics) -> exclusive scan -> unordered fill -> rank of every item
-//     among its segment's ids (ascending original id = the reference's sequential scatter order; the same rule as
-//     k_plan_ranksort) -> perm / inverse permutation to their global slices.  After the last round the two orders of each
-//     graph exchange their cross references (other endpoint, position in the destination order and back) through LDS.
+//     task -> LDS), then LDS-only phases that all tasks walk in step, each task on its own group of 4 / 2 / 1 waves
+//     (by-destination and by-source order of a graph are two tasks; small tasks share a wave): counts per node (LDS atomics)
+//     -> exclusive scan -> unordered fill -> rank of every item among its segment's ids (ascending original id = the
+//     reference's sequential scatter order; the same rule as k_plan_ranksort) -> perm / inverse permutation to their global
+//     slices.  After one more barrier the two orders of each graph exchange their cross references (other endpoint, position
+//     in the destination order and back) through LDS.
 //   * padding (static-shape batches, fn_stage_padded): items behind the real ones point at the last `pad_mod` nodes of their
 //     target space, item c at node hi - (c - n_real) % pad_mod, as self-loops.  Counts, positions and permutation of that tail
 //     are closed forms of (n_real, capacity, pad_mod): extra workgroups write them, one thread per item / node.
@@ -46,7 +47,6 @@ struct MpArgs {
     int64_t cap[FN_MAX_SPACES], pad_mod[FN_MAX_SPACES];
     int32_t *rowptr, *perm, *aux_a, *aux_b, *aux_c, *status;
     int pad_blocks;
-    int64_t total_segs;
     unsigned long long* stamps;     // nullable profiling aid (fn_debug_set_stamps): 16 values per molecule workgroup
 };
 
@@ -433,7 +433,6 @@ extern "C" int fn_plan_build_mol(const fn_csr_task* tasks, int n_tasks, const fn
     for (int s = 0; s < FN_MAX_SPACES; ++s) { A.cap[s] = s < lay->n_spaces ? lay->cap[s] : 0;  A.pad_mod[s] = s < lay->n_spaces ? lay->pad_mod[s] : 1; }
     A.rowptr = rowptr_all;  A.perm = perm_all;  A.aux_a = aux_a;  A.aux_b = aux_b;  A.aux_c = aux_c;
     A.status = ws_i32 + segs + items;
-    A.total_segs = segs;
     // padding workgroups: the tail is a few per cent of the items (none for an unpadded batch: one block writes the end entries)
     int64_t pad_work = 0;
     for (int s = 0; s < lay->n_spaces; ++s) pad_work = std::max(pad_work, lay->pad_hint[s]);
