@@ -80,7 +80,22 @@ __device__ __forceinline__ MpMol mp_mol(const MpTask& T, const int32_t* ext) {
 }
 __device__ __forceinline__ bool mp_fits(const MpTask& T, const MpMol& m) { return m.L <= T.cap_items && m.nn <= T.cap_nodes; }
 
-// The molecule's workgroup.  Round trip 1: the molecule's extents; every wave then looks up ITS tasks once (the schedule gives
+// inclusive prefix sum over the 64 lanes with DPP row operations (LLVM's scan idiom for GCN / CDNA: shifts 1, 2, 4, 8 inside
+// each row of 16, then row_bcast:15 / row_bcast:31 carry the row totals over) -- six VALU adds instead of six ds_bpermute
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int mp_dpp(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ int mp_wave_scan(int x) {
+    x += mp_dpp<0x111, 0xF>(x);          // row_shr:1
+    x += mp_dpp<0x112, 0xF>(x);          // row_shr:2
+    x += mp_dpp<0x114, 0xF>(x);          // row_shr:4
+    x += mp_dpp<0x118, 0xF>(x);          // row_shr:8
+    x += mp_dpp<0x142, 0xA>(x);          // row_bcast:15 into rows 1 and 3
+    x += mp_dpp<0x143, 0xC>(x);          // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+// The molecule's workgroup.  Round trip 1 (with the copy of the argument block): the molecule's extents; every wave then looks up ITS tasks once (the schedule gives
 // a task a group of 4 / 2 / 1 waves: the two orders of the bond graph, ~390 items each, take four waves each, small tasks share
 // a wave) and keeps their parameters in registers.  Round trip 2: the keys of its tasks -> LDS (all loads in flight together,
 // none inside a divergent branch); then LDS-only phases that all tasks walk in step: counts (LDS atomics) | scan by the
@@ -110,10 +125,8 @@ __device__ void mp_molecule(const MpArgs& A, int mol, int32_t* lds) {
     auto stamp = [&]() { if (sp && tid == 0 && si < 14) sp[si] = __builtin_amdgcn_s_memtime();  ++si; };
     if (sp && tid == 0) sp[14] = wall_clock64();
     stamp();
-    int32_t* ext = lds;                                            // [FN_MAX_SPACES][2]
+    int32_t* ext = lds;                                            // [FN_MAX_SPACES][2], written by the kernel's first lines
     int32_t* tiles = lds + 2 * FN_MAX_SPACES;
-    if (tid < 2 * FN_MAX_SPACES) ext[tid] = (tid >> 1) < A.n_spaces ? A.off[(size_t)(tid >> 1) * (A.n_mols + 1) + mol + (tid & 1)] : 0;
-    __syncthreads();
     stamp();
     // ---- this wave's tasks
     MpCtx c[kMpMine];
@@ -202,12 +215,7 @@ __device__ void mp_molecule(const MpArgs& A, int mol, int32_t* lds) {
         for (int k0 = 0; k0 < c[q].nn; k0 += 64) {
             const int k = k0 + lane;
             const int v = k < c[q].nn ? c[q].cnt[k] : 0;
-            int x = v;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int y = __shfl_up(x, off);
-                if (lane >= off) x += y;
-            }
+            const int x = mp_wave_scan(v);
             if (k < c[q].nn) {
                 c[q].cnt[k] = carry + x - v;
                 A.rowptr[c[q].seg_base + c[q].n0 + k] = c[q].base + carry + x - v;
@@ -293,16 +301,21 @@ __device__ __forceinline__ MpPad mp_pad(const MpArgs& A, const MpTask& T, const 
 // first time a CU touches it, and the phases below touch all of it in dependent steps (measured: 9 us before the first key
 // was loaded): every workgroup copies the block into LDS with one parallel vector load and works from there.
 constexpr int kMpArgWords = (sizeof(MpArgs) + 7) / 8 * 2;
-__global__ __launch_bounds__(kMpThreads) void k_plan_mol(const MpArgs A_) {
+// The four leading scalars repeat fields of the block: they arrive in preloaded registers, so the molecule's extents and the
+// real-molecule count are requested in the same round trip as the copy of the block, not behind it.
+__global__ __launch_bounds__(kMpThreads) void k_plan_mol(const int32_t* off, int n_mols, int n_spaces, const int32_t* counts_dev,
+                                                         const MpArgs A_) {
     extern __shared__ int32_t lds_all[];
+    int32_t* lds = lds_all + kMpArgWords;
+    const int n_real = counts_dev ? *counts_dev : n_mols;
+    if ((int)blockIdx.x < n_mols && threadIdx.x < 2 * FN_MAX_SPACES)           // mp_molecule's `ext`
+        lds[threadIdx.x] = (int)(threadIdx.x >> 1) < n_spaces ? off[(size_t)(threadIdx.x >> 1) * (n_mols + 1) + blockIdx.x + (threadIdx.x & 1)] : 0;
     {
         const int32_t* src = reinterpret_cast<const int32_t*>(&A_);
         for (int i = threadIdx.x; i < (int)(sizeof(MpArgs) / 4); i += kMpThreads) lds_all[i] = src[i];
     }
     __syncthreads();
     const MpArgs& A = *reinterpret_cast<const MpArgs*>(lds_all);
-    int32_t* lds = lds_all + kMpArgWords;
-    const int n_real = A.counts_dev ? *A.counts_dev : A.n_mols;
     if ((int)blockIdx.x < A.n_mols) {
         if ((int)blockIdx.x < n_real) mp_molecule(A, (int)blockIdx.x, lds);
         return;
@@ -442,6 +455,7 @@ extern "C" int fn_plan_build_mol(const fn_csr_task* tasks, int n_tasks, const fn
     A.stamps = n_stamps >= (int64_t)A.n_mols * 16 ? sbuf : nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!(flags & FN_PLAN_PREZEROED)) hipLaunchKernelGGL(k_zero_word, dim3(1), dim3(1), 0, st, A.status);
-    hipLaunchKernelGGL(k_plan_mol, dim3((unsigned)(A.n_mols + A.pad_blocks)), dim3(kMpThreads), (size_t)words * 4, st, A);
+    hipLaunchKernelGGL(k_plan_mol, dim3((unsigned)(A.n_mols + A.pad_blocks)), dim3(kMpThreads), (size_t)words * 4, st, A.off, A.n_mols,
+                       A.n_spaces, A.counts_dev, A);
     return launch_status("fn_plan_build_mol");
 }
