@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Kernel sequence of ONE training step from a rocprofv3 results .db (rocpd sqlite): the dispatches between the last two
-k_stage_padded launches, in start order, with duration and the gap to the previous kernel's end.
+"""Kernel sequence of ONE training step from a rocprofv3 results .db (rocpd sqlite): the dispatches between two consecutive
+k_stage_padded launches (the step of median wall time among the last nine), in start order, with duration and the gap to the
+previous kernel's end.
 
 usage: tools/rocpd_sequence.py <..._results.db> [anchor-kernel-substring]"""
 import re
@@ -34,10 +35,13 @@ def main():
     rows = list(cur.execute(f"select kernel_id,start,end,grid_size_x,workgroup_size_x from {disp} order by start"))
     seq = [(short(names[k]), s, e, g // max(1, w)) for k, s, e, g, w in rows]
     idx = [i for i, x in enumerate(seq) if anchor in x[0]]
-    a, b = idx[-2], idx[-1]
+    # the step of MEDIAN wall time among the last (up to) nine complete ones of the same length: a single sample now and then
+    # catches a stall between two kernels
+    cands = sorted((seq[q][1] - seq[p][1], p, q) for p, q in zip(idx[-10:-1], idx[-9:]) if q - p == idx[-1] - idx[-2])
+    _, a, b = cands[len(cands) // 2] if cands else (0, idx[-2], idx[-1])
     prev_end, busy = None, 0
-    print(f"# one step = dispatches between the last two {anchor} launches: {b - a} kernels, "
-          f"{(seq[b][1] - seq[a][1]) / 1e3:.1f} us wall")
+    print(f"# one step = dispatches between two consecutive {anchor} launches (median of the last {max(len(cands), 1)} steps): "
+          f"{b - a} kernels, {(seq[b][1] - seq[a][1]) / 1e3:.1f} us wall")
     for i in range(a, b):
         n, s, e, g = seq[i]
         gap = (s - prev_end) / 1e3 if prev_end is not None else 0.0
