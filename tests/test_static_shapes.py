@@ -1,0 +1,54 @@
+"""Static shapes on the CPU: the padding rule, the padded offsets table and the per-molecule bound (graphstep.pad_batch is the
+torch reference of the staging kernel; tests/test_gpu_plan_mol.py checks the kernel against it on the GPU)."""
+import torch
+
+from fragnet_amd import data, graphstep, synth
+from fragnet_amd.plan import SPACES, CollatedBatch
+
+
+def _batches():
+    big = data.collate_fn(synth.synth_molecules(24, seed=5, profile="esol"))
+    small = data.collate_fn(synth.synth_molecules(17, seed=6, profile="esol"))
+    return big, small
+
+
+def test_padding_rule_counts_from_the_first_padding_item():
+    """Padding item i of a field that points into space s holds cap[s] - 1 - (i - n_real) % slack[s]: the first padding item
+    points at the last slot, whatever n_real is (the closed forms of fn_plan_build_mol's padding tail rest on this)."""
+    big, small = _batches()
+    shapes = graphstep.StaticShapes.from_batches([big, small], margin=0.1)
+    p = graphstep.pad_batch(small, shapes)
+    for name, (space, layout, target) in graphstep.FIELDS.items():
+        if layout == "rows" or name not in small:
+            continue
+        n, cap = graphstep.batch_counts(small)[space], shapes.cap[space]
+        hi, mod = shapes.pad_rule(target)
+        want = hi - (torch.arange(cap) - n) % mod
+        got = p[name] if layout == "ids" else p[name][0]
+        assert torch.equal(got[n:], want[n:]), name
+        assert int(got[n]) == hi and int(got[n:].min()) >= shapes.cap[target] - shapes.slack[target], name
+        if layout == "cols":
+            assert torch.equal(p[name][1][n:], want[n:]), name
+
+
+def test_padded_batch_keeps_the_layout_promise_and_pads_the_offsets_table():
+    big, small = _batches()
+    shapes = graphstep.StaticShapes.from_batches([big, small], margin=0.1)
+    p = graphstep.pad_batch(small, shapes)
+    assert isinstance(p, CollatedBatch) and p.pad == shapes.pad_info() and p.max_per_mol == shapes.max_per_mol
+    B, cap = 17, shapes.cap["mol"]
+    assert tuple(p.offsets.shape) == (len(SPACES), cap + 1)
+    assert torch.equal(p.offsets[:, : B + 1], small.offsets)
+    assert bool((p.offsets[:, B + 1:] == small.offsets[:, B:]).all())       # padding molecules are empty
+    plain = graphstep.pad_batch(dict(small), shapes)
+    assert not isinstance(plain, CollatedBatch)
+
+
+def test_a_molecule_beyond_the_bound_does_not_fit():
+    big, small = _batches()
+    shapes = graphstep.StaticShapes.from_batches([big, small], margin=0.1)
+    counts = graphstep.batch_counts(small)
+    assert shapes.fits(counts, small.max_per_mol)
+    too_big = dict(small.max_per_mol, bedge=shapes.max_per_mol["bedge"] + 1)
+    assert not shapes.fits(counts, too_big)
+    assert shapes.fits(counts, None)           # a batch without the bound: the general plan builder takes it
