@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfragnet_hip.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 FN_D = 128
 FN_MAX_TASKS = 16
 FN_MAX_EDGE_K = 8
@@ -98,7 +98,7 @@ COLLATE_ROWS, COLLATE_BATCH, COLLATE_IDS = 0, 1, 2
 
 class AdamSlice(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i64), ("lr_dev", vp), ("step_dev", vp),
-                ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32)]
+                ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("launched", i32), ("pad_", i32)]
 
 
 class SmallDw(C.Structure):

@@ -1266,8 +1266,8 @@ __device__ __forceinline__ void row_dots_sorted_bwd_range(const RowDotsBwdArgs& 
                 v[u] = ld4(feat + e * FN_D + lane * 4);
                 gs[u] = ld4(g_s_sorted + e * 4);
                 ad[u] = addend ? ld4(addend + e * FN_D + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                o2[u] = (g_feat && T.cu_c) ? ld4(T.cu_out2 + e * FN_D + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                sgm[u] = (g_feat && T.cu_c) ? T.cu_sigma[e * 4 + (lane >> 3)] : 0.f;
+                o2[u] = (g_feat && T.cu_c && T.cu_out2) ? ld4(T.cu_out2 + e * FN_D + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                sgm[u] = (g_feat && T.cu_c && T.cu_out2) ? T.cu_sigma[e * 4 + (lane >> 3)] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1283,7 +1283,7 @@ __device__ __forceinline__ void row_dots_sorted_bwd_range(const RowDotsBwdArgs& 
                     if ((lane & 7) == 0) {
                         const int64_t at = e * 4 + (lane >> 3);
                         T.cu_c[at] = cc;
-                        T.cu_u[at] = uu - cc * sgm[u];
+                        if (T.cu_u) T.cu_u[at] = uu - cc * sgm[u];      // (null: the deferred one-pass backward wants c only)
                     }
                 }
             }
@@ -2259,13 +2259,31 @@ struct CuEpi {
     float *c, *u;             // c == null: no such epilogue
     int heads;
 };
-template <int KQ, bool VEC, bool PF, bool RA = false, bool CU = false>
+// The deferred form of the one-pass attention backward inside an input-gradient product (GS instances, four heads; gat_bwd_one.inc,
+// DF).  The product's A rows are the level's g_h WITHOUT the term g_s_dst[row] a_dst, and g_s_dst itself is not known yet: the
+// level's pass left dL/dz of every edge at its destination-order slot (dz [m][4]: a row's in-edges contiguous, four heads per edge).
+// The missing term is linear, (g_s_dst a_dst) W = sum_h g_s_dst[row, h] R[h, :] with R[h, :] = sum_{c in head h} a_dst[c] W[c, :]
+// ([4][128], from the parameters alone: the forward prologue writes it) -- exactly ONE more step of the 16x16x4 MFMA chain with
+// k = the four heads: lane (i, kq) supplies A[row i][k = kq] = g_s_dst[row, head kq] and the R rows are four more rows of the
+// operand tile in LDS.  So every lane sums ONE segment (its row, head kq: <= 12 strided loads that leave before the chain and are
+// added behind it -- no cross-lane step at all), the tile's workgroup of column half 0 writes the g_s_dst table for the
+// weight-gradient kernels (which add the term to their dY operand, wgrad128.inc), and the epilogue is the plain one.
+struct GsdEpi {
+    const float* dz;          // [m][4]; null: no such term
+    const int32_t* rowptr;    // the level's by-destination CSR (M + 1 words); positions are rowptr[.] - pos_base
+    int pos_base;
+    const float* R;           // [4][128], see above
+    float* gsd;               // out [M][4]
+};
+template <int KQ, bool VEC, bool PF, bool RA = false, bool CU = false, bool GS = false>
 __device__ __forceinline__ void linear128_body(float* sBt, const float* __restrict__ X, int K, const float* __restrict__ Bt,
                                                const float* __restrict__ bias, float* __restrict__ Y, int64_t M,
                                                const fn_act_epilogue& mk, const NodeScalarEpi& ns, int bid, int nblk,
                                                const RowAdd& ra = RowAdd{nullptr, nullptr, 0},
                                                const CuEpi& cu = CuEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0},
-                                               const int32_t* n_real = nullptr) {
+                                               const int32_t* n_real = nullptr,
+                                               const GsdEpi& gs = GsdEpi{nullptr, nullptr, 0, nullptr, nullptr}) {
+    static_assert(!GS || (CU && KQ == 32 && VEC), "the deferred term rides in the one-pass backward's K = 128 products");
     // A block is 4 waves = 64 rows x 64 COLUMNS (column half wc = bid & 1) and walks the row tiles bid>>1, += nblk>>1.
     // sBt: the [4*KQ][kLinLd] operand tile of this column half, staged ONCE; after that the block never synchronises
     // again: A rows live in registers (PF: the next tile's rows are requested before this tile's MFMA chain), and
@@ -2331,6 +2349,14 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
         }
     };
 
+    // GS: the by-destination extent of this lane's A row of a tile, requested with the row itself so that the segment loads can
+    // leave right before the MFMA chain and land behind it
+    int rp0 = 0, rp1 = 0;
+    auto load_rp = [&](int64_t t) {
+        const int64_t ra_ = t * kLinRows + w * 16 + i;
+        rp0 = gs.dz ? gs.rowptr[ra_ < M ? ra_ : M] : 0;
+        rp1 = gs.dz ? gs.rowptr[ra_ + 1 < M ? ra_ + 1 : M] : 0;
+    };
     float cur[KQ], nxt[KQ];
     {   // stage Bt [4*KQ][this half's 64 columns] -> LDS with 16-byte loads; the first A rows ride in the same round trip
         constexpr int N4 = 4 * KQ * 16;                 // float4 count
@@ -2342,11 +2368,17 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
             v[q] = (idx < N4 && k < K) ? ld4(Bt + (size_t)k * 128 + 64 * wc + n4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         load_rows(tile, cur);
+        float4 vr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (GS) {
+            load_rp(tile);
+            if (tid < 64 && gs.dz) vr = ld4(gs.R + (tid >> 4) * 128 + 64 * wc + (tid & 15) * 4);      // R: rows 4 KQ .. 4 KQ + 3 of the tile
+        }
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const int idx = tid + q * kLinThreads, k = idx >> 4, n4 = idx & 15;
             if (idx < N4) st4(sBt + k * kLinLd + n4 * 4, v[q]);
         }
+        if constexpr (GS) { if (tid < 64) st4(sBt + (4 * KQ + (tid >> 4)) * kLinLd + (tid & 15) * 4, vr); }
     }
     // this lane's four columns of bias and of the two attention vectors stay in registers for every tile
     const int col = 64 * wc + 4 * i;
@@ -2364,6 +2396,7 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
         for (int hh = 0; hh < 4; ++hh) ra_a[hh] = ra.z ? ld4(ra.a + hh * ra.lda + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
+    const int64_t nr_rows = n_real ? (int64_t)*n_real : M;          // rows at or behind it: padding (no gradient, segments never written)
 
     // MFMA tile t of a wave covers the columns {4 i + t}: one 16-byte LDS read per step feeds all four tiles
     const float* bbase = sBt + (IL ? 4 * kq : kq * KQ) * kLinLd + 4 * i;
@@ -2372,6 +2405,36 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
         const int64_t next = tile + stride;
         const bool more = next < tiles;
         if constexpr (PF) load_rows(more ? next : tile, nxt);
+        // GS: the dz segment of (this lane's A row, head kq), in flight across the MFMA chain: four / eight / twelve loads by the
+        // wave's largest in-degree (wave-uniform tiers), rows of more in-edges finish behind the chain
+        float dzv[12], ahub = 0.f;
+        int gdeg = 0, gbeg = 0;
+        if constexpr (GS) {
+            const int64_t ra_ = tile * kLinRows + w * 16 + i;
+            gbeg = rp0 - gs.pos_base;
+            gdeg = (gs.dz && ra_ < nr_rows) ? rp1 - rp0 : 0;
+            const float* dzl = gs.dz + kq;
+#pragma unroll
+            for (int jj = 0; jj < 12; ++jj) dzv[jj] = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) dzv[jj] = gs.dz ? ld1_off(dzl, jj < gdeg ? (uint32_t)(gbeg + jj) * 16u : 0u) : 0.f;
+            if (__any(gdeg > 4)) {
+#pragma unroll
+                for (int jj = 4; jj < 8; ++jj) dzv[jj] = ld1_off(dzl, jj < gdeg ? (uint32_t)(gbeg + jj) * 16u : 0u);
+            }
+            if (__any(gdeg > 8)) {
+#pragma unroll
+                for (int jj = 8; jj < 12; ++jj) dzv[jj] = ld1_off(dzl, jj < gdeg ? (uint32_t)(gbeg + jj) * 16u : 0u);
+            }
+            // hubs (in-degree > 12): rare; their tail is summed HERE, in front of the chain (dependent loads, a stall only for such a
+            // wave) -- the same loop between the chain and the last step made the register allocator spill 145 registers
+            if (__any(gdeg > 12)) {
+                for (int jj = 12; __any(jj < gdeg); ++jj) {
+                    const float x = ld1_off(dzl, jj < gdeg ? (uint32_t)(gbeg + jj) * 16u : 0u);
+                    ahub += jj < gdeg ? x : 0.f;
+                }
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[4];
 #pragma unroll
@@ -2402,6 +2465,19 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
                 }
             }
         }
+        if constexpr (GS) {      // step 4 KQ / 4 + 1 of the chain: k = the four heads
+            float a = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 12; ++jj) a += jj < gdeg ? dzv[jj] : 0.f;
+            a += ahub;
+            const int64_t ra_ = tile * kLinRows + w * 16 + i;
+            if (wc == 0 && gs.dz && ra_ < M) gs.gsd[ra_ * 4 + kq] = a;
+            const float4 b = *reinterpret_cast<const float4*>(sBt + (4 * KQ + kq) * kLinLd + 4 * i);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc[3], 0, 0, 0);
+        }
         // acc[t][r] is (row kq*4 + r, column 4 i + t) of the wave's 16 x 64 tile
         __builtin_amdgcn_sched_barrier(0);
         const int64_t r0 = tile * kLinRows + w * 16 + kq * 4;
@@ -2418,22 +2494,23 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
             const int cu_hd = cu.c ? col / (FN_D / cu.heads) : 0;
             float sgv[4];
             // all four rows' operands in one round trip (64 registers: the kernel runs three waves per SIMD)
+            constexpr int CR = kCuRows;
 #pragma unroll
-            for (int hb = 0; hb < 4; hb += kCuRows) {
-                float4 yv[kCuRows], ov[kCuRows], o2v[kCuRows], zv[kCuRows];
+            for (int hb = 0; hb < 4; hb += CR) {
+                float4 yv[CR], ov[CR], o2v[CR], zv[CR];
 #pragma unroll
-                for (int q = 0; q < kCuRows; ++q) {
+                for (int q = 0; q < CR; ++q) {
                     const int r = hb + q;
                     const int64_t row = r0 + r < M ? r0 + r : M - 1;
                     const int64_t at = row * 128 + col;
                     yv[q] = gate ? ld4(mk.y + at) : make_float4(1.f, 1.f, 1.f, 1.f);
                     ov[q] = cu.c && cu.out ? ld4(cu.out + at) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    o2v[q] = cu.c ? ld4(cu.out2 + at) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (!GS) o2v[q] = cu.c ? ld4(cu.out2 + at) : make_float4(0.f, 0.f, 0.f, 0.f);
                     zv[q] = ra.z ? ld4(ra.z + row * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    sgv[r] = cu.c ? cu.sigma[row * cu.heads + cu_hd] : 0.f;
+                    if constexpr (!GS) sgv[r] = cu.c ? cu.sigma[row * cu.heads + cu_hd] : 0.f;
                 }
 #pragma unroll
-                for (int q = 0; q < kCuRows; ++q) {
+                for (int q = 0; q < CR; ++q) {
                     const int r = hb + q;
                     float4 o = make_float4(acc[0][r] + bv.x, acc[1][r] + bv.y, acc[2][r] + bv.z, acc[3][r] + bv.w);
                     if (gate) {
@@ -2443,7 +2520,7 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
                     fma4(o, zv[q].x, ra_a[0]);  fma4(o, zv[q].y, ra_a[1]);  fma4(o, zv[q].z, ra_a[2]);  fma4(o, zv[q].w, ra_a[3]);
                     if (r0 + r < M) st4(Y + (r0 + r) * 128 + col, o);
                     pd[r] = dot4(o, cu.out ? ov[q] : yv[q]);
-                    ps[r] = dot4(o, o2v[q]);
+                    if constexpr (!GS) ps[r] = dot4(o, o2v[q]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -2452,14 +2529,20 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
                 const float cu_scale = cu.out ? 1.f : (mk.p > 0.f && mk.p < 1.f ? 1.f - mk.p : 1.f);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (cu_d >= 64) { pd[r] += dpp_mov<kDppMirror>(pd[r]); ps[r] += dpp_mov<kDppMirror>(ps[r]); }
-                    if (cu_d >= 32) { pd[r] += dpp_mov<kDppHalfMirror>(pd[r]); ps[r] += dpp_mov<kDppHalfMirror>(ps[r]); }
-                    pd[r] += dpp_mov<kDppXor2>(pd[r]); ps[r] += dpp_mov<kDppXor2>(ps[r]);
-                    pd[r] += dpp_mov<kDppXor1>(pd[r]); ps[r] += dpp_mov<kDppXor1>(ps[r]);
+                    if (cu_d >= 64) pd[r] += dpp_mov<kDppMirror>(pd[r]);
+                    if (cu_d >= 32) pd[r] += dpp_mov<kDppHalfMirror>(pd[r]);
+                    pd[r] += dpp_mov<kDppXor2>(pd[r]);
+                    pd[r] += dpp_mov<kDppXor1>(pd[r]);
+                    if constexpr (!GS) {
+                        if (cu_d >= 64) ps[r] += dpp_mov<kDppMirror>(ps[r]);
+                        if (cu_d >= 32) ps[r] += dpp_mov<kDppHalfMirror>(ps[r]);
+                        ps[r] += dpp_mov<kDppXor2>(ps[r]);
+                        ps[r] += dpp_mov<kDppXor1>(ps[r]);
+                    }
                     if ((4 * i) % cu_d == 0 && r0 + r < M) {
                         const float cc = cu_scale * pd[r];
                         cu.c[(r0 + r) * cu.heads + cu_hd] = cc;
-                        cu.u[(r0 + r) * cu.heads + cu_hd] = ps[r] - cc * sgv[r];
+                        if constexpr (!GS) cu.u[(r0 + r) * cu.heads + cu_hd] = ps[r] - cc * sgv[r];
                     }
                 }
             }
@@ -2517,6 +2600,7 @@ __device__ __forceinline__ void linear128_body(float* sBt, const float* __restri
         } else {
             load_rows(next, cur);
         }
+        if constexpr (GS) load_rp(next);
         tile = next;
     }
 }
@@ -2542,6 +2626,7 @@ struct LinTask {
     int K;                    // 0: the group's K (LinTasks::K); else this task's own reduction length (layer 0: 17 bond / 6 connection features)
     RowAdd ra;                // riding input-gradient products only (lin_side_block)
     CuEpi cu;                 // ... of the one-pass backward (lin_side_block<true>)
+    GsdEpi gs;                // ... of its deferred form (lin_side_block<true, true>)
     const int32_t* n_real;    // nullable device word: row tiles that start at or behind *n_real are padding and are not computed
 };
 struct LinTasks {
@@ -2591,12 +2676,12 @@ __global__ __launch_bounds__(kLinThreads) void k_linear128_layer0(LinTasks T) {
 // The attention passes are bound by dependent round trips with the matrix cores idle, the projections are a few microseconds
 // of MFMA work behind a launch floor of their own -- so the GEMM tiles ride along as extra workgroups of the attention launch
 // (one 64 x 64 tile each, the k_linear128_multi body) and the layer loses a kernel boundary per pass.
-template <bool CU = false>
+template <bool CU = false, bool GS = false>
 __device__ __forceinline__ void lin_side_block(float* sBt, const LinTasks& T, int b) {
     int ti = 0;
     while (ti + 1 < T.n && b >= T.t[ti + 1].first) ++ti;
     const LinTask& t = T.t[ti];
-    linear128_body<32, true, false, true, CU>(sBt, t.X, 128, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, b - t.first, t.nblk, t.ra, t.cu, t.n_real);
+    linear128_body<32, true, false, true, CU, GS>(sBt, t.X, 128, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, b - t.first, t.nblk, t.ra, t.cu, t.n_real, t.gs);
 }
 // Which workgroup is which: the GEMM workgroups are blocks [T.base, T.base + T.total) of the launch -- first, so that the
 // dispatcher starts them before the attention workgroups (measured best of first / last / interleaved: profiles/r02e_colaunch_ab.txt).
@@ -2685,11 +2770,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_lin_rd(LinTasks T, RowDotsBwdArgs
     row_dots_sorted_bwd_body(R, sR, b - T.total, R.nblk);
 }
 // the same launch in the one-pass backward: the products' epilogue also writes the dots c, g_s_dst of the rows it finishes (CuEpi)
+// (GS: the deferred form -- every lane sums one dz segment into g_s_dst, one more MFMA step adds the rank-4 term, GsdEpi; c is the only dot left)
+template <bool GS = false>
 __global__ __launch_bounds__(kBlock, 3) void k_lin_rd_cu(LinTasks T, RowDotsBwdArgs R) {
     extern __shared__ __attribute__((aligned(16))) float sBt[];
     __shared__ float sR[kRows][FN_D];
     const int b = (int)blockIdx.x;
-    if (b < T.total) { lin_side_block<true>(sBt, T, b);  return; }
+    if (b < T.total) { lin_side_block<true, GS>(sBt, T, b);  return; }
     row_dots_sorted_bwd_body(R, sR, b - T.total, R.nblk);
 }
 
@@ -2776,6 +2863,9 @@ struct EncPrologue {
     const float* ssr[2];  const float* sss[2];  float* sso[2];  int n_ss[2];   // the same two attributes in SOURCE order (one-pass backward): from raw, else from sorted
     float* zp;  int64_t zn;  int n_z;                               // buffer zeroed once per forward (edge-term scratch: loop positions stay 0)
     MolExtArgs mx;  int n_x;                                        // molecule extents for the molecule-resident backward (256 molecules per block)
+    // deferred one-pass backward (GsdEpi): R[z][h][k] = sum_{c < 32} att[z][h * att_w[z] + c] * W[z][(32 h + c) * 128 + k] for the K = 128
+    // projections z (four heads; two blocks per matrix)
+    const float* rW[3 * FN_MAX_LAYERS];  const float* rA[3 * FN_MAX_LAYERS];  int rAw[3 * FN_MAX_LAYERS];  float* rOut;  int n_r;
 };
 __global__ __launch_bounds__(256) void k_enc_prologue(EncPrologue A) {
     __shared__ float tile[32][33];
@@ -2812,16 +2902,33 @@ __global__ __launch_bounds__(256) void k_enc_prologue(EncPrologue A) {
         return;
     }
     b -= A.n_z;
-    if (b < A.n_x) mol_extents_body(A.mx, b);
+    if (b < A.n_x) { mol_extents_body(A.mx, b);  return; }
+    b -= A.n_x;
+    if (b < A.n_r) {
+        const int z = b >> 1, o = (b & 1) * 256 + (int)threadIdx.x, hh = o >> 7, k = o & 127;
+        const float* W = A.rW[z];
+        const float* a = A.rA[z] + hh * A.rAw[z];
+        float acc = 0.f;
+        if (W) {
+#pragma unroll 8
+            for (int c = 0; c < 32; ++c) acc = fmaf(a[c], W[(size_t)(32 * hh + c) * 128 + k], acc);
+        }
+        A.rOut[(size_t)z * 512 + o] = acc;
+    }
 }
 
 // Weight gradient: block = `rows_per_block` rows in chunks of 32 staged through double-buffered LDS.  Wave w owns
 // output rows o in [32(w&3), +32) and the (w>>2)-th group of CTW 16-column tiles of X, so NH = 2 column groups
 // put two waves on every SIMD.  part [grid][128*K + 128]: dW partial followed by the db partial.
 constexpr int kWgChunk = 32;
+// gsd != null (four heads): the deferred form of the one-pass attention backward, see wgrad128.inc -- the dY rows get their missing
+// term g_s_dst[row] a_dst as they are fetched, and the block also leaves U[h][k] = sum_rows g_s_dst[row, h] X[row, k], S[h] =
+// sum_rows g_s_dst[row, h] in upart [grid][4 K + 4] (the chunk's g_s_dst rows travel in the padding columns of the X tile)
 template <int CTW, int NH>
 __device__ __forceinline__ void wgrad_body(float* smem, const float* __restrict__ dY, const float* __restrict__ X, int K,
-                                           int64_t M, int rows_per_block, float* __restrict__ part, int bid) {
+                                           int64_t M, int rows_per_block, float* __restrict__ part, int bid,
+                                           const float* __restrict__ gsd = nullptr, const float* __restrict__ a_dst = nullptr,
+                                           int att_w = 0, float* __restrict__ upart = nullptr) {
     constexpr int NT = 256 * NH;
     constexpr int XW = 16 * CTW * NH;            // padded X width held in LDS
     constexpr int XLD = XW + 16;                 // XW is a multiple of 32 for every instantiation but <1,1>
@@ -2837,13 +2944,24 @@ __device__ __forceinline__ void wgrad_body(float* smem, const float* __restrict_
     constexpr int XPT = (kWgChunk * XW + NT - 1) / NT;        // X scalars per thread per chunk
     float4 ry[YPT];
     float rx[XPT];
+    float4 rg = make_float4(0.f, 0.f, 0.f, 0.f);           // threads 0..31: the chunk row's g_s_dst (deferred term)
+    float rgh[YPT];                                         // g_s_dst[row, head of this thread's dY columns] of the rows in ry
+    const int dfh = (tid & 31) >> 3;                        // head of this thread's four dY columns (NT is a multiple of 32)
+    const float4 dfa = gsd ? ld4(a_dst + dfh * att_w + ((tid & 7) * 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int UP = (XW + NT / 4 - 1) / (NT / 4);        // U columns per thread: thread = (head tid & 3, column tid >> 2 [+ NT / 4])
+    float uacc[UP];
+#pragma unroll
+    for (int q = 0; q < UP; ++q) uacc[q] = 0.f;
+    float sacc = 0.f;
     auto fetch = [&](int c) {
         const int64_t base = m_begin + (int64_t)c * kWgChunk;
 #pragma unroll
         for (int q = 0; q < YPT; ++q) {
             const int idx = tid + q * NT, r = idx >> 5, c4 = idx & 31;
             ry[q] = (base + r < m_end) ? ld4(dY + (base + r) * 128 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gsd) rgh[q] = (base + r < m_end) ? gsd[(base + r) * 4 + dfh] : 0.f;      // (used in stash: no wait here)
         }
+        if (gsd && tid < kWgChunk) rg = (base + tid < m_end) ? ld4(gsd + (base + tid) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < XPT; ++q) {
             const int idx = tid + q * NT, r = idx / XW, cc = idx % XW;
@@ -2854,6 +2972,10 @@ __device__ __forceinline__ void wgrad_body(float* smem, const float* __restrict_
 #pragma unroll
         for (int q = 0; q < YPT; ++q) {
             const int idx = tid + q * NT, r = idx >> 5, c4 = idx & 31;
+            if (gsd) {
+                ry[q].x = fmaf(rgh[q], dfa.x, ry[q].x);  ry[q].y = fmaf(rgh[q], dfa.y, ry[q].y);
+                ry[q].z = fmaf(rgh[q], dfa.z, ry[q].z);  ry[q].w = fmaf(rgh[q], dfa.w, ry[q].w);
+            }
             st4(sY + (buf * kWgChunk + r) * kBtLd + c4 * 4, ry[q]);
         }
 #pragma unroll
@@ -2861,6 +2983,7 @@ __device__ __forceinline__ void wgrad_body(float* smem, const float* __restrict_
             const int idx = tid + q * NT, r = idx / XW, cc = idx % XW;
             if (r < kWgChunk) sX[(buf * kWgChunk + r) * XLD + cc] = rx[q];
         }
+        if (gsd && tid < kWgChunk) st4(sX + (buf * kWgChunk + tid) * XLD + XW, rg);       // the row's padding columns XW .. XW + 3
     };
 
     f32x4 acc[2][CTW];
@@ -2891,8 +3014,31 @@ __device__ __forceinline__ void wgrad_body(float* smem, const float* __restrict_
                 acc[1][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[cc], acc[1][cc], 0, 0, 0);
             }
         }
+        if (gsd && upart) {  // the side product U, S of this chunk (rows past the end were stashed as zeros)
+            const int hh = tid & 3;
+#pragma unroll 8
+            for (int r = 0; r < kWgChunk; ++r) {
+                const float* xr = sX + (buf * kWgChunk + r) * XLD;
+                const float g = xr[XW + hh];
+#pragma unroll
+                for (int q = 0; q < UP; ++q) {
+                    const int k = (tid >> 2) + q * (NT / 4);
+                    if (k < XW) uacc[q] = fmaf(g, xr[k], uacc[q]);
+                }
+                sacc += g;
+            }
+        }
         if (c + 1 < n_chunks) stash(buf ^ 1);
         __syncthreads();
+    }
+    if (gsd && upart) {
+        float* up = upart + (size_t)bid * (4 * K + 4);
+#pragma unroll
+        for (int q = 0; q < UP; ++q) {
+            const int k = (tid >> 2) + q * (NT / 4);
+            if (k < K) up[(tid & 3) * K + k] = uacc[q];
+        }
+        if (tid < 4) up[4 * K + tid] = sacc;
     }
     // partials are written in the accumulators' native layout: one coalesced 16-byte store per lane and tile;
     // k_wgrad_reduce maps them back to dW[o][col] while summing over blocks
@@ -2931,6 +3077,11 @@ struct WgradTask {
     int rpb, first;
     int K;                    // k_linear128_wgrad_mixed only: this product's reduction length (0 elsewhere: WgradTasks::K)
     const int32_t* n_real;    // nullable device word: rows at or behind *n_real are padding (zero gradient rows) and are not read
+    // the deferred form of the one-pass attention backward (wgrad128.inc): dY lacks g_s_dst[row] a_dst; gsd == null: nothing to add
+    const float* gsd;         // [M][4]
+    const float* a_dst;       // att + dst_off: head h's 32 floats at a_dst + h * att_w
+    int att_w;
+    float* upart;             // [blocks][4 K + 4]: U[h][k] = sum_rows gsd[row, h] X[row, k], then S[h] = sum_rows gsd[row, h]
 };
 constexpr int kMaxWgradTasks = 3 * FN_MAX_LAYERS;
 struct WgradTasks {
@@ -2957,9 +3108,9 @@ __global__ __launch_bounds__(512) void k_linear128_wgrad_mixed(WgradTasks T) {
     const WgradTask& t = T.t[ti];
     const int bid = (int)blockIdx.x - t.first;
     const int64_t M = t.n_real && *t.n_real < t.M ? (int64_t)*t.n_real : t.M;
-    if (t.K <= 32) wgrad_body<1, 2>(smem, t.dY, t.X, t.K, M, t.rpb, t.part, bid);
-    else if (t.K <= 128) wgrad_body<4, 2>(smem, t.dY, t.X, t.K, M, t.rpb, t.part, bid);
-    else wgrad_body<6, 2>(smem, t.dY, t.X, t.K, M, t.rpb, t.part, bid);
+    if (t.K <= 32) wgrad_body<1, 2>(smem, t.dY, t.X, t.K, M, t.rpb, t.part, bid, t.gsd, t.a_dst, t.att_w, t.upart);
+    else if (t.K <= 128) wgrad_body<4, 2>(smem, t.dY, t.X, t.K, M, t.rpb, t.part, bid, t.gsd, t.a_dst, t.att_w, t.upart);
+    else wgrad_body<6, 2>(smem, t.dY, t.X, t.K, M, t.rpb, t.part, bid, t.gsd, t.a_dst, t.att_w, t.upart);
 }
 
 // every weight-gradient partial product of a backward pass in ONE launch: blocks [0, n128) run the direct K = 128 kernel
@@ -2979,9 +3130,9 @@ __global__ __launch_bounds__(512) void k_wgrad_all(const WgradTasks W, const Wgr
     const WgradTask& t = W0.t[ti];
     const int bid = b - t.first;
     const int64_t M = t.n_real && *t.n_real < t.M ? (int64_t)*t.n_real : t.M;
-    if (t.K <= 32) wgrad_body<1, 2>(smem, t.dY, t.X, t.K, M, t.rpb, t.part, bid);
-    else if (t.K <= 128) wgrad_body<4, 2>(smem, t.dY, t.X, t.K, M, t.rpb, t.part, bid);
-    else wgrad_body<6, 2>(smem, t.dY, t.X, t.K, M, t.rpb, t.part, bid);
+    if (t.K <= 32) wgrad_body<1, 2>(smem, t.dY, t.X, t.K, M, t.rpb, t.part, bid, t.gsd, t.a_dst, t.att_w, t.upart);
+    else if (t.K <= 128) wgrad_body<4, 2>(smem, t.dY, t.X, t.K, M, t.rpb, t.part, bid, t.gsd, t.a_dst, t.att_w, t.upart);
+    else wgrad_body<6, 2>(smem, t.dY, t.X, t.K, M, t.rpb, t.part, bid, t.gsd, t.a_dst, t.att_w, t.upart);
 }
 
 // sums the native-layout partials over blocks and scatters them to dW [128][K] / db [128]
@@ -3035,6 +3186,10 @@ struct ReduceTask {
     int att_w, dst_off, src_off, K;
     float *o0, *o1, *o2;
     int ld, off, cls, pad_;
+    // RT_FINALIZE, deferred form of the one-pass backward (gat_bwd_one.inc DF, four heads): the level's pass left no dL/da_dst partials;
+    // four extra blocks (one per head) form it from the weight-gradient kernels' side product: dL/da_dst[c] = sum_k W[c, k] U[h(c), k] + b[c] S[h(c)]
+    const float *up, *upW, *upb;      // up [n_up][4 upK + 4] per-block partials of U | S; the projection's weight [128][upK] and bias; up == null: none
+    int n_up, upK;
 };
 constexpr int kMaxReduceTasks = 36;      // one launch for all 30 tasks of a 4-layer backward pass (5.5 KB of kernel arguments)
 struct ReduceTasks {
@@ -3110,6 +3265,34 @@ __device__ __forceinline__ void wgrad_reduce_strip(int vb, float* sm, const floa
     }
 }
 
+// the four extra blocks (one per head) of a deferred level's RT_FINALIZE task (ReduceTask::up); sm: 4096 floats
+__device__ __forceinline__ void adst_from_u_body(const ReduceTask& t, float* sm, int hh) {
+    const int K = t.upK, UW = 4 * K + 4, tid = threadIdx.x;
+    // column sums of this head's K columns of the partial rows (+ its S): 256 columns x 4 row groups, four loads in flight
+    const int col = tid & 255, rg = tid >> 8;
+    const float* src = t.up + (col < K ? hh * K + col : 4 * K + hh);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (col <= K) {
+        int r = rg;
+        for (; r + 12 < t.n_up; r += 16) {
+            a0 += src[(size_t)r * UW];        a1 += src[(size_t)(r + 4) * UW];
+            a2 += src[(size_t)(r + 8) * UW];  a3 += src[(size_t)(r + 12) * UW];
+        }
+        for (; r < t.n_up; r += 4) a0 += src[(size_t)r * UW];
+    }
+    sm[rg * 256 + col] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (tid < 256) sm[1024 + tid] = (sm[tid] + sm[256 + tid]) + (sm[512 + tid] + sm[768 + tid]);       // U[hh][0..K), then S[hh] at K
+    __syncthreads();
+    const float* U = sm + 1024;
+    const int c = hh * 32 + (tid >> 5), part = tid & 31;     // 32 columns of the head x 32 lanes
+    float a = 0.f;
+    for (int k = part; k < K; k += 32) a = fmaf(t.upW[(size_t)c * K + k], U[k], a);
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if (part == 0) t.o0[hh * t.att_w + t.dst_off + (c & 31)] = fmaf(t.upb[c], U[K], a);
+}
+
 __global__ __launch_bounds__(1024) void k_reduce_tasks(ReduceTasks T, AdamRide R) {
     __shared__ float sm[16 * 256];
     if (R.nblk && (int)blockIdx.x >= R.first) { adam_ride(R);  return; }
@@ -3119,14 +3302,17 @@ __global__ __launch_bounds__(1024) void k_reduce_tasks(ReduceTasks T, AdamRide R
     const int vb = (int)blockIdx.x - T.first[ti];
     if (t.kind == RT_FINALIZE) {
         if (vb < 2 * FN_D / 32) {
+            if (t.up && vb < FN_D / 32) return;             // deferred form: dL/da_dst comes from the extra block below, not from partials
             const int col = vb * 32 + (threadIdx.x >> 5);
             const float v = colmajor_sum_32(t.p0 + (size_t)col * FN_MAX_PART, t.n0);
             if ((threadIdx.x & 31) == 0) {
                 const int DH = FN_D / t.H, cc = col & 127, part = col >> 7;
                 t.o0[(cc / DH) * t.att_w + (part ? t.src_off : t.dst_off) + (cc % DH)] = v;
             }
-        } else {
+        } else if (vb == 2 * FN_D / 32 && t.et.mode == 2) {
             gat_finalize_body(2 * FN_D, sm, t.p0, t.n0, t.p1, t.n1, t.et, t.att, t.att_w, t.dst_off, t.src_off, t.o0, t.o1, t.o2, t.H);
+        } else {
+            adst_from_u_body(t, sm, vb - 2 * FN_D / 32 - (t.et.mode == 2 ? 1 : 0));
         }
     } else if (t.kind == RT_COLSUM) {
         const int col = vb * 32 + (threadIdx.x >> 5);
@@ -3187,7 +3373,7 @@ bool bad_edge_term(const fn_edge_term* et) {
 namespace {
 unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
 int64_t g_mol_stamps_n = 0;
-int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 256, 2, -1, 0, 1, 0, 0, 1, 23, 1, 1024, 1, 0, 1, 1, 0};   // in the order of the FN_TUNE_* keys
+int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 256, 2, -1, 0, 1, 0, 0, 1, 23, 1, 1024, 1, 0, 1, 1, 0, 1};   // in the order of the FN_TUNE_* keys
 }  // namespace
 namespace fni {      // hooks for the other translation units (fn_internal.h)
 int fail(int code, const char* what) { return ::fail(code, what); }
@@ -3701,6 +3887,7 @@ static int launch_gat_bwd_dst_pair(const GatBwdDstArgs& A, const GatBwdDstArgs& 
 // plain launches (attention, then launch_linear128_group) whenever the combination has no kernel: the caller never needs to know.
 static_assert(kBlock == kLinThreads && kBwdRows * 32 == kLinThreads, "co-launched attention and GEMM workgroups share a block size");
 constexpr size_t kLinSideLds = (size_t)(4 * 32 * kLinLd) * sizeof(float);
+constexpr size_t kLinSideLdsGs = kLinSideLds + 4 * kLinLd * sizeof(float);    // + four operand rows: R of the deferred term (GsdEpi)
 // lays the tasks' workgroups out (one 64 x 64 output tile each); false: cannot ride along (empty, co-launch off, misaligned, or the
 // register-resident / wave-independent GEMM variants are selected, which have their own launch shapes)
 static bool lin_side_prepare(LinTasks& T, int gat_blocks, int* gat_base, int* grid) {
@@ -3864,8 +4051,18 @@ static int prep_gat_bwd_one(const float* g_out, const float* h, const float* p_s
     if (!one_pass_heads(heads)) return fail(FN_EUNSUPPORTED, "heads must be 1, 2, 4 or 8 (128 = heads * head_dim)");
     *n_part_a = 0;  *n_part_e = 0;
     *A = GatBwdOneArgs{g_out, h, p_sorted, cdot, g_s_dst, att, att_w, dst_off, src_off, *et, *plan, neg_slope, g_h, part_a, part_e,
-                       dz_sorted, g_s_orig, 1, 0, 0, et->x_src, nullptr, g_tune[FN_TUNE_ONE_TIER6] != 0 ? 1 : 0, nullptr};
+                       dz_sorted, g_s_orig, 1, 0, 0, et->x_src, nullptr, g_tune[FN_TUNE_ONE_TIER6] != 0 ? 1 : 0, nullptr, nullptr};
     if (plan->n == 0) return 0;
+    if (plan->m == 0) {
+        // a level with nodes but no edges (a batch of single-fragment molecules: the fragment-bond graph): the row loop's per-edge
+        // loads are unconditional with clamped indices (position 0), so every per-edge array needs SOME readable word behind it
+        // -- the [n, H] dots table stands in (the values are never used: no lane has an edge) -- and nothing per-edge is written
+        A->p_sorted = cdot;
+        A->et.x_sorted = cdot;
+        A->x_src = nullptr;
+        A->dz_sorted = nullptr;
+        A->g_s_orig = nullptr;
+    }
     if (plan->n > (1 << 23) || plan->m * heads > (1 << 28))
         return fail(FN_EUNSUPPORTED, "fn_gat_bwd_one_f32: level too large for 32-bit byte offsets (n <= 2^23 rows, m*heads <= 2^28)");
     // persistent half-waves pipelining R rows each; every block writes one row of partial sums (<= 1024 blocks).  The kernel runs
@@ -3884,6 +4081,13 @@ static int prep_gat_bwd_one(const float* g_out, const float* h, const float* p_s
 static int launch_gat_bwd_one(const GatBwdOneArgs& A, int heads, hipStream_t st) {
     if (A.nblk == 0) return 0;
     const int kl = edge_class(&A.et);
+    if (A.dz_em) {            // the deferred form (DF): four heads
+        if (heads != 4) return fail(FN_EUNSUPPORTED, "one-pass backward, deferred form: four heads");
+        if (kl == 0) hipLaunchKernelGGL((k_gat_bwd_one<4, 0, kBwdRows, true>), dim3(A.nblk), dim3(kBwdRows * 32), 0, st, A);
+        else if (kl == 1) hipLaunchKernelGGL((k_gat_bwd_one<4, 1, kBwdRows, true>), dim3(A.nblk), dim3(kBwdRows * 32), 0, st, A);
+        else hipLaunchKernelGGL((k_gat_bwd_one<4, FN_MAX_EDGE_K, kBwdRows, true>), dim3(A.nblk), dim3(kBwdRows * 32), 0, st, A);
+        return launch_status("fn_gat_bwd_one_f32 (deferred form)");
+    }
     FN_DISPATCH_H(heads, {
         if (kl == 0) hipLaunchKernelGGL((k_gat_bwd_one<HH, 0, kBwdRows>), dim3(A.nblk), dim3(kBwdRows * 32), 0, st, A);
         else if (kl == 1) hipLaunchKernelGGL((k_gat_bwd_one<HH, 1, kBwdRows>), dim3(A.nblk), dim3(kBwdRows * 32), 0, st, A);
@@ -3903,6 +4107,13 @@ static int launch_gat_bwd_one3(const GatBwdOneArgs& A, const GatBwdOneArgs& B, c
         return launch_gat_bwd_one(C, heads, st);
     }
     const int interleave = g_tune[FN_TUNE_ONE_INTERLEAVE] != 0 ? 1 : 0;
+    const bool df = (A.nblk && A.dz_em) || (B.nblk && B.dz_em) || (C.nblk && C.dz_em);
+    if (df) {
+        if (heads != 4 || (A.nblk && !A.dz_em) || (B.nblk && !B.dz_em) || (C.nblk && !C.dz_em))
+            return fail(FN_EUNSUPPORTED, "one-pass backward, deferred form: four heads, every level of the launch");
+        hipLaunchKernelGGL((k_gat_bwd_one3<4, kBwdRows, true>), dim3(A.nblk + B.nblk + C.nblk), dim3(kBwdRows * 32), 0, st, A, B, C, interleave);
+        return launch_status("attention backward, one pass, deferred form (bond + atom + fragment-bond levels)");
+    }
     FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_one3<HH, kBwdRows>), dim3(A.nblk + B.nblk + C.nblk), dim3(kBwdRows * 32), 0, st, A, B, C, interleave));
     return launch_status("attention backward, one pass (bond + atom + fragment-bond levels)");
 }
@@ -3911,7 +4122,7 @@ static int launch_gat_cu(CuTasks& T, int heads, hipStream_t st) {
     for (int i = 0; i < T.n; ++i) {
         if (T.t[i].n <= 0) continue;
         CuTask t = T.t[i];
-        if (!t.g || !t.out || !t.out2 || !t.sigma || !t.c || !t.u) return fail(FN_EINVAL, "fn_gat_cu_f32: null argument");
+        if (!t.g || !t.out || !t.c || (t.out2 && (!t.sigma || !t.u))) return fail(FN_EINVAL, "fn_gat_cu_f32: null argument");
         if (((uintptr_t)t.g | (uintptr_t)t.out | (uintptr_t)t.out2) & 15) return fail(FN_EINVAL, "fn_gat_cu_f32: rows must be 16-byte aligned");
         t.first = blocks;
         t.nblk = row_grid(t.n, kGridCap);
@@ -4589,6 +4800,7 @@ struct EncLayout {
     float* mol_ext;          // MolExt[n_mols] for the molecule-resident backward (null without molecule CSRs)
     float *xs_bond, *xs_fbond;   // one-pass backward: the two raw edge attributes in source order ([1][bond.m], [k_fattr][fbond.m])
     float* real_rows;            // pad_skip_on: int32 [4] = real atoms, bonds, fragments, connections (written by the forward prologue)
+    float* rmat;                 // defer_on: R [3 n_layers][4][128] of the K = 128 projections (GsdEpi; written by the forward prologue)
     int64_t total;
 };
 
@@ -4608,6 +4820,13 @@ bool one_pass_on(const fn_encoder* e) {
            g_tune[FN_TUNE_BWD_MOL] == 0 && e->atom.m_real == e->E;
 }
 
+// the deferred form of the one-pass backward (gat_bwd_one.inc DF, FN_TUNE_DEFER_GSD): no second output in the forward.  Four heads
+// (the 16-lane segment sums and the rank-4 epilogue are written for them), gat2, and the grouped direct weight-gradient kernels
+bool defer_on(const fn_encoder* e) {
+    return g_tune[FN_TUNE_DEFER_GSD] != 0 && one_pass_on(e) && e->heads == 4 && e->variant == 0 && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0 &&
+           g_tune[FN_TUNE_WGRAD_DIRECT] == 1;
+}
+
 EncLayout enc_layout(const fn_encoder* e, float* ws) {
     EncLayout o{};
     Bump b(ws);
@@ -4625,7 +4844,7 @@ EncLayout enc_layout(const fn_encoder* e, float* ws) {
         }
     }
     if (one_pass_on(e)) {
-        for (int l = 0; l < e->n_layers; ++l) {
+        for (int l = 0; l < e->n_layers && !defer_on(e); ++l) {
             LayerActs& a = o.L[l];
             a.o2_bond = b.take(e->E * FN_D);  a.o2_atom = b.take(e->N * FN_D);  a.o2_fbond = b.take(e->EF * FN_D);
             a.sg_bond = b.take(e->E * H);  a.sg_atom = b.take(e->N * H);  a.sg_fbond = b.take(e->EF * H);
@@ -4634,6 +4853,7 @@ EncLayout enc_layout(const fn_encoder* e, float* ws) {
         o.xs_fbond = b.take(e->fbond.m * e->k_fattr);
     }
     o.real_rows = pad_skip_on(e) ? b.take(64) : nullptr;
+    o.rmat = defer_on(e) ? b.take((int64_t)3 * e->n_layers * 512) : nullptr;
     o.in_atoms0 = drop ? b.take(e->N * e->k_atom0) : nullptr;
     o.atoms_new = b.take(e->N * FN_D);
     o.frags_new = b.take(e->F * FN_D);
@@ -4675,6 +4895,7 @@ bool tail_mol_on(const fn_encoder* e) {
 struct LevelScratch {
     float *g_h, *dz, *pz, *g_s_dst, *part_a, *part_e, *part_rd, *wg_ws;
     float* cdot;             // one-pass backward: c[n, H] = <g, out> per head (no pz then)
+    float *dz_em, *upart;    // its deferred form: dz at destination-order slots [m][H]; the weight-gradient kernels' side product U | S per block
 };
 struct BwdLayout {
     float *g_pre_atoms, *g_pre_frags, *g_pre_bond, *g_pre_fbond;   // grads w.r.t. pre-activation layer outputs (the chain)
@@ -4690,8 +4911,12 @@ BwdLayout bwd_layout(const fn_encoder* e, float* ws) {
     o.g_pre_atoms = b.take(e->N * FN_D);  o.g_pre_frags = b.take(e->F * FN_D);
     o.g_pre_bond = b.take(e->E * FN_D);   o.g_pre_fbond = b.take(e->EF * FN_D);
     o.g_frags = b.take(e->F * FN_D);
+    const bool df = defer_on(e);
     auto level = [&](LevelScratch& s, int64_t n, int64_t m, int k0, bool edge_params, bool row_dots, bool proj, bool one = false) {
         s.g_h = b.take(n * FN_D);
+        s.dz_em = one && df ? b.take(m * H) : nullptr;
+        // (a weight-gradient launch has at most n / wgrad_rows_per_block(n) + 1 blocks per product)
+        s.upart = one && df && proj ? b.take((n / wgrad_rows_per_block(n) + 2) * (int64_t)(4 * (k0 > FN_D ? k0 : FN_D) + 4)) : nullptr;
         s.dz = row_dots ? b.take(m * H) : nullptr;
         s.pz = one ? nullptr : b.take(2 * m * H);
         s.cdot = one ? b.take(n * H) : nullptr;
@@ -4750,13 +4975,15 @@ struct ReduceQueue {
     int blocks = 0, wblocks = 0, w0blocks = 0;
     bool defer_mixed = false;
     int w_reduce[kMaxWgradTasks] = {};      // index in T of each grouped product's reduction
+    int w_fin[kMaxWgradTasks] = {};         // ... and of its level's RT_FINALIZE task when the product carries the deferred term (n_up is set at flush)
+    int last_index = -1;                    // index in T of the task pushed last
     bool defer_wgrad = false;
     hipStream_t st = nullptr;
     // launches whatever the caller still holds back that the queued tasks read (the pipelined backward's pending source pass):
     // a flush in the middle of a pass -- more than kMaxReduceTasks / kMaxWgradTasks queued, i.e. six or more layers -- would
     // otherwise reduce partials and multiply rows that no kernel has written yet
     std::function<int()> before_flush;
-    const fn_adam_slice* rider = nullptr;   // fn_encoder.adam_rider: rides in the LAST deferred-reduction launch of the pass
+    fn_adam_slice* rider = nullptr;         // fn_encoder.adam_rider: rides in the LAST deferred-reduction launch of the pass
     int flush(bool last = false) {
         if (before_flush) { if (int rc = before_flush()) return rc; }
         if (int rc = flush_wgrad()) return rc;
@@ -4764,22 +4991,34 @@ struct ReduceQueue {
         if (T.n == 0 && R.nblk == 0) return 0;
         hipLaunchKernelGGL(k_reduce_tasks, dim3(blocks + R.nblk), dim3(1024), 0, st, T, R);
         T.n = 0;  blocks = 0;
-        return launch_status("deferred reductions");
+        const int rc = launch_status("deferred reductions");
+        if (rc == 0 && R.nblk > 0) rider->launched = 1;      // the caller's Adam launch may now skip the slice (fn_adam_slice.launched)
+        return rc;
     }
     int push(ReduceTask t, int nblk) {
         if (T.n == kMaxReduceTasks) { if (int rc = flush()) return rc; }
         t.first = blocks;  t.nblk = nblk;
         T.first[T.n] = blocks;
+        last_index = T.n;
         T.t[T.n++] = t;
         blocks += nblk;
         return 0;
     }
+    // room for `tasks` more reductions and one more product in every group WITHOUT a flush in between: a deferred level's finalize
+    // task and its weight-gradient product must leave in the same pair of launches (the first reads what the second's partner wrote)
+    int reserve(int tasks) {
+        if (T.n + tasks > kMaxReduceTasks || W.n == kMaxWgradTasks || W0.n == kMaxWgradTasks) return flush();
+        return 0;
+    }
+    // up != null: the deferred form (ReduceTask::up); n_up is filled in when the level's weight-gradient product is queued (wgrad below)
     int finalize(const float* part_a, int n_a, const float* part_e, int n_e, const fn_edge_term& et, const float* att, int att_w,
-                 int dst_off, int src_off, float* g_att, float* g_embW, float* g_embb, int H) {
+                 int dst_off, int src_off, float* g_att, float* g_embW, float* g_embb, int H, const float* up = nullptr,
+                 const float* upW = nullptr, const float* upb = nullptr, int upK = 0) {
         ReduceTask t{};
         t.kind = RT_FINALIZE;  t.H = H;  t.p0 = part_a;  t.n0 = n_a;  t.p1 = part_e;  t.n1 = n_e;  t.et = et;
         t.att = att;  t.att_w = att_w;  t.dst_off = dst_off;  t.src_off = src_off;  t.o0 = g_att;  t.o1 = g_embW;  t.o2 = g_embb;
-        return push(t, 2 * FN_D / 32 + (et.mode == 2 ? 1 : 0));
+        t.up = up;  t.upW = upW;  t.upb = upb;  t.upK = upK;  t.n_up = 0;
+        return push(t, 2 * FN_D / 32 + (et.mode == 2 ? 1 : 0) + (up ? 4 : 0));
     }
     int colsum(const float* part, int n_rows, int cols, float* out, int ld, int off) {
         ReduceTask t{};
@@ -4788,8 +5027,12 @@ struct ReduceQueue {
         return push(t, cols / 32);
     }
     // dW [128,K], db [128] of a projection: partial kernel now (on `launch_on`), reduction with the rest
+    // gsd != null: the deferred term (WgradTask::gsd ..); fin: index in T of the level's RT_FINALIZE task (queued just before, reserve())
     int wgrad(const float* dY, const float* X, int K, int64_t M, float* ws, float* dW, float* db, hipStream_t launch_on,
-              const int32_t* n_real = nullptr) {
+              const int32_t* n_real = nullptr, const float* gsd = nullptr, const float* a_dst = nullptr, int att_w = 0, float* upart = nullptr,
+              int fin = -1) {
+        if (gsd && !(defer_wgrad && (K == FN_D ? g_tune[FN_TUNE_WGRAD_DIRECT] != 0 : (defer_mixed && K <= 192))))
+            return fail(FN_EUNSUPPORTED, "weight gradient: the deferred term needs the grouped direct kernels");
         if (M == 0) {
             hipLaunchKernelGGL(k_zero2_i32, dim3(flat_grid(128 * (K + 1), kGridCap)), dim3(kBlock), 0, launch_on,
                                reinterpret_cast<int32_t*>(dW), (int64_t)128 * K, reinterpret_cast<int32_t*>(db), (int64_t)128);
@@ -4799,7 +5042,8 @@ struct ReduceQueue {
         int grid = 0;
         if (K == FN_D && defer_wgrad) {   // partial product joins the grouped launch in flush(); its block count is set there
             if (W.n == kMaxWgradTasks || T.n == kMaxReduceTasks) { if (int rc = flush()) return rc; }
-            W.t[W.n] = WgradTask{dY, X, ws, M, 0, 0, 0, n_real};
+            W.t[W.n] = WgradTask{dY, X, ws, M, 0, 0, 0, n_real, gsd, a_dst, att_w, upart};
+            w_fin[W.n] = gsd ? fin : -1;
             w_reduce[W.n++] = T.n;
             t.cls = g_tune[FN_TUNE_WGRAD_DIRECT] ? 4 : 2;
         } else if (defer_wgrad && defer_mixed && K <= 192) {      // layer 0's products: one launch for them too (flush_wgrad)
@@ -4812,7 +5056,8 @@ struct ReduceQueue {
             const int mult = std::max(1, K > FN_D ? tv / 10 : tv % 10);          // tens: the wide product (atoms), units: the narrow ones
             const int rpb = wgrad_rows_per_block(M) * mult;
             grid = (int)((M + rpb - 1) / rpb);
-            W0.t[W0.n++] = WgradTask{dY, X, ws, M, rpb, w0blocks, K, n_real};
+            W0.t[W0.n++] = WgradTask{dY, X, ws, M, rpb, w0blocks, K, n_real, gsd, a_dst, att_w, upart};
+            if (gsd && fin >= 0) T.t[fin].n_up = grid;
             w0blocks += grid;
             t.cls = K <= 32 ? 1 : K <= 128 ? 2 : 3;              // the instantiation k_linear128_wgrad_mixed runs for this K
         } else if (int rc = wgrad_partials(dY, X, K, M, ws, launch_on, &grid, &t.cls)) return rc;
@@ -4842,6 +5087,7 @@ struct ReduceQueue {
                 t.first = wblocks;
                 const int grid = (int)((t.M + t.rpb - 1) / t.rpb);
                 T.t[w_reduce[i]].n0 = grid;
+                if (w_fin[i] >= 0) T.t[w_fin[i]].n_up = grid;
                 wblocks += grid;
             }
             W.K = FN_D;
@@ -4873,6 +5119,7 @@ struct ReduceQueue {
             t.first = wblocks;
             const int grid = (int)((t.M + t.rpb - 1) / t.rpb);
             T.t[w_reduce[i]].n0 = grid;
+            if (w_fin[i] >= 0) T.t[w_fin[i]].n_up = grid;
             wblocks += grid;
         }
         W.K = FN_D;
@@ -4960,7 +5207,10 @@ static int launch_lin_rd(LinTasks& T, const RowDotsBwdArgs& R, hipStream_t st, b
             return 0;
         }
         if (!aligned) return fail(FN_EINVAL, "input-gradient products: operands must be 16-byte aligned");
-        hipLaunchKernelGGL(k_lin_rd_cu, dim3(blocks + R.nblk), dim3(kBlock), kLinSideLds, st, T, R);
+        bool gs = false;
+        for (int i = 0; i < T.n; ++i) gs = gs || T.t[i].gs.dz != nullptr;
+        if (gs) hipLaunchKernelGGL(k_lin_rd_cu<true>, dim3(blocks + R.nblk), dim3(kBlock), kLinSideLdsGs, st, T, R);
+        else hipLaunchKernelGGL(k_lin_rd_cu<false>, dim3(blocks + R.nblk), dim3(kBlock), kLinSideLds, st, T, R);
         return launch_status("input-gradient products (+ row dots) + edge-term backward");
     }
     if (!live || !aligned || R.nblk == 0) {
@@ -5262,7 +5512,9 @@ int launch_tail_bwd(const fn_encoder* e, const LayerActs& a, const fn_layer_weig
     else if (H == 4) hipLaunchKernelGGL((k_tail_bwd<4>), grid, dim3(kBlock), 0, st, T, R);
     else hipLaunchKernelGGL((k_tail_bwd<8>), grid, dim3(kBlock), 0, st, T, R);
     *n_part = (int)e->n_mols;
-    return launch_status("fragment tail backward, molecule-resident (gates + fragment graph + scatter to atoms)");
+    const int rc = launch_status("fragment tail backward, molecule-resident (gates + fragment graph + scatter to atoms)");
+    if (rc == 0 && R.nblk > 0) e->adam_rider->launched = 1;
+    return rc;
 }
 
 
@@ -5297,6 +5549,7 @@ int encoder_backward_one(const fn_encoder* e, const EncLayout& lay, const BwdLay
     const int64_t one_total = g_tune[FN_TUNE_ONE_BLOCKS] > 0 ? g_tune[FN_TUNE_ONE_BLOCKS] : 768;
     const int32_t* rr = pad_skip_on(e) ? reinterpret_cast<const int32_t*>(lay.real_rows) : nullptr;
     const int32_t *nr_atoms = rr, *nr_bonds = rr ? rr + 1 : nullptr, *nr_conns = rr ? rr + 3 : nullptr;
+    const bool df = defer_on(e);
     auto one_level = [&](const float* g_out, const float* h, const float* p_sorted, const fn_edge_term& et, const float* att, int att_w,
                          int src_off, const fn_gat_plan& pl, const LevelScratch& sc, float* g_s_orig, int* n_a, int* n_e, GatBwdOneArgs* A,
                          int64_t rows_in_launch) -> int {
@@ -5306,7 +5559,15 @@ int encoder_backward_one(const fn_encoder* e, const EncLayout& lay, const BwdLay
                                 sc.part_a, n_a, sc.part_e, n_e, H, A, share));
         A->p_edge_major = 1;
         A->n_real = &pl == &e->bond ? nr_bonds : (&pl == &e->atom ? nr_atoms : nr_conns);
+        if (df) A->dz_em = sc.dz_em;                        // the deferred form: dz at destination-order slots, no g_s_dst read
         return 0;
+    };
+    // the deferred term of a level's g_h rows, for the product that reads them / the weight-gradient kernels (null: not deferred)
+    struct DeferTerm { const float* dz; const float* gsd_c; GsdEpi gs; const float* a_dst; int att_w; };
+    // z: the projection's slot in EncLayout::rmat (3 l + {0: bond, 1: atom, 2: fragment bond}; layer 0 has no product)
+    auto gs_of = [&](const fn_gat_plan& pl, const LevelScratch& sc, const float* att, int att_w, int z) {
+        if (!df || pl.m <= 0) return DeferTerm{nullptr, nullptr, GsdEpi{nullptr, nullptr, 0, nullptr, nullptr}, nullptr, 0};
+        return DeferTerm{sc.dz_em, sc.g_s_dst, GsdEpi{sc.dz_em, pl.rowptr_d, pl.pos_base_d, lay.rmat + (size_t)z * 512, sc.g_s_dst}, att, att_w};
     };
 
     bool have_atoms = false, have_bond = false, have_fbond = false;       // g_pre_* of the CURRENT layer complete, dots written
@@ -5386,6 +5647,7 @@ int encoder_backward_one(const fn_encoder* e, const EncLayout& lay, const BwdLay
         if (have_atoms && !tail_dots_atoms) cu_add(cu_now, bw.g_pre_atoms, lay.atoms_new, a.o2_atom, a.sg_atom, bw.atom[l], e->N);
     }
 
+    GsdSegTasks seg0{};       // deferred form: layer 0's levels have no input-gradient product to form g_s_dst in: k_gsd_seg at the end
     bool pend_b = false, pend_fb = false;        // bond / fragment-bond level of layer l+1: gradient rows and dots ready, pass not launched
     for (int l = NL - 1; l >= 0; --l) {
         const fn_layer_weights& w = e->w[l];
@@ -5416,11 +5678,12 @@ int encoder_backward_one(const fn_encoder* e, const EncLayout& lay, const BwdLay
         LinTasks T{};
         CuTasks cu_after{};       // rows finished in L2 whose dots the epilogue could not write
         auto product = [&](const float* gh, const float* W, const float* Wt, float* gy, int64_t rows, const fn_act_epilogue& mk, const RowAdd* ra,
-                           const CuEpi& cu, const int32_t* n_real) {
+                           const CuEpi& cu, const int32_t* n_real, const GsdEpi& gs) {
             LinTask& t = T.t[T.n++];
             t = LinTask{Wt, gh, W, nullptr, gy, rows, mk, NodeScalarEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0}, 0, 0};
             if (ra) t.ra = *ra;
             t.cu = cu;
+            t.gs = gs;
             t.n_real = n_real;
         };
         bool nxt_bond = false, nxt_fbond = false, nxt_atoms = false;
@@ -5430,14 +5693,17 @@ int encoder_backward_one(const fn_encoder* e, const EncLayout& lay, const BwdLay
             const fn_layer_weights& wn = e->w[l + 1];
             const fn_layer_weights& gn = grads[l + 1];
             const LevelScratch& sb = bw.bond[l + 1];
-            FN_TRY(rq.finalize(sb.part_a, na_b, sb.part_e, ne_b, et_bond(wn), wn.a_b, 3 * d, 0, 2 * d, gn.a_b, gn.emb_b_w, gn.emb_b_b, H));
-            FN_TRY(rq.wgrad(sb.g_h, a.y_bond, FN_D, e->E, sb.wg_ws, gn.proj_b_w, gn.proj_b_b, hs, nr_bonds));
+            const DeferTerm gsb = gs_of(e->bond, sb, wn.a_b, 3 * d, 3 * (l + 1));
+            FN_TRY(rq.reserve(2));
+            FN_TRY(rq.finalize(sb.part_a, na_b, sb.part_e, ne_b, et_bond(wn), wn.a_b, 3 * d, 0, 2 * d, gn.a_b, gn.emb_b_w, gn.emb_b_b, H,
+                               gsb.dz ? sb.upart : nullptr, wn.proj_b_w, wn.proj_b_b, FN_D));
+            FN_TRY(rq.wgrad(sb.g_h, a.y_bond, FN_D, e->E, sb.wg_ws, gn.proj_b_w, gn.proj_b_b, hs, nr_bonds, gsb.gsd_c, gsb.a_dst, gsb.att_w, sb.upart, rq.last_index));
             const fn_act_epilogue mk{const_cast<float*>(a.y_bond), p, 1, e->seed, rng.y[l][2], e->offset_dev};
             const RowAdd ra{sa.dz, w.a + d, wide};
             // the rows are complete in this epilogue unless the edge term's rows' part is added behind the product (no RowAdd carrier)
             const bool complete = rd_rows_ride || gr == 0;
             const CuEpi cu{a.new_bond, a.o2_bond, a.sg_bond, complete ? bw.bond[l].cdot : nullptr, bw.bond[l].g_s_dst, H};
-            product(sb.g_h, wn.proj_b_w, lay.bt + (size_t)(3 * (l + 1)) * 192 * FN_D, bw.g_pre_bond, e->E, mk, rd_rows_ride ? &ra : nullptr, cu, nr_bonds);
+            product(sb.g_h, wn.proj_b_w, lay.bt + (size_t)(3 * (l + 1)) * 192 * FN_D, bw.g_pre_bond, e->E, mk, rd_rows_ride ? &ra : nullptr, cu, nr_bonds, gsb.gs);
             if (!complete) cu_add(cu_after, bw.g_pre_bond, a.new_bond, a.o2_bond, a.sg_bond, bw.bond[l], e->E);
             nxt_bond = true;
         }
@@ -5445,23 +5711,34 @@ int encoder_backward_one(const fn_encoder* e, const EncLayout& lay, const BwdLay
             const fn_layer_weights& wn = e->w[l + 1];
             const fn_layer_weights& gn = grads[l + 1];
             const LevelScratch& sfb = bw.fbond[l + 1];
-            FN_TRY(rq.finalize(sfb.part_a, na_fb, sfb.part_e, ne_fb, et_fbond(wn), wn.f_a_b, 3 * d, 0, 2 * d, gn.f_a_b, gn.emb_fb_w, gn.emb_fb_b, H));
-            FN_TRY(rq.wgrad(sfb.g_h, a.y_fbond, FN_D, e->EF, sfb.wg_ws, gn.proj_fb_w, gn.proj_fb_b, hs, nr_conns));
+            const DeferTerm gsf = gs_of(e->fbond, sfb, wn.f_a_b, 3 * d, 3 * (l + 1) + 2);
+            FN_TRY(rq.reserve(2));
+            FN_TRY(rq.finalize(sfb.part_a, na_fb, sfb.part_e, ne_fb, et_fbond(wn), wn.f_a_b, 3 * d, 0, 2 * d, gn.f_a_b, gn.emb_fb_w, gn.emb_fb_b, H,
+                               gsf.dz ? sfb.upart : nullptr, wn.proj_fb_w, wn.proj_fb_b, FN_D));
+            FN_TRY(rq.wgrad(sfb.g_h, a.y_fbond, FN_D, e->EF, sfb.wg_ws, gn.proj_fb_w, gn.proj_fb_b, hs, nr_conns, gsf.gsd_c, gsf.a_dst, gsf.att_w, sfb.upart, rq.last_index));
             const fn_act_epilogue mk{const_cast<float*>(a.y_fbond), p, 1, e->seed, rng.y[l][3], e->offset_dev};
             // this layer's fragment-bond rows get gradient through relu(dropout(.)) only (the fragment graph's edge term exists in the
             // last layer alone): the gate's saved output stands in for the raw row
             const CuEpi cu{nullptr, a.o2_fbond, a.sg_fbond, bw.fbond[l].cdot, bw.fbond[l].g_s_dst, H};
-            product(sfb.g_h, wn.proj_fb_w, lay.bt + (size_t)(3 * (l + 1) + 2) * 192 * FN_D, bw.g_pre_fbond, e->EF, mk, nullptr, cu, nr_conns);
+            product(sfb.g_h, wn.proj_fb_w, lay.bt + (size_t)(3 * (l + 1) + 2) * 192 * FN_D, bw.g_pre_fbond, e->EF, mk, nullptr, cu, nr_conns, gsf.gs);
             nxt_fbond = true;
         }
         RowDotsBwdArgs R{};
         if (have_atoms) {
-            FN_TRY(rq.finalize(sa.part_a, na_a, nullptr, 0, et_a, w.a, wide, 0, d + FN_D, g.a, nullptr, nullptr, H));
-            FN_TRY(rq.wgrad(sa.g_h, in_atoms, ka, e->N, sa.wg_ws, g.proj_a_w, g.proj_a_b, hs, nr_atoms));
+            const DeferTerm gsa = gs_of(e->atom, sa, w.a, wide, 3 * l + 1);
+            // (layer 0 has no input-gradient product to form g_s_dst in: k_gsd_seg at the end of the pass, which also leaves dL/da_dst)
+            const bool seg_a = gsa.dz && l == 0 && na_a > 0;
+            if (seg_a) seg0.t[seg0.n++] = GsdSegTask{sa.dz_em, e->atom.rowptr_d, e->atom.pos_base_d, e->N, sa.g_s_dst, nr_atoms, a.h_a, sa.part_a, 0, na_a};
+            const bool up_a = gsa.dz && !seg_a;
+            FN_TRY(rq.reserve(2));
+            FN_TRY(rq.finalize(sa.part_a, na_a, nullptr, 0, et_a, w.a, wide, 0, d + FN_D, g.a, nullptr, nullptr, H,
+                               up_a ? sa.upart : nullptr, w.proj_a_w, w.proj_a_b, ka));
+            FN_TRY(rq.wgrad(sa.g_h, in_atoms, ka, e->N, sa.wg_ws, g.proj_a_w, g.proj_a_b, hs, nr_atoms, gsa.gsd_c, gsa.a_dst, gsa.att_w,
+                            up_a ? sa.upart : nullptr, rq.last_index));
             if (l) {
                 const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_atoms), p, 1, e->seed, rng.y[l - 1][0], e->offset_dev};
                 const CuEpi cu{nullptr, lay.L[l - 1].o2_atom, lay.L[l - 1].sg_atom, bw.atom[l - 1].cdot, bw.atom[l - 1].g_s_dst, H};
-                product(sa.g_h, w.proj_a_w, lay.bt + (size_t)(3 * l + 1) * 192 * FN_D, bw.g_pre_atoms, e->N, mk, nullptr, cu, nr_atoms);
+                product(sa.g_h, w.proj_a_w, lay.bt + (size_t)(3 * l + 1) * 192 * FN_D, bw.g_pre_atoms, e->N, mk, nullptr, cu, nr_atoms, gsa.gs);
                 nxt_atoms = true;
             }
             // the edge term <new_bond[e], a[:, d:d+128]> of the atom graph: parameter partials always; the rows' term (dL/dnew_bond)
@@ -5510,13 +5787,30 @@ int encoder_backward_one(const fn_encoder* e, const EncLayout& lay, const BwdLay
         if (pend_b) FN_TRY(one_level(bw.g_pre_bond, lay.L[0].h_b, lay.L[0].p_bond, et_bond(w0), w0.a_b, 3 * d, 2 * d, e->bond, bw.bond[0], nullptr, &na_b, &ne_b, &oB, rows_l1));
         if (pend_fb) FN_TRY(one_level(bw.g_pre_fbond, lay.L[0].h_fb, lay.L[0].p_fbond, et_fbond(w0), w0.f_a_b, 3 * d, 2 * d, e->fbond, bw.fbond[0], nullptr, &na_fb, &ne_fb, &oFB, rows_l1));
         FN_TRY(launch_gat_bwd_one3(oB, GatBwdOneArgs{}, oFB, H, hs));
+        const DeferTerm gsb = gs_of(pend_b ? e->bond : fn_gat_plan{}, bw.bond[0], w0.a_b, 3 * d, 0);
+        const DeferTerm gsf = gs_of(pend_fb ? e->fbond : fn_gat_plan{}, bw.fbond[0], w0.f_a_b, 3 * d, 2);
+        if (gsb.dz && na_b > 0) seg0.t[seg0.n++] = GsdSegTask{gsb.dz, e->bond.rowptr_d, e->bond.pos_base_d, e->E, bw.bond[0].g_s_dst, nr_bonds, lay.L[0].h_b, bw.bond[0].part_a, 0, na_b};
+        if (gsf.dz && na_fb > 0) seg0.t[seg0.n++] = GsdSegTask{gsf.dz, e->fbond.rowptr_d, e->fbond.pos_base_d, e->EF, bw.fbond[0].g_s_dst, nr_conns, lay.L[0].h_fb, bw.fbond[0].part_a, 0, na_fb};
+        if (seg0.n) {         // g_s_dst and dL/da_dst of layer 0's levels (the inner layers' come out of their products' epilogues and the
+            int blocks = 0;   // weight-gradient kernels' side product): one small launch, a block per block of the level's pass
+            for (int i = 0; i < seg0.n; ++i) {
+                seg0.t[i].first = blocks;
+                blocks += seg0.t[i].nblk;
+            }
+            hipLaunchKernelGGL(k_gsd_seg, dim3(blocks), dim3(kBlock), 0, hs, seg0);
+            FN_TRY(launch_status("one-pass backward, deferred form: g_s_dst of layer 0"));
+        }
         if (pend_b) {
+            FN_TRY(rq.reserve(2));
             FN_TRY(rq.finalize(bw.bond[0].part_a, na_b, bw.bond[0].part_e, ne_b, et_bond(w0), w0.a_b, 3 * d, 0, 2 * d, g0.a_b, g0.emb_b_w, g0.emb_b_b, H));
-            FN_TRY(rq.wgrad(bw.bond[0].g_h, e->bond_nodes, e->k_bond0, e->E, bw.bond[0].wg_ws, g0.proj_b_w, g0.proj_b_b, hs, nr_bonds));
+            FN_TRY(rq.wgrad(bw.bond[0].g_h, e->bond_nodes, e->k_bond0, e->E, bw.bond[0].wg_ws, g0.proj_b_w, g0.proj_b_b, hs, nr_bonds,
+                            gsb.gsd_c, gsb.a_dst, gsb.att_w, nullptr, -1));
         }
         if (pend_fb) {
+            FN_TRY(rq.reserve(2));
             FN_TRY(rq.finalize(bw.fbond[0].part_a, na_fb, bw.fbond[0].part_e, ne_fb, et_fbond(w0), w0.f_a_b, 3 * d, 0, 2 * d, g0.f_a_b, g0.emb_fb_w, g0.emb_fb_b, H));
-            FN_TRY(rq.wgrad(bw.fbond[0].g_h, e->fbond_nodes, e->k_fbond0, e->EF, bw.fbond[0].wg_ws, g0.proj_fb_w, g0.proj_fb_b, hs, nr_conns));
+            FN_TRY(rq.wgrad(bw.fbond[0].g_h, e->fbond_nodes, e->k_fbond0, e->EF, bw.fbond[0].wg_ws, g0.proj_fb_w, g0.proj_fb_b, hs, nr_conns,
+                            gsf.gsd_c, gsf.a_dst, gsf.att_w, nullptr, -1));
         }
     }
     return rq.flush(true);
@@ -5605,7 +5899,17 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
         if (fuse_rd) {
             A.zp = lay.s_sorted;  A.zn = e->atom.m * H;  A.n_z = flat_grid(A.zn, 64);
         }
-        hipLaunchKernelGGL(k_enc_prologue, dim3(A.n_t + A.n_d + A.n_s[0] + A.n_s[1] + A.n_ss[0] + A.n_ss[1] + A.n_z + A.n_x), dim3(256), 0, S(st), A);
+        if (defer_on(e)) {        // R of every K = 128 projection (layers >= 1): slot 3 l + {0: bond, 1: atom, 2: fragment bond}
+            for (int l = 1; l < e->n_layers; ++l) {
+                const fn_layer_weights& wl = e->w[l];
+                A.rW[3 * l] = wl.proj_b_w;       A.rA[3 * l] = wl.a_b;        A.rAw[3 * l] = 3 * d;
+                A.rW[3 * l + 1] = wl.proj_a_w;   A.rA[3 * l + 1] = wl.a;      A.rAw[3 * l + 1] = wide;
+                A.rW[3 * l + 2] = wl.proj_fb_w;  A.rA[3 * l + 2] = wl.f_a_b;  A.rAw[3 * l + 2] = 3 * d;
+            }
+            A.rOut = lay.rmat;
+            A.n_r = 2 * 3 * e->n_layers;
+        }
+        hipLaunchKernelGGL(k_enc_prologue, dim3(A.n_t + A.n_d + A.n_s[0] + A.n_s[1] + A.n_ss[0] + A.n_ss[1] + A.n_z + A.n_x + A.n_r), dim3(256), 0, S(st), A);
         FN_TRY(launch_status("fn_encoder_forward: prologue"));
     }
 

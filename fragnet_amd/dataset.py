@@ -124,12 +124,22 @@ class FlatMolStore:
         # reading them back from the device was seven synchronisations per batch, each waiting for the training step enqueued
         # before it -- collate and step ran strictly one after the other (1.75 ms per step where the step alone is 0.78)
         totals = {}
+        idx = None
         if dev.type == "cuda" and not (torch.is_tensor(indices) and indices.is_cuda):
             host_idx = torch.as_tensor(indices, dtype=torch.long)
-            if host_idx.numel():
-                lens = self._host_lengths()
-                ix = host_idx.numpy()          # numpy, not torch: a CPU gather of 8192 elements goes through torch's thread pool, and
-                totals = {space: int(lens[space][ix].sum()) for space in _COUNT_OF}      # waking it cost up to 90 ms a batch beside the GPU work
+            if host_idx.numel() == 0:
+                raise ValueError("collate: empty batch")
+            lens = self._host_lengths()
+            ix = host_idx.numpy()          # numpy, not torch: a CPU gather of 8192 elements goes through torch's thread pool, and
+            # (numpy would wrap a negative index round to the store's end -- offs[-1] is the total row count -- and the kernel
+            # would then read past every store tensor; the torch path below raised for it, so does this one)
+            if int(ix.min()) < 0 or int(ix.max()) >= len(self):
+                raise IndexError(f"collate: molecule index out of range for a store of {len(self)} molecules")
+            totals = {space: int(lens[space][ix].sum()) for space in _COUNT_OF}      # waking it cost up to 90 ms a batch beside the GPU work
+            if FUSED_COLLATE:
+                fused = self._collate_fused(ix, pretrain)      # reads the host indices only: nothing is uploaded for it
+                if fused is not None:
+                    return fused
             # through pinned memory (torch's caching host allocator): an asynchronous copy from pageable memory of 64 KB and more
             # is pinned on the fly by the runtime, ~100 ms a time with a 66-GB store mapped (batches of 8192 molecules)
             idx = host_idx.pin_memory().to(dev, non_blocking=True)
@@ -137,10 +147,6 @@ class FlatMolStore:
             idx = torch.as_tensor(indices, dtype=torch.long, device=dev)
         if idx.numel() == 0:
             raise ValueError("collate: empty batch")
-        if totals and FUSED_COLLATE:
-            fused = self._collate_fused(ix, idx, pretrain)
-            if fused is not None:
-                return fused
         rows, length, seg = {}, {}, {}
         for space in _COUNT_OF:
             rows[space], length[space], seg[space] = _ragged_rows(self.off[space], idx, totals.get(space))
@@ -202,7 +208,7 @@ class FlatMolStore:
                   "edge_index_bonds_graph": ("edge_index_bonds", "bedge", "edge"), "edge_index_fbonds": ("edge_index_fbondg", "fbedge", "fedge"),
                   "atom_to_frag_ids": ("atom_id_frag_id", "atom", "frag")}
 
-    def _collate_fused(self, ix, idx, pretrain: bool):
+    def _collate_fused(self, ix, pretrain: bool):
         """The whole batch in ONE launch (fn_collate_store): the batch's offsets table and the molecules' first store rows are built
         on the host from the store's lengths (numpy, microseconds) and copied over in two small transfers; None when a tensor of
         the store is not laid out the way the kernel reads it (the torch path below then builds the batch)."""

@@ -136,12 +136,16 @@ class _EncoderFn(torch.autograd.Function):
         scratch = torch.empty(lib.fn_encoder_bwd_ws_floats(C.byref(e)), dtype=torch.float32, device=dev)
         rider = take_adam_rider()                # an optimiser slice that rides in this pass's last launch (arm_adam_rider)
         e.adam_rider = None if rider is None else C.addressof(rider)
+        if rider is not None:
+            rider.launched = 0
         try:
             _lib.check(lib.fn_encoder_backward(C.byref(e), *(o.data_ptr() for o in outs),
                                                *(None if g is None else g.data_ptr() for g in gs), gw, scratch.data_ptr(),
                                                scratch.numel(), _stream_ptr(dev)), "fn_encoder_backward")
         finally:
             e.adam_rider = None
+            if rider is not None:
+                _ADAM_RIDER[1] = bool(rider.launched)        # the library's word that a launch carried the slice, not ours that we offered it
         e.g_pooled = None
         out = []
         have_frags = gs[1] is not None or g_pooled is not None
@@ -161,7 +165,7 @@ _ADAM_RIDER = [None, False]       # [armed fn_adam_slice, was it handed to a bac
 
 
 def arm_adam_rider(slice_struct) -> None:
-    """The next encoder backward pass on this thread carries ``slice_struct`` (``_lib.AdamSlice``: parameters whose gradients are
+    """The next encoder backward pass of this process carries ``slice_struct`` (``_lib.AdamSlice``: parameters whose gradients are
     complete before that pass starts) in its last launch.  The caller checks ``adam_rider_taken()`` afterwards and updates
     whatever did not ride itself (graphstep.GraphedTrainStep)."""
     _ADAM_RIDER[0], _ADAM_RIDER[1] = slice_struct, False
@@ -170,12 +174,13 @@ def arm_adam_rider(slice_struct) -> None:
 def take_adam_rider():
     r = _ADAM_RIDER[0]
     if r is not None:
-        _ADAM_RIDER[0], _ADAM_RIDER[1] = None, True
+        _ADAM_RIDER[0], _ADAM_RIDER[1] = None, False
     return r
 
 
 def adam_rider_taken() -> bool:
-    """True if the armed slice rode in a backward pass; disarms either way."""
+    """True if a launch of a backward pass carried the armed slice (fn_adam_slice.launched, set by fn_encoder_backward); disarms
+    either way.  The state is per process (one training step at a time), not per thread."""
     taken = _ADAM_RIDER[1]
     _ADAM_RIDER[0], _ADAM_RIDER[1] = None, False
     return taken

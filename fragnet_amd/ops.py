@@ -101,7 +101,8 @@ class _GatLevel(torch.autograd.Function):
         p_sorted = torch.empty((heads, m), dtype=torch.float32, device=dev)      # head-major
         probs = torch.empty((m, heads), dtype=torch.float32, device=dev) if want_probs else None
         # the one-pass backward (fn_gat_bwd_one_f32) needs the forward's second output row and its per-head weight sum
-        one = BWD_ONE_PASS and any(ctx.needs_input_grad)
+        # (levels beyond the one-pass kernel's 32-bit byte offsets keep the destination + source passes)
+        one = BWD_ONE_PASS and any(ctx.needs_input_grad) and n <= (1 << 23) and m * heads <= (1 << 28)
         out2 = torch.empty((n, FN_D), dtype=torch.float32, device=dev) if one else None
         sigma = torch.empty((n, heads), dtype=torch.float32, device=dev) if one else None
         _lib.call("fn_gat_fwd_f32", h.data_ptr(), s_dst.data_ptr(), s_src.data_ptr(), att.data_ptr(), att_w,

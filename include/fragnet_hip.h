@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FN_ABI_VERSION 10
+#define FN_ABI_VERSION 11
 #define FN_D 128              /* feature width of every node table on the path (emb_dim) */
 #define FN_MAX_TASKS 16       /* CSR builds fused into one fn_plan_build call */
 #define FN_MAX_EDGE_K 8       /* widest raw edge attribute folded in-kernel (6 for fragment bonds) */
@@ -118,7 +118,12 @@ int fn_abi_version(void);
 #define FN_TUNE_RIDER_AT 28           /* which launch of the one-pass encoder backward carries fn_encoder.adam_rider: 0 (default) the last one (the
                                        * deferred reductions: + 7 us there for the 12.9 - 4.5 us the step's Adam launch saves), 1 the first one (the
                                        * molecule-resident fragment tail, when it runs: + 11.7 us) */
-#define FN_TUNE_COUNT 29
+#define FN_TUNE_DEFER_GSD 29           /* 1 (default): with the one-pass backward and four heads (gat2) the forward writes NO second output: the pass
+                                       * leaves dz at the edges' destination-order slots and the terms that need g_s_dst = the sum of a row's
+                                       * segment are added by whoever reads g_h next -- the input-gradient product's epilogue (rank-4 update of its
+                                       * output rows), the weight-gradient kernels (their dY operand; side product U = G^T X for dL/da_dst).
+                                       * 0: out2 / sigma in the forward, <g, out2> in the producers' epilogues (round 4) */
+#define FN_TUNE_COUNT 30
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * workgroups 64-bit words) is
  * set, every workgroup of the molecule-resident backward (FN_TUNE_BWD_MOL) writes s_memtime stamps of its phases into it
@@ -659,6 +664,9 @@ typedef struct fn_adam_slice {
     int64_t n;                       /* elements; p, g, m, v 16-byte aligned */
     const float* lr_dev;  const int64_t* step_dev;
     float beta1, beta2, eps, weight_decay;
+    int32_t launched, pad_;          /* OUT (fn_encoder.adam_rider only): set to 1 by fn_encoder_backward once the launch that carries
+                                      * the slice has been enqueued; the caller clears it before the call and updates the slice itself
+                                      * when it is still 0 afterwards (ABI 11) */
 } fn_adam_slice;
 
 typedef struct fn_encoder {
@@ -710,7 +718,7 @@ typedef struct fn_encoder {
      * gradients were complete before this backward pass began -- the prediction head's -- rides in the pass's last launch (the
      * deferred reductions), independent of everything that launch reduces.  The caller's own Adam launch then covers the rest
      * (torch.optim.Adam is element-wise: finetune_gat2.py:257).  ABI 10. */
-    const struct fn_adam_slice* adam_rider;
+    struct fn_adam_slice* adam_rider;
 } fn_encoder;
 
 int fn_encoder_fused_tail(const fn_encoder* e);      /* 1: fn_encoder_forward / _backward run the fused fragment tail */

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in fragnet_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
-    assert lib.fn_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.fn_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_plan_layout_is_host_side_and_validates():
