@@ -129,9 +129,10 @@ def _physical_cores():
 
 def cpu_baseline(budget_s=150.0):
     """The oracle's full training step (reference-faithful materialised form, oracle/fragnet_ref.py) on this host's cores, on the
-    metric's own batch: ESOL-shape, 512 molecules.  BASELINE.md section 3: 2 warm-up + 5 timed steps at all PHYSICAL cores and at
-    one thread; `value` is the faster of the two, `cores` the threads it used.  The leg is bounded (budget_s): a thread count whose
-    seven steps do not fit reports the timed steps it did."""
+    metric's own batch: ESOL-shape, 512 molecules.  BASELINE.md section 3: warm-up + up to 5 timed steps at all PHYSICAL cores, at 32,
+    at 8 and at one thread (torch's intra-op threading loses to a single core at all cores on this memory-bound path: the counts in
+    between say where the best is); `value` is the fastest count's median, `cores` the threads it used.  The leg is bounded
+    (budget_s, shared out evenly): a thread count whose steps do not fit reports the timed steps it did."""
     from fragnet_amd import data, synth
     from oracle import fragnet_ref as ref
     torch.manual_seed(0)
@@ -149,7 +150,10 @@ def cpu_baseline(budget_s=150.0):
     default_threads, phys = torch.get_num_threads(), _physical_cores()
     batch = data.collate_fn(synth.synth_molecules(PER_GPU_BATCH, seed=1000, profile="esol"))
     runs = {}
-    for threads, share in ((phys, 0.55), (1, 1.0)):          # the one-thread steps are the long ones: they get what is left
+    counts = sorted({c for c in (phys, 32, 8, 1) if 1 <= c <= phys}, reverse=True)
+    shares = {c: (i + 1) / len(counts) for i, c in enumerate(counts)}        # cumulative share of the time bound each count may use up
+    for threads in counts:
+        share = shares[threads]
         torch.set_num_threads(threads)
         stop_at = t_all + budget_s * share
         t0 = time.perf_counter()
@@ -172,14 +176,16 @@ def cpu_baseline(budget_s=150.0):
     return {"value": best["molecules_per_s"], "unit": "molecules/s", "cores": best["threads"], "kind": "port",
             "timed_steps": best["timed_steps"],
             "sample": f"full training steps (forward + MSE + backward + Adam) of ONE ESOL-shape batch of {PER_GPU_BATCH} molecules, the metric's own "
-                      f"workload: at {phys} threads (= physical cores) and at 1 thread, up to 2 warm-up + 5 timed steps each inside a "
-                      f"{budget_s:.0f}-s bound (see `runs` for what fitted); value = the faster thread count's median; "
+                      f"workload: at {', '.join(str(c) for c in counts)} threads ({phys} = physical cores), up to 2 warm-up + 5 timed steps each "
+                      f"inside a {budget_s:.0f}-s bound shared out evenly (see `runs` for what fitted); value = the fastest thread count's median; "
                       f"oracle/fragnet_ref.py, torch {torch.__version__} CPU",
             "runs": runs, "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(), "physical_cores": phys}
 
 
-def kernel_roofline(batch, model, iters=50):
-    """Dominant scatter kernels at the bond-graph level, timed back to back with HIP events on the launch stream."""
+def kernel_roofline(batch, model, iters=50, alternatives=False):
+    """Dominant scatter kernels at the bond-graph level, timed back to back with HIP events on the launch stream: the forward and the
+    one-pass backward in the deferred form the engine runs (`k_gat_fwd`, `k_gat_bwd_one`).  ``alternatives`` (the dev loop,
+    --kernels-only): also round 4's form of the pair (second forward output + the dots kernel) and the general two-pass backward."""
     import ctypes as C
     from fragnet_amd import _lib
     from fragnet_amd.plan import GraphPlan, _stream_ptr
@@ -217,16 +223,21 @@ def kernel_roofline(batch, model, iters=50):
         _lib.call("fn_gat_bwd_src_f32", gout.data_ptr(), h.data_ptr(), pz.data_ptr(), g_s_dst.data_ptr(),
                   att.data_ptr(), 96, 0, 64, C.byref(lv.c), g_h.data_ptr(), part_a.data_ptr(), C.byref(n_a), H, st)
 
-    # the engine's default backward: ONE source-owner pass (csrc/gat_bwd_one.inc).  It needs the forward's second output (out2, sigma:
-    # `k_gat_fwd(+out2)` is that forward) and the two node-local dots c, g_s_dst, which inside the step ride in the epilogue of the
-    # input-gradient GEMM that produces the gradient rows; `k_gat_cu` is the stand-alone kernel for them (last layer / operator path)
+    # the engine's default backward: ONE source-owner pass in its deferred form (csrc/gat_bwd_one.inc, DF): the forward writes no second
+    # output; the pass reads the node-local dot c = <g, out> (inside the step: the epilogue of the input-gradient GEMM that produces the
+    # gradient rows) and leaves dz at the edges' destination-order slots for the consumers of g_h
     out2, sigma, p_em = torch.empty(n, 128, **f32), torch.empty(n, H, **f32), torch.empty(m, H, **f32)
     cdot, g_s_dst1, g_h1 = torch.empty(n, H, **f32), torch.empty(n, H, **f32), torch.empty(n, 128, **f32)
     part_e1, part_a1 = torch.empty(4096, H * 2, **f32), torch.empty(4096, 256, **f32)
+    dz_em = torch.empty(m, H, **f32)
     x_src = torch.empty(1, m, **f32)
     _lib.call("fn_sort_edge_attr_src_f32", batch["edge_attr_bonds"].contiguous().data_ptr(), 1, C.byref(lv.c), x_src.data_ptr(), st)
     et1 = _lib.EdgeTerm(2, 1, 32, 32, None, x.data_ptr(), embW.data_ptr(), embb.data_ptr(), x_src.data_ptr())
     n_e1, n_a1 = C.c_int(0), C.c_int(0)
+
+    def fwd_em():          # the training forward: probabilities edge-major, as the one-pass backward gathers them
+        _lib.call("fn_gat_fwd_f32", h.data_ptr(), s_dst.data_ptr(), s_src.data_ptr(), att.data_ptr(), 96, C.byref(et),
+                  C.byref(lv.c), 0.2, out.data_ptr(), p_em.data_ptr(), None, None, None, 1, None, H, st)
 
     def fwd_o2():
         _lib.call("fn_gat_fwd_f32", h.data_ptr(), s_dst.data_ptr(), s_src.data_ptr(), att.data_ptr(), 96, C.byref(et),
@@ -236,26 +247,27 @@ def kernel_roofline(batch, model, iters=50):
         _lib.call("fn_gat_cu_f32", gout.data_ptr(), out.data_ptr(), out2.data_ptr(), sigma.data_ptr(), 1.0, cdot.data_ptr(),
                   g_s_dst1.data_ptr(), n, H, st)
 
-    def bwd_one():
+    def bwd_one(deferred=True):
         _lib.call("fn_gat_bwd_one_f32", gout.data_ptr(), h.data_ptr(), p_em.data_ptr(), cdot.data_ptr(), g_s_dst1.data_ptr(), C.byref(et1),
                   att.data_ptr(), 96, 0, 64, C.byref(lv.c), 0.2, g_h1.data_ptr(), None, None, part_a1.data_ptr(), C.byref(n_a1),
-                  part_e1.data_ptr(), C.byref(n_e1), 1, H, st)
+                  part_e1.data_ptr(), C.byref(n_e1), 1, dz_em.data_ptr() if deferred else None, H, st)
 
     D = 128
     fwd_b, bwd_b = level_bytes(n, m, H, D)         # B_agg (forward), B_agg' (the WHOLE backward of the level)
-    # B_agg' counts g_out and h once.  The two passes both read them, so per-pass figures are only a split of B_agg' for
-    # orientation (dst pass: g_out, h, probs, idx -> dz, g_s_dst; src pass: the rest); the roofline uses the sum over both.
-    bwd_dst_b = 4 * (2 * n * D + m * H + m + m * H + n * H)
-    bwd_src_b = bwd_b - bwd_dst_b
     res = {}
     fwd_o2()
-    cu()
-    fwd()
-    # the dots kernel reads three row tables and writes two [n, H] tables (it is not part of B_agg': inside the step its work is the
-    # GEMM epilogue's); the +out2 forward is priced against the plain forward's B_agg
-    cu_b = 4 * (3 * n * D + n * H + 2 * n * H)
-    for name, fn, nbytes in (("k_gat_fwd", fwd, fwd_b), ("k_gat_fwd(+out2)", fwd_o2, fwd_b), ("k_gat_bwd_one", bwd_one, bwd_b),
-                             ("k_gat_cu", cu, cu_b), ("k_gat_bwd_dst", bwd_dst, bwd_dst_b), ("k_gat_bwd_src", bwd_src, bwd_src_b)):
+    cu()           # (cdot / g_s_dst hold real dots for every variant below)
+    runs = [("k_gat_fwd", fwd_em, fwd_b), ("k_gat_bwd_one", bwd_one, bwd_b)]
+    if alternatives:
+        # B_agg' counts g_out and h once.  The two passes both read them, so per-pass figures are only a split of B_agg' for
+        # orientation (dst pass: g_out, h, probs, idx -> dz, g_s_dst; src pass: the rest).  The dots kernel reads three row tables and
+        # writes two [n, H] tables (not part of B_agg').
+        bwd_dst_b = 4 * (2 * n * D + m * H + m + m * H + n * H)
+        cu_b = 4 * (3 * n * D + n * H + 2 * n * H)
+        fwd()
+        runs += [("k_gat_fwd(+out2)", fwd_o2, fwd_b), ("k_gat_bwd_one(round 4: reads g_s_dst)", lambda: bwd_one(False), bwd_b), ("k_gat_cu", cu, cu_b),
+                 ("k_gat_bwd_dst", bwd_dst, bwd_dst_b), ("k_gat_bwd_src", bwd_src, bwd_b - bwd_dst_b)]
+    for name, fn, nbytes in runs:
         for _ in range(5):
             fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -268,45 +280,11 @@ def kernel_roofline(batch, model, iters=50):
         us = a.elapsed_time(b) * 1000.0 / iters
         res[name] = {"us_per_launch": round(us, 2), "algorithmic_bytes": nbytes, "GBps": round(nbytes / us / 1e3, 1),
                      "n": n, "m": m}
-    # the single-pass alternative (csrc/mol_bwd.hip, off by default): same inputs, same bytes model -- reported beside the two passes
-    try:
-        from fragnet_amd._lib import SegPlan
-        seg = lambda q: SegPlan(q.rowptr.data_ptr(), q.perm.data_ptr(), q.index.data_ptr(), q.n_seg, q.n_items, q.pos_base, 0)
-        L = plan.levels
-        ext = torch.zeros(plan.n_mols, 16, dtype=torch.int32, device=dev)
-        _lib.call("fn_mol_extents", C.byref(seg(plan.segs["mol_atoms"])), C.byref(seg(plan.segs["mol_frags"])), C.byref(L["bond"].c),
-                  C.byref(L["atom"].c), C.byref(L["fbond"].c), C.byref(L["frag"].c), plan.n_mols, ext.data_ptr(), st)
-        g_h2, scratch = torch.empty(n, 128, **f32), torch.empty(H * m + n * H, **f32)
-        status, n_p = torch.zeros(1, dtype=torch.int32, device=dev), C.c_int(0)
-
-        def bwd_mol():
-            _lib.call("fn_gat_bwd_mol_f32", gout.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), C.byref(et), att.data_ptr(), 96, 0, 64,
-                      C.byref(lv.c), 0.2, ext.data_ptr(), plan.n_mols, 0, 1, None, g_h2.data_ptr(), None, part_a.data_ptr(),
-                      part_e.data_ptr(), C.byref(n_p), scratch.data_ptr(), status.data_ptr(), H, st)
-        extra = (("k_mol_bwd(single pass, FN_TUNE_BWD_MOL; not the default)", bwd_mol, bwd_b),)
-    except Exception as exc:      # noqa: BLE001 -- an A/B figure must never cost the measurement
-        extra = ()
-        print(f"[bench] k_mol_bwd A/B skipped ({type(exc).__name__}: {exc})", file=sys.stderr, flush=True)
-    for name, fn, nbytes in extra:
-        try:
-            for _ in range(5):
-                fn()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            a.record()
-            for _ in range(iters):
-                fn()
-            b.record()
-            torch.cuda.synchronize()
-            us = a.elapsed_time(b) * 1000.0 / iters
-            res[name] = {"us_per_launch": round(us, 2), "algorithmic_bytes": nbytes, "GBps": round(nbytes / us / 1e3, 1), "n": n, "m": m}
-        except Exception as exc:      # noqa: BLE001
-            print(f"[bench] {name} A/B failed ({type(exc).__name__}: {exc})", file=sys.stderr, flush=True)
-    us_bwd = res["k_gat_bwd_dst"]["us_per_launch"] + res["k_gat_bwd_src"]["us_per_launch"]
-    res["k_gat_bwd(dst+src)"] = {"us_per_launch": round(us_bwd, 2), "algorithmic_bytes": bwd_b, "GBps": round(bwd_b / us_bwd / 1e3, 1),
-                                 "n": n, "m": m}
+    if alternatives:
+        us_bwd = res["k_gat_bwd_dst"]["us_per_launch"] + res["k_gat_bwd_src"]["us_per_launch"]
+        res["k_gat_bwd(dst+src)"] = {"us_per_launch": round(us_bwd, 2), "algorithmic_bytes": bwd_b, "GBps": round(bwd_b / us_bwd / 1e3, 1),
+                                     "n": n, "m": m}
     return res
-
 
 def forward_sweep(rank, world, dev, args):
     """Forward-only (eval mode) molecules/s on synthetic 40-atom / 12-fragment molecules: every
@@ -735,7 +713,7 @@ def main():
         from fragnet_amd.model import FragNetFineTune
         torch.manual_seed(0)
         model = FragNetFineTune(**MODEL_CFG, variant=args.model_version).to(dev)
-        print(json.dumps(kernel_roofline(make_pool(1, rank, dev, args.kbatch)[0], model)))
+        print(json.dumps(kernel_roofline(make_pool(1, rank, dev, args.kbatch)[0], model, alternatives=True)))
         return
 
     # headline configuration: one GPU = the 512-molecule batch; N > 1 = the global batch of 512 sharded over the ranks
@@ -850,9 +828,9 @@ def main():
             # the roofline object is quoted on the metric's configuration: a full 512-molecule batch (a rank of a strong-scaling
             # job holds only its shard)
             roof_batch = head["pool0"] if head["local_batch"] == PER_GPU_BATCH else make_pool(1, 0, dev, PER_GPU_BATCH)[0]
-            kr = kernel_roofline(roof_batch, run.model)
             one_pass = not any(kv.replace(" ", "") == "22=0" for kv in (args.tune or []))       # FN_TUNE_BWD_ONE (the default)
-            fwd_k, bwd_k = ("k_gat_fwd(+out2)", "k_gat_bwd_one") if one_pass else ("k_gat_fwd", "k_gat_bwd(dst+src)")
+            kr = kernel_roofline(roof_batch, run.model, alternatives=not one_pass)
+            fwd_k, bwd_k = ("k_gat_fwd", "k_gat_bwd_one") if one_pass else ("k_gat_fwd", "k_gat_bwd(dst+src)")
             nb, mb = kr["k_gat_fwd"]["n"], kr["k_gat_fwd"]["m"]
             f1, b1 = level_bytes(nb, mb)
             sa_us = kr[fwd_k]["us_per_launch"] + kr[bwd_k]["us_per_launch"]
@@ -888,8 +866,6 @@ def main():
                     grids = sorted((g, v["avg_us"]) for g, v in cand.items() if v["calls"] * 10 >= most)
                     if grids:
                         t_b, bwd_name = grids[0][1], f"k_gat_bwd_one3@{grids[0][0]} workgroups (layer 0: bond + fragment-bond levels)"
-                elif "k_gat_bwd_dst_pair" in ks and "k_gat_bwd_src_pair" in ks:
-                    t_b, bwd_name = ks["k_gat_bwd_dst_pair"]["avg_us"] + ks["k_gat_bwd_src_pair"]["avg_us"], "k_gat_bwd_dst_pair + k_gat_bwd_src_pair"
                 if t_f:
                     inside["k_gat_fwd_pair"] = {"us": t_f, "bytes": f1 + f2, "frac": round((f1 + f2) / t_f / 1e3 / HBM_PEAK_GBPS, 4)}
                 if t_b:
@@ -912,16 +888,16 @@ def main():
             # what the headline launches MOVE inside the step (whole-step PMC table, profiles/r04_pmc_step.json) next to what a streaming
             # kernel of that size gets with cold caches on this part (profiles/r04_hbm_cold_stream.md): context for `frac`, not a metric
             moved = None
-            ps = os.path.join(ROOT, "profiles", "r04_pmc_step.json")
-            if inside.get("fwd+bwd") and os.path.exists(ps):
+            ps = os.path.join(ROOT, "profiles", "r05_pmc_step.json")
+            if one_pass and inside.get("fwd+bwd") and os.path.exists(ps):
                 seq = json.load(open(ps)).get("sequence", [])
                 fw = [e for e in seq if e["kernel"] == "k_gat_fwd_pair"]
-                bw_ = sorted((e for e in seq if e["kernel"] == ("k_gat_bwd_one3" if one_pass else "k_gat_bwd_src_pair")), key=lambda e: e["workgroups"])
+                bw_ = sorted((e for e in seq if e["kernel"] == "k_gat_bwd_one3"), key=lambda e: e["workgroups"])
                 if fw and bw_:
                     mb = fw[0]["hbm_MB"] + bw_[0]["hbm_MB"]
                     moved = {"hbm_bytes_per_launch_pair": int(mb * 1e6), "GBps": round(mb * 1e3 / inside["fwd+bwd"]["us"], 1),
                              "over_algorithmic": round(mb * 1e6 / inside["fwd+bwd"]["bytes"], 2),
-                             "source": "profiles/r04_pmc_step.json (FETCH_SIZE x 2 + WRITE_SIZE of k_gat_fwd_pair and layer 0's backward launch in one "
+                             "source": "profiles/r05_pmc_step.json (FETCH_SIZE x 2 + WRITE_SIZE of k_gat_fwd_pair and layer 0's backward launch in one "
                                        "replayed step, another run) over the in-graph durations above",
                              "cold_stream_reference": "profiles/r04_hbm_cold_stream.md: a streaming kernel of 32-64 MB per direction moves 3.7-4.1 TB/s "
                                                       "when its operands are not cache-resident, 6.5-6.9 TB/s when they are"}
@@ -933,7 +909,9 @@ def main():
                                 "kernel": (fwd_k + " + " + bwd_k + "<4> @ bond-graph level, ") + ("inside the replayed step (layer 0's launches: + fragment-bond level)"
                                                                                                   if use else "stand-alone launches"),
                                 "achieved": headline["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": headline["frac"],
-                                "basis": "in_graph" if use else "standalone",
+                                "basis": ("in_graph: durations read from the committed rocprofv3 trace " + str(ig_source) + ", not measured in this run "
+                                          "(the source digest of the traced library equals this one's); `standalone` below IS measured in this run") if use
+                                         else "standalone: measured in this run (no committed trace of this library's sources)",
                                 # the same quantity on the bases earlier rounds quoted (round 3's headline was the stand-alone backward: 0.235)
                                 "frac_backward_standalone": standalone[bwd_k]["frac"],
                                 "frac_forward_standalone": standalone[fwd_k]["frac"],
@@ -945,15 +923,15 @@ def main():
                                 "algorithmic_bytes_per_launch": headline.get("bytes", f1 + b1),
                                 "algorithmic_bytes_backward_bond_level": b1,
                                 "bytes_model": "SURVEY.md 8d: B_agg = 4[(n+1)+m+mH+2nH+nD+nD+mH] forward; B_agg' = 4[2nD+2mH+2m+nD+mH+2nH] for "
-                                               "the whole backward of the level; the one-pass backward is priced against the same B_agg' (its "
-                                               "second forward output and the dots it reads are extra traffic, not extra algorithmic bytes)",
+                                               "the whole backward of the level; the one-pass backward is priced against the same B_agg' (the dz "
+                                               "it leaves for its consumers and the dot it reads are extra traffic, not extra algorithmic bytes)",
                                 "standalone": standalone,
                                 "in_graph": {"source": ig_source, **inside} if ig_source else None,
                                 "all": kr}
             # extra evidence (not part of the contract): the same kernels on a 2048-molecule batch, where a launch
             # is long enough for the per-launch fixed cost (~4 us) not to dominate
             big = make_pool(1, rank, dev, 2048)[0]
-            kb = kernel_roofline(big, run.model, iters=20)
+            kb = kernel_roofline(big, run.model, iters=20, alternatives=not one_pass)
             line["roofline"]["at_batch_2048"] = {k: {"us_per_launch": v["us_per_launch"], "GBps": v["GBps"],
                                                      "frac": round(v["GBps"] / HBM_PEAK_GBPS, 4)} for k, v in kb.items() if isinstance(v, dict)}
         if world == 1 and not args.no_cpu_baseline:

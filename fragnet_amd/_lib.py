@@ -134,17 +134,14 @@ SIGNATURES = {
     "fn_gat_fwd_f32": [vp, vp, vp, vp, C.c_int, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp, vp, vp, C.c_int,
                        C.POINTER(ActEpilogue), C.c_int, vp],
     "fn_gat_bwd_one_f32": [vp, vp, vp, vp, vp, C.POINTER(EdgeTerm), vp, C.c_int, C.c_int, C.c_int, C.POINTER(GatPlan), f32,
-                           vp, vp, vp, vp, ip, vp, ip, C.c_int, C.c_int, vp],
+                           vp, vp, vp, vp, ip, vp, ip, C.c_int, vp, C.c_int, vp],
+    "fn_gat_gsd_f32": [vp, C.POINTER(GatPlan), vp, vp, vp, C.c_int, vp],
     "fn_gat_cu_f32": [vp, vp, vp, vp, f32, vp, vp, i64, C.c_int, vp],
     "fn_gat_bwd_dst_f32": [vp, vp, vp, C.POINTER(EdgeTerm), C.POINTER(GatPlan), f32, vp, vp, vp, vp, vp, ip, C.c_int, vp],
     "fn_gat_bwd_src_f32": [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(GatPlan), vp, vp, ip, C.c_int, vp],
     "fn_tower_fwd_f32": [C.POINTER(Tower), C.c_int, vp],
     "fn_tower_bwd_ws": [C.POINTER(Tower), C.c_int],
     "fn_tower_bwd_f32": [C.POINTER(Tower), C.c_int, vp, vp],
-    "fn_mol_extents": [C.POINTER(SegPlan), C.POINTER(SegPlan), C.POINTER(GatPlan), C.POINTER(GatPlan), C.POINTER(GatPlan),
-                       C.POINTER(GatPlan), i64, vp, vp],
-    "fn_gat_bwd_mol_f32": [vp, vp, vp, C.POINTER(EdgeTerm), vp, C.c_int, C.c_int, C.c_int, C.POINTER(GatPlan), f32, vp, i64,
-                           C.c_int, C.c_int, vp, vp, vp, vp, vp, ip, vp, vp, C.c_int, vp],
     "fn_gat_bwd_finalize_f32": [vp, C.c_int, vp, C.c_int, C.POINTER(EdgeTerm), vp, C.c_int, C.c_int, C.c_int, vp, vp, vp,
                                 C.c_int, vp],
     "fn_attn_by_src_f32": [vp, C.POINTER(GatPlan), vp, C.c_int, vp],

@@ -195,30 +195,3 @@ __device__ __forceinline__ void dma_to_lds(const void* gsrc, void* lds_wave_base
 }
 
 }  // namespace
-
-// ---- molecule-resident single-pass backward of the attention levels (csrc/mol_bwd.hip)
-namespace fni {
-enum { LV_BOND = 0, LV_ATOM = 1, LV_FBOND = 2, LV_FRAG = 3 };      // which extents of MolExt a level's rows / edges are
-struct MolBwdLevel {
-    const float *g_out, *h, *p_sorted, *att;    // dL/d(out) [n,128], projected rows [n,128], signed probabilities [H,m], attention vector
-    int att_w, dst_off, src_off, which;
-    fn_edge_term et;                            // mode 0: dz goes to g_s_orig; mode 2: partials of sum dz (x, 1) go to part_e
-    fn_gat_plan pl;
-    float slope;
-    int mols_per_unit;                          // consecutive molecules a workgroup takes at a time (small levels: several)
-    float *g_h;                                 // [n,128]
-    float *g_s_orig;                            // mode 0: [m_real, H] dL/d(edge term) in ORIGINAL edge order (nullable)
-    float *part_a;                              // column-major [256][FN_MAX_PART] partials of dL/da_dst | dL/da_src
-    float *part_e;                              // mode 2: [n_blk][H * (K + 1)]
-    float *scr_z;                               // [H, m]  edge state of units that do not fit the LDS tile
-    float *scr_gsd;                             // [n, H]  ditto, per-node scalars
-    int first_blk, n_blk, n_fast, n_units;      // filled by launch_mol_bwd: n_blk = partial rows written (n_fast fast + the slow workgroups)
-};
-constexpr int kMolBwdMaxLevels = 3;
-// one launch for up to three independent levels; returns 0 / error code.  ext: MolExt[n_mols] (device); counts_dev: nullable
-// device count of the real molecules (rows behind them are padding: their outputs are zeroed); status: nullable, bit 2 = a unit
-// was not closed under the level's edges (the batch is not molecule-contiguous)
-FNI_HIDDEN int launch_mol_bwd(MolBwdLevel* lv, int n_lv, const MolExt* ext, int64_t n_mols, int64_t rows_hint, const int32_t* counts_dev,
-                              int32_t* status, int heads, hipStream_t st);
-FNI_HIDDEN bool mol_bwd_supported(int heads);
-}  // namespace fni

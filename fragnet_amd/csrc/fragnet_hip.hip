@@ -918,12 +918,6 @@ __global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(GatBwdDstArgs A) {
     __shared__ float sP[RB][8][kWfLd];
     gat_bwd_dst_body<H, KL, RB>(A, sP, (int)blockIdx.x, (int)gridDim.x);
 }
-template <int H, int KLA, int KLB, int RB>
-__global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst_pair(GatBwdDstArgs A, GatBwdDstArgs B) {
-    __shared__ float sP[RB][8][kWfLd];
-    if ((int)blockIdx.x < A.nblk) gat_bwd_dst_body<H, KLA, RB>(A, sP, (int)blockIdx.x, A.nblk);
-    else gat_bwd_dst_body<H, KLB, RB>(B, sP, (int)blockIdx.x - A.nblk, B.nblk);
-}
 
 struct GatBwdSrcArgs {
     const float *g_out, *h, *pz_src, *g_s_dst, *att;
@@ -1066,12 +1060,6 @@ template <int H, int RB>
 __global__ __launch_bounds__(RB * 32) void k_gat_bwd_src(GatBwdSrcArgs A) {
     __shared__ float sA[RB][2 * FN_D];
     gat_bwd_src_body<H, RB>(A, sA, (int)blockIdx.x, (int)gridDim.x);
-}
-template <int H, int RB>
-__global__ __launch_bounds__(RB * 32) void k_gat_bwd_src_pair(GatBwdSrcArgs A, GatBwdSrcArgs B) {
-    __shared__ float sA[RB][2 * FN_D];
-    if ((int)blockIdx.x < A.nblk) gat_bwd_src_body<H, RB>(A, sA, (int)blockIdx.x, A.nblk);
-    else gat_bwd_src_body<H, RB>(B, sA, (int)blockIdx.x - A.nblk, B.nblk);
 }
 
 #include "gat_bwd_one.inc"
@@ -2713,63 +2701,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_gat_fwd_pair_lin(GatFwdArgs A, Ga
     if (g < A.nblk) gat_fwd_body<H, KLA, RDA, O2>(A, sWf, g, A.nblk);
     else if (g < A.nblk + B.nblk) gat_fwd_body<H, KLB, false, O2>(B, sWf, g - A.nblk, B.nblk);
 }
-template <int H, int KL, int RB>
-__global__ __launch_bounds__(RB * 32, 4) void k_gat_bwd_dst_lin(GatBwdDstArgs A, LinTasks T, int gat_base) {
-    extern __shared__ __attribute__((aligned(16))) float sBt[];
-    __shared__ float sP[RB][8][kWfLd];
-    int g;
-    if (lin_side_role(T, gat_base, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
-    if (g < A.nblk) gat_bwd_dst_body<H, KL, RB>(A, sP, g, A.nblk);
-}
-template <int H, int KLA, int KLB, int RB>
-__global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst_pair_lin(GatBwdDstArgs A, GatBwdDstArgs B, LinTasks T, int gat_base) {
-    extern __shared__ __attribute__((aligned(16))) float sBt[];
-    __shared__ float sP[RB][8][kWfLd];
-    int g;
-    if (lin_side_role(T, gat_base, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
-    if (g < A.nblk) gat_bwd_dst_body<H, KLA, RB>(A, sP, g, A.nblk);
-    else if (g < A.nblk + B.nblk) gat_bwd_dst_body<H, KLB, RB>(B, sP, g - A.nblk, B.nblk);
-}
 
-// ---- the backward's two chains side by side.  Gradient flows atom level -> bond levels only (through the edge term), so the
-// atom chain of layer l (destination pass, source pass, input-gradient product) never waits for the bond chain of layer l:
-//   k_gat_bwd_src_pair_dst : source pass of the bond + fragment-bond levels of layer l+1  ||  destination pass of the atom level of layer l
-//   k_gat_bwd_src_lin_rd   : bond / fragment-bond input-gradient products of layer l+1 (the bond one adds the atom graph's
-//                            edge-term gradient of layer l in its epilogue, RowAdd)  ||  source pass of the atom level of layer l
-//                            ||  the edge term's parameter-gradient partials of layer l
-// (the third launch of a layer is k_gat_bwd_dst_pair_lin: bond levels' destination pass || atom input-gradient product).
-template <int H, int RB>
-__global__ __launch_bounds__(RB * 32) void k_gat_bwd_src_pair_dst(GatBwdSrcArgs A, GatBwdSrcArgs B, GatBwdDstArgs D) {
-    __shared__ float sA[RB][2 * FN_D];
-    __shared__ float sP[RB][8][kWfLd];
-    const int b = (int)blockIdx.x;
-    if (b < A.nblk) gat_bwd_src_body<H, RB>(A, sA, b, A.nblk);
-    else if (b < A.nblk + B.nblk) gat_bwd_src_body<H, RB>(B, sA, b - A.nblk, B.nblk);
-    else gat_bwd_dst_body<H, 0, RB>(D, sP, b - A.nblk - B.nblk, D.nblk);
-}
-template <int H, int RB>
-__global__ __launch_bounds__(RB * 32, 4) void k_gat_bwd_src_lin_rd(GatBwdSrcArgs A, LinTasks T, RowDotsBwdArgs R) {
-    static_assert(RB * 32 == kBlock && RB == kRows, "all three bodies run 256 threads");
-    extern __shared__ __attribute__((aligned(16))) float sBt[];
-    __shared__ float sA[RB][2 * FN_D];
-    const int b = (int)blockIdx.x;
-    if (b < T.total) { lin_side_block(sBt, T, b);  return; }               // GEMM workgroups first (FN_TUNE_GEMM_COLAUNCH = 2)
-    const int g = b - T.total;
-    if (g < A.nblk) gat_bwd_src_body<H, RB>(A, sA, g, A.nblk);
-    else row_dots_sorted_bwd_body(R, reinterpret_cast<float(*)[FN_D]>(&sA[0][0]), g - A.nblk, R.nblk);
-}
-
-// input-gradient products (one 64 x 64 tile per workgroup, RowAdd epilogue where a task carries one) || the parameter-gradient
-// partials (and, g_feat != null, the rows' term) of an attention level's edge term: the launch between two molecule-resident
-// backward passes (csrc/mol_bwd.hip), which leave no attention pass for the products to ride with
-__global__ __launch_bounds__(kBlock, 4) void k_lin_rd(LinTasks T, RowDotsBwdArgs R) {
-    extern __shared__ __attribute__((aligned(16))) float sBt[];
-    __shared__ float sR[kRows][FN_D];
-    const int b = (int)blockIdx.x;
-    if (b < T.total) { lin_side_block(sBt, T, b);  return; }
-    row_dots_sorted_bwd_body(R, sR, b - T.total, R.nblk);
-}
-// the same launch in the one-pass backward: the products' epilogue also writes the dots c, g_s_dst of the rows it finishes (CuEpi)
+// the one-pass backward's second launch of a layer: input-gradient products (one 64 x 64 tile per workgroup; RowAdd epilogue where a
+// task carries one; the epilogue also writes the dot c = <g, out> of the rows it finishes, CuEpi)  ||  the parameter-gradient partials of
+// the atom graph's edge term
 // (GS: the deferred form -- every lane sums one dz segment into g_s_dst, one more MFMA step adds the rank-4 term, GsdEpi; c is the only dot left)
 template <bool GS = false>
 __global__ __launch_bounds__(kBlock, 3) void k_lin_rd_cu(LinTasks T, RowDotsBwdArgs R) {
@@ -3358,11 +3293,12 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const float* __restrict__ 
         default: return fail(FN_EUNSUPPORTED, "heads must be 1, 2, 4 or 8 (128 = heads * head_dim)"); \
     }
 
-bool bad_edge_term(const fn_edge_term* et) {
+// m: the level's edge count (a level without edges has an empty attribute table, whose pointer may be null: nothing reads it)
+bool bad_edge_term(const fn_edge_term* et, int64_t m = 1) {
     if (!et) return true;
     if (et->mode == 0) return false;
     if (et->mode != 2) return true;
-    return et->K < 1 || et->K > FN_MAX_EDGE_K || et->d_e < 1 || et->d_e > 128 || !et->x_sorted || !et->embW || !et->embb;
+    return et->K < 1 || et->K > FN_MAX_EDGE_K || et->d_e < 1 || et->d_e > 128 || (!et->x_sorted && m > 0) || !et->embW || !et->embb;
 }
 
 }  // namespace
@@ -3746,7 +3682,7 @@ static int prep_gat_fwd(const float* h, const float* s_dst, const float* s_src, 
                         const fn_edge_term* et, const fn_gat_plan* plan, float neg_slope, float* out, float* p_sorted,
                         float* probs_orig, const fn_act_epilogue* act, int heads, GatFwdArgs* A, float* out2 = nullptr,
                         float* sigma = nullptr) {
-    if (!h || !s_dst || !s_src || !att || !plan || bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_fwd_f32: bad argument");
+    if (!h || !s_dst || !s_src || !att || !plan || bad_edge_term(et, plan->m)) return fail(FN_EINVAL, "fn_gat_fwd_f32: bad argument");
     if (!out && !(act && act->y)) return fail(FN_EINVAL, "fn_gat_fwd_f32: no output buffer");
     if (act && (act->p < 0.f || act->p > 1.f)) return fail(FN_EINVAL, "fn_gat_fwd_f32: dropout probability");
     if (plan->m > 0 && !p_sorted) return fail(FN_EINVAL, "fn_gat_fwd_f32: null p_sorted");
@@ -3834,7 +3770,7 @@ static int prep_gat_bwd_dst(const float* g_out, const float* h, const float* p_s
                             const fn_gat_plan* plan, float neg_slope, float* dz_sorted, float* g_s_orig, float* pz_src,
                             float* g_s_dst, float* part_e, int* n_part_e, int heads, GatBwdDstArgs* A) {
     if (!g_out || !h || !plan || !g_s_dst || !n_part_e || !et) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: bad argument");
-    if (et->mode != 0 && bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: bad edge term");
+    if (et->mode != 0 && bad_edge_term(et, plan ? plan->m : 1)) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: bad edge term");
     if (plan->m > 0 && (!p_sorted || !pz_src || !plan->spos_d || (et->mode == 0 && !dz_sorted && !g_s_orig)))
         return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: null edge buffer");
     if (et->mode == 2 && !part_e) return fail(FN_EINVAL, "fn_gat_bwd_dst_f32: null part_e");
@@ -3869,18 +3805,6 @@ static int launch_gat_bwd_dst(const GatBwdDstArgs& A, int heads, hipStream_t st)
         else hipLaunchKernelGGL((k_gat_bwd_dst<HH, FN_MAX_EDGE_K, kBwdRows>), dim3(A.nblk), dim3(kBwdRows * 32), 0, st, A);
     });
     return launch_status("fn_gat_bwd_dst_f32");
-}
-static int launch_gat_bwd_dst_pair(const GatBwdDstArgs& A, const GatBwdDstArgs& B, int heads, hipStream_t st) {
-    const int ka = edge_class(&A.et), kb = edge_class(&B.et);
-    if (A.nblk == 0 || B.nblk == 0 || ka != 1 || (kb != 1 && kb != FN_MAX_EDGE_K)) {
-        if (int rc = launch_gat_bwd_dst(A, heads, st)) return rc;
-        return launch_gat_bwd_dst(B, heads, st);
-    }
-    FN_DISPATCH_H(heads, {
-        if (kb == 1) hipLaunchKernelGGL((k_gat_bwd_dst_pair<HH, 1, 1, kBwdRows>), dim3(A.nblk + B.nblk), dim3(kBwdRows * 32), 0, st, A, B);
-        else hipLaunchKernelGGL((k_gat_bwd_dst_pair<HH, 1, FN_MAX_EDGE_K, kBwdRows>), dim3(A.nblk + B.nblk), dim3(kBwdRows * 32), 0, st, A, B);
-    });
-    return launch_status("attention backward, destination pass (two levels)");
 }
 
 // ---- co-launches: an attention pass + independent K = 128 projection tasks (k_gat_*_lin above).  Each returns through the
@@ -3955,34 +3879,6 @@ static int launch_gat_fwd_pair_lin(const GatFwdArgs& A, const GatFwdArgs& B, Lin
 #undef FN_PAIR_LIN
     return launch_status("attention forward (two levels) + atom projection");
 }
-static int launch_gat_bwd_dst_lin(const GatBwdDstArgs& A, LinTasks& T, int heads, hipStream_t st) {
-    int gb = 0, grid = 0;
-    if (A.nblk == 0 || edge_class(&A.et) != 0 || !lin_side_prepare(T, A.nblk, &gb, &grid)) {
-        if (T.n) if (int rc = launch_linear128_group(T, st)) return rc;          // the products first: the level below reads them
-        return launch_gat_bwd_dst(A, heads, st);
-    }
-    FN_DISPATCH_H(heads, {
-        hipLaunchKernelGGL((k_gat_bwd_dst_lin<HH, 0, kBwdRows>), dim3(grid), dim3(kBwdRows * 32), kLinSideLds, st, A, T, gb);
-    });
-    return launch_status("attention backward, destination pass + input-gradient products");
-}
-static int launch_gat_bwd_dst_pair_lin(const GatBwdDstArgs& A, const GatBwdDstArgs& B, LinTasks& T, int heads, hipStream_t st) {
-    const int ka = edge_class(&A.et), kb = edge_class(&B.et);
-    int gb = 0, nwg = 0;
-    if (A.nblk == 0 || B.nblk == 0 || ka != 1 || (kb != 1 && kb != FN_MAX_EDGE_K) || !lin_side_prepare(T, A.nblk + B.nblk, &gb, &nwg)) {
-        if (int rc = launch_gat_bwd_dst_pair(A, B, heads, st)) return rc;
-        return T.n ? launch_linear128_group(T, st) : 0;
-    }
-    const dim3 grid(nwg);
-    FN_DISPATCH_H(heads, {
-        if (kb == 1) {
-            hipLaunchKernelGGL((k_gat_bwd_dst_pair_lin<HH, 1, 1, kBwdRows>), grid, dim3(kBwdRows * 32), kLinSideLds, st, A, B, T, gb);
-        } else {
-            hipLaunchKernelGGL((k_gat_bwd_dst_pair_lin<HH, 1, FN_MAX_EDGE_K, kBwdRows>), grid, dim3(kBwdRows * 32), kLinSideLds, st, A, B, T, gb);
-        }
-    });
-    return launch_status("attention backward, destination pass (two levels) + atom input-gradient product");
-}
 
 int fn_gat_bwd_dst_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et,
                        const fn_gat_plan* plan, float neg_slope, float* dz_sorted, float* g_s_orig, float* pz_src,
@@ -4019,14 +3915,6 @@ static int launch_gat_bwd_src(const GatBwdSrcArgs& A, int heads, hipStream_t st)
     FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src<HH, kBwdRows>), dim3(A.nblk), dim3(kBwdRows * 32), 0, st, A));
     return launch_status("fn_gat_bwd_src_f32");
 }
-static int launch_gat_bwd_src_pair(const GatBwdSrcArgs& A, const GatBwdSrcArgs& B, int heads, hipStream_t st) {
-    if (A.nblk == 0 || B.nblk == 0) {
-        if (int rc = launch_gat_bwd_src(A, heads, st)) return rc;
-        return launch_gat_bwd_src(B, heads, st);
-    }
-    FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src_pair<HH, kBwdRows>), dim3(A.nblk + B.nblk), dim3(kBwdRows * 32), 0, st, A, B));
-    return launch_status("attention backward, source pass (two levels)");
-}
 
 int fn_gat_bwd_src_f32(const float* g_out, const float* h, const float* pz_src,
                        const float* g_s_dst, const float* att, int att_w, int dst_off, int src_off,
@@ -4044,7 +3932,7 @@ static int prep_gat_bwd_one(const float* g_out, const float* h, const float* p_s
                             int* n_part_e, int heads, GatBwdOneArgs* A, int64_t share = 0) {
     if (!g_out || !h || !cdot || !g_s_dst || !att || !plan || !g_h || !part_a || !n_part_a || !n_part_e || !et)
         return fail(FN_EINVAL, "fn_gat_bwd_one_f32: bad argument");
-    if (et->mode != 0 && bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_bwd_one_f32: bad edge term");
+    if (et->mode != 0 && bad_edge_term(et, plan ? plan->m : 1)) return fail(FN_EINVAL, "fn_gat_bwd_one_f32: bad edge term");
     if (plan->m > 0 && (!p_sorted || !plan->dpos_s || !plan->dst_s)) return fail(FN_EINVAL, "fn_gat_bwd_one_f32: null edge buffer");
     if (et->mode == 2 && !part_e) return fail(FN_EINVAL, "fn_gat_bwd_one_f32: null part_e");
     if ((att_w | dst_off | src_off) & 3) return fail(FN_EINVAL, "fn_gat_bwd_one_f32: att blocks must be 16-byte aligned");
@@ -4147,49 +4035,34 @@ int fn_gat_cu_f32(const float* g_out, const float* out, const float* out2, const
 int fn_gat_bwd_one_f32(const float* g_out, const float* h, const float* p_sorted, const float* cdot, const float* g_s_dst,
                        const fn_edge_term* et, const float* att, int att_w, int dst_off, int src_off, const fn_gat_plan* plan,
                        float neg_slope, float* g_h, float* dz_sorted, float* g_s_orig, float* part_a, int* n_part_a, float* part_e,
-                       int* n_part_e, int p_edge_major, int heads, fn_stream_t stream) {
+                       int* n_part_e, int p_edge_major, float* dz_em, int heads, fn_stream_t stream) {
     GatBwdOneArgs A;
-    if (int rc = prep_gat_bwd_one(g_out, h, p_sorted, cdot, g_s_dst, et, att, att_w, dst_off, src_off, plan, neg_slope, g_h, dz_sorted,
-                                  g_s_orig, part_a, n_part_a, part_e, n_part_e, heads, &A)) return rc;
+    if (dz_em && heads != 4) return fail(FN_EUNSUPPORTED, "fn_gat_bwd_one_f32: the deferred form (dz_em) is written for four heads");
+    // (the deferred form never reads g_s_dst: the dots table stands in where the argument check wants a pointer)
+    if (int rc = prep_gat_bwd_one(g_out, h, p_sorted, cdot, dz_em && !g_s_dst ? cdot : g_s_dst, et, att, att_w, dst_off, src_off, plan, neg_slope, g_h,
+                                  dz_sorted, g_s_orig, part_a, n_part_a, part_e, n_part_e, heads, &A)) return rc;
     A.p_edge_major = p_edge_major ? 1 : 0;
+    A.dz_em = dz_em;
     return launch_gat_bwd_one(A, heads, S(stream));
 }
 
-namespace {
-__global__ void k_mol_extents(MolExtArgs A) { mol_extents_body(A, (int)blockIdx.x); }
-}
-int fn_mol_extents(const fn_seg_plan* mol_atoms, const fn_seg_plan* mol_frags, const fn_gat_plan* bond, const fn_gat_plan* atom,
-                   const fn_gat_plan* fbond, const fn_gat_plan* frag, int64_t n_mols, int32_t* ext, fn_stream_t stream) {
-    if (!mol_atoms || !mol_frags || !bond || !atom || !frag || !ext || n_mols < 0) return fail(FN_EINVAL, "fn_mol_extents: bad argument");
-    if (mol_atoms->n_seg != n_mols || mol_frags->n_seg != n_mols) return fail(FN_EINVAL, "fn_mol_extents: the molecule CSRs must have n_mols segments");
-    if (n_mols == 0) return 0;
-    const MolExtArgs A{mol_atoms->rowptr, mol_frags->rowptr, mol_atoms->pos_base, mol_frags->pos_base, *bond, *atom,
-                       fbond ? *fbond : fn_gat_plan{}, *frag, (int)n_mols, reinterpret_cast<MolExt*>(ext)};
-    hipLaunchKernelGGL(k_mol_extents, dim3((unsigned)((n_mols + 255) / 256)), dim3(256), 0, S(stream), A);
-    return launch_status("fn_mol_extents");
-}
-
-int fn_gat_bwd_mol_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et, const float* att,
-                       int att_w, int dst_off, int src_off, const fn_gat_plan* plan, float slope, const int32_t* mol_ext,
-                       int64_t n_mols, int which, int mols_per_unit, const int32_t* counts_dev, float* g_h, float* g_s_orig,
-                       float* part_a, float* part_e, int* n_part, float* scratch, int32_t* status, int heads, fn_stream_t stream) {
-    if (!plan || !mol_ext || !n_part || bad_edge_term(et) || which < 0 || which > 3 || !scratch) return fail(FN_EINVAL, "fn_gat_bwd_mol_f32: bad argument");
-    fni::MolBwdLevel L{};
-    L.g_out = g_out;  L.h = h;  L.p_sorted = p_sorted;  L.att = att;  L.att_w = att_w;  L.dst_off = dst_off;  L.src_off = src_off;
-    L.which = which;  L.et = *et;  L.pl = *plan;  L.slope = slope;  L.mols_per_unit = mols_per_unit;
-    L.g_h = g_h;  L.g_s_orig = g_s_orig;  L.part_a = part_a;  L.part_e = part_e;
-    L.scr_z = scratch;  L.scr_gsd = scratch + (size_t)heads * plan->m;
-    int64_t rows = 0;       // size class: mean rows per molecule of this level
-    rows = plan->n;
-    if (int rc = fni::launch_mol_bwd(&L, 1, reinterpret_cast<const fni::MolExt*>(mol_ext), n_mols, rows, counts_dev, status, heads, S(stream))) return rc;
-    *n_part = L.n_blk;
-    return 0;
+int fn_gat_gsd_f32(const float* dz_em, const fn_gat_plan* plan, const float* h, float* g_s_dst, float* part_a, int n_part_a,
+                   fn_stream_t stream) {
+    if (!plan || !g_s_dst || !part_a || !h || n_part_a < 0 || n_part_a > FN_MAX_PART) return fail(FN_EINVAL, "fn_gat_gsd_f32: bad argument");
+    if (plan->n == 0 || n_part_a == 0) return 0;
+    if (plan->m > 0 && (!dz_em || !plan->rowptr_d)) return fail(FN_EINVAL, "fn_gat_gsd_f32: null edge buffer");
+    GsdSegTasks T{};
+    T.n = 1;
+    // (a level without edges: every extent is empty, nothing of dz is read -- any readable word will do)
+    T.t[0] = GsdSegTask{plan->m > 0 ? dz_em : h, plan->rowptr_d, plan->pos_base_d, plan->n, g_s_dst, nullptr, h, part_a, 0, n_part_a};
+    hipLaunchKernelGGL(k_gsd_seg, dim3(n_part_a), dim3(kBlock), 0, S(stream), T);
+    return launch_status("fn_gat_gsd_f32");
 }
 
 int fn_gat_bwd_finalize_f32(const float* part_a, int n_part_a, const float* part_e, int n_part_e, const fn_edge_term* et,
                             const float* att, int att_w, int dst_off, int src_off, float* g_att, float* g_embW,
                             float* g_embb, int heads, fn_stream_t stream) {
-    if (!part_a || n_part_a < 0 || n_part_e < 0 || !att || !g_att || bad_edge_term(et)) return fail(FN_EINVAL, "fn_gat_bwd_finalize_f32: bad argument");
+    if (!part_a || n_part_a < 0 || n_part_e < 0 || !att || !g_att || bad_edge_term(et, 0)) return fail(FN_EINVAL, "fn_gat_bwd_finalize_f32: bad argument");
     if (et->mode == 2 && (!part_e || !g_embW || !g_embb)) return fail(FN_EINVAL, "fn_gat_bwd_finalize_f32: null mode-2 buffer");
     if (heads != 1 && heads != 2 && heads != 4 && heads != 8) return fail(FN_EUNSUPPORTED, "heads must be 1, 2, 4 or 8");
     hipLaunchKernelGGL(k_gat_finalize, dim3(2 * FN_D + (et->mode == 2 ? 1 : 0)), dim3(1024), 0, S(stream), part_a, n_part_a, part_e, n_part_e, *et, att,
@@ -4817,7 +4690,7 @@ bool one_pass_on(const fn_encoder* e);
 bool pad_skip_on(const fn_encoder* e);
 bool one_pass_on(const fn_encoder* e) {
     return g_tune[FN_TUNE_BWD_ONE] != 0 && e->training != 0 && (e->heads == 2 || e->heads == 4 || e->heads == 8) &&
-           g_tune[FN_TUNE_BWD_MOL] == 0 && e->atom.m_real == e->E;
+           e->atom.m_real == e->E;
 }
 
 // the deferred form of the one-pass backward (gat_bwd_one.inc DF, FN_TUNE_DEFER_GSD): no second output in the forward.  Four heads
@@ -4877,14 +4750,10 @@ bool have_mol(const fn_encoder* e) {       // the caller handed over the molecul
 bool pad_skip_on(const fn_encoder* e) {
     return g_tune[FN_TUNE_PAD_SKIP] != 0 && one_pass_on(e) && have_mol(e) && e->mol_contiguous != 0 && e->counts_dev != nullptr && e->variant == 0;
 }
-// the backward of every attention level as one pass of the molecule-resident kernel (csrc/mol_bwd.hip)
-bool mol_bwd_on(const fn_encoder* e) {
-    return g_tune[FN_TUNE_BWD_MOL] != 0 && have_mol(e) && fni::mol_bwd_supported(e->heads);
-}
 // the last layer's fragment tail (fragment sums -> fragment graph -> readout, and its backward) as one molecule-resident launch
 // each way (csrc/mol_tail.inc): needs the caller's word that the batch has collate_fn's molecule-contiguous layout
 bool tail_mol_on(const fn_encoder* e) {
-    return g_tune[FN_TUNE_MOL_TAIL] != 0 && e->mol_contiguous != 0 && have_mol(e) && !mol_bwd_on(e) && e->variant == 0 &&
+    return g_tune[FN_TUNE_MOL_TAIL] != 0 && e->mol_contiguous != 0 && have_mol(e) && e->variant == 0 &&
            (e->heads == 2 || e->heads == 4 || e->heads == 8) && e->F > 0 && e->EF > 0 && e->frag.m > 1 && e->n_mols <= FN_MAX_PART &&
            !((uintptr_t)e->ws & 15);
 }
@@ -5137,34 +5006,6 @@ struct ReduceQueue {
     }
 };
 
-// ---- the two-chain launches of the backward (k_gat_bwd_src_pair_dst, k_gat_bwd_src_lin_rd); both fall back to plain launches
-// in dependency order when a part is empty or has no kernel
-static int launch_gat_bwd_src_pair_dst(const GatBwdSrcArgs& A, const GatBwdSrcArgs& B, const GatBwdDstArgs& D, int heads, hipStream_t st) {
-    if (A.nblk + B.nblk == 0) return launch_gat_bwd_dst(D, heads, st);
-    if (D.nblk == 0 || edge_class(&D.et) != 0) {
-        if (int rc = launch_gat_bwd_src_pair(A, B, heads, st)) return rc;
-        return launch_gat_bwd_dst(D, heads, st);
-    }
-    FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src_pair_dst<HH, kBwdRows>), dim3(A.nblk + B.nblk + D.nblk), dim3(kBwdRows * 32), 0, st, A, B, D));
-    return launch_status("bond levels' source pass + atom level's destination pass");
-}
-// R.g_feat == nullptr: the rows' term rides in T's bond product (RowAdd); R.nblk == 0: no edge term at all
-static int launch_gat_bwd_src_lin_rd(const GatBwdSrcArgs& A, LinTasks& T, const RowDotsBwdArgs& R, int heads, hipStream_t st) {
-    int gb = 0, grid = 0;
-    if (A.nblk == 0 || !lin_side_prepare(T, A.nblk + R.nblk, &gb, &grid)) {
-        if (T.n) if (int rc = launch_linear128_group(T, st)) return rc;
-        if (R.nblk == 0) return launch_gat_bwd_src(A, heads, st);
-        if (A.nblk == 0) {
-            hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(R.nblk), dim3(kBlock), 0, st, R);
-            return launch_status("edge-term backward");
-        }
-        FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src_rd<HH, kBwdRows>), dim3(A.nblk + R.nblk), dim3(kBlock), 0, st, A, R));
-        return launch_status("fn_gat_bwd_src_f32 + edge-term backward");
-    }
-    FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src_lin_rd<HH, kBwdRows>), dim3(T.total + A.nblk + R.nblk), dim3(kBlock), kLinSideLds, st, A, T, R));
-    return launch_status("bond input-gradient products + atom level's source pass + edge-term partials");
-}
-
 // source pass of a level + backward of its edge term <feat[e], att[:, mid block]> as ONE launch (k_gat_bwd_src_rd); they
 // share nothing but their input dz.  *n_rd = blocks of the edge-term part (0: the level has no real edges).
 int bwd_src_and_edge_term(const float* g_out, const float* h, const float* pz_src, const float* g_s_dst, const float* att, int att_w,
@@ -5184,8 +5025,8 @@ int bwd_src_and_edge_term(const float* g_out, const float* h, const float* pz_sr
     return launch_status("source pass + edge-term backward");
 }
 
-// GEMM tiles + edge-term blocks as one launch (k_lin_rd); falls back to separate launches when a part is empty or misaligned
-static int launch_lin_rd(LinTasks& T, const RowDotsBwdArgs& R, hipStream_t st, bool cu = false) {
+// GEMM tiles + edge-term blocks as one launch (k_lin_rd_cu: the dots ride in the products' epilogue; either part may be empty)
+static int launch_lin_rd(LinTasks& T, const RowDotsBwdArgs& R, hipStream_t st) {
     int blocks = 0, live = 0;
     bool aligned = true;
     for (int i = 0; i < T.n; ++i) {
@@ -5198,244 +5039,20 @@ static int launch_lin_rd(LinTasks& T, const RowDotsBwdArgs& R, hipStream_t st, b
         T.t[live++] = t;
     }
     T.n = live;  T.K = FN_D;  T.total = blocks;  T.base = 0;
-    if (cu) {        // one-pass backward: the dots ride in the products' epilogue; the kernel takes an empty edge-term part as well
-        if (!live) {
-            if (R.nblk) {
-                hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(R.nblk), dim3(kBlock), 0, st, R);
-                return launch_status("edge-term backward");
-            }
-            return 0;
-        }
-        if (!aligned) return fail(FN_EINVAL, "input-gradient products: operands must be 16-byte aligned");
-        bool gs = false;
-        for (int i = 0; i < T.n; ++i) gs = gs || T.t[i].gs.dz != nullptr;
-        if (gs) hipLaunchKernelGGL(k_lin_rd_cu<true>, dim3(blocks + R.nblk), dim3(kBlock), kLinSideLdsGs, st, T, R);
-        else hipLaunchKernelGGL(k_lin_rd_cu<false>, dim3(blocks + R.nblk), dim3(kBlock), kLinSideLds, st, T, R);
-        return launch_status("input-gradient products (+ row dots) + edge-term backward");
-    }
-    if (!live || !aligned || R.nblk == 0) {
-        if (live) if (int rc = launch_linear128_group(T, st)) return rc;
+    if (!live) {
         if (R.nblk) {
             hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(R.nblk), dim3(kBlock), 0, st, R);
             return launch_status("edge-term backward");
         }
         return 0;
     }
-    hipLaunchKernelGGL(k_lin_rd, dim3(blocks + R.nblk), dim3(kBlock), kLinSideLds, st, T, R);
-    return launch_status("input-gradient products + edge-term backward");
+    if (!aligned) return fail(FN_EINVAL, "input-gradient products: operands must be 16-byte aligned");
+    bool gs = false;
+    for (int i = 0; i < T.n; ++i) gs = gs || T.t[i].gs.dz != nullptr;
+    if (gs) hipLaunchKernelGGL(k_lin_rd_cu<true>, dim3(blocks + R.nblk), dim3(kBlock), kLinSideLdsGs, st, T, R);
+    else hipLaunchKernelGGL(k_lin_rd_cu<false>, dim3(blocks + R.nblk), dim3(kBlock), kLinSideLds, st, T, R);
+    return launch_status("input-gradient products (+ row dots) + edge-term backward");
 }
-
-// ---- fn_encoder_backward with every attention level as ONE pass of the molecule-resident kernel (csrc/mol_bwd.hip).
-// Gradient flows atom level -> bond levels only (through the edge term <new_bond[e], a[:, mid]>), so the atom chain of layer l
-// and the bond chain of layer l+1 run side by side, two launches per layer:
-//   L1  k_mol_bwd  { bond level (l+1), atom level (l), fragment-bond level (l+1) }           three independent levels
-//   L2  k_lin_rd   { dX of the atom projection (l), of the bond projection (l+1) + the atom graph's edge-term gradient of layer l
-//                    on the rows it writes (RowAdd), of the fragment-bond projection (l+1) }  ||  the edge term's parameter partials
-// and every weight-gradient partial product / parameter-gradient reduction is queued for the two launches at the very end.
-// A task is queued only after the launch that produces its operands has been enqueued, so a flush in the middle of the
-// pass (six or more layers) reads finished buffers.
-int encoder_backward_mol(const fn_encoder* e, const EncLayout& lay, const BwdLayout& bw, const RngPlan& rng, const float* out_atoms,
-                         const float* out_frags, const float* out_bond, const float* out_fbond, const float* g_atoms, const float* g_frags,
-                         const float* g_bond, const float* g_fbond, const fn_layer_weights* grads, hipStream_t hs) {
-    const int H = e->heads, d = FN_D / H, wide = 2 * d + FN_D, NL = e->n_layers;
-    const float p = e->training ? e->drop_p : 0.f;
-    const bool lite = e->variant == 1, edge = e->variant == 2, no_fb = lite || edge;
-    const fni::MolExt* ext = reinterpret_cast<const fni::MolExt*>(lay.mol_ext);
-    ReduceQueue rq;
-    rq.st = hs;
-    rq.defer_wgrad = true;
-    rq.defer_mixed = g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;
-    rq.rider = e->adam_rider;
-    auto mol_launch = [&](fni::MolBwdLevel* lv, int n) -> int {
-        return n ? fni::launch_mol_bwd(lv, n, ext, e->n_mols, e->E, e->counts_dev, e->status, H, hs) : 0;
-    };
-    auto level = [&](int which, const float* g_out, const float* h, const float* p_sorted, const float* att, int att_w, int src_off,
-                     const fn_edge_term& et, const fn_gat_plan& pl, const LevelScratch& sc, float* g_s_orig, int per_unit) {
-        fni::MolBwdLevel L{};
-        L.g_out = g_out;  L.h = h;  L.p_sorted = p_sorted;  L.att = att;  L.att_w = att_w;  L.dst_off = 0;  L.src_off = src_off;
-        L.which = which;  L.et = et;  L.pl = pl;  L.slope = 0.2f;  L.mols_per_unit = per_unit;
-        L.g_h = sc.g_h;  L.g_s_orig = g_s_orig;  L.part_a = sc.part_a;  L.part_e = sc.part_e;  L.scr_z = sc.pz;  L.scr_gsd = sc.g_s_dst;
-        return L;
-    };
-    const int kPerBond = 1, kPerAtom = 2, kPerFbond = 8, kPerFrag = 16;
-
-    bool have_atoms = g_atoms != nullptr, have_frags = g_frags != nullptr, have_bond = g_bond != nullptr, have_fbond = g_fbond != nullptr;
-    {   // backward of relu(dropout(.)) of the last layer's outputs (y > 0 already encodes the mask): one launch
-        GateTasks G{};
-        auto add = [&](const float* g, const float* y, float* o, int64_t numel) {
-            if (!g) return;
-            GateTask& t = G.t[G.n++];
-            t.g = g;  t.y = y;  t.o = o;  t.n4 = (numel + 3) / 4;  t.first = G.blocks;  t.nblk = flat_grid(t.n4, 512);
-            G.blocks += t.nblk;
-        };
-        add(g_atoms, out_atoms, bw.g_pre_atoms, e->N * FN_D);
-        add(g_frags, out_frags, bw.g_pre_frags, e->F * FN_D);
-        add(g_bond, out_bond, bw.g_pre_bond, e->E * FN_D);
-        add(g_fbond, out_fbond, bw.g_pre_fbond, e->EF * FN_D);
-        if (G.blocks) {
-            G.scale = p > 0.f ? (p < 1.f ? 1.f / (1.f - p) : 0.f) : 1.f;
-            hipLaunchKernelGGL(k_gate_many, dim3(G.blocks), dim3(kBlock), 0, hs, G);
-            FN_TRY(launch_status("fn_encoder_backward: activation backward"));
-        }
-    }
-
-    bool pend_b = false, pend_fb = false;        // bond / fragment-bond level of layer l+1: gradients ready, pass not launched yet
-    for (int l = NL - 1; l >= 0; --l) {
-        const fn_layer_weights& w = e->w[l];
-        const fn_layer_weights& g = grads[l];
-        const LayerActs& a = lay.L[l];
-        const bool last = l + 1 == NL;
-        const float* in_atoms = l ? lay.L[l - 1].y_atoms : (lay.in_atoms0 ? lay.in_atoms0 : e->x_atoms);
-        const int ka = l ? FN_D : e->k_atom0;
-        const LevelScratch &sa = bw.atom[l], &sf = bw.frag;
-
-        // ---- L4b fragment graph (only the last layer's output is ever read) and L3 atom -> fragment sum
-        if (last && have_frags) {
-            const float* g_frags_h = bw.g_frags;
-            if (lite) {
-                g_frags_h = bw.g_pre_frags;
-            } else if (edge) {       // gat2_edge: the edge term's parameters are the cnx_attr Linear (emb_fb_*) and f's middle block
-                fn_edge_term et_f{2, e->k_fattr, FN_D, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
-                LevelScratch sc = sf;  sc.g_h = bw.g_frags;
-                fni::MolBwdLevel F = level(fni::LV_FRAG, bw.g_pre_frags, a.frags, a.p_frag, w.f, wide, d + FN_D, et_f, e->frag, sc, nullptr, kPerFrag);
-                FN_TRY(mol_launch(&F, 1));
-                FN_TRY(rq.finalize(sf.part_a, F.n_blk, sf.part_e, F.n_blk, et_f, w.f, wide, 0, d + FN_D, g.f, g.emb_fb_w, g.emb_fb_b, H));
-            } else {
-                fn_edge_term et_f{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-                LevelScratch sc = sf;  sc.g_h = bw.g_frags;
-                fni::MolBwdLevel F = level(fni::LV_FRAG, bw.g_pre_frags, a.frags, a.p_frag, w.f, wide, d + FN_D, et_f, e->frag, sc, sf.dz, kPerFrag);
-                FN_TRY(mol_launch(&F, 1));
-                FN_TRY(rq.finalize(sf.part_a, F.n_blk, nullptr, 0, et_f, w.f, wide, 0, d + FN_D, g.f, nullptr, nullptr, H));
-                // edge term <new_fbond, f[:, d:d+128]>: dL/dnew_fbond (accumulates into g_pre_fbond) and dL/df's middle block
-                const int gr = e->frag.m_real > 0 ? row_grid(e->frag.m_real, g_tune[FN_TUNE_RD_BLOCKS] > 0 ? g_tune[FN_TUNE_RD_BLOCKS] : kRowDotsBwdBlocks) : 0;
-                if (gr) {
-                    const RowDotsBwdArgs T{sf.dz, a.new_fbond, w.f, wide, d, H, e->frag, bw.g_pre_fbond, sf.part_rd,
-                                           have_fbond ? (const float*)bw.g_pre_fbond : nullptr, 1, gr};
-                    hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(gr), dim3(kBlock), 0, hs, T);
-                    FN_TRY(launch_status("fragment graph: edge-term backward"));
-                    FN_TRY(rq.colsum(sf.part_rd, gr, H * FN_D, g.f, wide, d));
-                    have_fbond = true;
-                }
-            }
-            hipLaunchKernelGGL(k_gather_rows4, dim3(flat_grid(e->N * 32, kGridCap)), dim3(kBlock), 0, hs, g_frags_h, e->a2f.index,
-                               bw.g_pre_atoms, e->N, (int64_t)32, have_atoms ? (const float*)bw.g_pre_atoms : (const float*)nullptr);
-            FN_TRY(launch_status("fn_encoder_backward: gather(a2f)"));
-            have_atoms = true;
-        }
-
-        // ---- L1: the atom level of this layer beside the bond / fragment-bond levels of layer l+1
-        fni::MolBwdLevel lv[3];
-        int nl = 0, iA = -1, iB = -1, iFB = -1;
-        const fn_edge_term et_a{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-        if (pend_b) {
-            const fn_layer_weights& wn = e->w[l + 1];
-            const fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, wn.emb_b_w, wn.emb_b_b};
-            iB = nl;
-            lv[nl++] = level(fni::LV_BOND, bw.g_pre_bond, lay.L[l + 1].h_b, lay.L[l + 1].p_bond, wn.a_b, 3 * d, 2 * d, et_b, e->bond, bw.bond[l + 1], nullptr, kPerBond);
-        }
-        if (have_atoms) {
-            iA = nl;
-            lv[nl++] = level(fni::LV_ATOM, bw.g_pre_atoms, a.h_a, a.p_atom, w.a, wide, d + FN_D, et_a, e->atom, sa, sa.dz, kPerAtom);
-        }
-        if (pend_fb) {
-            const fn_layer_weights& wn = e->w[l + 1];
-            const fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, wn.emb_fb_w, wn.emb_fb_b};
-            iFB = nl;
-            lv[nl++] = level(fni::LV_FBOND, bw.g_pre_fbond, lay.L[l + 1].h_fb, lay.L[l + 1].p_fbond, wn.f_a_b, 3 * d, 2 * d, et_fb, e->fbond, bw.fbond[l + 1], nullptr, kPerFbond);
-        }
-        FN_TRY(mol_launch(lv, nl));
-
-        // ---- L2: input-gradient products of what L1 produced (+ the atom graph's edge term), and the deferred parameter work
-        LinTasks T{};
-        const fn_act_epilogue no_ns_mk{nullptr, 0.f, 0, 0, 0, nullptr};
-        (void)no_ns_mk;
-        auto product = [&](const float* gh, const float* W, const float* Wt, float* gy, int64_t rows, const fn_act_epilogue& mk, const RowAdd* ra) {
-            LinTask& t = T.t[T.n++];
-            t = LinTask{Wt, gh, W, nullptr, gy, rows, mk, NodeScalarEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0}, 0, 0};
-            if (ra) t.ra = *ra;
-        };
-        bool nxt_bond = false, nxt_fbond = false, nxt_atoms = false;
-        const bool rd_rows_ride = iA >= 0 && iB >= 0 && e->atom.m_real == e->E && e->E > 0;      // the bond product of layer l+1 carries the rows' term
-        if (iB >= 0) {       // layer l+1's bond level: parameter work + dL/d(pre-activation bond output of layer l)
-            const fn_layer_weights& wn = e->w[l + 1];
-            const fn_layer_weights& gn = grads[l + 1];
-            const LevelScratch& sb = bw.bond[l + 1];
-            const fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, wn.emb_b_w, wn.emb_b_b};
-            FN_TRY(rq.finalize(sb.part_a, lv[iB].n_blk, sb.part_e, lv[iB].n_blk, et_b, wn.a_b, 3 * d, 0, 2 * d, gn.a_b, gn.emb_b_w, gn.emb_b_b, H));
-            FN_TRY(rq.wgrad(sb.g_h, a.y_bond, FN_D, e->E, sb.wg_ws, gn.proj_b_w, gn.proj_b_b, hs));
-            const fn_act_epilogue mk{const_cast<float*>(a.y_bond), p, 1, e->seed, rng.y[l][2], e->offset_dev};
-            const RowAdd ra{sa.dz, w.a + d, wide};
-            product(sb.g_h, wn.proj_b_w, lay.bt + (size_t)(3 * (l + 1)) * 192 * FN_D, bw.g_pre_bond, e->E, mk, rd_rows_ride ? &ra : nullptr);
-            nxt_bond = true;
-        }
-        if (iFB >= 0) {
-            const fn_layer_weights& wn = e->w[l + 1];
-            const fn_layer_weights& gn = grads[l + 1];
-            const LevelScratch& sfb = bw.fbond[l + 1];
-            const fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, wn.emb_fb_w, wn.emb_fb_b};
-            FN_TRY(rq.finalize(sfb.part_a, lv[iFB].n_blk, sfb.part_e, lv[iFB].n_blk, et_fb, wn.f_a_b, 3 * d, 0, 2 * d, gn.f_a_b, gn.emb_fb_w, gn.emb_fb_b, H));
-            FN_TRY(rq.wgrad(sfb.g_h, a.y_fbond, FN_D, e->EF, sfb.wg_ws, gn.proj_fb_w, gn.proj_fb_b, hs));
-            const fn_act_epilogue mk{const_cast<float*>(a.y_fbond), p, 1, e->seed, rng.y[l][3], e->offset_dev};
-            product(sfb.g_h, wn.proj_fb_w, lay.bt + (size_t)(3 * (l + 1) + 2) * 192 * FN_D, bw.g_pre_fbond, e->EF, mk, nullptr);
-            nxt_fbond = true;
-        }
-        RowDotsBwdArgs R{};
-        if (iA >= 0) {
-            FN_TRY(rq.finalize(sa.part_a, lv[iA].n_blk, nullptr, 0, et_a, w.a, wide, 0, d + FN_D, g.a, nullptr, nullptr, H));
-            FN_TRY(rq.wgrad(sa.g_h, in_atoms, ka, e->N, sa.wg_ws, g.proj_a_w, g.proj_a_b, hs));
-            if (l) {
-                const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_atoms), p, 1, e->seed, rng.y[l - 1][0], e->offset_dev};
-                product(sa.g_h, w.proj_a_w, lay.bt + (size_t)(3 * l + 1) * 192 * FN_D, bw.g_pre_atoms, e->N, mk, nullptr);
-                nxt_atoms = true;
-            }
-            // the edge term <new_bond[e], a[:, d:d+128]> of the atom graph: parameter partials always; the rows' term (dL/dnew_bond)
-            // rides in the bond product above, or -- no product to ride in (top layer) -- is written / accumulated here
-            const int gr = e->atom.m_real > 0 ? row_grid(e->atom.m_real, g_tune[FN_TUNE_RD_BLOCKS] > 0 ? g_tune[FN_TUNE_RD_BLOCKS] : kRowDotsBwdBlocks) : 0;
-            if (gr) {
-                const bool have_b_now = iB >= 0 || (last && have_bond);
-                R = RowDotsBwdArgs{sa.dz, a.new_bond, w.a, wide, d, H, e->atom, rd_rows_ride ? nullptr : bw.g_pre_bond, sa.part_rd,
-                                   (!rd_rows_ride && have_b_now) ? (const float*)bw.g_pre_bond : nullptr, 1, gr};
-                FN_TRY(rq.colsum(sa.part_rd, gr, H * FN_D, g.a, wide, d));
-                nxt_bond = true;
-            }
-        }
-        if (R.nblk && !rd_rows_ride && iB >= 0) {
-            // (atom graph whose edges are not the bonds in order: the product first, the rows' term accumulates behind it)
-            FN_TRY(launch_linear128_group(T, hs));
-            T = LinTasks{};
-        }
-        FN_TRY(launch_lin_rd(T, R, hs));
-
-        // ---- what the next iteration's L1 finds
-        if (last) { nxt_bond = nxt_bond || have_bond;  nxt_fbond = nxt_fbond || have_fbond; }
-        pend_b = nxt_bond;
-        pend_fb = nxt_fbond && !no_fb;
-        have_atoms = nxt_atoms;
-        have_bond = have_fbond = have_frags = false;
-        // layer l's bond levels run in iteration l-1 (or behind the loop); their operands of THIS layer are named there via l+1
-    }
-    {   // the bond / fragment-bond levels of layer 0
-        fni::MolBwdLevel lv[2];
-        int nl = 0, iB = -1, iFB = -1;
-        const fn_layer_weights& w0 = e->w[0];
-        const fn_layer_weights& g0 = grads[0];
-        const fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w0.emb_b_w, w0.emb_b_b};
-        const fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w0.emb_fb_w, w0.emb_fb_b};
-        if (pend_b) { iB = nl;  lv[nl++] = level(fni::LV_BOND, bw.g_pre_bond, lay.L[0].h_b, lay.L[0].p_bond, w0.a_b, 3 * d, 2 * d, et_b, e->bond, bw.bond[0], nullptr, kPerBond); }
-        if (pend_fb) { iFB = nl;  lv[nl++] = level(fni::LV_FBOND, bw.g_pre_fbond, lay.L[0].h_fb, lay.L[0].p_fbond, w0.f_a_b, 3 * d, 2 * d, et_fb, e->fbond, bw.fbond[0], nullptr, kPerFbond); }
-        FN_TRY(mol_launch(lv, nl));
-        if (iB >= 0) {
-            FN_TRY(rq.finalize(bw.bond[0].part_a, lv[iB].n_blk, bw.bond[0].part_e, lv[iB].n_blk, et_b, w0.a_b, 3 * d, 0, 2 * d, g0.a_b, g0.emb_b_w, g0.emb_b_b, H));
-            FN_TRY(rq.wgrad(bw.bond[0].g_h, e->bond_nodes, e->k_bond0, e->E, bw.bond[0].wg_ws, g0.proj_b_w, g0.proj_b_b, hs));
-        }
-        if (iFB >= 0) {
-            FN_TRY(rq.finalize(bw.fbond[0].part_a, lv[iFB].n_blk, bw.fbond[0].part_e, lv[iFB].n_blk, et_fb, w0.f_a_b, 3 * d, 0, 2 * d, g0.f_a_b, g0.emb_fb_w, g0.emb_fb_b, H));
-            FN_TRY(rq.wgrad(bw.fbond[0].g_h, e->fbond_nodes, e->k_fbond0, e->EF, bw.fbond[0].wg_ws, g0.proj_fb_w, g0.proj_fb_b, hs));
-        }
-    }
-    return rq.flush(true);
-}
-
 
 int enc_check(const fn_encoder* e) {
     if (!e) return fail(FN_EINVAL, "fn_encoder: null descriptor");
@@ -5759,10 +5376,10 @@ int encoder_backward_one(const fn_encoder* e, const EncLayout& lay, const BwdLay
         }
         if (R.nblk && !rd_rows_ride && pend_b) {
             // (no RowAdd carrier: the product first, the rows' term accumulates behind it)
-            FN_TRY(launch_lin_rd(T, RowDotsBwdArgs{}, hs, true));
+            FN_TRY(launch_lin_rd(T, RowDotsBwdArgs{}, hs));
             T = LinTasks{};
         }
-        FN_TRY(launch_lin_rd(T, R, hs, true));
+        FN_TRY(launch_lin_rd(T, R, hs));
 
         // ---- what the next iteration's L1 finds
         if (last) {
@@ -5890,7 +5507,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
                 A.n_ss[1] = flat_grid(e->fbond.m * e->k_fattr, 512);
             }
         }
-        if (mol_bwd_on(e) || tail_mol_on(e) || pad_skip_on(e)) {
+        if (tail_mol_on(e) || pad_skip_on(e)) {
             A.mx = MolExtArgs{e->mol_atoms.rowptr, e->mol_frags.rowptr, e->mol_atoms.pos_base, e->mol_frags.pos_base,
                               e->bond, e->atom, no_fb ? fn_gat_plan{} : e->fbond, e->frag, (int)e->n_mols,
                               reinterpret_cast<MolExt*>(lay.mol_ext), e->counts_dev, reinterpret_cast<int32_t*>(lay.real_rows)};
@@ -6089,7 +5706,6 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
     if (bw.total > scratch_floats) return fail(FN_EINVAL, "fn_encoder_backward: scratch too small");
     const RngPlan rng = rng_plan(e);
     if (e->g_pooled && !tail_mol_on(e)) return fail(FN_EINVAL, "fn_encoder_backward: dL/d(readout) is only taken by the fused fragment tail (fn_encoder_fused_tail)");
-    if (mol_bwd_on(e)) return encoder_backward_mol(e, lay, bw, rng, out_atoms, out_frags, out_bond, out_fbond, g_atoms, g_frags, g_bond, g_fbond, grads, S(st));
     if (one_pass_on(e)) return encoder_backward_one(e, lay, bw, rng, out_atoms, out_frags, out_bond, out_fbond, g_atoms, g_frags, g_bond, g_fbond, grads, S(st));
     const int H = e->heads, d = FN_D / H;
     const float p = e->training ? e->drop_p : 0.f;
@@ -6102,21 +5718,10 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
     rq.defer_mixed = g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;      // ... and layer 0's
     rq.rider = e->adam_rider;
 
-    const bool colaunch = g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;
-    // two chains side by side (k_gat_bwd_src_pair_dst / k_gat_bwd_src_lin_rd): the bond levels' source pass of layer l+1 is held back
-    // and launched with the atom level's destination pass of layer l; the atom graph's edge-term gradient reaches the bond rows in
-    // the epilogue of the bond input-gradient product (RowAdd: every bond is edge e of the atom graph, in order)
-    const bool pipeline = colaunch && H == 4 && g_tune[FN_TUNE_BWD_PIPELINE] != 0 && e->atom.m_real == e->E && e->E > 0;
-    GatBwdSrcArgs pend_sb{}, pend_sfb{};
-    bool pend = false, carry_has_rd = false;
-    rq.before_flush = [&]() -> int {
-        if (!pend) return 0;
-        pend = false;
-        const int rc = launch_gat_bwd_src_pair(pend_sb, pend_sfb, H, hs);
-        pend_sb = GatBwdSrcArgs{};  pend_sfb = GatBwdSrcArgs{};
-        return rc;
-    };
-    LinTasks dx_carry{};             // input-gradient products handed from layer l+1 to layer l's first attention launch
+    // (This is the general path: any head count, hand-built atom graphs, gat2_edge's fragment graph.  The configurations the one-pass
+    // backward covers never get here, so its launches run in plain dependency order: per layer the gates, the fragment levels (last
+    // layer), the atom level's two passes, the bond and fragment-bond levels' two passes each, and one grouped launch for the layer's
+    // input-gradient products.  The co-launched / pipelined forms of rounds 2-3 are retired: tools/probe/retired/.)
     // gradients w.r.t. the current layer's post-activation outputs (null = zero)
     bool pre_atoms = false, pre_bond = false, pre_fbond = false;   // g_pre_* already hold layer l's pre-activation grads
     const float* gy_atoms = g_atoms;
@@ -6139,20 +5744,11 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         const int ka = l ? FN_D : e->k_atom0, kb = l ? FN_D : e->k_bond0, kfb = l ? FN_D : e->k_fbond0;
         const LevelScratch &sb = bw.bond[l], &sa = bw.atom[l], &sfb = bw.fbond[l], &sf = bw.frag;
         int n_a = 0, n_e = 0;
-        // the three input-gradient products of a layer feed layer l-1 only: one grouped launch at the end of the layer -- or, with
-        // co-launching, the atom product rides with this layer's bond-level destination pass (dxA) and the bond / fragment-bond
-        // products with layer l-1's atom-level destination pass (dx_carry, launched in the next iteration)
-        LinTasks dxT{}, dxA{};
-        LinTasks dx_now = dx_carry;          // products of layer l+1 that this layer's atom level launches
-        dx_carry = LinTasks{};
-        const bool now_has_rd = carry_has_rd;        // ... whose bond product adds this layer's edge-term gradient (RowAdd)
-        carry_has_rd = false;
-        // Wt: the transposed copy the forward prologue left in the workspace (k_proj128 wants the weight n-major)
-        auto input_grad = [&](const float* gh, const float* W, const float* Wt, float* gy, int64_t rows, const fn_act_epilogue& mk, fn_stream_t sq,
-                              int where, const RowAdd* ra = nullptr) -> int {
-            LinTasks& dst = !colaunch ? dxT : (where == 0 ? dxA : dx_carry);
-            dst.t[dst.n++] = LinTask{Wt, gh, W, nullptr, gy, rows, mk, NodeScalarEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0}, 0, 0};
-            if (ra) dst.t[dst.n - 1].ra = *ra;
+        // the three input-gradient products of a layer feed layer l-1 only: one grouped launch at the end of the layer
+        LinTasks dxT{};
+        // Wt: the transposed copy the forward prologue left in the workspace
+        auto input_grad = [&](const float* gh, const float* W, const float* Wt, float* gy, int64_t rows, const fn_act_epilogue& mk) -> int {
+            dxT.t[dxT.n++] = LinTask{Wt, gh, W, nullptr, gy, rows, mk, NodeScalarEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0}, 0, 0};
             return 0;
         };
         const float* bt_b = lay.bt + (size_t)(3 * l) * 192 * FN_D;
@@ -6233,57 +5829,23 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
         // ---- L2 atom graph
         if (have_atoms) {
             fn_edge_term et_a{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-            {
-                GatBwdDstArgs da{};
-                FN_TRY(prep_gat_bwd_dst(bw.g_pre_atoms, a.h_a, a.p_atom, &et_a, &e->atom, 0.2f, nullptr, sa.dz, sa.pz, sa.g_s_dst, nullptr, &n_e, H, &da));
-                if (pipeline) {          // + the source pass of layer l+1's bond levels, held back for this launch
-                    FN_TRY(launch_gat_bwd_src_pair_dst(pend_sb, pend_sfb, da, H, hs));
-                    pend = false;  pend_sb = GatBwdSrcArgs{};  pend_sfb = GatBwdSrcArgs{};
-                } else {
-                    FN_TRY(launch_gat_bwd_dst_lin(da, dx_now, H, hs));      // + layer l+1's bond / fragment-bond input-gradient products
-                    dx_now = LinTasks{};
-                }
-            }
+            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_atoms, a.h_a, a.p_atom, &et_a, &e->atom, 0.2f, nullptr, sa.dz, sa.pz, sa.g_s_dst, nullptr, &n_e, H, st));
+            // source pass + the edge term <new_bond, a[:, d:d+128]> (dL/dnew_bond accumulates into g_pre_bond, dL/da mid block)
             int gr = 0;
-            if (pipeline && dx_now.n && now_has_rd) {
-                // layer l+1's bond / fragment-bond products (the bond one adds THIS layer's edge-term gradient to the rows it writes),
-                // this level's source pass and the edge term's parameter partials: one launch
-                GatBwdSrcArgs sA{};
-                FN_TRY(prep_gat_bwd_src(bw.g_pre_atoms, a.h_a, sa.pz, sa.g_s_dst, w.a, wide, 0, d + FN_D, &e->atom, sa.g_h, sa.part_a, &n_a, H, &sA));
-                gr = row_grid(e->atom.m_real, g_tune[FN_TUNE_RD_BLOCKS] > 0 ? g_tune[FN_TUNE_RD_BLOCKS] : kRowDotsBwdBlocks);
-                const RowDotsBwdArgs R{sa.dz, a.new_bond, w.a, wide, d, H, e->atom, nullptr, sa.part_rd, nullptr, 1, gr};
-                FN_TRY(launch_gat_bwd_src_lin_rd(sA, dx_now, R, H, hs));
-                dx_now = LinTasks{};
-            } else {
-                if (dx_now.n) {          // (pipeline without a RowAdd carrier: the products first, the edge term accumulates into their rows)
-                    FN_TRY(launch_linear128_group(dx_now, hs));
-                    dx_now = LinTasks{};
-                }
-                FN_TRY(bwd_src_and_edge_term(bw.g_pre_atoms, a.h_a, sa.pz, sa.g_s_dst, w.a, wide, 0, d + FN_D, &e->atom, sa.g_h, sa.part_a, &n_a,
-                                             sa.dz, a.new_bond, d, bw.g_pre_bond, sa.part_rd, have_bond, &gr, H, hs));
-            }
+            FN_TRY(bwd_src_and_edge_term(bw.g_pre_atoms, a.h_a, sa.pz, sa.g_s_dst, w.a, wide, 0, d + FN_D, &e->atom, sa.g_h, sa.part_a, &n_a,
+                                         sa.dz, a.new_bond, d, bw.g_pre_bond, sa.part_rd, have_bond, &gr, H, hs));
             if (gr) have_bond = true;
             FN_TRY(rq.finalize(sa.part_a, n_a, nullptr, 0, et_a, w.a, wide, 0, d + FN_D, g.a, nullptr, nullptr, H));
             if (gr) FN_TRY(rq.colsum(sa.part_rd, gr, H * FN_D, g.a, wide, d));
             FN_TRY(rq.wgrad(sa.g_h, in_atoms, ka, e->N, sa.wg_ws, g.proj_a_w, g.proj_a_b, hs));
             if (l) {
                 const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_atoms), p, 1, e->seed, rng.y[l - 1][0], e->offset_dev};
-                FN_TRY(input_grad(sa.g_h, w.proj_a_w, bt_a, bw.g_pre_atoms, e->N, mk, st, 0));
+                FN_TRY(input_grad(sa.g_h, w.proj_a_w, bt_a, bw.g_pre_atoms, e->N, mk));
                 nxt_atoms = true;
             }
         }
-        if (pend) {              // no atom level ran in this layer: the held-back source pass and the carried products still have to
-            FN_TRY(launch_gat_bwd_src_pair(pend_sb, pend_sfb, H, hs));
-            pend = false;  pend_sb = GatBwdSrcArgs{};  pend_sfb = GatBwdSrcArgs{};
-        }
-        if (dx_now.n) {
-            for (int i = 0; i < dx_now.n; ++i) dx_now.t[i].ra = RowAdd{nullptr, nullptr, 0};     // no destination pass wrote the term's input
-            FN_TRY(launch_linear128_group(dx_now, hs));
-            dx_now = LinTasks{};
-        }
 
-        // ---- L1 bond graph and L4a fragment-bond graph: independent of each other, so their destination passes
-        // share one launch and so do their source passes (with side streams on: one launch each on their own stream)
+        // ---- L1 bond graph and L4a fragment-bond graph
         if (have_bond || have_fbond) {
             fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
             fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
@@ -6298,14 +5860,14 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
                 FN_TRY(prep_gat_bwd_dst(bw.g_pre_fbond, a.h_fb, a.p_fbond, &et_fb, &e->fbond, 0.2f, nullptr, nullptr, sfb.pz, sfb.g_s_dst, sfb.part_e, &n_e_fb, H, &dfb));
                 FN_TRY(prep_gat_bwd_src(bw.g_pre_fbond, a.h_fb, sfb.pz, sfb.g_s_dst, w.f_a_b, 3 * d, 0, 2 * d, &e->fbond, sfb.g_h, sfb.part_a, &n_a_fb, H, &sfbA));
             }
-            FN_TRY(launch_gat_bwd_dst_pair_lin(db, dfb, dxA, H, hs));        // + this layer's atom input-gradient product
-            dxA = LinTasks{};
-            if (pipeline && l > 0) { pend_sb = sbA;  pend_sfb = sfbA;  pend = true; }     // rides with layer l-1's atom destination pass
-            else FN_TRY(launch_gat_bwd_src_pair(sbA, sfbA, H, hs));
+            FN_TRY(launch_gat_bwd_dst(db, H, hs));
+            FN_TRY(launch_gat_bwd_dst(dfb, H, hs));
+            FN_TRY(launch_gat_bwd_src(sbA, H, hs));
+            FN_TRY(launch_gat_bwd_src(sfbA, H, hs));
             if (have_fbond) {
                 if (l) {     // dL/d(pre-activation fbond output of layer l-1), gated by that layer's dropout mask and ReLU
                     const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_fbond), p, 1, e->seed, rng.y[l - 1][3], e->offset_dev};
-                    FN_TRY(input_grad(sfb.g_h, w.proj_fb_w, bt_fb, bw.g_pre_fbond, e->EF, mk, st, 1));
+                    FN_TRY(input_grad(sfb.g_h, w.proj_fb_w, bt_fb, bw.g_pre_fbond, e->EF, mk));
                     nxt_fbond = true;
                 }
                 FN_TRY(rq.finalize(sfb.part_a, n_a_fb, sfb.part_e, n_e_fb, et_fb, w.f_a_b, 3 * d, 0, 2 * d, g.f_a_b, g.emb_fb_w, g.emb_fb_b, H));
@@ -6316,24 +5878,16 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
                     FN_TRY(rq.wgrad(sb.g_h, in_bond, kb, e->E, sb.wg_ws, g.proj_b_w, g.proj_b_b, hs));
                 if (l) {
                     const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_bond), p, 1, e->seed, rng.y[l - 1][2], e->offset_dev};
-                    if (pipeline && nxt_atoms) {      // layer l-1's atom level will run: its edge-term gradient rides in this product's epilogue
-                        const RowAdd ra{bw.atom[l - 1].dz, e->w[l - 1].a + d, wide};
-                        FN_TRY(input_grad(sb.g_h, w.proj_b_w, bt_b, bw.g_pre_bond, e->E, mk, st, 1, &ra));
-                        carry_has_rd = true;
-                    } else {
-                        FN_TRY(input_grad(sb.g_h, w.proj_b_w, bt_b, bw.g_pre_bond, e->E, mk, st, 1));
-                    }
+                    FN_TRY(input_grad(sb.g_h, w.proj_b_w, bt_b, bw.g_pre_bond, e->E, mk));
                     nxt_bond = true;
                 }
             }
         }
-        if (dxA.n) FN_TRY(launch_linear128_group(dxA, hs));          // no bond-level launch took it
         if (dxT.n) FN_TRY(launch_linear128_group(dxT, hs));
         pre_atoms = nxt_atoms;  pre_bond = nxt_bond;  pre_fbond = nxt_fbond;
         gy_atoms = gy_bond = gy_fbond = nullptr;
         gy_frags = nullptr;        // a layer's x_frags input is dead in the reference (overwritten at gat2.py:234)
     }
-    if (pend) FN_TRY(launch_gat_bwd_src_pair(pend_sb, pend_sfb, H, hs));
     return rq.flush(true);
 }
 

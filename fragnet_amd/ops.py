@@ -153,7 +153,7 @@ class _GatLevel(torch.autograd.Function):
                       g_s_dst.data_ptr(), n, heads, st)
             _lib.call("fn_gat_bwd_one_f32", g_out.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), cdot.data_ptr(), g_s_dst.data_ptr(),
                       C.byref(et), att.data_ptr(), att_w, dst_off, src_off, C.byref(level.c), NEG_SLOPE, g_h.data_ptr(), _ptr(dz), None,
-                      part_a.data_ptr(), C.byref(n_a), _ptr(part_e), C.byref(n_e), 0, heads, st)
+                      part_a.data_ptr(), C.byref(n_a), _ptr(part_e), C.byref(n_e), 0, None, heads, st)
         else:
             pz = torch.empty((heads, m, 2), dtype=torch.float32, device=dev)
             _lib.call("fn_gat_bwd_dst_f32", g_out.data_ptr(), h.data_ptr(), p_sorted.data_ptr(), C.byref(et),

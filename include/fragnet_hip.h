@@ -81,20 +81,11 @@ int fn_abi_version(void);
                                  * profiles/r02e_colaunch_ab.txt); 0: separate launches */
 #define FN_TUNE_RETIRED_15 15    /* (retired: persistent riding GEMM workgroups walking several tiles, slower) */
 #define FN_TUNE_RETIRED_16 16    /* (retired: raised wave priority of the riding workgroups, no effect) */
-#define FN_TUNE_BWD_PIPELINE 17   /* 1 (default): fn_encoder_backward runs the atom chain of layer l beside the bond chain of layer l+1
-                                  * (three launches per layer: k_gat_bwd_src_pair_dst, k_gat_bwd_src_lin_rd, k_gat_bwd_dst_pair_lin; the
-                                  * atom graph's edge-term gradient lands on the bond rows in the epilogue of the bond input-gradient
-                                  * product); 0: four launches per layer in series.  Needs 4 heads and FN_TUNE_GEMM_COLAUNCH != 0 */
-#define FN_TUNE_BWD_MOL 18        /* 1: fn_encoder_backward runs every attention level's backward as ONE pass of the molecule-resident
-                                  * kernel (csrc/mol_bwd.hip: a workgroup owns whole molecules, stages their gradient rows in LDS
-                                  * once, never sends (p, dz) through memory; two launches per layer) when the batch carries
-                                  * molecule CSRs (fn_encoder.n_mols) and heads == 4.  0 (default): destination pass + source pass.
-                                  * Measured (MI355X, ESOL batch 512, bond level): 39 us against 28.7 us for the two passes -- every
-                                  * workgroup carries one molecule through load -> three barrier-separated passes, and the largest
-                                  * molecule (2 x the mean) sets the launch time; DESIGN.md has the phase timings */
-#define FN_TUNE_BWD_MOL_FORCE_SLOW 19 /* test / dev hook of the molecule-resident backward: 1 = every unit takes the path for molecules
-                                  * that do not fit the LDS tile (rows and edge state in global memory); 2 = the large size class
-                                  * (1024-thread workgroups, 192 rows); 3, 4 = smaller LDS images */
+#define FN_TUNE_RETIRED_17 17    /* (retired in round 5: the two-pass backward's atom chain beside the bond chain -- superseded by the one-pass
+                                  * backward; the two passes remain as the general path, in plain dependency order) */
+#define FN_TUNE_RETIRED_18 18    /* (retired in round 5: the molecule-resident single-pass backward of round 3 -- 39 us against 28 for a level;
+                                  * source kept out of the build under tools/probe/retired/mol_bwd.hip) */
+#define FN_TUNE_RETIRED_19 19    /* (retired: test hook of that kernel) */
 #define FN_TUNE_MOL_TAIL 20           /* 1 (default): batches marked molecule-contiguous (fn_encoder.mol_contiguous) run the last layer's
                                        * fragment tail -- fragment sums, fragment graph, readout and their backward -- as one
                                        * molecule-resident launch each way (csrc/mol_tail.inc); 0: the separate launches;
@@ -125,11 +116,9 @@ int fn_abi_version(void);
                                        * 0: out2 / sigma in the forward, <g, out2> in the producers' epilogues (round 4) */
 #define FN_TUNE_COUNT 30
 int fn_set_tuning(int key, int value);
-/* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= FN_MOL_STAMPS * workgroups 64-bit words) is
- * set, every workgroup of the molecule-resident backward (FN_TUNE_BWD_MOL) writes s_memtime stamps of its phases into it
- * (tools/molbwd_check.py --stamps; words 14 / 15 = wall_clock64 at start / end).  NULL switches it off (the default: the kernel
- * then pays one uniform branch per phase). */
-#define FN_MOL_STAMPS 16
+/* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= 16 * 4 * workgroups 64-bit words) is set, every wave
+ * of the one-pass attention backward (fn_gat_bwd_one_f32) writes s_memtime stamps of its phases into it (tools/probe/bwd_one_probe.py
+ * --stamps).  NULL switches it off (the default: the kernel then pays one uniform branch per phase). */
 int fn_debug_set_stamps(void* buf, int64_t n_u64);
 const char* fn_last_error(void);
 
@@ -318,33 +307,20 @@ int fn_gat_bwd_one_f32(const float* g_out, const float* h, const float* p_sorted
                        const fn_edge_term* et, const float* att, int att_w, int dst_off, int src_off, const fn_gat_plan* plan,
                        float neg_slope, float* g_h, float* dz_sorted, float* g_s_orig, float* part_a, int* n_part_a,
                        float* part_e, int* n_part_e, int p_edge_major /*layout of p_sorted, as fn_gat_fwd_f32 wrote it*/,
-                       int heads, fn_stream_t stream);
+                       float* dz_em /*nullable; non-null (four heads): the DEFERRED form, see below*/, int heads, fn_stream_t stream);
+/* The deferred form (ABI 11; what fn_encoder_backward runs for four heads, FN_TUNE_DEFER_GSD): g_s_dst is not read and the forward
+ * needs no out2 / sigma.  The pass writes dz of every edge at its destination-order slot, dz_em [m,4] edge-major, and leaves the two
+ * terms that need g_s_dst[t,h] = the sum of row t's contiguous dz_em segment OUT of its results: g_h lacks g_s_dst[s] a_dst, and the
+ * a_dst columns of part_a are zero.  fn_gat_gsd_f32 forms g_s_dst [n,4] from dz_em and overwrites those columns of part_a (rows
+ * 0 .. n_part_a-1) with the partials of dL/da_dst = sum_t g_s_dst[t,h] h[t, head h's columns]; the caller adds g_s_dst[s] a_dst to
+ * g_h (inside the engine the consumers of g_h do: the input-gradient product as one more MFMA step, the weight-gradient kernels
+ * on their dY operand). */
+int fn_gat_gsd_f32(const float* dz_em, const fn_gat_plan* plan, const float* h, float* g_s_dst, float* part_a, int n_part_a,
+                   fn_stream_t stream);
 /* c[t,h] = scale <g_out[t,h,:], out[t,h,:]>, u[t,h] = <g_out[t,h,:], out2[t,h,:]> - c[t,h] sigma[t,h] for n rows.  `out` may be the
  * level's relu(dropout(.)) output with scale = 1 - p when g_out reaches the rows through that gate only. */
 int fn_gat_cu_f32(const float* g_out, const float* out, const float* out2, const float* sigma, float scale, float* c, float* u,
                   int64_t n, int heads, fn_stream_t stream);
-
-/* Molecule extents of a collated batch.  collate_fn concatenates molecules (dataset/data.py:877-948), so the atoms, directed
- * bonds, fragments, fragment connections and the edges of the four graphs of molecule i are contiguous ranges; ext [n_mols][16]
- * int32 = {a0, na, b0, nb, f0, nf, c0, nc, eb0, meb, ea0, mea, ef0, mef, ec0, mec}: first index and count of its atoms / bonds /
- * fragments / connections, then first destination-sorted position and count of its bond-graph edges, atom-graph items (edges +
- * self loops), fragment-bond-graph edges and fragment-graph items.  mol_atoms / mol_frags: fn_plan_build segment CSRs keyed by
- * `batch` / `frag_batch` (gat2.py:820-821); fbond may be NULL (gat2_lite / gat2_edge). */
-int fn_mol_extents(const fn_seg_plan* mol_atoms, const fn_seg_plan* mol_frags, const fn_gat_plan* bond, const fn_gat_plan* atom,
-                   const fn_gat_plan* fbond, const fn_gat_plan* frag, int64_t n_mols, int32_t* ext, fn_stream_t stream);
-
-/* Backward of one attention level in ONE pass (replaces fn_gat_bwd_dst_f32 + fn_gat_bwd_src_f32 for molecule-contiguous batches;
- * autograd of gat2.py:146-169): a workgroup owns `mols_per_unit` consecutive molecules, stages their g_out rows and edge state
- * in LDS once, and writes g_h [n,128], the edge-term gradient (mode 0: g_s_orig [m_real, H] in original edge order, nullable;
- * mode 2: part_e [*n_part, H*(K+1)] partials of sum dz (x, 1)) and part_a (column-major [256][FN_MAX_PART], *n_part rows used),
- * to be reduced by fn_gat_bwd_finalize_f32.  which: 0 bond graph, 1 atom graph, 2 fragment-bond graph, 3 fragment graph (the
- * extents of mol_ext the level's rows / edges are).  scratch: [H*m + n*H] floats, used by molecules beyond the LDS tile only.
- * counts_dev: nullable device int32 = number of real molecules (rows behind them get zero gradients).  status: nullable device
- * word, bit 1 (value 2) is set when a molecule's edges leave its rows (the batch is not molecule-contiguous).  heads must be 4. */
-int fn_gat_bwd_mol_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et, const float* att,
-                       int att_w, int dst_off, int src_off, const fn_gat_plan* plan, float slope, const int32_t* mol_ext,
-                       int64_t n_mols, int which, int mols_per_unit, const int32_t* counts_dev, float* g_h, float* g_s_orig,
-                       float* part_a, float* part_e, int* n_part, float* scratch, int32_t* status, int heads, fn_stream_t stream);
 
 /* Reduces the partials into g_att [H, att_w] (dst/src blocks, and the edge block in mode 2) and,
  * in mode 2, g_embW [d_e,K], g_embb [d_e].  g_att must be zero-initialised by the caller. */
@@ -697,8 +673,7 @@ typedef struct fn_encoder {
     int64_t ws_floats;                     /* >= fn_encoder_ws_floats() */
     /* Molecule CSRs (optional; n_mols = 0: absent).  collate_fn concatenates molecules, so the atoms / bonds / fragments /
      * connections / graph edges of molecule i are contiguous ranges (dataset/data.py:877-948).  They drive the molecule-resident
-     * single-pass backward (FN_TUNE_BWD_MOL, csrc/mol_bwd.hip; heads == 4).  A batch that violates the contiguity sets bit 1 of
-     * *status. */
+     * fragment tail (below) and the padding-row skip (FN_TUNE_PAD_SKIP). */
     fn_seg_plan mol_atoms, mol_frags;      /* atoms / fragments keyed by molecule (batch, frag_batch: gat2.py:820-821) */
     int64_t n_mols;
     const int32_t* counts_dev;             /* nullable device [1]: number of REAL molecules (the first ones) when the batch is

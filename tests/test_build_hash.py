@@ -8,7 +8,7 @@ def test_digest_covers_every_source_and_flags(tmp_path, monkeypatch):
     d0 = build.source_digest()
     assert len(d0) == 64 and d0 == build.source_digest()
     assert any(p.endswith("dense_head.inc") for p in build.INCLUDED) and any(p.endswith("fn_internal.h") for p in build.INCLUDED)
-    assert any(p.endswith("mol_bwd.hip") for p in build.SOURCES) and any(p.endswith("tower.hip") for p in build.SOURCES)
+    assert any(p.endswith("mol_plan.hip") for p in build.SOURCES) and any(p.endswith("tower.hip") for p in build.SOURCES)
     fake = tmp_path / "extra.inc"
     fake.write_text("// x\n")
     monkeypatch.setattr(build, "INCLUDED", build.INCLUDED + [str(fake)])

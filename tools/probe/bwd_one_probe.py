@@ -145,7 +145,7 @@ def main():
         def one():
             _lib.call("fn_gat_bwd_one_f32", gout.data_ptr(), h.data_ptr(), p_one.data_ptr(), cdot.data_ptr(), g_s_dst1.data_ptr(), C.byref(et_1),
                       att.data_ptr(), att_w, 0, src_off, C.byref(lv.c), 0.2, g_h1.data_ptr(), None, dz1.data_ptr() if orig else None,
-                      part_a1.data_ptr(), C.byref(n_a1), part_e1.data_ptr(), C.byref(n_e1), PEM, H, st)
+                      part_a1.data_ptr(), C.byref(n_a1), part_e1.data_ptr(), C.byref(n_e1), PEM, None, H, st)
 
         fwd(); fwd2(); bwd_dst(); bwd_src(); cu(); one()
         torch.cuda.synchronize()
