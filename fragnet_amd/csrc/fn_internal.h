@@ -29,9 +29,121 @@ struct MolExt {
     int ec0, mec;          // fragment-graph items
 };
 static_assert(sizeof(MolExt) == 64, "MolExt is sixteen int32 (include/fragnet_hip.h documents it as int32 [n_mols][16])");
+
+// ---- argument blocks and host-side entry points shared by the translation units (the forward attention family lives in
+// gat_fwd.hip / gat_fwd_lin.hip, everything else in fragnet_hip.hip)
+struct GatFwdArgs {
+    const float *h, *s_dst, *s_src, *att;
+    int att_w;
+    fn_edge_term et;
+    fn_gat_plan pl;
+    float slope;
+    float *out, *p_sorted, *probs_orig;
+    fn_act_epilogue ep;
+    int rows_per_hw, nblk;
+    // optional fused "row dots" of the level that consumes this one's raw output as its edge attribute (bond graph -> atom
+    // graph, gat2.py:203-208): rd_out[j * rd_m + rd_pos[t]] = <out[t, :], rd_A[j * rd_lda : +128]>, j < rd_J -- the edge term
+    // of the next level, written straight into ITS destination-sorted order (rd_pos = that level's inv_d)
+    const float* rd_A;
+    float* rd_out;
+    const int32_t* rd_pos;
+    int64_t rd_m;
+    int rd_lda, rd_J;
+    // optional second output for the one-pass backward (gat_bwd_one.inc): out2[t] = sum_e lambda_e p_e h[src_e] and
+    // sigma[t, h] = sum_e lambda_e p_e, lambda_e = 1 where z_e > 0, else the LeakyReLU slope
+    float *out2, *sigma;
+    int p_edge_major;     // p_sorted as [m][H] instead of [H][m]: what the one-pass backward gathers by position (one line per edge)
+    const int32_t* n_real;   // nullable device word: rows >= *n_real are padding (zero outputs, nothing gathered)
+    int tier6;               // gather tiers 4 / 6 / 8 (1) or 4 / 8 (0)
+};
+struct NodeScalarEpi {             // optional fused epilogue: s_dst/s_src[row, head] = <Y[row, head cols], att blocks>
+    const float* att;
+    float* s_dst;
+    float* s_src;
+    int att_w, dst_off, src_off, heads;     // heads in {2, 4, 8}: a head's columns must lie inside one wave's 64
+};
+struct RowAdd {
+    const float* z;           // [M][4]: dL/d(edge term) of row e, the four heads together; null: no term
+    const float* a;           // a[h * lda + column]
+    int lda;
+};
+struct CuEpi {
+    const float *out, *out2, *sigma;
+    float *c, *u;             // c == null: no such epilogue
+    int heads;
+};
+struct GsdEpi {
+    const float* dz;          // [m][4]; null: no such term
+    const int32_t* rowptr;    // the level's by-destination CSR (M + 1 words); positions are rowptr[.] - pos_base
+    int pos_base;
+    const float* R;           // [4][128], see above
+    float* gsd;               // out [M][4]
+};
+// up to three independent [M_i,K]·[K,128] products in one launch: the three projections of a layer (forward) or
+// their three input-gradient products (backward) depend only on the previous layer, never on each other
+struct LinTask {
+    const float* Wn;          // the same weight n-major ([128 n][K]) for k_proj128; null: only the k_linear128 form is available
+    const float *X, *Bt, *bias;
+    float* Y;
+    int64_t M;
+    fn_act_epilogue mk;
+    NodeScalarEpi ns;
+    int first, nblk;
+    int K;                    // 0: the group's K (LinTasks::K); else this task's own reduction length (layer 0: 17 bond / 6 connection features)
+    RowAdd ra;                // riding input-gradient products only (lin_side_block)
+    CuEpi cu;                 // ... of the one-pass backward (lin_side_block<true>)
+    GsdEpi gs;                // ... of its deferred form (lin_side_block<true, true>)
+    const int32_t* n_real;    // nullable device word: row tiles that start at or behind *n_real are padding and are not computed
+};
+struct LinTasks {
+    LinTask t[3];
+    int n, K;
+    int base, total;          // co-launched with an attention pass (below): the GEMM workgroups are blocks [base, base + total) of that launch
+};
+// gat_fwd.hip
+FNI_HIDDEN int prep_gat_fwd(const float* h, const float* s_dst, const float* s_src, const float* att, int att_w, const fn_edge_term* et,
+                            const fn_gat_plan* plan, float neg_slope, float* out, float* p_sorted, float* probs_orig,
+                            const fn_act_epilogue* act, int heads, GatFwdArgs* A, float* out2 = nullptr, float* sigma = nullptr);
+FNI_HIDDEN int launch_gat_fwd(const GatFwdArgs& A, int heads, hipStream_t st);
+FNI_HIDDEN int launch_gat_fwd_pair(const GatFwdArgs& A, const GatFwdArgs& B, int heads, hipStream_t st);
+// gat_fwd_lin.hip: an attention pass + the K = 128 projection tiles that do not depend on it, in one launch
+FNI_HIDDEN int launch_gat_fwd_lin(const GatFwdArgs& A, LinTasks& T, int heads, hipStream_t st);
+FNI_HIDDEN int launch_gat_fwd_pair_lin(const GatFwdArgs& A, const GatFwdArgs& B, LinTasks& T, int heads, hipStream_t st);
+// fragnet_hip.hip
+FNI_HIDDEN int launch_linear128_group(LinTasks& T, hipStream_t st);
+FNI_HIDDEN bool bad_edge_term(const fn_edge_term* et, int64_t m);
 }  // namespace fni
 
 namespace {
+inline hipStream_t S(fn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+#define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+#define FN_DISPATCH_H(heads, CALL)                         \
+    switch (heads) {                                       \
+        case 1: { constexpr int HH = 1; CALL; } break;     \
+        case 2: { constexpr int HH = 2; CALL; } break;     \
+        case 4: { constexpr int HH = 4; CALL; } break;     \
+        case 8: { constexpr int HH = 8; CALL; } break;     \
+        default: return fni::fail(FN_EUNSUPPORTED, "heads must be 1, 2, 4 or 8 (128 = heads * head_dim)"); \
+    }
+constexpr int kBlock = 256;
+constexpr int kRows = 8;          // rows (half-waves) per block
+constexpr int kGridCap = 2048;    // memory-bound kernels: ~8 blocks per CU, grid-stride the rest
+constexpr int kBwdRows = 8;       // rows (half-waves) per block in the attention backward kernels
+inline int row_grid(int64_t rows, int cap) {
+    int64_t g = (rows + kRows - 1) / kRows;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+inline int flat_grid(int64_t work, int cap) {
+    int64_t g = (work + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+// edge class of an attention level = the KL template argument of its kernels: 0 stored edge term, 1 / FN_MAX_EDGE_K raw attributes
+inline int edge_class(const fn_edge_term* et) { return et->mode == 0 ? 0 : (et->K == 1 ? 1 : FN_MAX_EDGE_K); }
+inline int lin_blocks(int64_t tiles, int iters) { return 2 * (int)((tiles + iters - 1) / iters); }     // 64 x 64 tiles: two column halves per row tile
 
 constexpr int kWfLd = FN_MAX_EDGE_K + 1;
 

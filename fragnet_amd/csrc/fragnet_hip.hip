@@ -37,13 +37,14 @@ int launch_status(const char* where) {
     return 0;
 }
 
-inline hipStream_t S(fn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
-
-constexpr int kBlock = 256;
-constexpr int kRows = 8;          // rows (half-waves) per block
-constexpr int kGridCap = 2048;    // memory-bound kernels: ~8 blocks per CU, grid-stride the rest
+// (S(), kBlock, kRows, kGridCap, kBwdRows, row_grid, flat_grid, edge_class, lin_blocks, FN_TRY, FN_DISPATCH_H: fn_internal.h)
 constexpr int kRowDotsBwdBlocks = 512;    // blocks of k_row_dots_sorted_bwd (each writes one J*128-wide partial row)
-constexpr int kBwdRows = 8;       // rows (half-waves) per block in the attention backward kernels
+using fni::GatFwdArgs;
+using fni::prep_gat_fwd;
+using fni::launch_gat_fwd;
+using fni::launch_gat_fwd_pair;
+using fni::launch_gat_fwd_lin;
+using fni::launch_gat_fwd_pair_lin;
 
 inline int bwd_grid(int64_t rows) {
     int64_t g = (rows + kBwdRows - 1) / kBwdRows;
@@ -52,19 +53,6 @@ inline int bwd_grid(int64_t rows) {
     return (int)g;
 }
 
-inline int row_grid(int64_t rows, int cap) {
-    int64_t g = (rows + kRows - 1) / kRows;
-    if (g < 1) g = 1;
-    if (g > cap) g = cap;
-    return (int)g;
-}
-
-inline int flat_grid(int64_t work, int cap) {
-    int64_t g = (work + kBlock - 1) / kBlock;
-    if (g < 1) g = 1;
-    if (g > cap) g = cap;
-    return (int)g;
-}
 
 // =====================================================================================
 // Graph plan
@@ -255,436 +243,7 @@ __global__ void k_plan_ranksort(PlanTasks P, const int32_t* __restrict__ rowptr_
 // =====================================================================================
 // Attention level
 // =====================================================================================
-// folded edge-embedding weights: Wf[h][k] = sum_c att[h, mid+c] * embW[c,k],  Wf[h][K] = sum_c att[h, mid+c] * embb[c]
-__device__ __forceinline__ void fold_edge_embed(const fn_edge_term& et, const float* att, int att_w, int H,
-                                                float (*sWf)[kWfLd]) {
-    // one wave per output scalar, lanes over the d_e-long dot product (two loads per lane, no serial chain: every
-    // block of the launch pays this prologue before its first node)
-    if (et.mode == 2) {
-        const int ne = H * (et.K + 1);
-        const int wid = threadIdx.x >> 6, l64 = threadIdx.x & 63, nw = blockDim.x >> 6;
-        for (int i = wid; i < ne; i += nw) {
-            const int hh = i / (et.K + 1), k = i % (et.K + 1);
-            float part = 0.f;
-            for (int c = l64; c < et.d_e; c += 64)
-                part = fmaf(att[hh * att_w + et.mid_off + c], (k < et.K) ? et.embW[c * et.K + k] : et.embb[c], part);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-            if (l64 == 0) sWf[hh][k] = part;
-        }
-    }
-    __syncthreads();
-}
-
-// edge term of the logit for the edge at destination-sorted position pos.  Per-edge arrays are HEAD-MAJOR
-// ([H][m], [K][m]) so that the two consecutive edges a lane owns are one 8-byte load.
-template <int H>
-__device__ __forceinline__ float edge_term_at(int pos, int head, int64_t m, const fn_edge_term& et, const float (*sWf)[kWfLd]) {
-    if (et.mode == 0) return et.s_sorted[(size_t)head * m + pos];
-    float e = sWf[head][et.K];
-    for (int k = 0; k < et.K; ++k) e = fmaf(et.x_sorted[(size_t)k * m + pos], sWf[head][k], e);
-    return e;
-}
-
-template <int H>
-__global__ __launch_bounds__(kBlock) void k_node_scalars(const float* __restrict__ h, const float* __restrict__ att,
-                                                         int att_w, int dst_off, int src_off,
-                                                         float* __restrict__ s_dst, float* __restrict__ s_src, int64_t n) {
-    constexpr int LPH = 32 / H;
-    const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH;
-    const float4 ad = ld4(att + head * att_w + dst_off + j * 4);
-    const float4 as = ld4(att + head * att_w + src_off + j * 4);
-    int64_t g0, g1;
-    block_groups(n, kRows, g0, g1);
-    for (int64_t gi = g0; gi < g1; ++gi) {
-        const int64_t r = gi * kRows + (threadIdx.x >> 5);
-        if (r >= n) continue;
-        const float4 x = ld4(h + r * FN_D + lane * 4);
-        const float pd = head_sum<LPH>(dot4(x, ad));
-        const float ps = head_sum<LPH>(dot4(x, as));
-        if (j == 0) { s_dst[r * H + head] = pd; s_src[r * H + head] = ps; }
-    }
-}
-
-// What bounds these kernels at molecule-batch sizes is neither HBM nor L2 bandwidth but the CHAIN of dependent
-// global round trips a row needs (row extent -> edge ids/terms -> source rows + source scalars -> store), ~1.2 us
-// each when ~100 rows per CU is all the work there is (ablation in DESIGN.md: gathering the same rows from an LDS
-// window instead of L2 changed nothing; an empty skeleton with two round trips already costs 9.5 us).  So:
-//  * every per-edge scalar is fetched ONCE by the lane that owns the edge -- lane j of a head group owns the
-//    consecutive in-edges 2j and 2j+1, one 8-byte load per array -- and handed round through LDS-crossbar
-//    broadcasts (__shfl), never through repeated uniform global loads (TA: one wave instruction per ~16 cycles);
-//  * up to eight source rows are in flight per half-wave before the softmax needs anything;
-//  * a half-wave owns R CONSECUTIVE rows and software-pipelines them: while row i's gathers fly, the edge data of
-//    row i+1 and the extent of row i+2 are already being fetched, so a row costs one round trip, not four.
-struct FwdExtent { int beg, deg; float sd; };                 // deg < 0: no row
-struct FwdEdges { int src0, src1; float z0, z1; };            // the lane's two in-edges: source ids, edge terms
-struct FwdRaw {                                               // the same, as loaded (folded one iteration later)
-    int pos;
-    i32x2u sp;
-    f32x2u e[FN_MAX_EDGE_K];
-};
-template <int NE> struct FwdRawT {                            // sized to the loads a kernel instance makes
-    int pos;
-    i32x2u sp;
-    f32x2u e[NE];
-};
-// The hot loop is STRAIGHT-LINE: every load is unconditional (addresses clamped into the arrays, results masked
-// afterwards).  A load inside a divergent branch whose value is used inside that branch makes the compiler wait
-// for vmcnt(0) right there -- which serialised the row gathers, the two source-scalar gathers and the prefetches
-// into separate round trips in the previous version of this kernel.
-// KL: 0 = the edge term is a stored per-edge scalar (mode 0); 1 / FN_MAX_EDGE_K = folded Linear(K -> d) of a raw
-// attribute with K == 1 / K <= FN_MAX_EDGE_K (attribute columns beyond K are re-loads of column K-1 with weight 0,
-// so that the number of loads is a compile-time constant and none of them sits in a branch).
-struct GatFwdArgs {
-    const float *h, *s_dst, *s_src, *att;
-    int att_w;
-    fn_edge_term et;
-    fn_gat_plan pl;
-    float slope;
-    float *out, *p_sorted, *probs_orig;
-    fn_act_epilogue ep;
-    int rows_per_hw, nblk;
-    // optional fused "row dots" of the level that consumes this one's raw output as its edge attribute (bond graph -> atom
-    // graph, gat2.py:203-208): rd_out[j * rd_m + rd_pos[t]] = <out[t, :], rd_A[j * rd_lda : +128]>, j < rd_J -- the edge term
-    // of the next level, written straight into ITS destination-sorted order (rd_pos = that level's inv_d)
-    const float* rd_A;
-    float* rd_out;
-    const int32_t* rd_pos;
-    int64_t rd_m;
-    int rd_lda, rd_J;
-    // optional second output for the one-pass backward (gat_bwd_one.inc): out2[t] = sum_e lambda_e p_e h[src_e] and
-    // sigma[t, h] = sum_e lambda_e p_e, lambda_e = 1 where z_e > 0, else the LeakyReLU slope
-    float *out2, *sigma;
-    int p_edge_major;     // p_sorted as [m][H] instead of [H][m]: what the one-pass backward gathers by position (one line per edge)
-    const int32_t* n_real;   // nullable device word: rows >= *n_real are padding (zero outputs, nothing gathered)
-    int tier6;               // gather tiers 4 / 6 / 8 (1) or 4 / 8 (0)
-};
-// rows [blk0, te) of the level, taken interleaved by the block's half-waves (row = blk0 + i * kRows + hw, i < rows_per_hw);
-// sWf: the folded edge-embedding weights (KL != 0), already in LDS
-template <int H, int KL, bool RD = false, bool O2 = false>
-__device__ __forceinline__ void gat_fwd_rows(const GatFwdArgs& A, float (*sWf)[kWfLd], int blk0, int te, int rows_per_hw) {
-    const float* __restrict__ h = A.h;
-    const float* __restrict__ s_dst = A.s_dst;
-    const float* __restrict__ s_src = A.s_src;
-    const fn_edge_term& et = A.et;
-    const fn_gat_plan& pl = A.pl;
-    const float slope = A.slope;
-    float* __restrict__ out = A.out;
-    float* __restrict__ p_sorted = A.p_sorted;
-    float* __restrict__ probs_orig = A.probs_orig;
-    const fn_act_epilogue& ep = A.ep;
-    float* __restrict__ out2 = A.out2;
-    constexpr bool o2 = O2;               // the second output (out2, sigma) is a compile-time variant: its accumulators cost registers
-    constexpr int LPH = 32 / H;
-    constexpr int NE = KL ? KL : 1;                       // 8-byte edge loads per lane and row
-    // source rows gathered in one round trip.  12 (the bond graph's top degree class, as the one-pass backward has it) measured SLOWER
-    // here: the forward kernels sit at the 128-register mark of four waves per SIMD and the four extra rows spill (plain 15.4 -> 15.8 us,
-    // with the second output 17.4 -> 20.5 us at B = 512)
-    constexpr int NG = 8;
-    const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH;
-    const int m = (int)pl.m, n = (int)pl.n;
-    const int K = KL ? et.K : 0;
-    float wf[NE];                                         // this head's folded edge-embedding weights
-#pragma unroll
-    for (int k = 0; k < NE; ++k) wf[k] = (KL && k < K) ? sWf[head][k] : 0.f;
-    const float wbias = KL ? sWf[head][K] : 0.f;
-    const int tb = blk0 + (int)(threadIdx.x >> 5);
-    const bool pairs = m >= 2;                            // paired edge loads need two edges in the level
-    const float* e_sorted = KL ? nullptr : et.s_sorted + (size_t)head * m;
-    const int nr = A.n_real ? *A.n_real : n;              // rows behind it: padding of a static-shape batch -> rows without edges
-
-    auto load_extent = [&](int t) {
-        const int tc = t < n ? t : n - 1;
-        const i32x2u rp = ldp(pl.rowptr_d + tc);
-        FwdExtent x;
-        x.beg = rp.x - pl.pos_base_d;
-        x.deg = t < te ? (t < nr ? rp.y - rp.x : 0) : -1;
-        x.sd = s_dst[(uint32_t)tc * H + head];
-        return x;
-    };
-    auto issue_edges = [&](const FwdExtent& x, FwdRawT<NE>& r) {
-        int pos = x.beg + 2 * j;
-        pos = pos > m - 2 ? m - 2 : pos;
-        pos = pos < 0 ? 0 : pos;
-        r.pos = pos;
-        if (!pairs) { r.sp.x = r.sp.y = 0;  return; }
-        r.sp = ldp(pl.src_d + pos);
-        if (KL == 0) r.e[0] = ldp(e_sorted + pos);
-        else {
-#pragma unroll
-            for (int k = 0; k < NE; ++k) r.e[k] = ldp(et.x_sorted + (size_t)(k < K ? k : K - 1) * m + pos);
-        }
-    };
-    auto fold_edges = [&](const FwdExtent& x, const FwdRawT<NE>& r) {
-        FwdEdges e;
-        float za, zb;
-        if (KL == 0) { za = r.e[0].x;  zb = r.e[0].y; }
-        else {
-            za = zb = wbias;
-#pragma unroll
-            for (int k = 0; k < NE; ++k) { za = fmaf(r.e[k].x, wf[k], za);  zb = fmaf(r.e[k].y, wf[k], zb); }
-        }
-        const bool shifted = x.beg + 2 * j != r.pos;      // only the very last edge of the level: its pair starts one early
-        e.src0 = shifted ? r.sp.y : r.sp.x;  e.z0 = shifted ? zb : za;
-        e.src1 = r.sp.y;  e.z1 = zb;
-        return e;
-    };
-
-    const uint64_t rng_base = ep.offset + ((ep.y && ep.p > 0.f && ep.offset_dev) ? *ep.offset_dev : 0);
-    FwdRawT<NE> raw;
-    FwdExtent cur = load_extent(tb);
-    issue_edges(cur, raw);
-    FwdExtent nxt = load_extent(tb + kRows);
-    FwdEdges ed = fold_edges(cur, raw);
-    // drain the prologue's loads here: otherwise the compiler, unable to tell the first iteration from the others,
-    // puts a vmcnt(0) at the loop head, where it also waits for the previous iteration's STORES
-    asm volatile("" ::"v"(nxt.sd), "v"(nxt.beg), "v"(nxt.deg), "v"(ed.src0), "v"(ed.src1), "v"(ed.z0), "v"(ed.z1));
-    for (int t = tb; t < tb + kRows * rows_per_hw; t += kRows) {     // uniform trip count: both half-waves of a wave stay in step
-        const int beg = cur.beg, deg = cur.deg;
-        const bool fast = pairs && deg >= 0 && deg <= 2 * LPH;
-        const bool has0 = fast && 2 * j < deg, has1 = fast && 2 * j + 1 < deg;
-        // a lane without an edge gathers the destination row itself (weight 0): always a row this launch may read -- the
-        // molecule-resident callers (mol_tail.inc) have only their own molecule's rows written, and 0 * stale NaN is NaN
-        const int src0 = has0 ? ed.src0 : (t < n ? t : n - 1), src1 = has1 ? ed.src1 : src0;
-        // one round trip: next row's edge data, the row after's extent, this row's source rows and source scalars
-        issue_edges(nxt, raw);
-        const FwdExtent nn = load_extent(t + 2 * kRows);
-        const int rd_p = RD ? A.rd_pos[t < n ? t : n - 1] : 0;            // requested with the gathers, consumed after them
-        // source rows in flight per half-wave: 4, 8 or NG (wave-uniform tiers; NG = 12 for the single-attribute class = the bond graph,
-        // whose rows between two four-valent atoms have 10 or 12 in-edges: 28 % of the ESOL-shape rows); rows beyond the tier take a
-        // second, dependent round trip further down
-        const bool wide = __any(fast && deg > 4), wide2 = NG > 8 && __any(fast && deg > 8);
-        const bool live = __any(!fast || deg > 0);        // false: neither row of the wave has an edge (padding, isolated nodes) -> nothing to gather
-        float4 r0[NG];
-        if (live) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int sk = __shfl((i & 1) ? src1 : src0, i >> 1, LPH);
-                r0[i] = ld4_off(h, (uint32_t)sk * (FN_D * 4) + lane * 16);
-            }
-        }
-        // (a tier at 6 -- 57 % of the bond graph's rows have six in-edges: two loads less for the waves whose two rows stop there)
-        const bool wide8 = __any(fast && deg > (A.tier6 ? 6 : 4));
-        if (wide) {
-#pragma unroll
-            for (int i = 4; i < 6; ++i) {
-                const int sk = __shfl((i & 1) ? src1 : src0, i >> 1, LPH);
-                r0[i] = ld4_off(h, (uint32_t)sk * (FN_D * 4) + lane * 16);
-            }
-        }
-        if (wide8) {
-#pragma unroll
-            for (int i = 6; i < 8; ++i) {
-                const int sk = __shfl((i & 1) ? src1 : src0, i >> 1, LPH);
-                r0[i] = ld4_off(h, (uint32_t)sk * (FN_D * 4) + lane * 16);
-            }
-        }
-        if (wide2) {
-#pragma unroll
-            for (int i = 8; i < NG; ++i) {
-                const int sk = __shfl((i & 1) ? src1 : src0, i >> 1, LPH);
-                r0[i] = ld4_off(h, (uint32_t)sk * (FN_D * 4) + lane * 16);
-            }
-        }
-        const float ss0 = ld1_off(s_src, ((uint32_t)src0 * H + head) * 4);
-        const float ss1 = ld1_off(s_src, ((uint32_t)src1 * H + head) * 4);
-
-        const float z0 = ed.z0 + cur.sd + ss0, z1 = ed.z1 + cur.sd + ss1;
-        const float l0 = has0 ? fmaxf(z0, slope * z0) : -INFINITY;       // LeakyReLU, 0 < slope < 1
-        const float l1 = has1 ? fmaxf(z1, slope * z1) : -INFINITY;
-        const float mx = head_max<LPH>(fmaxf(l0, l1));
-        const float e0 = has0 ? __expf(l0 - mx) : 0.f;
-        const float e1 = has1 ? __expf(l1 - mx) : 0.f;
-        const float inv = __builtin_amdgcn_rcpf(head_sum<LPH>(e0 + e1));
-        const float p0 = has0 ? e0 * inv : 0.f;
-        const float p1 = has1 ? e1 * inv : 0.f;
-        // everything issued above has arrived by now (loads return in order): fold the next row's edge data BEFORE
-        // this row's stores, so that nothing at the top of the next iteration has to wait behind those stores
-        const FwdEdges ed_n = fold_edges(nxt, raw);
-        const float sd_cur = cur.sd;
-        cur = nxt;  nxt = nn;  ed = ed_n;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
-        // signed probabilities (sign bit = the LeakyReLU branch z <= 0): what the backward reads, and what out2 weighs by
-        const float sp0 = has0 ? (z0 > 0.f ? p0 : -p0) : 0.f, sp1 = has1 ? (z1 > 0.f ? p1 : -p1) : 0.f;
-        auto lam = [&](float sp) { return sp < 0.f ? -slope * sp : sp; };        // lambda_e p_e
-        if (!live) {
-            // (no row of this wave has an edge: r0 was not loaded)
-        } else if constexpr (!o2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fma4(acc, __shfl((i & 1) ? p1 : p0, i >> 1, LPH), r0[i]);
-            if (wide) {
-#pragma unroll
-                for (int i = 4; i < 6; ++i) fma4(acc, __shfl((i & 1) ? p1 : p0, i >> 1, LPH), r0[i]);
-            }
-            if (wide8) {
-#pragma unroll
-                for (int i = 6; i < 8; ++i) fma4(acc, __shfl((i & 1) ? p1 : p0, i >> 1, LPH), r0[i]);
-            }
-            if (wide2) {
-#pragma unroll
-                for (int i = 8; i < NG; ++i) fma4(acc, __shfl((i & 1) ? p1 : p0, i >> 1, LPH), r0[i]);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float spk = __shfl((i & 1) ? sp1 : sp0, i >> 1, LPH);
-                fma4(acc, fabsf(spk), r0[i]);
-                fma4(acc2, lam(spk), r0[i]);
-            }
-            if (wide) {
-#pragma unroll
-                for (int i = 4; i < 6; ++i) {
-                    const float spk = __shfl((i & 1) ? sp1 : sp0, i >> 1, LPH);
-                    fma4(acc, fabsf(spk), r0[i]);
-                    fma4(acc2, lam(spk), r0[i]);
-                }
-            }
-            if (wide8) {
-#pragma unroll
-                for (int i = 6; i < 8; ++i) {
-                    const float spk = __shfl((i & 1) ? sp1 : sp0, i >> 1, LPH);
-                    fma4(acc, fabsf(spk), r0[i]);
-                    fma4(acc2, lam(spk), r0[i]);
-                }
-            }
-            if (wide2) {
-#pragma unroll
-                for (int i = 8; i < NG; ++i) {
-                    const float spk = __shfl((i & 1) ? sp1 : sp0, i >> 1, LPH);
-                    fma4(acc, fabsf(spk), r0[i]);
-                    fma4(acc2, lam(spk), r0[i]);
-                }
-            }
-        }
-        float sg = 0.f;
-        if constexpr (o2) sg = head_sum<LPH>(lam(sp0) + lam(sp1));
-        if (fast) {
-            const int pos0 = beg + 2 * j;
-            if (A.p_edge_major) {
-                if (has0) p_sorted[(size_t)pos0 * H + head] = sp0;
-                if (has1) p_sorted[(size_t)(pos0 + 1) * H + head] = sp1;
-            } else {
-                float* pdst = p_sorted + (size_t)head * m + pos0;
-                if (has1) stp(pdst, sp0, sp1);
-                else if (has0) pdst[0] = sp0;
-            }
-            if (probs_orig) {
-                if (has0) probs_orig[(size_t)pl.eid_d[pos0] * H + head] = p0;
-                if (has1) probs_orig[(size_t)pl.eid_d[pos0 + 1] * H + head] = p1;
-            }
-            for (int k0 = NG; k0 < deg; k0 += 4) {        // in-degree NG + 1 .. 2*LPH
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int k = k0 + i;
-                    const int sk = __shfl((i & 1) ? src1 : src0, k >> 1, LPH);
-                    const float spk = __shfl((i & 1) ? sp1 : sp0, k >> 1, LPH);
-                    const float4 row = ld4_off(h, (uint32_t)sk * (FN_D * 4) + lane * 16);
-                    fma4(acc, fabsf(spk), row);
-                    if constexpr (o2) fma4(acc2, lam(spk), row);
-                }
-            }
-        } else if (deg >= 0) {
-            // rare high in-degree node (or a level with a single edge): every lane walks the edge list (three passes)
-            acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            sg = 0.f;
-            auto logit = [&](int pos, int& sk) {
-                sk = pl.src_d[pos];
-                const float z = sd_cur + s_src[(size_t)sk * H + head] + edge_term_at<H>(pos, head, m, et, sWf);
-                return z > 0.f ? z : slope * z;
-            };
-            int sk = 0;
-            float mxs = -INFINITY;
-            for (int i = 0; i < deg; ++i) mxs = fmaxf(mxs, logit(beg + i, sk));
-            float den = 0.f;
-            for (int i = 0; i < deg; ++i) den += expf(logit(beg + i, sk) - mxs);
-            for (int i = 0; i < deg; ++i) {
-                const float l = logit(beg + i, sk);
-                const float p = expf(l - mxs) / den;
-                if (j == 0) {
-                    p_sorted[A.p_edge_major ? (size_t)(beg + i) * H + head : (size_t)head * m + beg + i] = l > 0.f ? p : -p;
-                    if (probs_orig) probs_orig[(size_t)pl.eid_d[beg + i] * H + head] = p;
-                }
-                const float4 row = ld4(h + (size_t)sk * FN_D + lane * 4);
-                fma4(acc, p, row);
-                if constexpr (o2) { const float q = l > 0.f ? p : slope * p;  fma4(acc2, q, row);  sg += q; }
-            }
-        }
-        if (deg >= 0) {
-            if (out) st4(out + (size_t)t * FN_D + lane * 4, acc);
-            if constexpr (o2) {
-                st4(out2 + (size_t)t * FN_D + lane * 4, acc2);
-                if (j == 0) A.sigma[(size_t)t * H + head] = sg;
-            }
-            if (RD) {            // the next level's edge term from the row in registers (saves a launch that re-reads every row)
-                float mine = 0.f;
-                for (int q = 0; q < A.rd_J; ++q) {
-                    // (staging these J rows in LDS once per block instead of loading them per row changed nothing: 31.2 -> 32.1 us)
-                    const float dsum = head_sum<32>(dot4(acc, ld4(A.rd_A + q * A.rd_lda + lane * 4)));
-                    if (lane == q) mine = dsum;
-                }
-                if (lane < A.rd_J) A.rd_out[(size_t)lane * A.rd_m + rd_p] = mine;
-            }
-            if (ep.y) {          // fused act(dropout(.)): same Philox block index (element / 4) as k_dropout_act
-                float4 r = acc;
-                if (ep.p > 0.f) {
-                    const uint4 rnd = philox4x32_10(rng_base + (uint64_t)t * 32 + lane, ep.seed);
-                    const float ik = ep.p < 1.f ? 1.f / (1.f - ep.p) : 0.f;
-                    r.x *= keep_scale(rnd.x, ep.p, ik); r.y *= keep_scale(rnd.y, ep.p, ik);
-                    r.z *= keep_scale(rnd.z, ep.p, ik); r.w *= keep_scale(rnd.w, ep.p, ik);
-                }
-                if (ep.relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
-                st4(ep.y + (size_t)t * FN_D + lane * 4, r);
-            }
-        }
-    }
-}
-
-// a block owns kRows * R consecutive rows; its half-waves take them INTERLEAVED (row = base + i * kRows + hw), so
-// that at any moment the block works on kRows neighbouring rows whose source rows overlap (L1 reuse across waves)
-template <int H, int KL, bool RD = false, bool O2 = false>
-__device__ __forceinline__ void gat_fwd_body(const GatFwdArgs& A, float (*sWf)[kWfLd], int bid, int nblk) {
-    const int n = (int)A.pl.n, per = kRows * A.rows_per_hw;
-    const int nr = A.n_real ? *A.n_real : n;
-    const int blk0 = xcd_block_real(bid, nblk, A.n_real ? (nr + per - 1) / per : nblk) * per;      // real rows dealt evenly over the XCDs
-    if (FN_PAD_BLOCK_EXIT && blk0 >= nr) {
-        // a workgroup whose rows are all padding: what the row loop would write for rows without edges -- zero rows (raw, second output,
-        // activated), zero sigma, zero edge-term dots -- without the loop (softmax bookkeeping, Philox, the dots: ~70 % of a real row)
-        const int lane = threadIdx.x & 31, hw = threadIdx.x >> 5, end = blk0 + per < n ? blk0 + per : n;
-        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int t = blk0 + hw; t < end; t += kRows) {
-            if (A.out) st4(A.out + (size_t)t * FN_D + lane * 4, zero);
-            if constexpr (O2) {
-                st4(A.out2 + (size_t)t * FN_D + lane * 4, zero);
-                if (lane < H) A.sigma[(size_t)t * H + lane] = 0.f;
-            }
-            if (RD) { if (lane < A.rd_J) A.rd_out[(size_t)lane * A.rd_m + A.rd_pos[t]] = 0.f; }
-            if (A.ep.y) st4(A.ep.y + (size_t)t * FN_D + lane * 4, zero);
-        }
-        return;
-    }
-    fold_edge_embed(A.et, A.att, A.att_w, H, sWf);
-    gat_fwd_rows<H, KL, RD, O2>(A, sWf, blk0, blk0 + per < n ? blk0 + per : n, A.rows_per_hw);
-}
-
-// (O2 instances -- the training forward of the one-pass backward, gat_bwd_one.inc -- ask for four waves per SIMD explicitly: their
-// second accumulator would otherwise tip the allocation over 128 registers)
-template <int H, int KL, bool O2 = false>
-__global__ __launch_bounds__(kBlock, 4) void k_gat_fwd(GatFwdArgs A) {
-    __shared__ float sWf[8][kWfLd];
-    gat_fwd_body<H, KL, false, O2>(A, sWf, (int)blockIdx.x, (int)gridDim.x);
-}
-// two independent levels in one launch (bond graph + fragment-bond graph: neither reads the other's output)
-template <int H, int KLA, int KLB, bool RDA = false, bool O2 = false>
-__global__ __launch_bounds__(kBlock, 4) void k_gat_fwd_pair(GatFwdArgs A, GatFwdArgs B) {
-    __shared__ float sWf[8][kWfLd];
-    if ((int)blockIdx.x < A.nblk) gat_fwd_body<H, KLA, RDA, O2>(A, sWf, (int)blockIdx.x, A.nblk);
-    else gat_fwd_body<H, KLB, false, O2>(B, sWf, (int)blockIdx.x - A.nblk, B.nblk);
-}
-template <int H, bool O2 = false>
-__global__ __launch_bounds__(kBlock, 4) void k_gat_fwd_rd(GatFwdArgs A) {          // single bond-graph level with the row-dots epilogue
-    __shared__ float sWf[8][kWfLd];
-    gat_fwd_body<H, 1, true, O2>(A, sWf, (int)blockIdx.x, (int)gridDim.x);
-}
+#include "gat_fwd.inc"
 
 // Backward kernels use RB rows (half-waves) per block.
 // Destination pass: dz[e] = p[e] * (<g_out[dst], h[src]> - sum_e' p[e'] <g_out[dst], h[src']>) * LeakyReLU', per head.
@@ -2200,398 +1759,7 @@ __global__ __launch_bounds__(256) void k_small_linear_loss(const float* __restri
     if (threadIdx.x == 0) loss_part[blockIdx.x] = ((s4[0] + s4[1]) + (s4[2] + s4[3])) / den;
 }
 
-// =====================================================================================
-// Projection GEMMs on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains, so the 1e-4
-// parity budget is untouched).  All three node projections have N = 128 outputs and K <= 168 inputs:
-//   forward    Y[M,128]  = X[M,K]   * Bt[K,128] + bias      (Bt = W^T, transposed once per step)
-//   input grad dX[M,128] = dY[M,128] * W[128,128]            (same kernel, Bt = W as stored, no bias)
-//   weight grad dW[128,K] = dY^T X, db = colsum(dY)           (split over row chunks, deterministic 2-stage sum)
-// =====================================================================================
-struct __attribute__((packed, aligned(4))) f32x4_u4 { float v[4]; };      // 16 bytes at a 4-byte-aligned address
-constexpr int kBtLd = 144;     // LDS leading dimension of the [K][128] operand: 144 % 32 == 16
-constexpr int kLinLd = 64;     // k_linear128's operand tile [K][64 columns], unpadded: a lane reads 4 consecutive columns (ds_read_b128) and the
-                               // 16-lane groups of that instruction then cover all 64 banks exactly once (rows 4 apart share the bank alignment)
-
-// A block = 8 waves = 64 rows x 128 columns: wave w owns rows 16*(w&3).. and columns 64*(w>>2).. (4 accumulator
-// tiles), so two waves share every SIMD and one wave's LDS reads hide under the other's MFMAs.  Bt is staged in
-// LDS once per block; blocks loop over row tiles.  The MFMA k index is "blocked": lane group kq supplies
-// k = kq*KQ + s at step s, so a lane's A operands are KQ consecutive floats of one row, loaded with 16-byte loads
-// straight from global memory (no LDS round trip for X) and prefetched one tile ahead.  The result tile goes
-// through LDS so that every lane stores whole 16-byte pieces of a row (scattered 4-byte stores cost 4 us a tile).
-constexpr int kLinWaves = 4, kLinThreads = 64 * kLinWaves, kLinRows = 16 * kLinWaves;   // a block: kLinRows rows x 64 columns
-constexpr int kLinOutLd = 68;      // LDS leading dimension of a wave's 16 x 64 result tile
-struct NodeScalarEpi {             // optional fused epilogue: s_dst/s_src[row, head] = <Y[row, head cols], att blocks>
-    const float* att;
-    float* s_dst;
-    float* s_src;
-    int att_w, dst_off, src_off, heads;     // heads in {2, 4, 8}: a head's columns must lie inside one wave's 64
-};
-// VEC (K == 4*KQ, KQ % 4 == 0): lane (i, kq) owns the k's {16 s + 4 kq + c}: one wave-instruction then reads 64
-// contiguous bytes of each of its 16 rows (a blocked split, k = kq*KQ + .., made every lane touch its own 128-byte
-// line and re-fetched each line eight times through a thrashing L1).  The B rows in LDS are indexed to match.
-// optional epilogue term of an input-gradient product (RA instances): Y[row, :] += sum_h z[row, h] * a[h * lda + :], h < 4 -- the
-// backward of the atom graph's edge term <new_bond[e], a[h, mid block]> lands on the bond rows without a pass of its own
-struct RowAdd {
-    const float* z;           // [M][4]: dL/d(edge term) of row e, the four heads together; null: no term
-    const float* a;           // a[h * lda + column]
-    int lda;
-};
-// optional epilogue of an input-gradient product (CU instances): the two node-local dots of the finished gradient row the one-pass
-// attention backward needs (gat_bwd_one.inc): c[row, h] = scale <Y[row, head cols], out[row, head cols]> and
-// u[row, h] = <Y[row, ...], out2[row, ...]> - c sigma[row, h].  out == null: the row reaches its level through relu(dropout(.))
-// only, and the gate's saved output y (loaded for the gate anyway) stands in for it with scale = 1 - p.
-constexpr int kCuRows = 4;        // rows of a lane's four whose epilogue operands are in flight together (CuEpi): all four.  Two at a time
-                                  // fit four waves per SIMD only with spills: the launch measured 43-45 us against 34-36
-struct CuEpi {
-    const float *out, *out2, *sigma;
-    float *c, *u;             // c == null: no such epilogue
-    int heads;
-};
-// The deferred form of the one-pass attention backward inside an input-gradient product (GS instances, four heads; gat_bwd_one.inc,
-// DF).  The product's A rows are the level's g_h WITHOUT the term g_s_dst[row] a_dst, and g_s_dst itself is not known yet: the
-// level's pass left dL/dz of every edge at its destination-order slot (dz [m][4]: a row's in-edges contiguous, four heads per edge).
-// The missing term is linear, (g_s_dst a_dst) W = sum_h g_s_dst[row, h] R[h, :] with R[h, :] = sum_{c in head h} a_dst[c] W[c, :]
-// ([4][128], from the parameters alone: the forward prologue writes it) -- exactly ONE more step of the 16x16x4 MFMA chain with
-// k = the four heads: lane (i, kq) supplies A[row i][k = kq] = g_s_dst[row, head kq] and the R rows are four more rows of the
-// operand tile in LDS.  So every lane sums ONE segment (its row, head kq: <= 12 strided loads that leave before the chain and are
-// added behind it -- no cross-lane step at all), the tile's workgroup of column half 0 writes the g_s_dst table for the
-// weight-gradient kernels (which add the term to their dY operand, wgrad128.inc), and the epilogue is the plain one.
-struct GsdEpi {
-    const float* dz;          // [m][4]; null: no such term
-    const int32_t* rowptr;    // the level's by-destination CSR (M + 1 words); positions are rowptr[.] - pos_base
-    int pos_base;
-    const float* R;           // [4][128], see above
-    float* gsd;               // out [M][4]
-};
-template <int KQ, bool VEC, bool PF, bool RA = false, bool CU = false, bool GS = false>
-__device__ __forceinline__ void linear128_body(float* sBt, const float* __restrict__ X, int K, const float* __restrict__ Bt,
-                                               const float* __restrict__ bias, float* __restrict__ Y, int64_t M,
-                                               const fn_act_epilogue& mk, const NodeScalarEpi& ns, int bid, int nblk,
-                                               const RowAdd& ra = RowAdd{nullptr, nullptr, 0},
-                                               const CuEpi& cu = CuEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0},
-                                               const int32_t* n_real = nullptr,
-                                               const GsdEpi& gs = GsdEpi{nullptr, nullptr, 0, nullptr, nullptr}) {
-    static_assert(!GS || (CU && KQ == 32 && VEC), "the deferred term rides in the one-pass backward's K = 128 products");
-    // A block is 4 waves = 64 rows x 64 COLUMNS (column half wc = bid & 1) and walks the row tiles bid>>1, += nblk>>1.
-    // sBt: the [4*KQ][kLinLd] operand tile of this column half, staged ONCE; after that the block never synchronises
-    // again: A rows live in registers (PF: the next tile's rows are requested before this tile's MFMA chain), and
-    // with column-interleaved MFMA tiles (tile t = columns {4 i + t}) a lane's four accumulators of one row ARE a
-    // float4 of four consecutive columns, so results, bias and fused epilogues go straight from registers to global
-    // memory (16 lanes = 256 contiguous bytes of a row) — no LDS transpose, 33 KB per block, four blocks per CU whose
-    // waves drift out of phase (in-phase staging / multiply / store rounds left the MFMA pipe 70 % idle, PMC).
-    const uint64_t mk_base = mk.offset + ((mk.y && mk.p > 0.f && mk.offset_dev) ? *mk.offset_dev : 0);   // read once, not per tile
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
-    const int stride = nblk >> 1;
-    int64_t tiles = (M + kLinRows - 1) / kLinRows;
-    if (n_real) {                                            // padding rows of a static-shape batch: their tiles are skipped
-        const int64_t live = ((int64_t)*n_real + kLinRows - 1) / kLinRows;
-        tiles = live < tiles ? live : tiles;
-    }
-    // Which (row tile, column half) this block starts with.  The two halves of a row tile read the same 32 KB of A rows; workgroups
-    // are dealt round-robin over the 8 XCDs, so neighbours b, b + 1 never share an L2 and the rows crossed the fabric twice
-    // (PMC: the one-pass backward's product launch fetched 118 MB for 87 MB of operands).  Blocks b and b + 8 do share one: within
-    // every group of 16 blocks the first eight take half 0 of eight tiles, the second eight half 1 of the same tiles.
-#ifndef FN_LIN_PAIR_XCD
-#define FN_LIN_PAIR_XCD 1
-#endif
-    int wc;
-    int64_t tile;
-    const int full = FN_LIN_PAIR_XCD ? (nblk >> 4) << 4 : 0;
-    if (bid < full) { wc = (bid >> 3) & 1;  tile = (int64_t)(bid >> 4) * 8 + (bid & 7); }
-    else { wc = (bid - full) & 1;  tile = (full >> 1) + ((bid - full) >> 1); }        // the last, incomplete group: neighbours
-    // (Also giving XCD x the x-th CONTIGUOUS eighth of the row tiles -- the rows the same XCD gathers in the next launch's attention
-    // pass -- measured slower: the attention launches did not change, i.e. nothing survives in an L2 across the kernel boundary, and
-    // the product launches lost 2 us each with every XCD streaming one address range: 0.795-0.798 -> 0.806-0.809 ms per step.)
-    if (tile >= tiles) return;                               // whole block
-
-    // IL: the interleaved k split also for rows that are only 4-byte aligned (K % 4 != 0: the 167 atom features of layer 0):
-    // the same 64 contiguous bytes per row and instruction, loaded as unaligned 16-byte pieces; only the piece that
-    // straddles the end of the row is loaded element by element.  (The blocked split it replaces ran that projection
-    // at 22 us for 0.6 GFLOP.)
-    constexpr bool IL = VEC || (KQ % 4 == 0);
-    auto load_rows = [&](int64_t t, float (&xa)[KQ]) {
-        int64_t row = t * kLinRows + w * 16 + i;
-        row = row < M ? row : M - 1;
-        const float* src = X + row * K + (IL ? 4 * kq : kq * KQ);
-        if (VEC) {
-#pragma unroll
-            for (int s = 0; s < KQ / 4; ++s) {
-                const float4 v = ld4(src + s * 16);
-                xa[4 * s + 0] = v.x; xa[4 * s + 1] = v.y; xa[4 * s + 2] = v.z; xa[4 * s + 3] = v.w;
-            }
-        } else if (IL) {
-#pragma unroll
-            for (int s = 0; s < KQ / 4; ++s) {
-                const int col = 16 * s + 4 * kq;
-                if (col + 3 < K) {
-                    const f32x4_u4 v = *reinterpret_cast<const f32x4_u4*>(src + s * 16);
-                    xa[4 * s + 0] = v.v[0]; xa[4 * s + 1] = v.v[1]; xa[4 * s + 2] = v.v[2]; xa[4 * s + 3] = v.v[3];
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) xa[4 * s + c] = (col + c < K) ? src[s * 16 + c] : 0.f;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < KQ; ++s) xa[s] = (kq * KQ + s < K) ? src[s] : 0.f;
-        }
-    };
-
-    // GS: the by-destination extent of this lane's A row of a tile, requested with the row itself so that the segment loads can
-    // leave right before the MFMA chain and land behind it
-    int rp0 = 0, rp1 = 0;
-    auto load_rp = [&](int64_t t) {
-        const int64_t ra_ = t * kLinRows + w * 16 + i;
-        rp0 = gs.dz ? gs.rowptr[ra_ < M ? ra_ : M] : 0;
-        rp1 = gs.dz ? gs.rowptr[ra_ + 1 < M ? ra_ + 1 : M] : 0;
-    };
-    float cur[KQ], nxt[KQ];
-    {   // stage Bt [4*KQ][this half's 64 columns] -> LDS with 16-byte loads; the first A rows ride in the same round trip
-        constexpr int N4 = 4 * KQ * 16;                 // float4 count
-        constexpr int PER = (N4 + kLinThreads - 1) / kLinThreads;
-        float4 v[PER];
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int idx = tid + q * kLinThreads, k = idx >> 4, n4 = idx & 15;
-            v[q] = (idx < N4 && k < K) ? ld4(Bt + (size_t)k * 128 + 64 * wc + n4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        load_rows(tile, cur);
-        float4 vr = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (GS) {
-            load_rp(tile);
-            if (tid < 64 && gs.dz) vr = ld4(gs.R + (tid >> 4) * 128 + 64 * wc + (tid & 15) * 4);      // R: rows 4 KQ .. 4 KQ + 3 of the tile
-        }
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int idx = tid + q * kLinThreads, k = idx >> 4, n4 = idx & 15;
-            if (idx < N4) st4(sBt + k * kLinLd + n4 * 4, v[q]);
-        }
-        if constexpr (GS) { if (tid < 64) st4(sBt + (4 * KQ + (tid >> 4)) * kLinLd + (tid & 15) * 4, vr); }
-    }
-    // this lane's four columns of bias and of the two attention vectors stay in registers for every tile
-    const int col = 64 * wc + 4 * i;
-    const float4 bv = bias ? ld4(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int ns_d = ns.att ? FN_D / ns.heads : FN_D, ns_head = col / ns_d;
-    float4 a_dst = make_float4(0.f, 0.f, 0.f, 0.f), a_src = a_dst;
-    if (ns.att) {
-        a_dst = ld4(ns.att + ns_head * ns.att_w + ns.dst_off + col % ns_d);
-        a_src = ld4(ns.att + ns_head * ns.att_w + ns.src_off + col % ns_d);
-    }
-    const float ik = mk.p < 1.f ? 1.f / (1.f - mk.p) : 0.f;
-    float4 ra_a[4];
-    if (RA) {
-#pragma unroll
-        for (int hh = 0; hh < 4; ++hh) ra_a[hh] = ra.z ? ld4(ra.a + hh * ra.lda + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-    const int64_t nr_rows = n_real ? (int64_t)*n_real : M;          // rows at or behind it: padding (no gradient, segments never written)
-
-    // MFMA tile t of a wave covers the columns {4 i + t}: one 16-byte LDS read per step feeds all four tiles
-    const float* bbase = sBt + (IL ? 4 * kq : kq * KQ) * kLinLd + 4 * i;
-    auto brow = [](int s) { return IL ? 16 * (s >> 2) + (s & 3) : s; };       // LDS row of MFMA step s, relative to bbase
-    for (;;) {
-        const int64_t next = tile + stride;
-        const bool more = next < tiles;
-        if constexpr (PF) load_rows(more ? next : tile, nxt);
-        // GS: the dz segment of (this lane's A row, head kq), in flight across the MFMA chain: four / eight / twelve loads by the
-        // wave's largest in-degree (wave-uniform tiers), rows of more in-edges finish behind the chain
-        float dzv[12], ahub = 0.f;
-        int gdeg = 0, gbeg = 0;
-        if constexpr (GS) {
-            const int64_t ra_ = tile * kLinRows + w * 16 + i;
-            gbeg = rp0 - gs.pos_base;
-            gdeg = (gs.dz && ra_ < nr_rows) ? rp1 - rp0 : 0;
-            const float* dzl = gs.dz + kq;
-#pragma unroll
-            for (int jj = 0; jj < 12; ++jj) dzv[jj] = 0.f;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) dzv[jj] = gs.dz ? ld1_off(dzl, jj < gdeg ? (uint32_t)(gbeg + jj) * 16u : 0u) : 0.f;
-            if (__any(gdeg > 4)) {
-#pragma unroll
-                for (int jj = 4; jj < 8; ++jj) dzv[jj] = ld1_off(dzl, jj < gdeg ? (uint32_t)(gbeg + jj) * 16u : 0u);
-            }
-            if (__any(gdeg > 8)) {
-#pragma unroll
-                for (int jj = 8; jj < 12; ++jj) dzv[jj] = ld1_off(dzl, jj < gdeg ? (uint32_t)(gbeg + jj) * 16u : 0u);
-            }
-            // hubs (in-degree > 12): rare; their tail is summed HERE, in front of the chain (dependent loads, a stall only for such a
-            // wave) -- the same loop between the chain and the last step made the register allocator spill 145 registers
-            if (__any(gdeg > 12)) {
-                for (int jj = 12; __any(jj < gdeg); ++jj) {
-                    const float x = ld1_off(dzl, jj < gdeg ? (uint32_t)(gbeg + jj) * 16u : 0u);
-                    ahub += jj < gdeg ? x : 0.f;
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // B operands are read four steps (16 MFMAs) ahead, in two register groups
-        constexpr int NG = (KQ + 3) / 4;
-        float4 bg[2][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bg[0][q] = q < KQ ? *reinterpret_cast<const float4*>(bbase + brow(q) * kLinLd) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int sn = 4 * (g + 1) + q;
-                    if (sn < KQ) bg[(g + 1) & 1][q] = *reinterpret_cast<const float4*>(bbase + brow(sn) * kLinLd);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int sc = 4 * g + q;
-                if (sc < KQ) {
-                    const float4 b = bg[g & 1][q];
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[sc], b.x, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[sc], b.y, acc[1], 0, 0, 0);
-                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[sc], b.z, acc[2], 0, 0, 0);
-                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[sc], b.w, acc[3], 0, 0, 0);
-                }
-            }
-        }
-        if constexpr (GS) {      // step 4 KQ / 4 + 1 of the chain: k = the four heads
-            float a = 0.f;
-#pragma unroll
-            for (int jj = 0; jj < 12; ++jj) a += jj < gdeg ? dzv[jj] : 0.f;
-            a += ahub;
-            const int64_t ra_ = tile * kLinRows + w * 16 + i;
-            if (wc == 0 && gs.dz && ra_ < M) gs.gsd[ra_ * 4 + kq] = a;
-            const float4 b = *reinterpret_cast<const float4*>(sBt + (4 * KQ + kq) * kLinLd + 4 * i);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc[3], 0, 0, 0);
-        }
-        // acc[t][r] is (row kq*4 + r, column 4 i + t) of the wave's 16 x 64 tile
-        __builtin_amdgcn_sched_barrier(0);
-        const int64_t r0 = tile * kLinRows + w * 16 + kq * 4;
-        float pd[4], ps[4];
-        if constexpr (CU) {
-            // one-pass backward: the gate's saved output, the raw / second output rows and the edge-term gradient of all four rows
-            // in ONE round trip (row by row, as below, each row's loads wait behind the previous row's stores)
-            static_assert(!CU || RA, "the row-dots epilogue rides in the RowAdd instances");
-            const bool gate = mk.y && mk.relu;           // (the engine's gates are all relu(dropout(.)): no Philox replay here.  Round 4: for the
-                                                         // bond level, whose raw rows are loaded for the dots anyway, the gate regenerated from
-                                                         // out > 0 and a Philox call per lane and row instead of reading y -- 13.6 MB of 124 less
-                                                         // per inner layer -- measured slower, 32.9 -> 37.5 us: 168 VGPRs with spills; not kept)
-            const float sc = mk.p > 0.f ? ik : 1.f;
-            const int cu_hd = cu.c ? col / (FN_D / cu.heads) : 0;
-            float sgv[4];
-            // all four rows' operands in one round trip (64 registers: the kernel runs three waves per SIMD)
-            constexpr int CR = kCuRows;
-#pragma unroll
-            for (int hb = 0; hb < 4; hb += CR) {
-                float4 yv[CR], ov[CR], o2v[CR], zv[CR];
-#pragma unroll
-                for (int q = 0; q < CR; ++q) {
-                    const int r = hb + q;
-                    const int64_t row = r0 + r < M ? r0 + r : M - 1;
-                    const int64_t at = row * 128 + col;
-                    yv[q] = gate ? ld4(mk.y + at) : make_float4(1.f, 1.f, 1.f, 1.f);
-                    ov[q] = cu.c && cu.out ? ld4(cu.out + at) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    if constexpr (!GS) o2v[q] = cu.c ? ld4(cu.out2 + at) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    zv[q] = ra.z ? ld4(ra.z + row * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    if constexpr (!GS) sgv[r] = cu.c ? cu.sigma[row * cu.heads + cu_hd] : 0.f;
-                }
-#pragma unroll
-                for (int q = 0; q < CR; ++q) {
-                    const int r = hb + q;
-                    float4 o = make_float4(acc[0][r] + bv.x, acc[1][r] + bv.y, acc[2][r] + bv.z, acc[3][r] + bv.w);
-                    if (gate) {
-                        o.x = yv[q].x > 0.f ? o.x * sc : 0.f; o.y = yv[q].y > 0.f ? o.y * sc : 0.f;
-                        o.z = yv[q].z > 0.f ? o.z * sc : 0.f; o.w = yv[q].w > 0.f ? o.w * sc : 0.f;
-                    }
-                    fma4(o, zv[q].x, ra_a[0]);  fma4(o, zv[q].y, ra_a[1]);  fma4(o, zv[q].z, ra_a[2]);  fma4(o, zv[q].w, ra_a[3]);
-                    if (r0 + r < M) st4(Y + (r0 + r) * 128 + col, o);
-                    pd[r] = dot4(o, cu.out ? ov[q] : yv[q]);
-                    if constexpr (!GS) ps[r] = dot4(o, o2v[q]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (cu.c) {          // per-head sums over the head's cu_d / 4 neighbouring lanes of the 16-lane DPP row, as for the node scalars
-                const int cu_d = FN_D / cu.heads;
-                const float cu_scale = cu.out ? 1.f : (mk.p > 0.f && mk.p < 1.f ? 1.f - mk.p : 1.f);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (cu_d >= 64) pd[r] += dpp_mov<kDppMirror>(pd[r]);
-                    if (cu_d >= 32) pd[r] += dpp_mov<kDppHalfMirror>(pd[r]);
-                    pd[r] += dpp_mov<kDppXor2>(pd[r]);
-                    pd[r] += dpp_mov<kDppXor1>(pd[r]);
-                    if constexpr (!GS) {
-                        if (cu_d >= 64) ps[r] += dpp_mov<kDppMirror>(ps[r]);
-                        if (cu_d >= 32) ps[r] += dpp_mov<kDppHalfMirror>(ps[r]);
-                        ps[r] += dpp_mov<kDppXor2>(ps[r]);
-                        ps[r] += dpp_mov<kDppXor1>(ps[r]);
-                    }
-                    if ((4 * i) % cu_d == 0 && r0 + r < M) {
-                        const float cc = cu_scale * pd[r];
-                        cu.c[(r0 + r) * cu.heads + cu_hd] = cc;
-                        if constexpr (!GS) cu.u[(r0 + r) * cu.heads + cu_hd] = ps[r] - cc * sgv[r];
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float4 o = make_float4(acc[0][r] + bv.x, acc[1][r] + bv.y, acc[2][r] + bv.z, acc[3][r] + bv.w);
-            pd[r] = dot4(o, a_dst);
-            ps[r] = dot4(o, a_src);
-            if (r0 + r < M) {
-                float4 yy = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (mk.y) {      // backward of act(dropout(.)) fused into the input-gradient GEMM: o *= mask * (y > 0)
-                    const int64_t e4 = (r0 + r) * 32 + 16 * wc + i;              // Philox block = element / 4
-                    if (mk.relu) {
-                        // y = relu(dropout(x)) is positive only where the element was kept AND passed the ReLU: the saved
-                        // output already encodes the mask, so the Philox stream is not replayed (240 VALU ops a tile)
-                        yy = ld4(mk.y + e4 * 4);
-                        const float sc = mk.p > 0.f ? ik : 1.f;
-                        o.x = yy.x > 0.f ? o.x * sc : 0.f; o.y = yy.y > 0.f ? o.y * sc : 0.f;
-                        o.z = yy.z > 0.f ? o.z * sc : 0.f; o.w = yy.w > 0.f ? o.w * sc : 0.f;
-                    } else if (mk.p > 0.f) {
-                        const uint4 rnd = philox4x32_10(mk_base + (uint64_t)e4, mk.seed);
-                        o.x *= keep_scale(rnd.x, mk.p, ik); o.y *= keep_scale(rnd.y, mk.p, ik);
-                        o.z *= keep_scale(rnd.z, mk.p, ik); o.w *= keep_scale(rnd.w, mk.p, ik);
-                    }
-                }
-                if (RA) {
-                    if (ra.z) {          // after the gate: the term is a gradient w.r.t. the pre-activation row itself
-                        const float4 z = ld4(ra.z + (r0 + r) * 4);
-                        fma4(o, z.x, ra_a[0]);  fma4(o, z.y, ra_a[1]);  fma4(o, z.z, ra_a[2]);  fma4(o, z.w, ra_a[3]);
-                    }
-                }
-                st4(Y + (r0 + r) * 128 + col, o);
-            }
-            __builtin_amdgcn_sched_barrier(0);               // one row at a time: four interleaved Philox chains cost 60 VGPRs
-        }
-        }
-        if (!CU && ns.att) {     // node scalars: a head's ns_d columns are ns_d/4 neighbouring lanes of the 16-lane DPP row
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (ns_d >= 64) { pd[r] += dpp_mov<kDppMirror>(pd[r]); ps[r] += dpp_mov<kDppMirror>(ps[r]); }
-                if (ns_d >= 32) { pd[r] += dpp_mov<kDppHalfMirror>(pd[r]); ps[r] += dpp_mov<kDppHalfMirror>(ps[r]); }
-                pd[r] += dpp_mov<kDppXor2>(pd[r]); ps[r] += dpp_mov<kDppXor2>(ps[r]);
-                pd[r] += dpp_mov<kDppXor1>(pd[r]); ps[r] += dpp_mov<kDppXor1>(ps[r]);
-                if ((4 * i) % ns_d == 0 && r0 + r < M) {
-                    ns.s_dst[(r0 + r) * ns.heads + ns_head] = pd[r];
-                    ns.s_src[(r0 + r) * ns.heads + ns_head] = ps[r];
-                }
-            }
-        }
-        if (!more) break;
-        if constexpr (PF) {
-#pragma unroll
-            for (int s = 0; s < KQ; ++s) cur[s] = nxt[s];
-        } else {
-            load_rows(next, cur);
-        }
-        if constexpr (GS) load_rp(next);
-        tile = next;
-    }
-}
+#include "linear128.inc"
 
 template <int KQ, bool VEC, bool PF>
 __global__ __launch_bounds__(kLinThreads) void k_linear128(const float* __restrict__ X, int K, const float* __restrict__ Bt,
@@ -2601,27 +1769,6 @@ __global__ __launch_bounds__(kLinThreads) void k_linear128(const float* __restri
     linear128_body<KQ, VEC, PF>(sBt, X, K, Bt, bias, Y, M, mk, ns, (int)blockIdx.x, (int)gridDim.x);
 }
 
-// up to three independent [M_i,K]·[K,128] products in one launch: the three projections of a layer (forward) or
-// their three input-gradient products (backward) depend only on the previous layer, never on each other
-struct LinTask {
-    const float* Wn;          // the same weight n-major ([128 n][K]) for k_proj128; null: only the k_linear128 form is available
-    const float *X, *Bt, *bias;
-    float* Y;
-    int64_t M;
-    fn_act_epilogue mk;
-    NodeScalarEpi ns;
-    int first, nblk;
-    int K;                    // 0: the group's K (LinTasks::K); else this task's own reduction length (layer 0: 17 bond / 6 connection features)
-    RowAdd ra;                // riding input-gradient products only (lin_side_block)
-    CuEpi cu;                 // ... of the one-pass backward (lin_side_block<true>)
-    GsdEpi gs;                // ... of its deferred form (lin_side_block<true, true>)
-    const int32_t* n_real;    // nullable device word: row tiles that start at or behind *n_real are padding and are not computed
-};
-struct LinTasks {
-    LinTask t[3];
-    int n, K;
-    int base, total;          // co-launched with an attention pass (below): the GEMM workgroups are blocks [base, base + total) of that launch
-};
 template <int KQ, bool VEC, bool PF>
 __global__ __launch_bounds__(kLinThreads) void k_linear128_multi(LinTasks T) {
     extern __shared__ __attribute__((aligned(16))) float sBt[];
@@ -2654,52 +1801,6 @@ __global__ __launch_bounds__(kLinThreads) void k_linear128_layer0(LinTasks T) {
     const CuEpi no_cu{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (t.K > 20) linear128_body<44, false, false>(sBt, t.X, t.K, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, (int)blockIdx.x - t.first, t.nblk, no_ra, no_cu, t.n_real);
     else linear128_body<5, false, false>(sBt, t.X, t.K, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, (int)blockIdx.x - t.first, t.nblk, no_ra, no_cu, t.n_real);
-}
-
-// ---- an attention pass and the projection GEMMs that do not depend on it, in ONE launch.
-// Inside a layer the chain is  projections -> bond + fragment-bond levels -> atom level, but only a third of it is a true
-// dependency: the atom projection of layer l needs layer l-1's atom level and nothing of layer l's bond levels, and the bond /
-// fragment-bond projections of layer l+1 need layer l's bond levels and nothing of its atom level (the backward mirrors this:
-// the atom input-gradient product does not wait for the bond levels' passes, and theirs not for the next layer's atom pass).
-// The attention passes are bound by dependent round trips with the matrix cores idle, the projections are a few microseconds
-// of MFMA work behind a launch floor of their own -- so the GEMM tiles ride along as extra workgroups of the attention launch
-// (one 64 x 64 tile each, the k_linear128_multi body) and the layer loses a kernel boundary per pass.
-template <bool CU = false, bool GS = false>
-__device__ __forceinline__ void lin_side_block(float* sBt, const LinTasks& T, int b) {
-    int ti = 0;
-    while (ti + 1 < T.n && b >= T.t[ti + 1].first) ++ti;
-    const LinTask& t = T.t[ti];
-    linear128_body<32, true, false, true, CU, GS>(sBt, t.X, 128, t.Bt, t.bias, t.Y, t.M, t.mk, t.ns, b - t.first, t.nblk, t.ra, t.cu, t.n_real, t.gs);
-}
-// Which workgroup is which: the GEMM workgroups are blocks [T.base, T.base + T.total) of the launch -- first, so that the
-// dispatcher starts them before the attention workgroups (measured best of first / last / interleaved: profiles/r02e_colaunch_ab.txt).
-// Returns the role's own block index in *idx.
-__device__ __forceinline__ bool lin_side_role(const LinTasks& T, int gat_base, int* idx) {
-    const int b = (int)blockIdx.x - T.base;
-    if ((unsigned)b < (unsigned)T.total) { *idx = b;  return true; }
-    *idx = (int)blockIdx.x - gat_base;
-    return false;
-}
-// gat_base: block id of the first attention workgroup (= T.total: the GEMM blocks come first).
-// __launch_bounds__(.., 4): four waves per SIMD as for the plain attention kernels -- without it the accumulators of the GEMM
-// branch go to AGPRs ON TOP of the attention branch's VGPRs and the launch drops to three (the two-level destination pass
-// with the 8-attribute edge class is at three either way and would spill, so it keeps the default).
-template <int H, int KL, bool O2 = false>
-__global__ __launch_bounds__(kBlock, 4) void k_gat_fwd_lin(GatFwdArgs A, LinTasks T, int gat_base) {
-    extern __shared__ __attribute__((aligned(16))) float sBt[];
-    __shared__ float sWf[8][kWfLd];
-    int g;
-    if (lin_side_role(T, gat_base, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
-    if (g < A.nblk) gat_fwd_body<H, KL, false, O2>(A, sWf, g, A.nblk);
-}
-template <int H, int KLA, int KLB, bool RDA, bool O2 = false>
-__global__ __launch_bounds__(kBlock, 4) void k_gat_fwd_pair_lin(GatFwdArgs A, GatFwdArgs B, LinTasks T, int gat_base) {
-    extern __shared__ __attribute__((aligned(16))) float sBt[];
-    __shared__ float sWf[8][kWfLd];
-    int g;
-    if (lin_side_role(T, gat_base, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
-    if (g < A.nblk) gat_fwd_body<H, KLA, RDA, O2>(A, sWf, g, A.nblk);
-    else if (g < A.nblk + B.nblk) gat_fwd_body<H, KLB, false, O2>(B, sWf, g - A.nblk, B.nblk);
 }
 
 // the one-pass backward's second launch of a layer: input-gradient products (one 64 x 64 tile per workgroup; RowAdd epilogue where a
@@ -3284,17 +2385,9 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const float* __restrict__ 
     }
 }
 
-#define FN_DISPATCH_H(heads, CALL)                         \
-    switch (heads) {                                       \
-        case 1: { constexpr int HH = 1; CALL; } break;     \
-        case 2: { constexpr int HH = 2; CALL; } break;     \
-        case 4: { constexpr int HH = 4; CALL; } break;     \
-        case 8: { constexpr int HH = 8; CALL; } break;     \
-        default: return fail(FN_EUNSUPPORTED, "heads must be 1, 2, 4 or 8 (128 = heads * head_dim)"); \
-    }
 
 // m: the level's edge count (a level without edges has an empty attribute table, whose pointer may be null: nothing reads it)
-bool bad_edge_term(const fn_edge_term* et, int64_t m = 1) {
+bool bad_edge_term(const fn_edge_term* et, int64_t m = 1) {      // (the other translation units: fni::bad_edge_term)
     if (!et) return true;
     if (et->mode == 0) return false;
     if (et->mode != 2) return true;
@@ -3316,9 +2409,9 @@ int fail(int code, const char* what) { return ::fail(code, what); }
 int launch_status(const char* where) { return ::launch_status(where); }
 int tune(int key) { return key >= 0 && key < FN_TUNE_COUNT ? g_tune[key] : 0; }
 unsigned long long* stamps(int64_t* n_u64) { *n_u64 = g_mol_stamps_n;  return g_mol_stamps; }
+bool bad_edge_term(const fn_edge_term* et, int64_t m) { return ::bad_edge_term(et, m); }
 }  // namespace fni
 namespace {
-#define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -3326,7 +2419,6 @@ template <typename Kern> int allow_lds(Kern kern, size_t bytes) {
     return 0;
 }
 // blocks of a product with `tiles` row tiles when every block walks `iters` of them (two column halves per tile)
-inline int lin_blocks(int64_t tiles, int iters) { return 2 * (int)((tiles + iters - 1) / iters); }
 inline int lin_iters(int64_t total_tiles) {     // row tiles per block so that the launch is resident at once (four blocks per CU)
     const int64_t slots = g_tune[FN_TUNE_GEMM_SLOTS];
     if (slots <= 0) return 1;                   // default: one output tile per workgroup (measured best, tools/probe/gemm_probe.hip)
@@ -3354,7 +2446,7 @@ int launch_linear128(const float* X, int K, const float* Bt, const float* bias, 
     }
     return 0;
 }
-int launch_linear128_group(LinTasks& T, hipStream_t st) {
+int linear128_group_impl(LinTasks& T, hipStream_t st) {
     constexpr int KQ = 32;
     const size_t lds = (size_t)(4 * KQ * kLinLd) * sizeof(float);
     int64_t total = 0;
@@ -3577,6 +2669,9 @@ __global__ void k_zero2_i32(int32_t* __restrict__ a, int64_t na, int32_t* __rest
     }
 }
 }  // namespace
+namespace fni {
+int launch_linear128_group(LinTasks& T, hipStream_t st) { return ::linear128_group_impl(T, st); }
+}  // namespace fni
 
 extern "C" {
 
@@ -3676,95 +2771,7 @@ int fn_node_scalars_f32(const float* h, const float* att, int att_w, int dst_off
 
 // ---- argument validation + launch geometry of the three attention kernels (shared by the single-level C-ABI
 // entry points and the engine's two-level launches); nblk == 0 means "nothing to do"
-static int edge_class(const fn_edge_term* et) { return et->mode == 0 ? 0 : (et->K == 1 ? 1 : FN_MAX_EDGE_K); }
 
-static int prep_gat_fwd(const float* h, const float* s_dst, const float* s_src, const float* att, int att_w,
-                        const fn_edge_term* et, const fn_gat_plan* plan, float neg_slope, float* out, float* p_sorted,
-                        float* probs_orig, const fn_act_epilogue* act, int heads, GatFwdArgs* A, float* out2 = nullptr,
-                        float* sigma = nullptr) {
-    if (!h || !s_dst || !s_src || !att || !plan || bad_edge_term(et, plan->m)) return fail(FN_EINVAL, "fn_gat_fwd_f32: bad argument");
-    if (!out && !(act && act->y)) return fail(FN_EINVAL, "fn_gat_fwd_f32: no output buffer");
-    if (act && (act->p < 0.f || act->p > 1.f)) return fail(FN_EINVAL, "fn_gat_fwd_f32: dropout probability");
-    if (plan->m > 0 && !p_sorted) return fail(FN_EINVAL, "fn_gat_fwd_f32: null p_sorted");
-    if (et->mode == 0 && plan->m > 0 && !et->s_sorted) return fail(FN_EINVAL, "fn_gat_fwd_f32: null s_sorted");
-    if (heads != 1 && heads != 2 && heads != 4 && heads != 8) return fail(FN_EUNSUPPORTED, "heads must be 1, 2, 4 or 8 (128 = heads * head_dim)");
-    *A = GatFwdArgs{h, s_dst, s_src, att, att_w, *et, *plan, neg_slope, out, p_sorted, probs_orig,
-                    act ? *act : fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr}, 1, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, 0, nullptr, g_tune[FN_TUNE_ONE_TIER6] != 0 ? 1 : 0};
-    if ((out2 == nullptr) != (sigma == nullptr)) return fail(FN_EINVAL, "fn_gat_fwd_f32: out2 and sigma come together");
-    A->out2 = out2;  A->sigma = sigma;
-    if (plan->n == 0) return 0;
-    if (!(neg_slope >= 0.f && neg_slope <= 1.f)) return fail(FN_EUNSUPPORTED, "fn_gat_fwd_f32: LeakyReLU slope must be in [0, 1]");
-    if (plan->n > (1 << 23) || plan->m * heads > (1 << 29))
-        return fail(FN_EUNSUPPORTED, "fn_gat_fwd_f32: level too large for 32-bit byte offsets (n <= 2^23 rows, m*heads <= 2^29)");
-    // persistent half-waves: as many as fit on the chip at once, each pipelining R rows
-    const int64_t groups = (plan->n + kRows - 1) / kRows;
-    // with the dropout epilogue (training) fewer, longer-lived half-waves win (5 rows each at B = 512: 27.7 -> 22.4 us for the
-    // bond + fragment-bond launch); the plain forward (inference) wants the chip full of them
-    const int64_t resident = (int64_t)g_tune[act && act->y && act->p > 0.f ? FN_TUNE_FWD_BLOCKS : FN_TUNE_FWD_BLOCKS_EVAL];
-    A->rows_per_hw = (int)((groups + resident - 1) / resident);
-    A->nblk = (int)((plan->n + (int64_t)kRows * A->rows_per_hw - 1) / ((int64_t)kRows * A->rows_per_hw));
-    return 0;
-}
-
-static int launch_gat_fwd(const GatFwdArgs& A, int heads, hipStream_t st) {
-    if (A.nblk == 0) return 0;
-    const int kl = edge_class(&A.et);
-    const bool o2 = A.out2 != nullptr;
-    if (A.rd_out) {
-        if (kl != 1) return fail(FN_EUNSUPPORTED, "attention forward: the row-dots epilogue exists for the single-attribute (bond graph) level");
-        FN_DISPATCH_H(heads, {
-            if (o2) hipLaunchKernelGGL((k_gat_fwd_rd<HH, true>), dim3(A.nblk), dim3(kBlock), 0, st, A);
-            else hipLaunchKernelGGL((k_gat_fwd_rd<HH>), dim3(A.nblk), dim3(kBlock), 0, st, A);
-        });
-        return launch_status("fn_gat_fwd_f32 (+ row dots)");
-    }
-#define FN_FWD1(KLV)                                                                                          \
-    do {                                                                                                      \
-        if (o2) hipLaunchKernelGGL((k_gat_fwd<HH, KLV, true>), dim3(A.nblk), dim3(kBlock), 0, st, A);         \
-        else hipLaunchKernelGGL((k_gat_fwd<HH, KLV>), dim3(A.nblk), dim3(kBlock), 0, st, A);                  \
-    } while (0)
-    FN_DISPATCH_H(heads, {
-        if (kl == 0) FN_FWD1(0);
-        else if (kl == 1) FN_FWD1(1);
-        else FN_FWD1(FN_MAX_EDGE_K);
-    });
-#undef FN_FWD1
-    return launch_status("fn_gat_fwd_f32");
-}
-// two levels, one launch, when their edge classes are (1, FN_MAX_EDGE_K) or (1, 1); two launches otherwise
-static int launch_gat_fwd_pair(const GatFwdArgs& A, const GatFwdArgs& B, int heads, hipStream_t st) {
-    const int ka = edge_class(&A.et), kb = edge_class(&B.et);
-    if (A.nblk == 0 || B.nblk == 0 || ka != 1 || (kb != 1 && kb != FN_MAX_EDGE_K)) {
-        if (int rc = launch_gat_fwd(A, heads, st)) return rc;
-        return launch_gat_fwd(B, heads, st);
-    }
-    const bool o2 = A.out2 != nullptr;
-    if (o2 != (B.out2 != nullptr)) {
-        if (int rc = launch_gat_fwd(A, heads, st)) return rc;
-        return launch_gat_fwd(B, heads, st);
-    }
-#define FN_FWD2(KB, RD)                                                                                                            \
-    do {                                                                                                                           \
-        if (o2) hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, KB, RD, true>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);       \
-        else hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, KB, RD>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);                \
-    } while (0)
-    FN_DISPATCH_H(heads, {
-        if (A.rd_out) { if (kb == 1) FN_FWD2(1, true); else FN_FWD2(FN_MAX_EDGE_K, true); }
-        else { if (kb == 1) FN_FWD2(1, false); else FN_FWD2(FN_MAX_EDGE_K, false); }
-    });
-#undef FN_FWD2
-    return launch_status("attention forward (two levels)");
-}
-
-int fn_gat_fwd_f32(const float* h, const float* s_dst, const float* s_src, const float* att, int att_w,
-                   const fn_edge_term* et, const fn_gat_plan* plan, float neg_slope, float* out, float* p_sorted,
-                   float* probs_orig, float* out2, float* sigma, int p_edge_major, const fn_act_epilogue* act, int heads,
-                   fn_stream_t stream) {
-    GatFwdArgs A;
-    if (int rc = prep_gat_fwd(h, s_dst, s_src, att, att_w, et, plan, neg_slope, out, p_sorted, probs_orig, act, heads, &A, out2, sigma)) return rc;
-    A.p_edge_major = p_edge_major ? 1 : 0;
-    return launch_gat_fwd(A, heads, S(stream));
-}
 
 static int prep_gat_bwd_dst(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et,
                             const fn_gat_plan* plan, float neg_slope, float* dz_sorted, float* g_s_orig, float* pz_src,
@@ -3807,78 +2814,6 @@ static int launch_gat_bwd_dst(const GatBwdDstArgs& A, int heads, hipStream_t st)
     return launch_status("fn_gat_bwd_dst_f32");
 }
 
-// ---- co-launches: an attention pass + independent K = 128 projection tasks (k_gat_*_lin above).  Each returns through the
-// plain launches (attention, then launch_linear128_group) whenever the combination has no kernel: the caller never needs to know.
-static_assert(kBlock == kLinThreads && kBwdRows * 32 == kLinThreads, "co-launched attention and GEMM workgroups share a block size");
-constexpr size_t kLinSideLds = (size_t)(4 * 32 * kLinLd) * sizeof(float);
-constexpr size_t kLinSideLdsGs = kLinSideLds + 4 * kLinLd * sizeof(float);    // + four operand rows: R of the deferred term (GsdEpi)
-// lays the tasks' workgroups out (one 64 x 64 output tile each); false: cannot ride along (empty, co-launch off, misaligned, or the
-// register-resident / wave-independent GEMM variants are selected, which have their own launch shapes)
-static bool lin_side_prepare(LinTasks& T, int gat_blocks, int* gat_base, int* grid) {
-    if (!g_tune[FN_TUNE_GEMM_COLAUNCH] || g_tune[FN_TUNE_GEMM_SLOTS] > 0) return false;
-    for (int i = 0; i < T.n; ++i) {
-        const LinTask& t = T.t[i];
-        if (t.M <= 0) continue;
-        if (t.K && t.K != FN_D) return false;
-        if (((uintptr_t)t.X | (uintptr_t)t.Bt | (uintptr_t)t.Y | (uintptr_t)t.bias | (uintptr_t)t.mk.y) & 15) return false;
-    }
-    // one 64 x 64 tile per GEMM workgroup, all of them in front of the attention workgroups: the launch then takes what both
-    // parts take back to back minus one kernel boundary (interleaving the two kinds, GEMM workgroups last, persistent GEMM
-    // workgroups walking several tiles and raised wave priority all measured slower or equal: DESIGN.md section 4)
-    int blocks = 0, live = 0;
-    for (int i = 0; i < T.n; ++i) {
-        if (T.t[i].M <= 0) continue;
-        LinTask t = T.t[i];
-        t.first = blocks;
-        t.nblk = lin_blocks((t.M + kLinRows - 1) / kLinRows, 1);
-        blocks += t.nblk;
-        T.t[live++] = t;
-    }
-    T.n = live;
-    T.K = FN_D;
-    if (!live) return false;
-    T.total = blocks;
-    T.base = 0;
-    *gat_base = blocks;
-    *grid = gat_blocks + blocks;
-    return true;
-}
-static_assert(kLinSideLds <= 64 * 1024, "the co-launched GEMM tile fits the default dynamic LDS limit");
-
-static int launch_gat_fwd_lin(const GatFwdArgs& A, LinTasks& T, int heads, hipStream_t st) {
-    int gb = 0, grid = 0;
-    if (A.nblk == 0 || A.rd_out || edge_class(&A.et) != 0 || !lin_side_prepare(T, A.nblk, &gb, &grid)) {
-        if (int rc = launch_gat_fwd(A, heads, st)) return rc;
-        return T.n ? launch_linear128_group(T, st) : 0;
-    }
-    FN_DISPATCH_H(heads, {
-        if (A.out2) hipLaunchKernelGGL((k_gat_fwd_lin<HH, 0, true>), dim3(grid), dim3(kBlock), kLinSideLds, st, A, T, gb);
-        else hipLaunchKernelGGL((k_gat_fwd_lin<HH, 0>), dim3(grid), dim3(kBlock), kLinSideLds, st, A, T, gb);
-    });
-    return launch_status("attention forward + projections of the next level");
-}
-static int launch_gat_fwd_pair_lin(const GatFwdArgs& A, const GatFwdArgs& B, LinTasks& T, int heads, hipStream_t st) {
-    const int ka = edge_class(&A.et), kb = edge_class(&B.et);
-    int gb = 0, nwg = 0;
-    const bool o2 = A.out2 != nullptr;
-    if (A.nblk == 0 || B.nblk == 0 || ka != 1 || (kb != 1 && kb != FN_MAX_EDGE_K) || o2 != (B.out2 != nullptr) ||
-        !lin_side_prepare(T, A.nblk + B.nblk, &gb, &nwg)) {
-        if (int rc = launch_gat_fwd_pair(A, B, heads, st)) return rc;
-        return T.n ? launch_linear128_group(T, st) : 0;
-    }
-    const dim3 grid(nwg);
-#define FN_PAIR_LIN(KB, RD)                                                                                                  \
-    do {                                                                                                                     \
-        if (o2) hipLaunchKernelGGL((k_gat_fwd_pair_lin<HH, 1, KB, RD, true>), grid, dim3(kBlock), kLinSideLds, st, A, B, T, gb); \
-        else hipLaunchKernelGGL((k_gat_fwd_pair_lin<HH, 1, KB, RD>), grid, dim3(kBlock), kLinSideLds, st, A, B, T, gb);      \
-    } while (0)
-    FN_DISPATCH_H(heads, {
-        if (A.rd_out) { if (kb == 1) FN_PAIR_LIN(1, true); else FN_PAIR_LIN(FN_MAX_EDGE_K, true); }
-        else { if (kb == 1) FN_PAIR_LIN(1, false); else FN_PAIR_LIN(FN_MAX_EDGE_K, false); }
-    });
-#undef FN_PAIR_LIN
-    return launch_status("attention forward (two levels) + atom projection");
-}
 
 int fn_gat_bwd_dst_f32(const float* g_out, const float* h, const float* p_sorted, const fn_edge_term* et,
                        const fn_gat_plan* plan, float neg_slope, float* dz_sorted, float* g_s_orig, float* pz_src,
