@@ -192,11 +192,19 @@ __device__ __forceinline__ void block_groups(int64_t n_rows, int rb, int64_t& be
     end = begin + per < groups ? begin + per : groups;
 }
 
-__device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t seed) {
+// Philox-4x32 counter-based generator (Salmon et al., SC'11): 128 random bits per (counter, key), no state.  SEVEN rounds: the
+// smallest count that passes BigCrush in the paper (Table 2; ten is its safety-margin default).  The bits only draw dropout masks,
+// and the attention forward kernels are VALU-bound enough for the three rounds to matter: two 32 x 32 -> 64 multiplies (quarter
+// rate) per round and lane, 1.2 % of the whole training step (0.809 -> 0.799 ms, profiles/r05_*; -DFN_PHILOX_ROUNDS=10 for the A/B).
+// Every consumer of a mask -- the fused epilogues, fn_dropout_act_f32, its backward, the tests that replay masks -- calls this.
+#ifndef FN_PHILOX_ROUNDS
+#define FN_PHILOX_ROUNDS 7
+#endif
+__device__ __forceinline__ uint4 philox4x32(uint64_t ctr, uint64_t seed) {
     uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < FN_PHILOX_ROUNDS; ++r) {
         const uint64_t m0 = (uint64_t)0xD2511F53u * c0, m1 = (uint64_t)0xCD9E8D57u * c2;       // one v_mad_u64_u32 each
         const uint32_t hi0 = (uint32_t)(m0 >> 32), lo0 = (uint32_t)m0, hi1 = (uint32_t)(m1 >> 32), lo1 = (uint32_t)m1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
@@ -206,9 +214,11 @@ __device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t seed) {
     return make_uint4(c0, c1, c2, c3);
 }
 
+// keep an element iff u >= p with u = (bits >> 8) / 2^24 -- decided on the integers: k / 2^24 >= p  <=>  k >= ceil(p 2^24) (both sides
+// exact in fp32), which saves the conversion and the multiply per element; the threshold is loop-invariant
 __device__ __forceinline__ float keep_scale(uint32_t bits, float p, float inv_keep) {
-    const float u = (float)(bits >> 8) * (1.0f / 16777216.0f);
-    return u >= p ? inv_keep : 0.f;
+    const uint32_t thresh = (uint32_t)ceilf(p * 16777216.0f);
+    return (bits >> 8) >= thresh ? inv_keep : 0.f;
 }
 
 template <int W> __device__ __forceinline__ float group_sum(float v) {

@@ -1286,7 +1286,7 @@ __device__ __forceinline__ void dropout_act_body(const float* __restrict__ a, co
     for (int64_t i = (int64_t)vb * blockDim.x + threadIdx.x; i < n4; i += (int64_t)nb * blockDim.x) {
         float m[4] = {1.f, 1.f, 1.f, 1.f};
         if (p > 0.f) {
-            const uint4 r = philox4x32_10(offset + (uint64_t)i, seed);
+            const uint4 r = philox4x32(offset + (uint64_t)i, seed);
             m[0] = keep_scale(r.x, p, inv_keep); m[1] = keep_scale(r.y, p, inv_keep);
             m[2] = keep_scale(r.z, p, inv_keep); m[3] = keep_scale(r.w, p, inv_keep);
         }

@@ -406,7 +406,7 @@ int fn_dense_bwd_f32(const float* g_y, const float* X, const float* W, float* g_
                      int64_t M_out /*rows [M, M_out) of g_x are set to 0 (padding rows); <= M: none*/, fn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * act(dropout(x)) between layers (gat2.py:396-397, 414-418, 436-440): Philox-4x32-10 mask keyed by
+ * act(dropout(x)) between layers (gat2.py:396-397, 414-418, 436-440): Philox-4x32 mask (seven rounds, csrc/fn_internal.h) keyed by
  * (seed, offset + element/4), y = relu(keep ? x/(1-p) : 0); relu = 0 gives plain dropout.
  * Backward recomputes the mask from the same (seed, offset).
  * ------------------------------------------------------------------------------------------ */
