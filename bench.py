@@ -82,6 +82,41 @@ def step_bytes(batch):
     return total
 
 
+def forward_bytes(batch):
+    """The forward half of step_bytes (eval mode: no dropout): 4 layers x 4 levels, projections, node scalars, edge terms, L3, readout."""
+    N = batch["x_atoms"].shape[0]
+    E = batch["node_features_bonds"].shape[0]
+    Eb = batch["edge_index_bonds_graph"].shape[1]
+    F = batch["x_frags"].shape[0]
+    EF = batch["node_features_fbonds"].shape[0]
+    EFB = batch["edge_index_fbonds"].shape[1]
+    B = batch["y"].shape[0]
+    D, H = 128, 4
+    total = 0
+    for layer in range(4):
+        k_b, k_a, k_fb = (17, 167, 6) if layer == 0 else (128, 128, 128)
+        for n, m, K in ((E, Eb, k_b), (N, E + N, k_a), (EF, EFB, k_fb), (F, EF, None)):
+            total += level_bytes(n, m)[0]
+            if K is not None:
+                total += 4 * (n * K + n * D)                                  # projection
+            total += 4 * 2 * n * H                                           # node-scalar epilogue
+        total += 4 * (E * D + (E + N) * H) + 4 * (EF * D + EF * H)           # full-width edge terms (L2, L4b)
+        total += 4 * (N * D + N + F * D)                                      # L3
+    total += 4 * (N * D + N + B * D) + 4 * (F * D + F + B * D)               # readout
+    return total
+
+
+def batch_bytes(batch):
+    """Bytes of a collated batch (every tensor once): what a collate reads from the store and writes."""
+    return sum(v.numel() * v.element_size() for v in batch.values() if torch.is_tensor(v))
+
+
+def sweep_roofline(alg_bytes, seconds_per_step, what):
+    gbps = alg_bytes / seconds_per_step / 1e9
+    return {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+            "algorithmic_bytes_per_step": int(alg_bytes), "what": what}
+
+
 def make_pool(n_batches, rank, device, batch=PER_GPU_BATCH, world=1, scaling="weak"):
     """weak: ``batch`` molecules per rank, rank-specific seeds.  strong: the same ``batch`` molecules on every rank (seeds do
     not depend on the rank), of which this rank collates its shard parallel.shard_indices(batch, rank, world)."""
@@ -322,7 +357,10 @@ def forward_sweep(rank, world, dev, args):
                               "per_gpu_batch": B, "steps": args.steps, "ms_per_step": round(sec / args.steps * 1e3, 3),
                               "atoms": int(pool[0]["x_atoms"].shape[0]),
                               "bond_graph_edges": int(pool[0]["edge_index_bonds_graph"].shape[1]), "dtype": "f32",
-                              "data": "synthetic", "scaling": "weak"}), flush=True)
+                              "data": "synthetic", "scaling": "weak",
+                              "roofline": sweep_roofline(forward_bytes(pool[0]), sec / args.steps,
+                                                         "the WHOLE forward step (plan build + 4 layers + head) against the forward half of the "
+                                                         "SURVEY 8d compulsory-traffic model (forward_bytes); per GPU")}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -354,6 +392,9 @@ def forward_sweep_store(rank, world, dev, args):
         steps = max(4, min(steps, len(store) // B - WU))
         idx_lists = [next(it) for _ in range(steps + WU)]          # host indices: FlatMolStore.collate sizes the batch from its host-side lengths (no read-back)
         with torch.no_grad():
+            probe = store.collate(idx_lists[0])
+            alg_fwd, alg_coll = forward_bytes(probe), 2 * batch_bytes(probe)          # (batches differ by a fraction of a per cent)
+            del probe
             for idx in idx_lists[:WU]:
                 model(store.collate(idx))
             if world > 1:
@@ -364,24 +405,37 @@ def forward_sweep_store(rank, world, dev, args):
                 model(store.collate(idx))
             torch.cuda.synchronize()
             total = time.perf_counter() - t0
+            # the collate alone over the same index lists: wall time of the loop (host-bound when the host's table work is longer than
+            # the kernel) and, from events around every call, the time the GPU spends on it -- that is its share of the pipeline above,
+            # where the host works on batch k + 1 while the GPU runs batch k
+            evs = []
+            store._collate_events = evs                     # (start, end) events right around the collate's two launches
             t0 = time.perf_counter()
             for idx in idx_lists[WU:]:
                 store.collate(idx)
             torch.cuda.synchronize()
             coll = time.perf_counter() - t0
+            store._collate_events = None
+            coll_dev = sum(a.elapsed_time(b) for a, b in evs) * 1e-3
         if world > 1:
             torch.distributed.barrier()
-        el = torch.tensor([total, coll], dtype=torch.float64, device=dev)
+        el = torch.tensor([total, coll, coll_dev], dtype=torch.float64, device=dev)
         if world > 1:
             torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
         if rank == 0:
-            total, coll = float(el[0]), float(el[1])
+            total, coll, coll_dev = float(el[0]), float(el[1]), float(el[2])
             print(json.dumps({"metric": "molecules/sec forward only (eval) from a resident store: collate + plan + forward",
                               "value": round(B * world * steps / total, 1), "unit": "molecules/s", "n_gpus": world,
                               "per_gpu_batch": B, "steps": steps, "ms_per_step": round(total / steps * 1e3, 3),
-                              "collate_ms_per_step": round(coll / steps * 1e3, 3), "collate_share": round(coll / total, 3),
+                              "collate_ms_per_step": round(coll_dev / steps * 1e3, 3), "collate_share": round(coll_dev / total, 3),
+                              "collate_loop_ms_per_step": round(coll / steps * 1e3, 3),
+                              "collate_note": "collate_ms_per_step / collate_share: GPU time of the collate's launches (events right around them); "
+                                              "collate_loop_ms_per_step: wall time of a loop of collates alone (host + GPU, whichever is longer)",
                               "store_molecules": len(store), "store_distinct_molecules": distinct, "store_GB": round(store_gb, 2),
-                              "store_build_s": round(build_s, 1), "dtype": "f32", "data": "synthetic (synth40 profile)", "scaling": "weak"}),
+                              "store_build_s": round(build_s, 1), "dtype": "f32", "data": "synthetic (synth40 profile)", "scaling": "weak",
+                              "roofline": sweep_roofline(alg_fwd + alg_coll, total / steps,
+                                                         "collate (the batch's bytes once in, once out) + the whole forward step (forward_bytes); per GPU"),
+                              "roofline_collate": sweep_roofline(alg_coll, coll_dev / steps, "fn_collate_store alone (GPU time): the batch's bytes once in, once out")}),
                   flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

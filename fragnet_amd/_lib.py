@@ -89,7 +89,7 @@ class MseTask(C.Structure):
 
 class CollateField(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("rows", i64), ("src_rows", i64), ("width_words", i32), ("space", i32), ("kind", i32),
-                ("rebase_space", i32), ("src_global", i32), ("pad_", i32)]
+                ("rebase_space", i32), ("src_global", i32), ("max_seg_rows", i32)]
 
 
 FN_MAX_COLLATE_FIELDS = 24

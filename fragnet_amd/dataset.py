@@ -129,15 +129,18 @@ class FlatMolStore:
             host_idx = torch.as_tensor(indices, dtype=torch.long)
             if host_idx.numel() == 0:
                 raise ValueError("collate: empty batch")
-            lens = self._host_lengths()
             ix = host_idx.numpy()          # numpy, not torch: a CPU gather of 8192 elements goes through torch's thread pool, and
             # (numpy would wrap a negative index round to the store's end -- offs[-1] is the total row count -- and the kernel
             # would then read past every store tensor; the torch path below raised for it, so does this one)
             if int(ix.min()) < 0 or int(ix.max()) >= len(self):
                 raise IndexError(f"collate: molecule index out of range for a store of {len(self)} molecules")
-            totals = {space: int(lens[space][ix].sum()) for space in _COUNT_OF}      # waking it cost up to 90 ms a batch beside the GPU work
+            # ONE gather of the molecules' records (lengths | first store rows of every index space, a row of <= 128 bytes per molecule):
+            # fourteen separate gathers out of 8-MB arrays were ~1.3 ms of cache misses a batch of 8192 on a store of a million molecules
+            cols, table = self._host_table()
+            rec = table[ix]
+            totals = {space: int(rec[:, cols[space]].sum()) for space in _COUNT_OF}      # waking it cost up to 90 ms a batch beside the GPU work
             if FUSED_COLLATE:
-                fused = self._collate_fused(ix, pretrain)      # reads the host indices only: nothing is uploaded for it
+                fused = self._collate_fused(ix, pretrain, rec, cols)      # reads the host indices only: nothing is uploaded for it
                 if fused is not None:
                     return fused
             # through pinned memory (torch's caching host allocator): an asynchronous copy from pageable memory of 64 KB and more
@@ -208,7 +211,7 @@ class FlatMolStore:
                   "edge_index_bonds_graph": ("edge_index_bonds", "bedge", "edge"), "edge_index_fbonds": ("edge_index_fbondg", "fbedge", "fedge"),
                   "atom_to_frag_ids": ("atom_id_frag_id", "atom", "frag")}
 
-    def _collate_fused(self, ix, pretrain: bool):
+    def _collate_fused(self, ix, pretrain: bool, rec, cols):
         """The whole batch in ONE launch (fn_collate_store): the batch's offsets table and the molecules' first store rows are built
         on the host from the store's lengths (numpy, microseconds) and copied over in two small transfers; None when a tensor of
         the store is not laid out the way the kernel reads it (the torch path below then builds the batch)."""
@@ -231,8 +234,7 @@ class FlatMolStore:
                 return None
         if self.y.element_size() != 4 or not self.y.is_contiguous():
             return None
-        lens, offs = self._host_lengths(), self._host_offsets()
-        S = len(SPACES)
+        S, nsp = len(SPACES), len(cols)
         # one pinned buffer [starts int64 [S, B] | offsets int32 [S, B + 1]] and one device buffer of the same layout: the collate's
         # own first launch copies it (no copy-engine transfer in the step's stream)
         n_st, n_off = S * B, S * (B + 1)
@@ -248,18 +250,20 @@ class FlatMolStore:
                 sn[s] = ix
                 total[name] = B
             else:
-                on[s, 1:] = np.cumsum(lens[name][ix])
-                sn[s] = offs[name][ix]
+                on[s, 1:] = np.cumsum(rec[:, cols[name]])
+                sn[s] = rec[:, nsp + cols[name]]
                 total[name] = int(on[s, B])
         st_d, off_d = tab_d[: 2 * n_st].view(torch.long).view(S, B), tab_d[2 * n_st:].view(S, B + 1)
         out = CollatedBatch()
         fields = (_lib.CollateField * _lib.FN_MAX_COLLATE_FIELDS)()
         n = 0
 
+        bound = self.max_per_mol()          # a molecule's largest extent per index space: how many chunks its segment is cut into
+
         def add(dst, src, rows, src_rows, width, space, kind, rebase=0):
             nonlocal n
             fields[n] = _lib.CollateField(None if src is None else src.data_ptr(), dst.data_ptr(), rows, src_rows, width, SPACES.index(space), kind,
-                                          SPACES.index(rebase) if rebase else 0, 0, 0)
+                                          SPACES.index(rebase) if rebase else 0, 0, int(bound.get(space, 0)))
             n += 1
         for key, (f, space) in rows_spec.items():
             src = t[f]
@@ -276,7 +280,15 @@ class FlatMolStore:
             add(out[key], None, total[space], 0, 1, space, _lib.COLLATE_BATCH)
         out["y"] = torch.empty((B,) + tuple(self.y.shape[1:]), dtype=self.y.dtype, device=dev)
         add(out["y"], self.y, B, 0, max(1, self.y.numel() // max(1, self.y.shape[0])), "mol", _lib.COLLATE_ROWS)
+        timing = self.__dict__.get("_collate_events")       # measurement hook (bench.py): a list -> (start, end) events around the launches
+        if timing is not None:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream(dev))
         _lib.call("fn_collate_store", fields, n, st_d.data_ptr(), off_d.data_ptr(), S, B, tab_h.data_ptr(), _stream_ptr(dev))
+        if timing is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record(torch.cuda.current_stream(dev))
+            timing.append((ev0, ev1))
         slot[1] = torch.cuda.Event()
         slot[1].record(torch.cuda.current_stream(dev))      # the pinned buffer is free again once the launch above has read it
         out._keep = (tab_d,)
@@ -306,6 +318,20 @@ class FlatMolStore:
         if getattr(self, "_off_cpu", None) is None:
             self._off_cpu = {s: o.to("cpu", torch.long).numpy() for s, o in self.off.items()}
         return self._off_cpu
+
+    def _host_table(self):
+        """(column of every index space, int64 [n_molecules, 2 x spaces]): a molecule's extents in all spaces, then its first store rows --
+        one row per molecule, so that a batch's records are one gather (copied once; the store is immutable)."""
+        if getattr(self, "_tab_cpu", None) is None:
+            import numpy as np
+            lens, offs = self._host_lengths(), self._host_offsets()
+            names = list(self.off)
+            tab = np.empty((len(self), 2 * len(names)), dtype=np.int64)
+            for j, s in enumerate(names):
+                tab[:, j] = lens[s]
+                tab[:, len(names) + j] = offs[s][:-1]
+            self._tab_cpu = ({s: j for j, s in enumerate(names)}, tab)
+        return self._tab_cpu
 
     def _host_lengths(self):
         """Per-molecule extent in every index space as numpy arrays on the host (copied once; the store is immutable)."""

@@ -109,11 +109,13 @@ int fn_abi_version(void);
 #define FN_TUNE_RIDER_AT 28           /* which launch of the one-pass encoder backward carries fn_encoder.adam_rider: 0 (default) the last one (the
                                        * deferred reductions: + 7 us there for the 12.9 - 4.5 us the step's Adam launch saves), 1 the first one (the
                                        * molecule-resident fragment tail, when it runs: + 11.7 us) */
-#define FN_TUNE_DEFER_GSD 29           /* 1 (default): with the one-pass backward and four heads (gat2) the forward writes NO second output: the pass
-                                       * leaves dz at the edges' destination-order slots and the terms that need g_s_dst = the sum of a row's
-                                       * segment are added by whoever reads g_h next -- the input-gradient product's epilogue (rank-4 update of its
-                                       * output rows), the weight-gradient kernels (their dY operand; side product U = G^T X for dL/da_dst).
-                                       * 0: out2 / sigma in the forward, <g, out2> in the producers' epilogues (round 4) */
+#define FN_TUNE_DEFER_GSD 29           /* 1: with the one-pass backward and four heads (gat2) the forward writes NO second output (out2 / sigma): the
+                                       * pass leaves dz at the edges' destination-order slots and the terms that need g_s_dst = the sum of a row's
+                                       * segment are added by whoever reads g_h next -- the input-gradient product (one more MFMA step, k = the four
+                                       * heads), the weight-gradient kernels (the block's partial; side product U = G^T X for dL/da_dst), one small
+                                       * launch for layer 0.  0 (default): out2 / sigma in the forward, <g, out2> in the producers' epilogues.
+                                       * Measured at ESOL batch 512 (round 5, same call): the forward launches 18 us shorter, the backward 32 us
+                                       * longer (weight-gradient launch + 21, layer 0's launch + 12): 0.797 against 0.783 ms per step */
 #define FN_TUNE_COUNT 30
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= 16 * 4 * workgroups 64-bit words) is set, every wave
@@ -516,7 +518,9 @@ typedef struct fn_collate_field {
     int64_t src_rows;        /* FN_COLLATE_IDS: rows of src (its second dimension) */
     int32_t width_words;     /* ROWS: 4-byte words per row; IDS: first dimension (1 or 2) */
     int32_t space, kind, rebase_space;
-    int32_t src_global, pad_;
+    int32_t src_global;
+    int32_t max_seg_rows;    /* upper bound on one molecule's rows in `space` (the store's maximum); 0: unknown.  Sizes the launch only: a
+                              * molecule's segment is cut into chunks that half-waves copy side by side */
 } fn_collate_field;
 int fn_collate_store(const fn_collate_field* fields, int n_fields, const int64_t* starts, const int32_t* offsets, int n_spaces, int64_t B,
                      const void* tables_host /*nullable: pinned host memory holding [starts | offsets]; a kernel then copies it into

@@ -335,6 +335,28 @@ def test_finetune_matches_reference_golden(case, use_engine):
     check_grads(model, grads, atol=ATOL, rtol=2e-3)
 
 
+@pytest.mark.parametrize("case", ["ft_esol_b8", "ft_edge_b6"])
+def test_deferred_backward_form_matches_reference_golden(case):
+    """FN_TUNE_DEFER_GSD = 1 (include/fragnet_hip.h key 29): the engine's one-pass backward WITHOUT the forward's second output -- dz at
+    destination-order slots, g_s_dst summed by the input-gradient product (one more MFMA step) / fn_gat_gsd's kernel for layer 0,
+    dL/da_dst from the weight-gradient kernels' side product -- against the reference's golden logits, loss and gradients
+    (four heads; the edge-case molecules of ft_edge_b6 include one-fragment and fully cut molecules: edge-less levels)."""
+    from fragnet_amd import _lib
+    try:
+        _lib.call("fn_set_tuning", 29, 1)
+        cfg, b, out, grads, model, logits, _ = _run_ft(case, True)
+        torch.testing.assert_close(logits.detach().cpu(), torch.from_numpy(out["logits"]), atol=ATOL, rtol=1e-4)
+        from oracle import fragnet_ref as ref
+        loss = torch.nn.functional.mse_loss(logits.view(-1), b["y"]) if cfg["loss"] == "mse" else ref.finetune_bce_loss(logits, b["y"])
+        assert abs(loss.item() - float(out["loss"])) < ATOL
+        loss.backward()
+        torch.cuda.synchronize()
+        b["_fragnet_plan"].check()
+        check_grads(model, grads, atol=ATOL, rtol=2e-3)
+    finally:
+        _lib.call("fn_set_tuning", 29, 0)
+
+
 @pytest.mark.parametrize("use_engine", [True, False], ids=["engine", "per_level_ops"])
 def test_gat2_lite_matches_reference_golden(use_engine):
     """model_version gat2_lite: per-layer outputs, logits, loss and gradients of the reference's

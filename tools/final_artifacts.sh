@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the per-round evidence set on a GPU box:  bash tools/final_artifacts.sh <tag>   (writes gpurun_out/<tag>/, copy into profiles/)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -16,8 +16,6 @@ timeout 300 python3 tools/tox21_bench.py > $O/tox21.txt 2>&1
 timeout 300 python3 tools/pretrain_bench.py > $O/pretrain.txt 2>&1
 timeout 300 python3 bench.py --gpus 1 --spawn --no-cpu-baseline --no-roofline > $O/bench_spawn_1rank.json 2> $O/bench_spawn_1rank.err
 FRAGNET_BENCH_BACKEND=gloo timeout 300 python3 bench.py --gpus 2 --overlap off --no-cpu-baseline --no-roofline --steps 10 > $O/bench_2ranks_gloo_one_gpu.json 2> /dev/null
-timeout 300 python3 tools/molbwd_check.py --stamps > $O/molbwd_check.txt 2>&1
-timeout 300 python3 tools/molbwd_check.py --batch 2048 --levels bond,atom --stamps > $O/molbwd_check_b2048.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pd /tmp/pd2 /tmp/pmc_fetch /tmp/pmc_write
 timeout 300 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/pd -o d -- python3 $R/bench.py --no-cpu-baseline --no-roofline --epoch-batches 0 > /dev/null 2>&1
@@ -51,7 +49,10 @@ python3 $R/tools/pmc_step_traffic.py /tmp/ps_fetch /tmp/ps_write $ALGO $O/step_s
 rm -rf /tmp/ph
 timeout 300 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/ph -o d -- python3 $R/tools/probe/hbm_cold_probe.py > /dev/null 2>&1
 python3 $R/tools/probe/hbm_cold_probe.py --summarise $(ls /tmp/ph/*/*.db /tmp/ph/*.db 2>/dev/null | head -1) > $O/hbm_cold_stream_table.md 2>&1
-for t in "22=0"; do timeout 300 python3 $R/bench.py --no-cpu-baseline --no-roofline --epoch-batches 0 --tune $t 2>/dev/null | tail -1; done > $O/bench_two_pass.json
+# A/B in the same call: the general two-pass backward (22=0) and round 4's form of the one-pass backward (29=0: second forward output, no deferred term)
+timeout 300 python3 $R/bench.py --no-cpu-baseline --no-roofline --epoch-batches 0 --tune 22=0 2>/dev/null | tail -1 > $O/bench_two_pass.json
+timeout 300 python3 $R/bench.py --no-cpu-baseline --no-roofline --epoch-batches 0 --tune 29=0 2>/dev/null | tail -1 > $O/bench_round4_form.json
+bash $R/tools/step_trace.sh $O/step_sequence_round4_form.txt --steps 20 --warmup 5 --epoch-batches 0 --tune 29=0
 # the riders of round 4 off (last Linear / loss / its backward as three launches; one Adam launch over everything)
 (cd $R && FRAGNET_FUSED_HEAD_LOSS=0 FRAGNET_ADAM_RIDER=0 timeout 300 python3 bench.py --no-cpu-baseline --no-roofline --epoch-batches 0 2>/dev/null | tail -1) > $O/bench_no_riders.json
 ls -la $O
