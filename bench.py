@@ -57,8 +57,9 @@ def level_bytes(n, m, H=4, D=128):
     return fwd, bwd
 
 
-def step_bytes(batch):
-    """Whole-step algorithmic bytes (4 layers x 4 levels fwd+bwd + L3 + pooling + projections), §8d."""
+def step_bytes(batch, variant="gat2"):
+    """Whole-step algorithmic bytes (4 layers x 4 levels fwd+bwd + L3 + pooling + projections), §8d.  ``variant``: gat2_lite has no
+    fragment-bond and no fragment graph (its layers stop after the atom -> fragment sum), gat2_edge no fragment-bond graph."""
     N = batch["x_atoms"].shape[0]
     E = batch["node_features_bonds"].shape[0]
     Eb = batch["edge_index_bonds_graph"].shape[1]
@@ -70,13 +71,20 @@ def step_bytes(batch):
     total = 0
     for layer in range(4):
         k_b, k_a, k_fb = (17, 167, 6) if layer == 0 else (128, 128, 128)
-        for n, m, K in ((E, Eb, k_b), (N, E + N, k_a), (EF, EFB, k_fb), (F, EF, None)):
+        levels = ((E, Eb, k_b), (N, E + N, k_a), (EF, EFB, k_fb), (F, EF, None))
+        if variant == "gat2_lite":
+            levels = levels[:2]
+        elif variant == "gat2_edge":
+            levels = (levels[0], levels[1], levels[3])
+        for n, m, K in levels:
             f, b = level_bytes(n, m)
             total += f + b
             if K is not None:
                 total += 4 * (n * K + n * D) + 4 * (n * D + 2 * n * K)      # projection fwd + bwd
             total += 2 * 4 * 2 * n * H                                       # node-scalar epilogue fwd+bwd
-        total += 2 * 4 * (E * D + (E + N) * H) + 2 * 4 * (EF * D + EF * H)  # full-width edge terms (L2, L4b)
+        total += 2 * 4 * (E * D + (E + N) * H)                               # full-width edge term of the atom graph (L2)
+        if variant == "gat2":
+            total += 2 * 4 * (EF * D + EF * H)                               # ... and of the fragment graph (L4b)
         total += 2 * 4 * (N * D + N + F * D)                                  # L3 each way
     total += 2 * 4 * (N * D + N + B * D) + 2 * 4 * (F * D + F + B * D)       # pooling each way
     return total
@@ -218,9 +226,10 @@ def cpu_baseline(budget_s=150.0):
 
 
 def kernel_roofline(batch, model, iters=50, alternatives=False):
-    """Dominant scatter kernels at the bond-graph level, timed back to back with HIP events on the launch stream: the forward and the
-    one-pass backward in the deferred form the engine runs (`k_gat_fwd`, `k_gat_bwd_one`).  ``alternatives`` (the dev loop,
-    --kernels-only): also round 4's form of the pair (second forward output + the dots kernel) and the general two-pass backward."""
+    """Dominant scatter kernels at the bond-graph level, timed back to back with HIP events on the launch stream: the pair the engine
+    runs by default -- the training forward with its second output (`k_gat_fwd(+out2)`) and the one-pass backward (`k_gat_bwd_one`).
+    ``alternatives`` (the dev loop, --kernels-only): also the plain forward, the dots kernel, the deferred form of the pass
+    (FN_TUNE_DEFER_GSD) and the general two-pass backward."""
     import ctypes as C
     from fragnet_amd import _lib
     from fragnet_amd.plan import GraphPlan, _stream_ptr
@@ -258,9 +267,10 @@ def kernel_roofline(batch, model, iters=50, alternatives=False):
         _lib.call("fn_gat_bwd_src_f32", gout.data_ptr(), h.data_ptr(), pz.data_ptr(), g_s_dst.data_ptr(),
                   att.data_ptr(), 96, 0, 64, C.byref(lv.c), g_h.data_ptr(), part_a.data_ptr(), C.byref(n_a), H, st)
 
-    # the engine's default backward: ONE source-owner pass in its deferred form (csrc/gat_bwd_one.inc, DF): the forward writes no second
-    # output; the pass reads the node-local dot c = <g, out> (inside the step: the epilogue of the input-gradient GEMM that produces the
-    # gradient rows) and leaves dz at the edges' destination-order slots for the consumers of g_h
+    # the engine's default backward: ONE source-owner pass (csrc/gat_bwd_one.inc).  It needs the forward's second output (out2, sigma:
+    # `k_gat_fwd(+out2)` is that forward) and the two node-local dots c, g_s_dst, which inside the step ride in the epilogue of the
+    # input-gradient GEMM that produces the gradient rows; `k_gat_cu` is the stand-alone kernel for them (last layer / operator path).
+    # The deferred form (dz_em) needs neither out2 nor g_s_dst: its consumers add the term
     out2, sigma, p_em = torch.empty(n, 128, **f32), torch.empty(n, H, **f32), torch.empty(m, H, **f32)
     cdot, g_s_dst1, g_h1 = torch.empty(n, H, **f32), torch.empty(n, H, **f32), torch.empty(n, 128, **f32)
     part_e1, part_a1 = torch.empty(4096, H * 2, **f32), torch.empty(4096, 256, **f32)
@@ -292,7 +302,7 @@ def kernel_roofline(batch, model, iters=50, alternatives=False):
     res = {}
     fwd_o2()
     cu()           # (cdot / g_s_dst hold real dots for every variant below)
-    runs = [("k_gat_fwd", fwd_em, fwd_b), ("k_gat_bwd_one", bwd_one, bwd_b)]
+    runs = [("k_gat_fwd(+out2)", fwd_o2, fwd_b), ("k_gat_bwd_one", lambda: bwd_one(False), bwd_b)]
     if alternatives:
         # B_agg' counts g_out and h once.  The two passes both read them, so per-pass figures are only a split of B_agg' for
         # orientation (dst pass: g_out, h, probs, idx -> dz, g_s_dst; src pass: the rest).  The dots kernel reads three row tables and
@@ -300,7 +310,7 @@ def kernel_roofline(batch, model, iters=50, alternatives=False):
         bwd_dst_b = 4 * (2 * n * D + m * H + m + m * H + n * H)
         cu_b = 4 * (3 * n * D + n * H + 2 * n * H)
         fwd()
-        runs += [("k_gat_fwd(+out2)", fwd_o2, fwd_b), ("k_gat_bwd_one(round 4: reads g_s_dst)", lambda: bwd_one(False), bwd_b), ("k_gat_cu", cu, cu_b),
+        runs += [("k_gat_fwd", fwd_em, fwd_b), ("k_gat_bwd_one(deferred form)", lambda: bwd_one(True), bwd_b), ("k_gat_cu", cu, cu_b),
                  ("k_gat_bwd_dst", bwd_dst, bwd_dst_b), ("k_gat_bwd_src", bwd_src, bwd_b - bwd_dst_b)]
     for name, fn, nbytes in runs:
         for _ in range(5):
@@ -848,7 +858,7 @@ def main():
         value = head["global_batch"] * args.steps / elapsed
         if args.shard_of > 1 and world == 1:      # dev line: one rank's shard of a strong-scaling job, measured alone
             value = head["local_batch"] * args.steps / elapsed
-        sb = step_bytes(head["pool0"])
+        sb = step_bytes(head["pool0"], args.model_version)
         line = {
             "metric": "molecules/sec fwd+bwd (full training step), ESOL-shape batch=512 " + ("per GPU" if head_scaling == "weak" else "global"),
             "value": round(value, 1), "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -884,8 +894,8 @@ def main():
             roof_batch = head["pool0"] if head["local_batch"] == PER_GPU_BATCH else make_pool(1, 0, dev, PER_GPU_BATCH)[0]
             one_pass = not any(kv.replace(" ", "") == "22=0" for kv in (args.tune or []))       # FN_TUNE_BWD_ONE (the default)
             kr = kernel_roofline(roof_batch, run.model, alternatives=not one_pass)
-            fwd_k, bwd_k = ("k_gat_fwd", "k_gat_bwd_one") if one_pass else ("k_gat_fwd", "k_gat_bwd(dst+src)")
-            nb, mb = kr["k_gat_fwd"]["n"], kr["k_gat_fwd"]["m"]
+            fwd_k, bwd_k = ("k_gat_fwd(+out2)", "k_gat_bwd_one") if one_pass else ("k_gat_fwd", "k_gat_bwd(dst+src)")
+            nb, mb = kr[fwd_k]["n"], kr[fwd_k]["m"]
             f1, b1 = level_bytes(nb, mb)
             sa_us = kr[fwd_k]["us_per_launch"] + kr[bwd_k]["us_per_launch"]
             standalone = {fwd_k: {"us": kr[fwd_k]["us_per_launch"], "GBps": kr[fwd_k]["GBps"], "frac": round(kr[fwd_k]["GBps"] / HBM_PEAK_GBPS, 4)},
@@ -977,8 +987,8 @@ def main():
                                 "algorithmic_bytes_per_launch": headline.get("bytes", f1 + b1),
                                 "algorithmic_bytes_backward_bond_level": b1,
                                 "bytes_model": "SURVEY.md 8d: B_agg = 4[(n+1)+m+mH+2nH+nD+nD+mH] forward; B_agg' = 4[2nD+2mH+2m+nD+mH+2nH] for "
-                                               "the whole backward of the level; the one-pass backward is priced against the same B_agg' (the dz "
-                                               "it leaves for its consumers and the dot it reads are extra traffic, not extra algorithmic bytes)",
+                                               "the whole backward of the level; the one-pass backward is priced against the same B_agg' (its "
+                                               "second forward output and the dots it reads are extra traffic, not extra algorithmic bytes)",
                                 "standalone": standalone,
                                 "in_graph": {"source": ig_source, **inside} if ig_source else None,
                                 "all": kr}

@@ -279,6 +279,15 @@ __device__ __forceinline__ float4 ld4_off(const float* base, uint32_t byte_off) 
 __device__ __forceinline__ float ld1_off(const float* base, uint32_t byte_off) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
+// the same for stores: a wave-uniform base pointer + a 32-bit byte offset is ONE address register per lane (global_store ... saddr);
+// `p + (size_t)row * 128 + lane * 4` is a 64-bit multiply-add per lane and store (v_lshl_add_u64: 72 of the 672 vector instructions
+// of the forward attention loop in round 4)
+__device__ __forceinline__ void st4_off(float* base, uint32_t byte_off, float4 v) {
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+__device__ __forceinline__ void st1_off(float* base, uint32_t byte_off, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
 
 
 

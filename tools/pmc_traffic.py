@@ -17,8 +17,8 @@ import sys
 # key in the output -> (kernel base name, wanted value of the forward's O2 template flag or None).  k_gat_fwd<H, KL, O2>: the plain
 # forward and the one that also writes out2 / sigma (the one-pass backward's forward) share a base name.
 KERNELS = {"k_gat_fwd": ("k_gat_fwd", False), "k_gat_fwd(+out2)": ("k_gat_fwd", True),
-           # k_gat_bwd_one<H, KL, RB, DF>: the deferred form (DF, what the engine runs) and round 4's form share a base name too
-           "k_gat_bwd_one": ("k_gat_bwd_one", True), "k_gat_bwd_one(round 4: reads g_s_dst)": ("k_gat_bwd_one", False),
+           # k_gat_bwd_one<H, KL, RB, DF>: the form the engine runs (DF = false) and the deferred form share a base name too
+           "k_gat_bwd_one": ("k_gat_bwd_one", False), "k_gat_bwd_one(deferred form)": ("k_gat_bwd_one", True),
            "k_gat_cu": ("k_gat_cu", None), "k_gat_bwd_dst": ("k_gat_bwd_dst", None), "k_gat_bwd_src": ("k_gat_bwd_src", None)}
 
 
