@@ -2154,7 +2154,7 @@ bool bad_edge_term(const fn_edge_term* et, int64_t m = 1) {      // (the other t
 namespace {
 unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
 int64_t g_mol_stamps_n = 0;
-int g_tune[FN_TUNE_COUNT] = {768, 0, 0, 256, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 256, 2, -1, 0, 1, 0, 0, 1, 23, 1, 1024, 1, 0, 1, 1, 0, 0};   // in the order of the FN_TUNE_* keys
+int g_tune[FN_TUNE_COUNT] = {1024, 0, 0, 192, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 512, 2, -1, 0, 1, 0, 0, 1, 23, 1, 768, 1, 0, 1, 1, 0, 0};   // in the order of the FN_TUNE_* keys
 }  // namespace
 namespace fni {      // hooks for the other translation units (fn_internal.h)
 int fail(int code, const char* what) { return ::fail(code, what); }

@@ -47,8 +47,9 @@ int fn_abi_version(void);
 
 /* Process-wide tuning knobs (defaults are the measured best for MI355X; the bench uses them for A/B runs).
  * FN_TUNE_FWD_BLOCKS: workgroups of the attention kernels that are resident at once in a TRAINING pass (forward with the
- *   dropout epilogue, source pass of the backward): default 768 = 256 CUs x 3; a level with more row groups than that gives
- *   every half-wave several consecutive rows to software-pipeline (5 at ESOL batch 512).  FN_TUNE_FWD_BLOCKS_EVAL (1792 =
+ *   dropout epilogue, source pass of the backward): default 1024 = 256 CUs x 4 (768 until round 5's re-sweep of the launch
+ *   shapes, profiles/r05_launch_shape_sweep.txt); a level with more row groups than that gives
+ *   every half-wave several consecutive rows to software-pipeline (4 at ESOL batch 512).  FN_TUNE_FWD_BLOCKS_EVAL (1792 =
  *   256 x 7) is the same for the plain forward (inference, or training without dropout). */
 #define FN_TUNE_FWD_BLOCKS 0
 #define FN_TUNE_GEMM_SLOTS 1   /* > 0: cap on the workgroups of a projection GEMM launch (1024 = 256 CUs x 4 resident); a launch with
@@ -56,7 +57,7 @@ int fn_abi_version(void);
                                 * rows.  Default 0 = one tile per workgroup (faster at every measured size) */
 #define FN_TUNE_RETIRED_2 2     /* (retired in round 3, no effect: parameter-gradient work and the fragment-bond chain forked onto side streams --
                                 * a forked hipGraph replays SLOWER than the serial one on ROCm 7.2, 1.84 vs 1.69 ms per step) */
-#define FN_TUNE_WGRAD_BLOCKS 3 /* target workgroup count of the grouped weight-gradient launch of a backward pass (default 256: one per CU; 512 wrote twice the partials and measured 1 % slower per step) */
+#define FN_TUNE_WGRAD_BLOCKS 3 /* target workgroup count of the grouped weight-gradient launch of a backward pass (default 192 since round 5's re-sweep -- with layer 0's workgroups the launch then has 1.6 per CU; 256: + 1 % per step; 512 wrote twice the partials) */
 #define FN_TUNE_RETIRED_4 4     /* (retired in round 3, no effect: the molecule-resident fused FORWARD of round 2 -- measured equal at 512
                                 * molecules, slower elsewhere; source kept out of the build under tools/probe/retired/mol_fused.inc) */
 #define FN_TUNE_RETIRED_5 5     /* (retired: phase skew of that kernel) */
@@ -71,7 +72,7 @@ int fn_abi_version(void);
 #define FN_TUNE_DST_BLOCKS 11  /* target workgroup count of the backward destination pass (default 1536: three rows per half-wave at ESOL batch
                                 * 512; never more than three rows, see prep_gat_bwd_dst) */
 #define FN_TUNE_SRC_BLOCKS 12  /* resident workgroups of the backward source pass (default 512; <= 1024: every block writes a row of partial sums) */
-#define FN_TUNE_RD_BLOCKS 13   /* (default 256) workgroups of the edge-term backward that shares the source pass's launch (each writes a row of partial sums) */
+#define FN_TUNE_RD_BLOCKS 13   /* (default 512; 256 until round 5) workgroups of the edge-term backward that shares the source pass's launch (each writes a row of partial sums) */
 #define FN_TUNE_GEMM_COLAUNCH 14 /* inside fn_encoder_*: the 128 -> 128 projections (forward) and input-gradient products (backward) that do
                                  * not depend on an attention pass ride along as extra workgroups of that pass's launch (the atom projection
                                  * beside the bond + fragment-bond levels, the next layer's bond / fragment-bond projections beside the atom
@@ -96,8 +97,8 @@ int fn_abi_version(void);
 #define FN_TUNE_BWD_ONE 22            /* 1: fn_encoder_backward runs every attention level's backward (bond / atom / fragment-bond graph) as
                                        * ONE source-owner pass (csrc/gat_bwd_one.inc): the forward then also writes out2 / sigma and the
                                        * producers of the gradient rows write the node-local dots c, g_s_dst; 0: the two-pass backward */
-#define FN_TUNE_ONE_BLOCKS 23         /* target workgroups per LEVEL of a one-pass backward launch (default 1024; every block writes a row of
-                                       * partial sums, so at most FN_MAX_PART); fewer, longer-lived workgroups measured slower inside the step */
+#define FN_TUNE_ONE_BLOCKS 23         /* target workgroups per LEVEL of a one-pass backward launch (default 768 = five rows per half-wave at the bond level of ESOL batch 512; every block writes a row of
+                                       * partial sums, so at most FN_MAX_PART).  Round 5's re-sweep: 1024 + 1.0 %, 512-896 within noise, 384 and fewer slower */
 #define FN_TUNE_PAD_SKIP 24           /* 1 (default): with the one-pass backward on a molecule-contiguous static-shape batch the kernels skip the
                                        * padding rows (zero rows out, no gathers, no GEMM tiles, no weight-gradient rows); 0: they are processed */
 #define FN_TUNE_ONE_INTERLEAVE 25      /* 1: in the one-pass backward's three-level launch the bond level's workgroups alternate with the atom /
