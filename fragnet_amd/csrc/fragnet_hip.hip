@@ -2154,7 +2154,7 @@ bool bad_edge_term(const fn_edge_term* et, int64_t m = 1) {      // (the other t
 namespace {
 unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
 int64_t g_mol_stamps_n = 0;
-int g_tune[FN_TUNE_COUNT] = {1024, 0, 0, 192, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 512, 2, -1, 0, 1, 0, 0, 1, 23, 1, 768, 1, 0, 1, 1, 0, 0};   // in the order of the FN_TUNE_* keys
+int g_tune[FN_TUNE_COUNT] = {1024, 0, 0, 192, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 512, 2, -1, 0, 1, 0, 0, 1, 23, 1, 768, 1, 0, 1, 1, 0, 0, 6144, 1};   // in the order of the FN_TUNE_* keys
 }  // namespace
 namespace fni {      // hooks for the other translation units (fn_internal.h)
 int fail(int code, const char* what) { return ::fail(code, what); }
@@ -3959,6 +3959,10 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
                                         a.p_fbond, nullptr, &ep_fbond, H, &gfb, a.o2_fbond, a.sg_fbond));
         gb.p_edge_major = gfb.p_edge_major = one ? 1 : 0;
         gb.n_real = nr_bonds;  gfb.n_real = nr_conns;
+        if (const int tail_rows = g_tune[FN_TUNE_FWD_TAIL_ROWS]; tail_rows > 0 && gfb.rows_per_hw > tail_rows) {
+            gfb.rows_per_hw = tail_rows;             // (the second level's workgroups start last: short ones)
+            gfb.nblk = (int)((e->fbond.n + (int64_t)kRows * tail_rows - 1) / ((int64_t)kRows * tail_rows));
+        }
         if (fuse_rd) {
             gb.rd_A = w.a + d;  gb.rd_lda = wide;  gb.rd_J = H;  gb.rd_out = lay.s_sorted;  gb.rd_pos = e->atom.inv_d;  gb.rd_m = e->atom.m;
         }

@@ -55,7 +55,12 @@ int prep_gat_fwd(const float* h, const float* s_dst, const float* s_src, const f
     const int64_t groups = (plan->n + kRows - 1) / kRows;
     // with the dropout epilogue (training) fewer, longer-lived half-waves win (5 rows each at B = 512: 27.7 -> 22.4 us for the
     // bond + fragment-bond launch); the plain forward (inference) wants the chip full of them
-    const int64_t resident = (int64_t)tune(act && act->y && act->p > 0.f ? FN_TUNE_FWD_BLOCKS : FN_TUNE_FWD_BLOCKS_EVAL);
+    const bool training = act && act->y && act->p > 0.f;
+    int64_t resident = (int64_t)tune(training ? FN_TUNE_FWD_BLOCKS : FN_TUNE_FWD_BLOCKS_EVAL);
+    // ... but not arbitrarily long-lived: a large level (2048+ molecules per batch) made every half-wave of the plain forward walk
+    // 12-46 rows and the launch wait for its slowest workgroups -- it gets FN_TUNE_FWD_BLOCKS_EVAL_LARGE workgroups instead (round 5)
+    const int64_t large = (int64_t)tune(FN_TUNE_FWD_BLOCKS_EVAL_LARGE);
+    if (!training && large > resident && groups > 4 * resident) resident = large;
     A->rows_per_hw = (int)((groups + resident - 1) / resident);
     A->nblk = (int)((plan->n + (int64_t)kRows * A->rows_per_hw - 1) / ((int64_t)kRows * A->rows_per_hw));
     return 0;

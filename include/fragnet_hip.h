@@ -117,7 +117,13 @@ int fn_abi_version(void);
                                        * launch for layer 0.  0 (default): out2 / sigma in the forward, <g, out2> in the producers' epilogues.
                                        * Measured at ESOL batch 512 (round 5, same call): the forward launches 18 us shorter, the backward 32 us
                                        * longer (weight-gradient launch + 21, layer 0's launch + 12): 0.797 against 0.783 ms per step */
-#define FN_TUNE_COUNT 30
+#define FN_TUNE_FWD_BLOCKS_EVAL_LARGE 30 /* the plain forward (inference) of a level with more than 4 x FN_TUNE_FWD_BLOCKS_EVAL row groups (2048+ molecules
+                                       * per batch) runs this many workgroups instead (default 6144): with the fixed count every half-wave walked 12-46
+                                       * rows and the launch waited for its slowest workgroups.  0: one count for every size (rounds 1-4) */
+#define FN_TUNE_FWD_TAIL_ROWS 31       /* > 0: in the two-level forward launch (bond + fragment-bond graph) the SECOND level's half-waves take at most this
+                                       * many rows: its workgroups are dispatched last, so long-lived ones are the launch's tail (only large batches
+                                       * reach the cap: 2048 molecules per batch forward-only 1.13 -> 1.28 M molecules/s).  Default 1; 0: no cap */
+#define FN_TUNE_COUNT 32
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= 16 * 4 * workgroups 64-bit words) is set, every wave
  * of the one-pass attention backward (fn_gat_bwd_one_f32) writes s_memtime stamps of its phases into it (tools/probe/bwd_one_probe.py
