@@ -110,6 +110,52 @@ FNI_HIDDEN int launch_gat_fwd_pair(const GatFwdArgs& A, const GatFwdArgs& B, int
 // gat_fwd_lin.hip: an attention pass + the K = 128 projection tiles that do not depend on it, in one launch
 FNI_HIDDEN int launch_gat_fwd_lin(const GatFwdArgs& A, LinTasks& T, int heads, hipStream_t st);
 FNI_HIDDEN int launch_gat_fwd_pair_lin(const GatFwdArgs& A, const GatFwdArgs& B, LinTasks& T, int heads, hipStream_t st);
+// ---- the one-pass attention backward (gat_bwd_one.hip / gat_bwd_one.inc)
+struct GatBwdOneArgs {
+    const float *g_out, *h, *p_sorted, *cdot, *g_s_dst, *att;
+    int att_w, dst_off, src_off;
+    fn_edge_term et;
+    fn_gat_plan pl;
+    float slope;
+    float *g_h, *part_a, *part_e, *dz_sorted, *g_s_orig;
+    int rows_per_hw, nblk;
+    int p_edge_major;       // p_sorted is [m][H] (the engine's forward writes it so: one cache line per edge) instead of [H][m]
+    const float* x_src;     // mode 2, nullable: the raw attribute [K][m] in SOURCE order (streamed) instead of gathers from et.x_sorted
+    const int32_t* n_real;        // nullable device word: source rows >= *n_real are padding (zero gradient row out, nothing gathered)
+    int tier6;                    // gather tiers 4 / 6 / 8 / 12 (1) or 4 / 8 / 12 (0)
+    float* dz_em;                 // deferred form (DF instances, below): dL/dz of every edge at its destination-order slot, EDGE-major [m][H]
+    unsigned long long* stamps;   // dev aid (fn_debug_set_stamps): 16 s_memtime values per wave -- entry, loop start, per row (loads issued,
+                                  // data arrived, row done) x 4, loop end, exit; null in production (one uniform branch per stamp)
+};
+struct CuTask {
+    const float *g, *out, *out2, *sigma;
+    float scale;
+    float *c, *u;
+    int64_t n;
+    int first, nblk;
+};
+constexpr int kMaxCuTasks = 4;
+struct CuTasks { CuTask t[kMaxCuTasks]; int n; };
+struct GsdSegTask {
+    const float* dz;          // [m][4]
+    const int32_t* rowptr;    // by-destination CSR, n + 1 words; positions are rowptr[.] - pos_base
+    int pos_base;
+    int64_t n;
+    float* gsd;               // out [n][4]
+    const int32_t* n_real;    // nullable: rows at or behind *n_real are padding (their segments were never written): zeros
+    const float* h;           // [n][128] the level's projected rows
+    float* part_a;            // column-major [2 * 128][FN_MAX_PART]: columns 0..127, rows 0..nblk-1 are written
+    int first, nblk;
+};
+struct GsdSegTasks { GsdSegTask t[3]; int n; };
+FNI_HIDDEN int prep_gat_bwd_one(const float* g_out, const float* h, const float* p_sorted, const float* cdot, const float* g_s_dst,
+                                const fn_edge_term* et, const float* att, int att_w, int dst_off, int src_off, const fn_gat_plan* plan,
+                                float neg_slope, float* g_h, float* dz_sorted, float* g_s_orig, float* part_a, int* n_part_a, float* part_e,
+                                int* n_part_e, int heads, GatBwdOneArgs* A, int64_t share = 0);
+FNI_HIDDEN int launch_gat_bwd_one(const GatBwdOneArgs& A, int heads, hipStream_t st);
+FNI_HIDDEN int launch_gat_bwd_one3(const GatBwdOneArgs& A, const GatBwdOneArgs& B, const GatBwdOneArgs& C, int heads, hipStream_t st);
+FNI_HIDDEN int launch_gat_cu(CuTasks& T, int heads, hipStream_t st);
+FNI_HIDDEN int launch_gsd_seg(const GsdSegTasks& T, int blocks, hipStream_t st);
 // fragnet_hip.hip
 FNI_HIDDEN int launch_linear128_group(LinTasks& T, hipStream_t st);
 FNI_HIDDEN bool bad_edge_term(const fn_edge_term* et, int64_t m);
