@@ -49,3 +49,31 @@ def test_alternative_kernels_behind_tuning_keys_stay_parity_green(key, value):
     assert set(g0) == set(g1)
     for n in g0:
         torch.testing.assert_close(g1[n], g0[n], atol=1e-5, rtol=2e-3, msg=lambda m: f"{n}: {m}")
+
+
+def test_launch_geometry_keys_of_the_plain_forward_do_not_change_a_bit():
+    """FN_TUNE_FWD_BLOCKS_EVAL (10), FN_TUNE_FWD_BLOCKS_EVAL_LARGE (30) and FN_TUNE_FWD_TAIL_ROWS (31) only decide how many rows a
+    half-wave of the attention forward walks; a row's arithmetic does not depend on it.  Forced into play on a small batch (8 workgroups
+    per level -> many rows per half-wave; then the large-level count and the second level's cap), the inference outputs stay bit-identical."""
+    from fragnet_amd import _lib, data, model as M, synth
+    torch.manual_seed(1)
+    net = M.FragNetFineTune(n_classes=1, num_layer=3, drop_ratio=0.1, h1=32, h2=32, h3=32, h4=32, act="relu", fthead="FTHead3").to(DEV)
+    net.eval()
+    batch = data.batch_to(data.collate_fn(synth.synth_molecules(96, seed=23, profile="esol")), DEV)
+
+    def run():
+        batch.pop("_fragnet_plan", None)
+        with torch.no_grad():
+            out = net(batch)
+        torch.cuda.synchronize()
+        return out.detach().clone()
+
+    base = run()
+    try:
+        for settings in ({10: 8, 30: 0, 31: 0}, {10: 8, 30: 64, 31: 0}, {10: 8, 30: 0, 31: 1}, {10: 8, 30: 64, 31: 1}):
+            for k, v in settings.items():
+                _lib.call("fn_set_tuning", k, v)
+            assert torch.equal(run(), base), settings
+    finally:
+        for k, v in {10: 1792, 30: 6144, 31: 1}.items():
+            _lib.call("fn_set_tuning", k, v)
