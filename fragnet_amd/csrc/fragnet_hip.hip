@@ -2694,12 +2694,11 @@ int fn_small_linear_loss_f32(const float* x, const float* w, const float* b, con
     return launch_status("fn_small_linear_loss_f32");
 }
 
-namespace {
-bool dense_shape_ok(int64_t M, int64_t K, int64_t N) {
+// (static, not an anonymous namespace: inside this extern "C" block clang gives a namespace-scope function C linkage and exports it)
+static bool dense_shape_ok(int64_t M, int64_t K, int64_t N) {
     return M >= 0 && M <= FN_DENSE_MAX_ROWS && K >= 4 && N >= 4 && !(K & 3) && !(N & 3) && K <= 65536 && N <= 65536;
 }
-int dense_tiles(int64_t n, int t) { return (int)((n + t - 1) / t); }
-}  // namespace
+static int dense_tiles(int64_t n, int t) { return (int)((n + t - 1) / t); }
 
 int fn_dense_fwd_f32(const float* X, const float* W, const float* bias, float* Y, int64_t M, int64_t K, int64_t N,
                      const fn_act_epilogue* act, fn_stream_t stream) {

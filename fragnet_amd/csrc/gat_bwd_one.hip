@@ -120,7 +120,7 @@ int launch_gat_cu(CuTasks& T, int heads, hipStream_t st) {
 int launch_gsd_seg(const GsdSegTasks& T, int blocks, hipStream_t st) {
     if (blocks <= 0) return 0;
     hipLaunchKernelGGL(k_gsd_seg, dim3(blocks), dim3(kBlock), 0, st, T);
-    return 0;
+    return launch_status("k_gsd_seg");
 }
 }  // namespace fni
 
@@ -159,7 +159,8 @@ int fn_gat_gsd_f32(const float* dz_em, const fn_gat_plan* plan, const float* h, 
                    fn_stream_t stream) {
     if (!plan || !g_s_dst || !part_a || !h || n_part_a < 0 || n_part_a > FN_MAX_PART) return fail(FN_EINVAL, "fn_gat_gsd_f32: bad argument");
     if (plan->n == 0 || n_part_a == 0) return 0;
-    if (plan->m > 0 && (!dz_em || !plan->rowptr_d)) return fail(FN_EINVAL, "fn_gat_gsd_f32: null edge buffer");
+    // (k_gsd_seg reads rowptr[row], rowptr[row + 1] of every row, edges or not)
+    if (!plan->rowptr_d || (plan->m > 0 && !dz_em)) return fail(FN_EINVAL, "fn_gat_gsd_f32: null edge buffer");
     GsdSegTasks T{};
     T.n = 1;
     // (a level without edges: every extent is empty, nothing of dz is read -- any readable word will do)

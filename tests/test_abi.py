@@ -28,6 +28,19 @@ def test_library_exports_every_declared_symbol():
     assert lib.fn_abi_version() == _lib.ABI_VERSION == 11
 
 
+def test_library_exports_nothing_but_the_declared_entry_points():
+    """Every defined function symbol of the .so is a declared fn_* entry point (helpers must be static: a namespace-scope
+    function inside the extern "C" block is exported under its plain name)."""
+    import shutil
+    import subprocess
+    from fragnet_amd.build import OUT, build_lib
+    build_lib()
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", OUT], capture_output=True, text=True, check=True).stdout
+    funcs = sorted(line.split()[-1] for line in out.splitlines() if len(line.split()) == 3 and line.split()[1] == "T")
+    assert funcs == _declared(), f"exported but not declared: {sorted(set(funcs) - set(_declared()))}"
+
+
 def test_plan_layout_is_host_side_and_validates():
     import ctypes as C
     from fragnet_amd import _lib
