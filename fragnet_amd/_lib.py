@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfragnet_hip.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 FN_D = 128
 FN_MAX_TASKS = 16
 FN_MAX_EDGE_K = 8
@@ -127,6 +127,7 @@ SIGNATURES = {
     "fn_last_error": [],
     "fn_set_tuning": [C.c_int, C.c_int],
     "fn_debug_set_stamps": [vp, i64],
+    "fn_debug_set_profile_events": [vp],
     "fn_plan_layout": [C.POINTER(CsrTask), C.c_int, C.POINTER(i64), C.POINTER(i64)],
     "fn_plan_build": [C.POINTER(CsrTask), C.c_int, vp, vp, vp, vp, vp, vp, i32, vp],
     "fn_plan_build_mol": [C.POINTER(CsrTask), C.c_int, C.POINTER(MolLayout), vp, vp, vp, vp, vp, vp, i32, vp],

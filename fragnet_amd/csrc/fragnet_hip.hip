@@ -10,6 +10,7 @@
 //     per-block partial-sum rows any backward kernel writes is bounded by FN_MAX_PART.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <mutex>
 #include <functional>
 #include <math.h>
 #include <stdint.h>
@@ -2162,6 +2163,17 @@ bool bad_edge_term(const fn_edge_term* et, int64_t m = 1) {      // (the other t
 namespace {
 unsigned long long* g_mol_stamps = nullptr;     // fn_debug_set_stamps
 int64_t g_mol_stamps_n = 0;
+hipEvent_t g_prof_ev[4] = {nullptr, nullptr, nullptr, nullptr};      // fn_debug_set_profile_events: forward begin / end, backward begin / end
+// records profiling event `i` (if set) on the stream: as an EXTERNAL event node while the stream is being captured, so that the
+// time between two of them can be read after a replay of the graph
+int prof_event(int i, hipStream_t st) {
+    if (!g_prof_ev[i]) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError();  cs = hipStreamCaptureStatusNone; }
+    const hipError_t rc = hipEventRecordWithFlags(g_prof_ev[i], st, cs == hipStreamCaptureStatusActive ? hipEventRecordExternal : 0);
+    if (rc != hipSuccess) { (void)hipGetLastError();  return fail(FN_EUNSUPPORTED, "fn_debug_set_profile_events: hipEventRecordWithFlags failed"); }
+    return 0;
+}
 int g_tune[FN_TUNE_COUNT] = {1024, 0, 0, 192, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 512, 2, -1, 0, 1, 0, 0, 1, 23, 1, 768, 1, 0, 1, 1, 0, 0, 6144, 1};   // in the order of the FN_TUNE_* keys
 }  // namespace
 namespace fni {      // hooks for the other translation units (fn_internal.h)
@@ -2310,6 +2322,11 @@ int fn_abi_version(void) { return FN_ABI_VERSION; }
 int fn_debug_set_stamps(void* buf, int64_t n_u64) {
     g_mol_stamps = static_cast<unsigned long long*>(buf);
     g_mol_stamps_n = buf ? n_u64 : 0;
+    return 0;
+}
+
+int fn_debug_set_profile_events(void* const* events) {
+    for (int i = 0; i < 4; ++i) g_prof_ev[i] = events ? static_cast<hipEvent_t>(events[i]) : nullptr;
     return 0;
 }
 
@@ -2920,6 +2937,29 @@ bool one_pass_on(const fn_encoder* e) {
 bool defer_on(const fn_encoder* e) {
     return g_tune[FN_TUNE_DEFER_GSD] != 0 && one_pass_on(e) && e->heads == 4 && e->variant == 0 && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0 &&
            g_tune[FN_TUNE_WGRAD_DIRECT] == 1;
+}
+
+// The form a forward pass ran in (bit 0: one-pass backward = out2 / sigma or dz tables exist; bit 1: its deferred form = no out2 /
+// sigma, rmat written), latched per activation workspace: fn_encoder_backward refuses a descriptor whose form -- read from the
+// process-wide tuning table -- is no longer the one its forward wrote the workspace in (FN_TUNE_BWD_ONE / FN_TUNE_DEFER_GSD flipped
+// in between would leave out2 / sigma / rmat null or unwritten for the other half).
+int enc_form(const fn_encoder* e) { return (one_pass_on(e) ? 1 : 0) | (defer_on(e) ? 2 : 0); }
+struct FormLatch { const float* ws; int form; };
+FormLatch g_form_latch[64];
+int g_form_latch_next = 0;
+std::mutex g_form_latch_mu;
+void latch_form(const fn_encoder* e) {
+    std::lock_guard<std::mutex> lk(g_form_latch_mu);
+    for (FormLatch& f : g_form_latch)
+        if (f.ws == e->ws) { f.form = enc_form(e);  return; }
+    g_form_latch[g_form_latch_next] = FormLatch{e->ws, enc_form(e)};
+    g_form_latch_next = (g_form_latch_next + 1) % 64;
+}
+bool form_matches_forward(const fn_encoder* e) {      // (a workspace this process ran no forward into: nothing to compare with)
+    std::lock_guard<std::mutex> lk(g_form_latch_mu);
+    for (const FormLatch& f : g_form_latch)
+        if (f.ws == e->ws && f.ws) return f.form == enc_form(e);
+    return true;
 }
 
 EncLayout enc_layout(const fn_encoder* e, float* ws) {
@@ -3625,7 +3665,9 @@ int encoder_backward_one(const fn_encoder* e, const EncLayout& lay, const BwdLay
         const int64_t rows_l1 = (pend_b ? e->bond.m + e->E : 0) + (pend_fb ? e->fbond.m + e->EF : 0);
         if (pend_b) FN_TRY(one_level(bw.g_pre_bond, lay.L[0].h_b, lay.L[0].p_bond, et_bond(w0), w0.a_b, 3 * d, 2 * d, e->bond, bw.bond[0], nullptr, &na_b, &ne_b, &oB, rows_l1));
         if (pend_fb) FN_TRY(one_level(bw.g_pre_fbond, lay.L[0].h_fb, lay.L[0].p_fbond, et_fbond(w0), w0.f_a_b, 3 * d, 2 * d, e->fbond, bw.fbond[0], nullptr, &na_fb, &ne_fb, &oFB, rows_l1));
+        FN_TRY(prof_event(2, hs));
         FN_TRY(launch_gat_bwd_one3(oB, GatBwdOneArgs{}, oFB, H, hs));
+        FN_TRY(prof_event(3, hs));
         const DeferTerm gsb = gs_of(pend_b ? e->bond : fn_gat_plan{}, bw.bond[0], w0.a_b, 3 * d, 0);
         const DeferTerm gsf = gs_of(pend_fb ? e->fbond : fn_gat_plan{}, bw.fbond[0], w0.f_a_b, 3 * d, 2);
         if (gsb.dz && na_b > 0) seg0.t[seg0.n++] = GsdSegTask{gsb.dz, e->bond.rowptr_d, e->bond.pos_base_d, e->E, bw.bond[0].g_s_dst, nr_bonds, lay.L[0].h_b, bw.bond[0].part_a, 0, na_b};
@@ -3676,6 +3718,7 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
     if (e->pooled && !tail_mol_on(e)) return fail(FN_EINVAL, "fn_encoder_forward: the readout is only produced by the fused fragment tail (fn_encoder_fused_tail)");
     const EncLayout lay = enc_layout(e, e->ws);
     if (lay.total > e->ws_floats) return fail(FN_EINVAL, "fn_encoder_forward: workspace too small");
+    latch_form(e);
     const RngPlan rng = rng_plan(e);
     const int H = e->heads, d = FN_D / H;
     const float p = e->training ? e->drop_p : 0.f;
@@ -3831,18 +3874,22 @@ int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, 
                                         a.p_fbond, nullptr, &ep_fbond, H, &gfb, a.o2_fbond, a.sg_fbond));
         gb.p_edge_major = gfb.p_edge_major = one ? 1 : 0;
         gb.n_real = nr_bonds;  gfb.n_real = nr_conns;
-        if (const int tail_rows = g_tune[FN_TUNE_FWD_TAIL_ROWS]; tail_rows > 0 && gfb.rows_per_hw > tail_rows) {
+        // (evaluation passes only, like FN_TUNE_FWD_BLOCKS_EVAL_LARGE: a training pass gets fewer, longer-lived half-waves from prep_gat_fwd
+        // on purpose, and the cap was only ever measured forward-only)
+        if (const int tail_rows = g_tune[FN_TUNE_FWD_TAIL_ROWS]; !(ep_fbond.y && ep_fbond.p > 0.f) && tail_rows > 0 && gfb.rows_per_hw > tail_rows) {
             gfb.rows_per_hw = tail_rows;             // (the second level's workgroups start last: short ones)
             gfb.nblk = (int)((e->fbond.n + (int64_t)kRows * tail_rows - 1) / ((int64_t)kRows * tail_rows));
         }
         if (fuse_rd) {
             gb.rd_A = w.a + d;  gb.rd_lda = wide;  gb.rd_J = H;  gb.rd_out = lay.s_sorted;  gb.rd_pos = e->atom.inv_d;  gb.rd_m = e->atom.m;
         }
+        if (l == 0) FN_TRY(prof_event(0, S(st)));
         if (with_pair.n) {
             FN_TRY(launch_gat_fwd_pair_lin(gb, gfb, with_pair, H, S(st)));
         } else {
             FN_TRY(launch_gat_fwd_pair(gb, gfb, H, S(st)));
         }
+        if (l == 0) FN_TRY(prof_event(1, S(st)));
 
         // L2 atom graph (+ self loops), edge term = <new_bond, a[:, d:d+128]>
         if (!grouped && !atoms_projected) FN_TRY(project(in_atoms, ka, bt_a, w.proj_a_b, a.h_a, e->N, w.a, wide, d + FN_D, lay.s_dst_a, lay.s_src_a, st));
@@ -3930,6 +3977,8 @@ int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float
                                       (((uintptr_t)a->p | (uintptr_t)a->g | (uintptr_t)a->m | (uintptr_t)a->v) & 15))))
             return fail(FN_EINVAL, "fn_encoder_backward: bad adam_rider (null or misaligned buffer, or no device step count / learning rate)");
     }
+    if (!form_matches_forward(e))
+        return fail(FN_EINVAL, "fn_encoder_backward: FN_TUNE_BWD_ONE / FN_TUNE_DEFER_GSD changed since the forward pass that wrote this workspace");
     const EncLayout lay = enc_layout(e, e->ws);
     const BwdLayout bw = bwd_layout(e, scratch);
     if (bw.total > scratch_floats) return fail(FN_EINVAL, "fn_encoder_backward: scratch too small");

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FN_ABI_VERSION 11
+#define FN_ABI_VERSION 12
 #define FN_D 128              /* feature width of every node table on the path (emb_dim) */
 #define FN_MAX_TASKS 16       /* CSR builds fused into one fn_plan_build call */
 #define FN_MAX_EDGE_K 8       /* widest raw edge attribute folded in-kernel (6 for fragment bonds) */
@@ -122,13 +122,21 @@ int fn_abi_version(void);
                                        * rows and the launch waited for its slowest workgroups.  0: one count for every size (rounds 1-4) */
 #define FN_TUNE_FWD_TAIL_ROWS 31       /* > 0: in the two-level forward launch (bond + fragment-bond graph) the SECOND level's half-waves take at most this
                                        * many rows: its workgroups are dispatched last, so long-lived ones are the launch's tail (only large batches
-                                       * reach the cap: 2048 molecules per batch forward-only 1.13 -> 1.28 M molecules/s).  Default 1; 0: no cap */
+                                       * reach the cap: 2048 molecules per batch forward-only 1.13 -> 1.28 M molecules/s).  Evaluation passes only (no dropout
+                                       * epilogue), as FN_TUNE_FWD_BLOCKS_EVAL_LARGE.  Default 1; 0: no cap */
 #define FN_TUNE_COUNT 32
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= 16 * 4 * workgroups 64-bit words) is set, every wave
  * of the one-pass attention backward (fn_gat_bwd_one_f32) writes s_memtime stamps of its phases into it (tools/probe/bwd_one_probe.py
  * --stamps).  NULL switches it off (the default: the kernel then pays one uniform branch per phase). */
 int fn_debug_set_stamps(void* buf, int64_t n_u64);
+/* Profiling aid (process-wide; ABI 12): four hipEvent_t (created with timing enabled) or NULL entries -- events[0] / [1] are recorded
+ * right before / behind the bond-graph level's forward launch of layer 0 in fn_encoder_forward (k_gat_fwd_pair: bond + fragment-bond
+ * levels), events[2] / [3] around the same level's one-pass backward launch in fn_encoder_backward (k_gat_bwd_one3 of layer 0).
+ * On a capturing stream they become EXTERNAL event-record nodes (hipEventRecordExternal), so hipEventElapsedTime between a pair
+ * after a replay is that launch's duration INSIDE the captured step -- what bench.py's `roofline` quotes.  NULL (the default, also
+ * `events` == NULL) records nothing.  The events stay the caller's. */
+int fn_debug_set_profile_events(void* const* events);
 const char* fn_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -317,7 +325,7 @@ int fn_gat_bwd_one_f32(const float* g_out, const float* h, const float* p_sorted
                        float neg_slope, float* g_h, float* dz_sorted, float* g_s_orig, float* part_a, int* n_part_a,
                        float* part_e, int* n_part_e, int p_edge_major /*layout of p_sorted, as fn_gat_fwd_f32 wrote it*/,
                        float* dz_em /*nullable; non-null (four heads): the DEFERRED form, see below*/, int heads, fn_stream_t stream);
-/* The deferred form (ABI 11; what fn_encoder_backward runs for four heads, FN_TUNE_DEFER_GSD): g_s_dst is not read and the forward
+/* The deferred form (ABI 11; what fn_encoder_backward runs for four heads when FN_TUNE_DEFER_GSD is set -- it is OFF by default): g_s_dst is not read and the forward
  * needs no out2 / sigma.  The pass writes dz of every edge at its destination-order slot, dz_em [m,4] edge-major, and leaves the two
  * terms that need g_s_dst[t,h] = the sum of row t's contiguous dz_em segment OUT of its results: g_h lacks g_s_dst[s] a_dst, and the
  * a_dst columns of part_a are zero.  fn_gat_gsd_f32 forms g_s_dst [n,4] from dz_em and overwrites those columns of part_a (rows

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in fragnet_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
-    assert lib.fn_abi_version() == _lib.ABI_VERSION == 11
+    assert lib.fn_abi_version() == _lib.ABI_VERSION == 12
 
 
 def test_library_exports_nothing_but_the_declared_entry_points():
