@@ -426,14 +426,17 @@ def forward_sweep_store(rank, world, dev, args):
             torch.cuda.synchronize()
             coll = time.perf_counter() - t0
             store._collate_events = None
-            coll_dev = sum(a.elapsed_time(b) for a, b in evs) * 1e-3
+            # (no events: the collate did not take the fused one-launch path -- unsupported layout or FUSED_COLLATE off -- and nothing timed
+            # its launches; the loop's wall time stands in and the collate gets no roofline line of its own)
+            coll_timed = len(evs) > 0
+            coll_dev = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 if coll_timed else coll
         if world > 1:
             torch.distributed.barrier()
-        el = torch.tensor([total, coll, coll_dev], dtype=torch.float64, device=dev)
+        el = torch.tensor([total, coll, coll_dev, 0.0 if coll_timed else 1.0], dtype=torch.float64, device=dev)
         if world > 1:
             torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
         if rank == 0:
-            total, coll, coll_dev = float(el[0]), float(el[1]), float(el[2])
+            total, coll, coll_dev, coll_timed_all = float(el[0]), float(el[1]), float(el[2]), float(el[3]) == 0.0
             print(json.dumps({"metric": "molecules/sec forward only (eval) from a resident store: collate + plan + forward",
                               "value": round(B * world * steps / total, 1), "unit": "molecules/s", "n_gpus": world,
                               "per_gpu_batch": B, "steps": steps, "ms_per_step": round(total / steps * 1e3, 3),
@@ -445,7 +448,8 @@ def forward_sweep_store(rank, world, dev, args):
                               "store_build_s": round(build_s, 1), "dtype": "f32", "data": "synthetic (synth40 profile)", "scaling": "weak",
                               "roofline": sweep_roofline(alg_fwd + alg_coll, total / steps,
                                                          "collate (the batch's bytes once in, once out) + the whole forward step (forward_bytes); per GPU"),
-                              "roofline_collate": sweep_roofline(alg_coll, coll_dev / steps, "fn_collate_store alone (GPU time): the batch's bytes once in, once out")}),
+                              "roofline_collate": (sweep_roofline(alg_coll, coll_dev / steps, "fn_collate_store alone (GPU time): the batch's bytes once in, once out")
+                                                   if coll_timed_all else None)}),
                   flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -571,6 +575,52 @@ def parse_args(argv=None):
     ap.add_argument("--tune", action="append", default=None, help="A/B: KEY=VALUE for fn_set_tuning (include/fragnet_hip.h FN_TUNE_*)")
     ap.add_argument("--scatter-blocks", type=int, default=None, help="A/B: resident workgroups of the scatter kernels (FN_TUNE_FWD_BLOCKS)")
     return ap.parse_args(argv)
+
+
+def in_step_launch_times(args, rank, world, dev, scaling, overlap, shape_batches, replays=40):
+    """Durations of layer 0's bond-graph launches INSIDE the captured step, measured in this run: a second capture of the same
+    step with four external HIP event-record nodes around them (fn_debug_set_profile_events; the library records them with
+    hipEventRecordWithFlags(..., hipEventRecordExternal) on the capturing stream), `replays` replays, hipEventElapsedTime after
+    each.  The timed headline loop runs WITHOUT these nodes.  Returns {"fwd_us", "bwd_us", "n", ...} or None (with a reason)."""
+    import ctypes as C
+    from fragnet_amd import _lib
+    try:
+        evs = [torch.cuda.Event(enable_timing=True, external=True) for _ in range(4)]
+    except TypeError:
+        return None, "torch.cuda.Event has no external= flag"
+    for e in evs:
+        e.record()                                        # creates the handles
+    torch.cuda.synchronize()
+    arr = (C.c_void_p * 4)(*[int(e.cuda_event) for e in evs])
+    run = None
+    try:
+        _lib.call("fn_debug_set_profile_events", arr)
+        run = StepRun(args, rank, world, dev, scaling, overlap, shape_batches=shape_batches)
+    finally:
+        _lib.call("fn_debug_set_profile_events", None)    # (the captured graph keeps its event nodes; nothing else records them)
+    if run.gstep is None:
+        run.release()
+        return None, "no captured step"
+    fwd, bwd = [], []
+    try:
+        for i in range(5 + replays):
+            run.step(i)
+            torch.cuda.synchronize()
+            if i >= 5:
+                fwd.append(evs[0].elapsed_time(evs[1]) * 1e3)
+                bwd.append(evs[2].elapsed_time(evs[3]) * 1e3)
+    except Exception as exc:      # noqa: BLE001 -- e.g. the runtime refuses elapsed time between graph event nodes
+        run.release()
+        return None, f"{type(exc).__name__}: {exc}"
+    run.release()
+    med = statistics.median
+    if not fwd or min(fwd) <= 0 or min(bwd) <= 0:
+        return None, "event-node timestamps not usable (non-positive elapsed time)"
+    return {"fwd_us": round(med(fwd), 2), "bwd_us": round(med(bwd), 2), "fwd_min_us": round(min(fwd), 2), "bwd_min_us": round(min(bwd), 2),
+            "n": len(fwd),
+            "method": "median over %d replays of a second capture of the same step with external HIP event-record nodes right before / behind "
+                      "k_gat_fwd_pair (layer 0: bond + fragment-bond levels) and layer 0's k_gat_bwd_one3; hipEventElapsedTime after every replay "
+                      "(the interval holds the launch and the event nodes' own hand-over, so it is an UPPER bound on the kernel's duration)" % len(fwd)}, None
 
 
 class StepRun:
@@ -941,9 +991,12 @@ def main():
             traffic, traffic_source, traffic_by_kernel = None, None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_per_launch.json")
             if os.path.exists(pmc):
+                from fragnet_amd import build
                 pj = json.load(open(pmc))
                 parts = (bwd_k,) if one_pass else ("k_gat_bwd_dst", "k_gat_bwd_src")
-                if all(k in pj for k in parts):
+                if pj.get("source_digest") not in (None, build.source_digest()):
+                    traffic_source = "profiles/pmc_per_launch.json -- STALE: collected with other kernel sources than this library, figures dropped"
+                elif all(k in pj for k in parts):
                     traffic = sum(pj[k]["hbm_bytes_per_launch"] for k in parts)
                     traffic_by_kernel = {k: v["hbm_bytes_per_launch"] for k, v in pj.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
                     traffic_source = ("profiles/pmc_per_launch.json (" + pj.get("_collected", "?") + "): separate rocprofv3 --pmc FETCH_SIZE / "
@@ -952,35 +1005,63 @@ def main():
             # what the headline launches MOVE inside the step (whole-step PMC table, profiles/r04_pmc_step.json) next to what a streaming
             # kernel of that size gets with cold caches on this part (profiles/r04_hbm_cold_stream.md): context for `frac`, not a metric
             moved = None
-            ps = os.path.join(ROOT, "profiles", "r05_pmc_step.json")
-            if one_pass and inside.get("fwd+bwd") and os.path.exists(ps):
-                seq = json.load(open(ps)).get("sequence", [])
+            # (the newest committed table; dropped -- like the trace's durations -- when it was collected with other kernel sources)
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_step.json")))
+            ps = cands[-1] if cands else ""
+            psj = json.load(open(ps)) if ps else {}
+            if ps and psj.get("source_digest") is not None:
+                from fragnet_amd import build
+                if psj["source_digest"] != build.source_digest():
+                    psj = {}
+            base = (live or inside).get("fwd+bwd")
+            if one_pass and base and psj:
+                seq = psj.get("sequence", [])
                 fw = [e for e in seq if e["kernel"] == "k_gat_fwd_pair"]
                 bw_ = sorted((e for e in seq if e["kernel"] == "k_gat_bwd_one3"), key=lambda e: e["workgroups"])
                 if fw and bw_:
                     mb = fw[0]["hbm_MB"] + bw_[0]["hbm_MB"]
-                    moved = {"hbm_bytes_per_launch_pair": int(mb * 1e6), "GBps": round(mb * 1e3 / inside["fwd+bwd"]["us"], 1),
-                             "over_algorithmic": round(mb * 1e6 / inside["fwd+bwd"]["bytes"], 2),
-                             "source": "profiles/r05_pmc_step.json (FETCH_SIZE x 2 + WRITE_SIZE of k_gat_fwd_pair and layer 0's backward launch in one "
-                                       "replayed step, another run) over the in-graph durations above",
-                             "cold_stream_reference": "profiles/r04_hbm_cold_stream.md: a streaming kernel of 32-64 MB per direction moves 3.7-4.1 TB/s "
+                    moved = {"hbm_bytes_per_launch_pair": int(mb * 1e6), "GBps": round(mb * 1e3 / base["us"], 1),
+                             "over_algorithmic": round(mb * 1e6 / base["bytes"], 2),
+                             "source": "profiles/" + os.path.basename(ps) + " (FETCH_SIZE x 2 + WRITE_SIZE of k_gat_fwd_pair and layer 0's backward launch in "
+                                       "one replayed step, another run; same kernel sources by digest where the table carries one) over the in-step durations above",
+                             "cold_stream_reference": "profiles/r05_hbm_cold_stream.md: a streaming kernel of 32-64 MB per direction moves 3.7-4.1 TB/s "
                                                       "when its operands are not cache-resident, 6.5-6.9 TB/s when they are"}
-            # headline = what the step obeys: the bond-graph level's forward + backward bytes over its in-step durations when the
-            # committed trace describes this library, else the stand-alone launches (and the line says which)
-            use = inside.get("fwd+bwd")
+            # ---- the same two launches timed IN THIS RUN (external event-record nodes in a second capture of the step)
+            measured, measured_why = None, "not attempted (needs the single-rank captured one-pass step)"
+            if one_pass and world == 1 and run.gstep is not None and args.shard_of <= 1 and head["local_batch"] == PER_GPU_BATCH:
+                measured, measured_why = in_step_launch_times(args, rank, world, dev, head_scaling, head_overlap, shape_batches)
+            live = {}
+            if measured:
+                fb_n, fb_m = int(head["pool0"]["node_features_fbonds"].shape[0]), int(head["pool0"]["edge_index_fbonds"].shape[1])
+                f2, b2 = level_bytes(fb_n, fb_m)
+                t_f, t_b = measured["fwd_us"], measured["bwd_us"]
+                live["k_gat_fwd_pair"] = {"us": t_f, "bytes": f1 + f2, "frac": round((f1 + f2) / t_f / 1e3 / HBM_PEAK_GBPS, 4)}
+                live["k_gat_bwd_one3 (layer 0: bond + fragment-bond levels)"] = {"us": t_b, "bytes": b1 + b2, "frac": round((b1 + b2) / t_b / 1e3 / HBM_PEAK_GBPS, 4)}
+                live["fwd+bwd"] = {"us": round(t_f + t_b, 2), "bytes": f1 + f2 + b1 + b2, "GBps": round((f1 + f2 + b1 + b2) / (t_f + t_b) / 1e3, 1),
+                                   "frac": round((f1 + f2 + b1 + b2) / (t_f + t_b) / 1e3 / HBM_PEAK_GBPS, 4)}
+            # headline = what the step obeys: the bond-graph level's forward + backward bytes over its in-step durations -- measured in
+            # this run when the event nodes gave usable times, else read from the committed trace when it describes this library, else the
+            # stand-alone launches (and the line says which)
+            use = live.get("fwd+bwd") or inside.get("fwd+bwd")
             headline = use if use else standalone["fwd+bwd"]
             line["roofline"] = {"bound": "hbm",
                                 "kernel": (fwd_k + " + " + bwd_k + "<4> @ bond-graph level, ") + ("inside the replayed step (layer 0's launches: + fragment-bond level)"
                                                                                                   if use else "stand-alone launches"),
                                 "achieved": headline["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": headline["frac"],
-                                "basis": ("in_graph: durations read from the committed rocprofv3 trace " + str(ig_source) + ", not measured in this run "
-                                          "(the source digest of the traced library equals this one's); `standalone` below IS measured in this run") if use
-                                         else "standalone: measured in this run (no committed trace of this library's sources)",
+                                "basis": ("measured in this run: in-step durations of layer 0's two launches from external HIP event-record nodes "
+                                          "(`in_graph_measured`); the committed rocprofv3 trace of the same command is the cross-check (`in_graph`)") if live
+                                         else (("in_graph: durations read from the committed rocprofv3 trace " + str(ig_source) + ", not measured in this "
+                                                "run (event nodes: " + str(measured_why) + "); `standalone` below IS measured in this run") if use
+                                               else "standalone: measured in this run (no committed trace of this library's sources; event nodes: "
+                                                    + str(measured_why) + ")"),
                                 # the same quantity on the bases earlier rounds quoted (round 3's headline was the stand-alone backward: 0.235)
                                 "frac_backward_standalone": standalone[bwd_k]["frac"],
                                 "frac_forward_standalone": standalone[fwd_k]["frac"],
-                                "frac_backward_in_graph": next((v["frac"] for k, v in inside.items() if k.startswith("k_gat_bwd")), None),
-                                "frac_forward_in_graph": inside.get("k_gat_fwd_pair", {}).get("frac"),
+                                "frac_backward_in_graph": next((v["frac"] for k, v in (live or inside).items() if k.startswith("k_gat_bwd")), None),
+                                "frac_forward_in_graph": (live or inside).get("k_gat_fwd_pair", {}).get("frac"),
+                                "in_graph_measured": ({**live, **{k: measured[k] for k in ("fwd_min_us", "bwd_min_us", "n", "method")}} if live
+                                                      else {"unavailable": measured_why}),
                                 "traffic": traffic, "traffic_source": traffic_source, "traffic_by_kernel": traffic_by_kernel,
                                 "moved_in_graph": moved,
                                 "us_per_launch": headline["us"],

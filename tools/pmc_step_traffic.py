@@ -78,6 +78,11 @@ def main():
            "traffic_over_algorithmic": round((tot_f + tot_w) / 1e9 / algo_gb, 3) if algo_gb else None, "sequence": seq}
     if len(sys.argv) > 4:
         out = join_sequence(out, sys.argv[4])
+    # the kernel sources these counters belong to (bench.py marks the table STALE when its library was built from others)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from fragnet_amd import build
+    out["source_digest"] = build.source_digest()
     print(json.dumps(out, indent=1))
 
 

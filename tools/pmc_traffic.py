@@ -57,7 +57,12 @@ def main():
             f, w = fetch[k] * 1024 * 2, write[k] * 1024
             out[k] = {"hbm_bytes_per_launch": int(f + w), "fetch_bytes_corrected_x2": int(f), "write_bytes": int(w),
                       "raw_FETCH_SIZE_KiB": round(fetch[k], 1), "raw_WRITE_SIZE_KiB": round(write[k], 1)}
-    out["_collected"] = "round 4, tools/final_artifacts.sh"
+    import datetime
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from fragnet_amd import build
+    out["_collected"] = "tools/final_artifacts.sh, " + datetime.date.today().isoformat()
+    out["source_digest"] = build.source_digest()          # the kernel sources these counters belong to
     out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --kernels-only` (bond-graph level, "
                     "B=512 ESOL shape), averaged over the launches of each kernel; FETCH_SIZE doubled per MI355X_MICROARCH.md "
                     "section HBM; tools/pmc_traffic.py")
