@@ -1002,6 +1002,19 @@ def main():
                     traffic_source = ("profiles/pmc_per_launch.json (" + pj.get("_collected", "?") + "): separate rocprofv3 --pmc FETCH_SIZE / "
                                       "WRITE_SIZE passes over `bench.py --kernels-only`, NOT this run; `traffic` = the backward of the level (" +
                                       " + ".join(parts) + "), to be held against algorithmic_bytes_per_launch of the backward")
+            # ---- the same two launches timed IN THIS RUN (external event-record nodes in a second capture of the step)
+            measured, measured_why = None, "not attempted (needs the single-rank captured one-pass step)"
+            if one_pass and world == 1 and run.gstep is not None and args.shard_of <= 1 and head["local_batch"] == PER_GPU_BATCH:
+                measured, measured_why = in_step_launch_times(args, rank, world, dev, head_scaling, head_overlap, shape_batches)
+            live = {}
+            if measured:
+                fb_n, fb_m = int(head["pool0"]["node_features_fbonds"].shape[0]), int(head["pool0"]["edge_index_fbonds"].shape[1])
+                f2, b2 = level_bytes(fb_n, fb_m)
+                t_f, t_b = measured["fwd_us"], measured["bwd_us"]
+                live["k_gat_fwd_pair"] = {"us": t_f, "bytes": f1 + f2, "frac": round((f1 + f2) / t_f / 1e3 / HBM_PEAK_GBPS, 4)}
+                live["k_gat_bwd_one3 (layer 0: bond + fragment-bond levels)"] = {"us": t_b, "bytes": b1 + b2, "frac": round((b1 + b2) / t_b / 1e3 / HBM_PEAK_GBPS, 4)}
+                live["fwd+bwd"] = {"us": round(t_f + t_b, 2), "bytes": f1 + f2 + b1 + b2, "GBps": round((f1 + f2 + b1 + b2) / (t_f + t_b) / 1e3, 1),
+                                   "frac": round((f1 + f2 + b1 + b2) / (t_f + t_b) / 1e3 / HBM_PEAK_GBPS, 4)}
             # what the headline launches MOVE inside the step (whole-step PMC table, profiles/r04_pmc_step.json) next to what a streaming
             # kernel of that size gets with cold caches on this part (profiles/r04_hbm_cold_stream.md): context for `frac`, not a metric
             moved = None
@@ -1027,19 +1040,6 @@ def main():
                                        "one replayed step, another run; same kernel sources by digest where the table carries one) over the in-step durations above",
                              "cold_stream_reference": "profiles/r05_hbm_cold_stream.md: a streaming kernel of 32-64 MB per direction moves 3.7-4.1 TB/s "
                                                       "when its operands are not cache-resident, 6.5-6.9 TB/s when they are"}
-            # ---- the same two launches timed IN THIS RUN (external event-record nodes in a second capture of the step)
-            measured, measured_why = None, "not attempted (needs the single-rank captured one-pass step)"
-            if one_pass and world == 1 and run.gstep is not None and args.shard_of <= 1 and head["local_batch"] == PER_GPU_BATCH:
-                measured, measured_why = in_step_launch_times(args, rank, world, dev, head_scaling, head_overlap, shape_batches)
-            live = {}
-            if measured:
-                fb_n, fb_m = int(head["pool0"]["node_features_fbonds"].shape[0]), int(head["pool0"]["edge_index_fbonds"].shape[1])
-                f2, b2 = level_bytes(fb_n, fb_m)
-                t_f, t_b = measured["fwd_us"], measured["bwd_us"]
-                live["k_gat_fwd_pair"] = {"us": t_f, "bytes": f1 + f2, "frac": round((f1 + f2) / t_f / 1e3 / HBM_PEAK_GBPS, 4)}
-                live["k_gat_bwd_one3 (layer 0: bond + fragment-bond levels)"] = {"us": t_b, "bytes": b1 + b2, "frac": round((b1 + b2) / t_b / 1e3 / HBM_PEAK_GBPS, 4)}
-                live["fwd+bwd"] = {"us": round(t_f + t_b, 2), "bytes": f1 + f2 + b1 + b2, "GBps": round((f1 + f2 + b1 + b2) / (t_f + t_b) / 1e3, 1),
-                                   "frac": round((f1 + f2 + b1 + b2) / (t_f + t_b) / 1e3 / HBM_PEAK_GBPS, 4)}
             # headline = what the step obeys: the bond-graph level's forward + backward bytes over its in-step durations -- measured in
             # this run when the event nodes gave usable times, else read from the committed trace when it describes this library, else the
             # stand-alone launches (and the line says which)
