@@ -584,10 +584,9 @@ def in_step_launch_times(args, rank, world, dev, scaling, overlap, shape_batches
     each.  The timed headline loop runs WITHOUT these nodes.  Returns {"fwd_us", "bwd_us", "n", ...} or None (with a reason)."""
     import ctypes as C
     from fragnet_amd import _lib
-    try:
-        evs = [torch.cuda.Event(enable_timing=True, external=True) for _ in range(4)]
-    except TypeError:
-        return None, "torch.cuda.Event has no external= flag"
+    # plain timing events: torch only creates the handles and reads the elapsed time -- the LIBRARY records them, as external
+    # event-record nodes (torch's own external=True events are refused on ROCm builds)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     for e in evs:
         e.record()                                        # creates the handles
     torch.cuda.synchronize()
@@ -596,11 +595,14 @@ def in_step_launch_times(args, rank, world, dev, scaling, overlap, shape_batches
     try:
         _lib.call("fn_debug_set_profile_events", arr)
         run = StepRun(args, rank, world, dev, scaling, overlap, shape_batches=shape_batches)
+    except Exception as exc:      # noqa: BLE001
+        return None, f"capture with event nodes failed: {type(exc).__name__}: {exc}"
     finally:
         _lib.call("fn_debug_set_profile_events", None)    # (the captured graph keeps its event nodes; nothing else records them)
     if run.gstep is None:
+        why = run.capture_note
         run.release()
-        return None, "no captured step"
+        return None, f"no captured step ({why})"
     fwd, bwd = [], []
     try:
         for i in range(5 + replays):

@@ -2170,8 +2170,28 @@ int prof_event(int i, hipStream_t st) {
     if (!g_prof_ev[i]) return 0;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError();  cs = hipStreamCaptureStatusNone; }
-    const hipError_t rc = hipEventRecordWithFlags(g_prof_ev[i], st, cs == hipStreamCaptureStatusActive ? hipEventRecordExternal : 0);
-    if (rc != hipSuccess) { (void)hipGetLastError();  return fail(FN_EUNSUPPORTED, "fn_debug_set_profile_events: hipEventRecordWithFlags failed"); }
+    hipError_t rc;
+    if (cs != hipStreamCaptureStatusActive) rc = hipEventRecord(g_prof_ev[i], st);
+    else {
+        rc = hipEventRecordWithFlags(g_prof_ev[i], st, hipEventRecordExternal);
+        if (rc != hipSuccess) {      // the same node by hand: an event-record node behind the stream's current capture dependencies
+            (void)hipGetLastError();
+            hipGraph_t graph = nullptr;
+            const hipGraphNode_t* deps = nullptr;
+            size_t n_deps = 0;
+            unsigned long long id = 0;
+            rc = hipStreamGetCaptureInfo_v2(st, &cs, &id, &graph, &deps, &n_deps);
+            hipGraphNode_t node = nullptr;
+            if (rc == hipSuccess) rc = hipGraphAddEventRecordNode(&node, graph, deps, n_deps, g_prof_ev[i]);
+            if (rc == hipSuccess) rc = hipStreamUpdateCaptureDependencies(st, &node, 1, hipStreamSetCaptureDependencies);
+        }
+    }
+    if (rc != hipSuccess) {
+        (void)hipGetLastError();
+        static thread_local char msg[160];
+        snprintf(msg, sizeof msg, "fn_debug_set_profile_events: recording the event failed (%s)", hipGetErrorString(rc));
+        return fail(FN_EUNSUPPORTED, msg);
+    }
     return 0;
 }
 int g_tune[FN_TUNE_COUNT] = {1024, 0, 0, 192, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 512, 2, -1, 0, 1, 0, 0, 1, 23, 1, 768, 1, 0, 1, 1, 0, 0, 6144, 1};   // in the order of the FN_TUNE_* keys
