@@ -69,492 +69,7 @@ inline int bwd_grid(int64_t rows) {
 // =====================================================================================
 #include "gat_fwd.inc"
 
-// Backward kernels use RB rows (half-waves) per block.
-// Destination pass: dz[e] = p[e] * (<g_out[dst], h[src]> - sum_e' p[e'] <g_out[dst], h[src']>) * LeakyReLU', per head.
-// Same shape as the forward kernel: persistent half-waves over R consecutive rows, straight-line body with clamped
-// unconditional loads, the next row's edge data fetched while this row's source rows fly.
-template <int NE> struct BwdRaw {
-    int pos;
-    i32x2u sp, sq, eq;        // source ids, positions in source order, original edge ids
-    f32x2u pp;                // signed probabilities
-    f32x2u x[NE];             // raw edge attributes (mode 2)
-};
-
-struct GatBwdDstArgs {
-    const float *g_out, *h, *p_sorted;
-    fn_edge_term et;
-    fn_gat_plan pl;
-    float slope;
-    float *dz_sorted, *g_s_orig, *pz_src, *g_s_dst, *part_e;
-    int rows_per_hw, nblk;
-};
-// rows [blk0, te) interleaved over the block's RB half-waves; bid: the block's slot in part_e (KL != 0)
-template <int H, int KL, int RB>
-__device__ __forceinline__ void gat_bwd_dst_rows(const GatBwdDstArgs& A, float (*sP)[8][kWfLd], int blk0, int te, int rows_per_hw, int bid) {
-    const float* __restrict__ g_out = A.g_out;
-    const float* __restrict__ h = A.h;
-    const float* __restrict__ p_sorted = A.p_sorted;
-    const fn_edge_term& et = A.et;
-    const fn_gat_plan& pl = A.pl;
-    const float slope = A.slope;
-    float* __restrict__ dz_sorted = A.dz_sorted;
-    float* __restrict__ g_s_orig = A.g_s_orig;
-    float* __restrict__ pz_src = A.pz_src;
-    float* __restrict__ g_s_dst = A.g_s_dst;
-    float* __restrict__ part_e = A.part_e;
-    constexpr int LPH = 32 / H;
-    constexpr int NE = KL ? KL : 1;
-    const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH, hw = threadIdx.x >> 5;
-    const int m = (int)pl.m, n = (int)pl.n;
-    const int K = KL ? et.K : 0;
-    const bool pairs = m >= 2;
-    const bool want_orig = KL == 0 && g_s_orig != nullptr;
-    float pw[NE + 1];
-#pragma unroll
-    for (int k = 0; k <= NE; ++k) pw[k] = 0.f;
-    const float* p_head = p_sorted + (size_t)head * m;
-    float* pz_head = pz_src + (size_t)head * m * 2;
-    const int tb = blk0 + hw;
-
-    auto load_extent = [&](int t, int& beg, int& deg) {
-        const int tc = t < n ? t : n - 1;
-        const i32x2u rp = ldp(pl.rowptr_d + tc);
-        beg = rp.x - pl.pos_base_d;
-        deg = t < te ? rp.y - rp.x : -1;
-    };
-    auto issue_edges = [&](int beg, BwdRaw<NE>& r) {
-        int pos = beg + 2 * j;
-        pos = pos > m - 2 ? m - 2 : pos;
-        pos = pos < 0 ? 0 : pos;
-        r.pos = pos;
-        if (!pairs) { r.sp.x = r.sp.y = 0;  r.sq.x = r.sq.y = 0;  r.eq.x = r.eq.y = 0;  r.pp.x = r.pp.y = 0.f;  return; }
-        r.sp = ldp(pl.src_d + pos);
-        r.pp = ldp(p_head + pos);
-        r.sq = ldp(pl.spos_d + pos);
-        if (want_orig) r.eq = ldp(pl.eid_d + pos);
-        if (KL) {
-#pragma unroll
-            for (int k = 0; k < NE; ++k) r.x[k] = ldp(et.x_sorted + (size_t)(k < K ? k : K - 1) * m + pos);
-        }
-    };
-
-    int beg, deg, beg_n, deg_n;
-    BwdRaw<NE> raw, cur;
-    load_extent(tb, beg, deg);
-    issue_edges(beg, raw);
-    load_extent(tb + RB, beg_n, deg_n);
-    cur = raw;
-    asm volatile("" ::"v"(beg_n), "v"(deg_n), "v"(cur.sp.x), "v"(cur.sp.y), "v"(cur.pp.x), "v"(cur.pp.y), "v"(cur.sq.x), "v"(cur.sq.y));
-    for (int t = tb; t < tb + RB * rows_per_hw; t += RB) {
-        const bool fast = pairs && deg >= 0 && deg <= 2 * LPH;
-        const bool has0 = fast && 2 * j < deg, has1 = fast && 2 * j + 1 < deg;
-        const bool shifted = beg + 2 * j != cur.pos;              // only the very last edge of the level
-        // (a lane without an edge gathers the destination row itself, see gat_fwd_rows)
-        const int src0 = has0 ? (shifted ? cur.sp.y : cur.sp.x) : (t < n ? t : n - 1), src1 = has1 ? cur.sp.y : src0;
-        const float ps0 = has0 ? (shifted ? cur.pp.y : cur.pp.x) : 0.f, ps1 = has1 ? cur.pp.y : 0.f;
-        const int sq0 = shifted ? cur.sq.y : cur.sq.x, sq1 = cur.sq.y;
-        const int eq0 = shifted ? cur.eq.y : cur.eq.x, eq1 = cur.eq.y;
-        // one round trip: next row's edge data, the row after's extent, this row's gradient row and source rows
-        issue_edges(beg_n, raw);
-        int beg_nn, deg_nn;
-        load_extent(t + 2 * RB, beg_nn, deg_nn);
-        const int tc = t < n ? t : n - 1;
-        const float4 g = ld4_off(g_out, (uint32_t)tc * (FN_D * 4) + lane * 16);
-        const bool wide = __any(fast && deg > 4);
-        float4 r0[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int sk = __shfl((i & 1) ? src1 : src0, i >> 1, LPH);
-            r0[i] = ld4_off(h, (uint32_t)sk * (FN_D * 4) + lane * 16);
-        }
-        if (wide) {
-#pragma unroll
-            for (int i = 4; i < 8; ++i) {
-                const int sk = __shfl((i & 1) ? src1 : src0, i >> 1, LPH);
-                r0[i] = ld4_off(h, (uint32_t)sk * (FN_D * 4) + lane * 16);
-            }
-        }
-        float dp0 = 0.f, dp1 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float dsum = head_sum<LPH>(dot4(g, r0[i]));
-            if ((i >> 1) == j) { if (i & 1) dp1 = dsum; else dp0 = dsum; }
-        }
-        if (wide) {
-#pragma unroll
-            for (int i = 4; i < 8; ++i) {
-                const float dsum = head_sum<LPH>(dot4(g, r0[i]));
-                if ((i >> 1) == j) { if (i & 1) dp1 = dsum; else dp0 = dsum; }
-            }
-        }
-        if (fast) {
-            for (int k0 = 8; k0 < deg; k0 += 4) {                 // in-degree 9 .. 2*LPH
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int k = k0 + i;
-                    const int sk = __shfl((i & 1) ? src1 : src0, k >> 1, LPH);
-                    const float dsum = head_sum<LPH>(dot4(g, ld4_off(h, (uint32_t)sk * (FN_D * 4) + lane * 16)));
-                    if ((k >> 1) == j) { if (i & 1) dp1 = dsum; else dp0 = dsum; }
-                }
-            }
-        }
-        const float p0 = fabsf(ps0), p1 = fabsf(ps1);
-        const float c = head_sum<LPH>(p0 * dp0 + p1 * dp1);
-        const float dz0 = p0 * (dp0 - c) * ((__float_as_uint(ps0) >> 31) ? slope : 1.f);
-        const float dz1 = p1 * (dp1 - c) * ((__float_as_uint(ps1) >> 31) ? slope : 1.f);
-        // the raw data of this row is consumed: take over the next row's before the stores (see k_gat_fwd)
-        float xa[NE], xb[NE];
-#pragma unroll
-        for (int k = 0; k < NE; ++k) { xa[k] = shifted ? cur.x[k].y : cur.x[k].x;  xb[k] = cur.x[k].y; }
-        const int pos0 = beg + 2 * j, t_cur_deg = deg, t_cur_beg = beg;
-        cur = raw;
-        beg = beg_n;  deg = deg_n;  beg_n = beg_nn;  deg_n = deg_nn;
-        if (fast) {
-            if (has0) stp(pz_head + (size_t)sq0 * 2, p0, dz0);
-            if (has1) stp(pz_head + (size_t)sq1 * 2, p1, dz1);
-            if (KL == 0) {
-                if (dz_sorted) {
-                    if (has1) stp(dz_sorted + (size_t)head * m + pos0, dz0, dz1);
-                    else if (has0) dz_sorted[(size_t)head * m + pos0] = dz0;
-                }
-                if (want_orig) {                                  // gradient of the edge term in ORIGINAL edge order, [m_real][H]
-                    if (has0 && eq0 < pl.m_real) g_s_orig[(size_t)eq0 * H + head] = dz0;
-                    if (has1 && eq1 < pl.m_real) g_s_orig[(size_t)eq1 * H + head] = dz1;
-                }
-            } else {
-                pw[NE] += dz0 + dz1;                              // dz is 0 where the lane has no edge
-#pragma unroll
-                for (int k = 0; k < NE; ++k) pw[k] = fmaf(dz0, xa[k], fmaf(dz1, xb[k], pw[k]));
-            }
-            const float gs = head_sum<LPH>(dz0 + dz1);
-            if (j == 0) g_s_dst[(size_t)t * H + head] = gs;
-        } else if (t_cur_deg >= 0) {
-            // rare high in-degree node (or a level with a single edge): every lane walks the edge list
-            const int bg = t_cur_beg, dg = t_cur_deg;
-            float cs = 0.f;
-            for (int k = 0; k < dg; ++k) {
-                const int sk = pl.src_d[bg + k];
-                const float dsum = head_sum<LPH>(dot4(g, ld4(h + (size_t)sk * FN_D + lane * 4)));
-                cs = fmaf(fabsf(p_head[bg + k]), dsum, cs);
-            }
-            float gs = 0.f;
-            for (int k = 0; k < dg; ++k) {
-                const int sk = pl.src_d[bg + k];
-                const float dsum = head_sum<LPH>(dot4(g, ld4(h + (size_t)sk * FN_D + lane * 4)));
-                const float ps = p_head[bg + k];
-                const float dz = fabsf(ps) * (dsum - cs) * ((__float_as_uint(ps) >> 31) ? slope : 1.f);
-                if (j == 0) {
-                    stp(pz_head + (size_t)pl.spos_d[bg + k] * 2, fabsf(ps), dz);
-                    if (KL == 0) {
-                        if (dz_sorted) dz_sorted[(size_t)head * m + bg + k] = dz;
-                        if (g_s_orig) { const int eid = pl.eid_d[bg + k]; if (eid < pl.m_real) g_s_orig[(size_t)eid * H + head] = dz; }
-                    } else {
-                        pw[NE] += dz;
-#pragma unroll
-                        for (int kk = 0; kk < NE; ++kk)
-                            if (kk < K) pw[kk] = fmaf(dz, et.x_sorted[(size_t)kk * m + bg + k], pw[kk]);
-                    }
-                }
-                gs += dz;
-            }
-            if (j == 0) g_s_dst[(size_t)t * H + head] = gs;
-        }
-    }
-
-    if (KL) {
-        // deterministic block partial of sum_e dz[e,h] * (x[e,0..K), 1); columns k >= K carry weight-0 duplicates
-#pragma unroll
-        for (int k = 0; k <= NE; ++k) {
-            const float v = head_sum<LPH>(pw[k]);
-            if (j == 0) sP[hw][head][k == NE ? FN_MAX_EDGE_K : k] = v;
-        }
-        __syncthreads();
-        const int ne = H * (K + 1);
-        for (int i = threadIdx.x; i < ne; i += blockDim.x) {
-            const int hh = i / (K + 1), k = i % (K + 1);
-            const int kk = (k == K) ? FN_MAX_EDGE_K : k;
-            float a = 0.f;
-#pragma unroll
-            for (int w = 0; w < RB; ++w) a += sP[w][hh][kk];
-            part_e[(size_t)bid * ne + i] = a;
-        }
-    }
-}
-
-// Source pass: g_h[s] = sum over out-edges p * g_out[dst] + g_s_dst[s] * a_dst + (sum dz) * a_src, and the block
-// partials of dL/da_dst, dL/da_src.  Its stores are whole rows, so it pipelines like the forward kernel: persistent
-// half-waves over R consecutive source rows, straight-line body, next row's (dst ids, p, dz) in flight during the
-// gathers of this one.
-struct SrcRaw {
-    int pos;
-    i32x2u tp;
-    f32x4u v;               // p0, dz0, p1, dz1
-};
-
-template <int H, int KL, int RB>
-__device__ __forceinline__ void gat_bwd_dst_body(const GatBwdDstArgs& A, float (*sP)[8][kWfLd], int bid, int nblk) {
-    const int blk0 = xcd_block(bid, nblk) * RB * A.rows_per_hw, n = (int)A.pl.n;      // rows interleaved over the half-waves
-    gat_bwd_dst_rows<H, KL, RB>(A, sP, blk0, blk0 + RB * A.rows_per_hw < n ? blk0 + RB * A.rows_per_hw : n, A.rows_per_hw, bid);
-}
-template <int H, int KL, int RB>
-__global__ __launch_bounds__(RB * 32) void k_gat_bwd_dst(GatBwdDstArgs A) {
-    __shared__ float sP[RB][8][kWfLd];
-    gat_bwd_dst_body<H, KL, RB>(A, sP, (int)blockIdx.x, (int)gridDim.x);
-}
-
-struct GatBwdSrcArgs {
-    const float *g_out, *h, *pz_src, *g_s_dst, *att;
-    int att_w, dst_off, src_off;
-    fn_gat_plan pl;
-    float *g_h, *part_a;
-    int rows_per_hw, nblk;
-};
-// source rows [blk0, se) interleaved over the block's RB half-waves; bid: the block's slot (row) in part_a
-template <int H, int RB>
-__device__ __forceinline__ void gat_bwd_src_rows(const GatBwdSrcArgs& A, float (*sA)[2 * FN_D], int blk0, int se, int rows_per_hw, int bid) {
-    const float* __restrict__ g_out = A.g_out;
-    const float* __restrict__ h = A.h;
-    const float* __restrict__ pz_src = A.pz_src;
-    const float* __restrict__ g_s_dst = A.g_s_dst;
-    const float* __restrict__ att = A.att;
-    const int att_w = A.att_w, dst_off = A.dst_off, src_off = A.src_off;
-    const fn_gat_plan& pl = A.pl;
-    float* __restrict__ g_h = A.g_h;
-    float* __restrict__ part_a = A.part_a;
-    constexpr int LPH = 32 / H;
-    const int lane = threadIdx.x & 31, head = lane / LPH, j = lane % LPH, hw = threadIdx.x >> 5;
-    const int m = (int)pl.m, n = (int)pl.n;
-    const bool pairs = m >= 2;
-    const float4 ad = ld4(att + head * att_w + dst_off + j * 4);
-    const float4 as = ld4(att + head * att_w + src_off + j * 4);
-    const float* pz_head = pz_src + (size_t)head * m * 2;
-    float4 qd = make_float4(0.f, 0.f, 0.f, 0.f), qs = qd;
-    const int sb = blk0 + hw;
-
-    auto load_extent = [&](int s, int& beg, int& deg, float& gsd) {
-        const int sc = s < n ? s : n - 1;
-        const i32x2u rp = ldp(pl.rowptr_s + sc);
-        beg = rp.x - pl.pos_base_s;
-        deg = s < se ? rp.y - rp.x : -1;
-        gsd = g_s_dst[(uint32_t)sc * H + head];
-    };
-    auto issue_edges = [&](int beg, SrcRaw& r) {
-        int pos = beg + 2 * j;
-        pos = pos > m - 2 ? m - 2 : pos;
-        pos = pos < 0 ? 0 : pos;
-        r.pos = pos;
-        if (!pairs) { r.tp.x = r.tp.y = 0;  r.v.x = r.v.y = r.v.z = r.v.w = 0.f;  return; }
-        r.tp = ldp(pl.dst_s + pos);
-        r.v = *reinterpret_cast<const f32x4u*>(pz_head + (size_t)pos * 2);
-    };
-
-    int beg, deg, beg_n, deg_n;
-    float gsd, gsd_n;
-    SrcRaw raw, cur;
-    load_extent(sb, beg, deg, gsd);
-    issue_edges(beg, raw);
-    load_extent(sb + RB, beg_n, deg_n, gsd_n);
-    cur = raw;
-    asm volatile("" ::"v"(beg_n), "v"(deg_n), "v"(gsd_n), "v"(cur.tp.x), "v"(cur.tp.y), "v"(cur.v.x), "v"(cur.v.y), "v"(cur.v.z), "v"(cur.v.w));
-    for (int s = sb; s < sb + RB * rows_per_hw; s += RB) {
-        const bool fast = pairs && deg >= 0 && deg <= 2 * LPH;
-        const bool has0 = fast && 2 * j < deg, has1 = fast && 2 * j + 1 < deg;
-        const bool shifted = beg + 2 * j != cur.pos;              // only the very last edge of the level
-        const int t0 = has0 ? (shifted ? cur.tp.y : cur.tp.x) : (s < n ? s : n - 1), t1 = has1 ? cur.tp.y : t0;      // (no edge: the row itself)
-        const float p0 = has0 ? (shifted ? cur.v.z : cur.v.x) : 0.f, z0 = has0 ? (shifted ? cur.v.w : cur.v.y) : 0.f;
-        const float p1 = has1 ? cur.v.z : 0.f, z1 = has1 ? cur.v.w : 0.f;
-        issue_edges(beg_n, raw);
-        int beg_nn, deg_nn;
-        float gsd_nn;
-        load_extent(s + 2 * RB, beg_nn, deg_nn, gsd_nn);
-        const int sc = s < n ? s : n - 1;
-        const float4 hr = ld4_off(h, (uint32_t)sc * (FN_D * 4) + lane * 16);
-        const bool wide = __any(fast && deg > 4);
-        float4 r0[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int tk = __shfl((i & 1) ? t1 : t0, i >> 1, LPH);
-            r0[i] = ld4_off(g_out, (uint32_t)tk * (FN_D * 4) + lane * 16);
-        }
-        if (wide) {
-#pragma unroll
-            for (int i = 4; i < 8; ++i) {
-                const int tk = __shfl((i & 1) ? t1 : t0, i >> 1, LPH);
-                r0[i] = ld4_off(g_out, (uint32_t)tk * (FN_D * 4) + lane * 16);
-            }
-        }
-        float gss = head_sum<LPH>(z0 + z1);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fma4(acc, __shfl((i & 1) ? p1 : p0, i >> 1, LPH), r0[i]);
-        if (wide) {
-#pragma unroll
-            for (int i = 4; i < 8; ++i) fma4(acc, __shfl((i & 1) ? p1 : p0, i >> 1, LPH), r0[i]);
-        }
-        const int cur_beg = beg, cur_deg = deg;
-        const float cur_gsd = gsd;
-        cur = raw;
-        beg = beg_n;  deg = deg_n;  gsd = gsd_n;  beg_n = beg_nn;  deg_n = deg_nn;  gsd_n = gsd_nn;
-        if (fast) {
-            for (int k0 = 8; k0 < cur_deg; k0 += 4) {             // out-degree 9 .. 2*LPH
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int k = k0 + i;
-                    const int tk = __shfl((i & 1) ? t1 : t0, k >> 1, LPH);
-                    const float pk = __shfl((i & 1) ? p1 : p0, k >> 1, LPH);
-                    fma4(acc, pk, ld4_off(g_out, (uint32_t)tk * (FN_D * 4) + lane * 16));
-                }
-            }
-        } else if (cur_deg >= 0) {
-            acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            gss = 0.f;
-            for (int i = 0; i < cur_deg; ++i) {
-                const int t = pl.dst_s[cur_beg + i];
-                const f32x2u v = ldp(pz_head + (size_t)(cur_beg + i) * 2);
-                fma4(acc, v.x, ld4(g_out + (size_t)t * FN_D + lane * 4));
-                gss += v.y;
-            }
-        }
-        if (cur_deg >= 0) {
-            fma4(acc, cur_gsd, ad);
-            fma4(acc, gss, as);
-            st4(g_h + (size_t)s * FN_D + lane * 4, acc);
-            fma4(qd, cur_gsd, hr);
-            fma4(qs, gss, hr);
-        }
-    }
-    st4(&sA[hw][lane * 4], qd);
-    st4(&sA[hw][FN_D + lane * 4], qs);
-    __syncthreads();
-    for (int c = threadIdx.x; c < 2 * FN_D; c += blockDim.x) {
-        float a = 0.f;
-#pragma unroll
-        for (int w = 0; w < RB; ++w) a += sA[w][c];
-        part_a[(size_t)c * FN_MAX_PART + bid] = a;          // column-major: finalize reads a column contiguously
-    }
-}
-
-template <int H, int RB>
-__device__ __forceinline__ void gat_bwd_src_body(const GatBwdSrcArgs& A, float (*sA)[2 * FN_D], int bid, int nblk) {
-    const int blk0 = xcd_block(bid, nblk) * RB * A.rows_per_hw, n = (int)A.pl.n;      // rows interleaved over the half-waves
-    gat_bwd_src_rows<H, RB>(A, sA, blk0, blk0 + RB * A.rows_per_hw < n ? blk0 + RB * A.rows_per_hw : n, A.rows_per_hw, bid);
-}
-template <int H, int RB>
-__global__ __launch_bounds__(RB * 32) void k_gat_bwd_src(GatBwdSrcArgs A) {
-    __shared__ float sA[RB][2 * FN_D];
-    gat_bwd_src_body<H, RB>(A, sA, (int)blockIdx.x, (int)gridDim.x);
-}
-
-
-// sum of up to 1024 values, one per thread (deterministic: wave butterflies, then 16 wave sums in order)
-__device__ __forceinline__ float block_sum_1024(float v, float* s16) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if ((threadIdx.x & 63) == 0) s16[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) t += s16[w];
-    return t;
-}
-
-// blocks 0..255: one column each of the column-major [256][FN_MAX_PART] a_dst/a_src partials; block 256 (mode 2
-// only): the [n_e, H*(K+1)] edge-embedding partials and the chain rule through the folded weights.
-// (body shared by k_gat_finalize and the deferred task-table kernel k_reduce_tasks; vb = virtual block index,
-// sm = 1200 floats of shared memory)
-__device__ __forceinline__ void gat_finalize_body(int vb, float* sm, const float* __restrict__ part_a, int n_a,
-                                                  const float* __restrict__ part_e, int n_e, const fn_edge_term& et,
-                                                  const float* __restrict__ att, int att_w, int dst_off, int src_off,
-                                                  float* __restrict__ g_att, float* __restrict__ g_embW,
-                                                  float* __restrict__ g_embb, int H) {
-    float* s16 = sm;
-    float(*redE)[128] = reinterpret_cast<float(*)[128]>(sm + 16);
-    float* sE = sm + 16 + 1024;
-    const int tid = threadIdx.x;
-    if (vb < 2 * FN_D) {
-        const int col = vb;
-        float mine = 0.f;
-        for (int r = tid; r < n_a; r += 1024) mine += part_a[(size_t)col * FN_MAX_PART + r];
-        const float v = block_sum_1024(mine, s16);
-        if (tid == 0) {
-            const int DH = FN_D / H;
-            const int cc = col & 127, part = col >> 7;
-            g_att[(cc / DH) * att_w + (part ? src_off : dst_off) + (cc % DH)] = v;
-        }
-        return;
-    }
-    const int K = et.K, d_e = et.d_e;
-    const int ne = H * (K + 1);     // <= 72
-    {   // column sums of part_e [n_e][ne]: the 1024 threads form (1024 / cp) row groups x cp columns, cp = pow2 >= ne
-        float* red = &redE[0][0];   // 1024 floats
-        int cp = 8;
-        while (cp < ne) cp <<= 1;
-        const int groups = 1024 / cp, col = tid % cp, grp = tid / cp;
-        float acc = 0.f;
-        if (col < ne) {
-            // four loads in flight per thread: with one, this single block was a chain of ~30 dependent round trips (n_e =
-            // 3888 partial rows for the bond level) and the whole deferred-reduction launch waited for it (25 -> 14 us)
-            float a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            int r = grp;
-            for (; r + 3 * groups < n_e; r += 4 * groups) {
-                acc += part_e[(size_t)r * ne + col];
-                a1 += part_e[(size_t)(r + groups) * ne + col];
-                a2 += part_e[(size_t)(r + 2 * groups) * ne + col];
-                a3 += part_e[(size_t)(r + 3 * groups) * ne + col];
-            }
-            for (; r < n_e; r += groups) acc += part_e[(size_t)r * ne + col];
-            acc = (acc + a1) + (a2 + a3);
-        }
-        red[grp * cp + col] = acc;
-        __syncthreads();
-        if (tid < 128) {
-            float v = 0.f;
-            if (tid < ne)
-                for (int g = 0; g < groups; ++g) v += red[g * cp + tid];
-            sE[tid] = v;
-        }
-        __syncthreads();
-    }
-    if (tid < H * d_e) {
-        const int hh = tid / d_e, c = tid % d_e;
-        float a = sE[hh * (K + 1) + K] * et.embb[c];
-        for (int k = 0; k < K; ++k) a = fmaf(sE[hh * (K + 1) + k], et.embW[c * K + k], a);
-        g_att[hh * att_w + et.mid_off + c] = a;
-    }
-    if (tid < d_e * K) {
-        const int c = tid / K, k = tid % K;
-        float a = 0.f;
-        for (int hh = 0; hh < H; ++hh) a = fmaf(sE[hh * (K + 1) + k], att[hh * att_w + et.mid_off + c], a);
-        g_embW[tid] = a;
-    }
-    if (tid < d_e) {
-        float a = 0.f;
-        for (int hh = 0; hh < H; ++hh) a = fmaf(sE[hh * (K + 1) + K], att[hh * att_w + et.mid_off + tid], a);
-        g_embb[tid] = a;
-    }
-}
-
-__global__ __launch_bounds__(1024) void k_gat_finalize(const float* __restrict__ part_a, int n_a,
-                                                       const float* __restrict__ part_e, int n_e, fn_edge_term et,
-                                                       const float* __restrict__ att, int att_w, int dst_off,
-                                                       int src_off, float* __restrict__ g_att,
-                                                       float* __restrict__ g_embW, float* __restrict__ g_embb, int H) {
-    __shared__ float sm[1200];
-    gat_finalize_body(blockIdx.x, sm, part_a, n_a, part_e, n_e, et, att, att_w, dst_off, src_off, g_att, g_embW, g_embb, H);
-}
-
-template <int H>
-__global__ void k_attn_by_src(const float* __restrict__ p_sorted, fn_gat_plan pl, float* __restrict__ attn) {
-    const int64_t total = pl.n * H;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t s = i / H;
-        const int head = (int)(i % H);
-        const int beg = pl.rowptr_s[s] - pl.pos_base_s, deg = pl.rowptr_s[s + 1] - pl.rowptr_s[s];
-        float a = 0.f;
-        for (int k = 0; k < deg; ++k) a += fabsf(p_sorted[(size_t)head * pl.m + pl.dpos_s[beg + k]]);
-        attn[i] = a;
-    }
-}
+#include "gat_bwd_two.inc"
 
 // =====================================================================================
 // Full-width edge term (atom graph / fragment graph), produced directly in destination-sorted order
@@ -2899,1294 +2414,4 @@ int fn_masked_mse_multi_f32(const fn_mse_task* tasks, int n_tasks, const float* 
 
 }  // extern "C"
 
-// =====================================================================================
-// Encoder engine: FragNet.forward / its backward as ONE call each (reference gat2.py:381-442 and, per layer,
-// gat2.py:121-330).  The host only walks the layer list and enqueues kernels on the caller's stream; nothing is
-// allocated, nothing synchronises.  Activations the backward pass needs live in the caller's workspace.
-// =====================================================================================
-namespace {
-
-struct Bump {
-    float* base;
-    int64_t used = 0;
-    explicit Bump(float* b) : base(b) {}
-    float* take(int64_t n) {
-        float* p = base ? base + used : nullptr;
-        used += (n + 63) / 64 * 64;          // 256-byte granules keep every buffer 16-byte aligned
-        return p;
-    }
-};
-
-struct LayerActs {           // kept from forward for backward
-    float *h_b, *h_a, *h_fb, *frags, *new_bond, *new_fbond, *p_bond, *p_atom, *p_fbond, *p_frag;
-    float *y_atoms, *y_frags, *y_bond, *y_fbond;    // post dropout+ReLU outputs (null for the last layer: caller's buffers)
-    // one-pass backward (FN_TUNE_BWD_ONE, training): the forward's second output rows and their weight sums, per level
-    float *o2_bond, *o2_atom, *o2_fbond, *sg_bond, *sg_atom, *sg_fbond;
-};
-
-struct EncLayout {
-    LayerActs L[FN_MAX_LAYERS];
-    float* in_atoms0;        // dropout(x_atoms) when training with p > 0, else null (use x_atoms)
-    // forward scratch
-    float *atoms_new, *frags_new, *s_sorted, *s_dst, *s_src, *s_dst_a, *s_src_a, *s_dst_fb, *s_src_fb, *bt;
-    float* mol_ext;          // MolExt[n_mols] for the molecule-resident backward (null without molecule CSRs)
-    float *xs_bond, *xs_fbond;   // one-pass backward: the two raw edge attributes in source order ([1][bond.m], [k_fattr][fbond.m])
-    float* real_rows;            // pad_skip_on: int32 [4] = real atoms, bonds, fragments, connections (written by the forward prologue)
-    float* rmat;                 // defer_on: R [3 n_layers][4][128] of the K = 128 projections (GsdEpi; written by the forward prologue)
-    int64_t total;
-};
-
-inline int64_t max4(int64_t a, int64_t b, int64_t c, int64_t d) { return std::max(std::max(a, b), std::max(c, d)); }
-
-// every attention level's backward as one source-owner pass (csrc/gat_bwd_one.inc).  Decided from the descriptor and the
-// process-wide tuning table alone, so that fn_encoder_forward (which then writes out2 / sigma), fn_encoder_backward and the
-// workspace sizes agree; gat2_edge's fragment graph (edge class FN_MAX_EDGE_K on 128-wide embeddings) keeps the two passes
-bool one_pass_on(const fn_encoder* e);
-// Padding rows of a static-shape batch are skipped by the kernels of the one-pass path: the rows behind the real ones in every index
-// space (collate appends the padding molecules) get zero outputs / zero gradients without gathers or matrix work, GEMM tiles and
-// weight-gradient rows beyond them are not touched.  Needs the molecule CSRs (the real counts are the extents of the last real
-// molecule, written by the forward prologue) and the device count of real molecules.
-bool pad_skip_on(const fn_encoder* e);
-bool one_pass_on(const fn_encoder* e) {
-    return g_tune[FN_TUNE_BWD_ONE] != 0 && e->training != 0 && (e->heads == 2 || e->heads == 4 || e->heads == 8) &&
-           e->atom.m_real == e->E;
-}
-
-// the deferred form of the one-pass backward (gat_bwd_one.inc DF, FN_TUNE_DEFER_GSD): no second output in the forward.  Four heads
-// (the 16-lane segment sums and the rank-4 epilogue are written for them), gat2, and the grouped direct weight-gradient kernels
-bool defer_on(const fn_encoder* e) {
-    return g_tune[FN_TUNE_DEFER_GSD] != 0 && one_pass_on(e) && e->heads == 4 && e->variant == 0 && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0 &&
-           g_tune[FN_TUNE_WGRAD_DIRECT] == 1;
-}
-
-// The form a forward pass ran in (bit 0: one-pass backward = out2 / sigma or dz tables exist; bit 1: its deferred form = no out2 /
-// sigma, rmat written), latched per activation workspace: fn_encoder_backward refuses a descriptor whose form -- read from the
-// process-wide tuning table -- is no longer the one its forward wrote the workspace in (FN_TUNE_BWD_ONE / FN_TUNE_DEFER_GSD flipped
-// in between would leave out2 / sigma / rmat null or unwritten for the other half).
-int enc_form(const fn_encoder* e) { return (one_pass_on(e) ? 1 : 0) | (defer_on(e) ? 2 : 0); }
-struct FormLatch { const float* ws; int form; };
-FormLatch g_form_latch[64];
-int g_form_latch_next = 0;
-std::mutex g_form_latch_mu;
-void latch_form(const fn_encoder* e) {
-    std::lock_guard<std::mutex> lk(g_form_latch_mu);
-    for (FormLatch& f : g_form_latch)
-        if (f.ws == e->ws) { f.form = enc_form(e);  return; }
-    g_form_latch[g_form_latch_next] = FormLatch{e->ws, enc_form(e)};
-    g_form_latch_next = (g_form_latch_next + 1) % 64;
-}
-bool form_matches_forward(const fn_encoder* e) {      // (a workspace this process ran no forward into: nothing to compare with)
-    std::lock_guard<std::mutex> lk(g_form_latch_mu);
-    for (const FormLatch& f : g_form_latch)
-        if (f.ws == e->ws && f.ws) return f.form == enc_form(e);
-    return true;
-}
-
-EncLayout enc_layout(const fn_encoder* e, float* ws) {
-    EncLayout o{};
-    Bump b(ws);
-    const int H = e->heads;
-    const bool drop = e->training && e->drop_p > 0.f;
-    for (int l = 0; l < e->n_layers; ++l) {
-        LayerActs& a = o.L[l];
-        a.h_b = b.take(e->E * FN_D);  a.h_a = b.take(e->N * FN_D);  a.h_fb = b.take(e->EF * FN_D);  a.frags = b.take(e->F * FN_D);
-        a.new_bond = b.take(e->E * FN_D);  a.new_fbond = b.take(e->EF * FN_D);
-        a.p_bond = b.take(e->bond.m * H);  a.p_atom = b.take(e->atom.m * H);
-        a.p_fbond = b.take(e->fbond.m * H);  a.p_frag = b.take(e->frag.m * H);
-        if (l + 1 < e->n_layers) {
-            a.y_atoms = b.take(e->N * FN_D);  a.y_frags = b.take(e->F * FN_D);
-            a.y_bond = b.take(e->E * FN_D);  a.y_fbond = b.take(e->EF * FN_D);
-        }
-    }
-    if (one_pass_on(e)) {
-        for (int l = 0; l < e->n_layers && !defer_on(e); ++l) {
-            LayerActs& a = o.L[l];
-            a.o2_bond = b.take(e->E * FN_D);  a.o2_atom = b.take(e->N * FN_D);  a.o2_fbond = b.take(e->EF * FN_D);
-            a.sg_bond = b.take(e->E * H);  a.sg_atom = b.take(e->N * H);  a.sg_fbond = b.take(e->EF * H);
-        }
-        o.xs_bond = b.take(e->bond.m);
-        o.xs_fbond = b.take(e->fbond.m * e->k_fattr);
-    }
-    o.real_rows = pad_skip_on(e) ? b.take(64) : nullptr;
-    o.rmat = defer_on(e) ? b.take((int64_t)3 * e->n_layers * 512) : nullptr;
-    o.in_atoms0 = drop ? b.take(e->N * e->k_atom0) : nullptr;
-    o.atoms_new = b.take(e->N * FN_D);
-    o.frags_new = b.take(e->F * FN_D);
-    o.s_sorted = b.take(std::max(e->atom.m, e->frag.m) * H);
-    const int64_t nmax = max4(e->E, e->N, e->EF, e->F);
-    o.s_dst = b.take(nmax * H);
-    o.s_src = b.take(nmax * H);
-    o.s_dst_a = b.take(e->N * H);
-    o.s_src_a = b.take(e->N * H);
-    o.s_dst_fb = b.take(e->EF * H);
-    o.s_src_fb = b.take(e->EF * H);
-    o.bt = b.take((int64_t)3 * e->n_layers * 192 * FN_D);
-    o.mol_ext = e->n_mols > 0 ? b.take(e->n_mols * (int64_t)(sizeof(MolExt) / sizeof(float))) : nullptr;
-    o.total = b.used;
-    return o;
-}
-
-bool have_mol(const fn_encoder* e) {       // the caller handed over the molecule CSRs: every level is block-diagonal per molecule
-    return e->n_mols > 0 && e->mol_atoms.rowptr && e->mol_frags.rowptr && e->mol_atoms.n_seg == e->n_mols && e->mol_frags.n_seg == e->n_mols;
-}
-bool pad_skip_on(const fn_encoder* e) {
-    return g_tune[FN_TUNE_PAD_SKIP] != 0 && one_pass_on(e) && have_mol(e) && e->mol_contiguous != 0 && e->counts_dev != nullptr && e->variant == 0;
-}
-// the last layer's fragment tail (fragment sums -> fragment graph -> readout, and its backward) as one molecule-resident launch
-// each way (csrc/mol_tail.inc): needs the caller's word that the batch has collate_fn's molecule-contiguous layout
-bool tail_mol_on(const fn_encoder* e) {
-    return g_tune[FN_TUNE_MOL_TAIL] != 0 && e->mol_contiguous != 0 && have_mol(e) && e->variant == 0 &&
-           (e->heads == 2 || e->heads == 4 || e->heads == 8) && e->F > 0 && e->EF > 0 && e->frag.m > 1 && e->n_mols <= FN_MAX_PART &&
-           !((uintptr_t)e->ws & 15);
-}
-
-// Backward scratch.  Nothing is reused across levels or layers: the kernels that only produce parameter gradients
-// (finalize, weight-gradient GEMMs, column sums) run on an auxiliary stream behind the main dependency chain, so a
-// buffer they read must not be rewritten by the next level.  ~60 MB per layer at ESOL batch 512.
-struct LevelScratch {
-    float *g_h, *dz, *pz, *g_s_dst, *part_a, *part_e, *part_rd, *wg_ws;
-    float* cdot;             // one-pass backward: c[n, H] = <g, out> per head (no pz then)
-    float *dz_em, *upart;    // its deferred form: dz at destination-order slots [m][H]; the weight-gradient kernels' side product U | S per block
-};
-struct BwdLayout {
-    float *g_pre_atoms, *g_pre_frags, *g_pre_bond, *g_pre_fbond;   // grads w.r.t. pre-activation layer outputs (the chain)
-    float* g_frags;
-    LevelScratch bond[FN_MAX_LAYERS], atom[FN_MAX_LAYERS], fbond[FN_MAX_LAYERS], frag;
-    int64_t total;
-};
-
-BwdLayout bwd_layout(const fn_encoder* e, float* ws) {
-    BwdLayout o{};
-    Bump b(ws);
-    const int H = e->heads;
-    o.g_pre_atoms = b.take(e->N * FN_D);  o.g_pre_frags = b.take(e->F * FN_D);
-    o.g_pre_bond = b.take(e->E * FN_D);   o.g_pre_fbond = b.take(e->EF * FN_D);
-    o.g_frags = b.take(e->F * FN_D);
-    const bool df = defer_on(e);
-    auto level = [&](LevelScratch& s, int64_t n, int64_t m, int k0, bool edge_params, bool row_dots, bool proj, bool one = false) {
-        s.g_h = b.take(n * FN_D);
-        s.dz_em = one && df ? b.take(m * H) : nullptr;
-        // (a weight-gradient launch has at most n / wgrad_rows_per_block(n) + 1 blocks per product)
-        s.upart = one && df && proj ? b.take((n / wgrad_rows_per_block(n) + 2) * (int64_t)(4 * (k0 > FN_D ? k0 : FN_D) + 4)) : nullptr;
-        s.dz = row_dots ? b.take(m * H) : nullptr;
-        s.pz = one ? nullptr : b.take(2 * m * H);
-        s.cdot = one ? b.take(n * H) : nullptr;
-        s.g_s_dst = b.take(n * H);
-        s.part_a = b.take((int64_t)FN_MAX_PART * 2 * FN_D);
-        s.part_e = edge_params ? b.take((int64_t)FN_MAX_PART * H * (FN_MAX_EDGE_K + 1)) : nullptr;
-        s.part_rd = row_dots ? b.take((int64_t)FN_MAX_PART * H * FN_D) : nullptr;
-        s.wg_ws = proj ? b.take(fn_linear128_wgrad_ws(n, k0 > FN_D ? k0 : FN_D)) : nullptr;
-    };
-    for (int l = 0; l < e->n_layers; ++l) {
-        level(o.bond[l], e->E, e->bond.m, e->k_bond0, true, false, true, one_pass_on(e));
-        level(o.atom[l], e->N, e->atom.m, e->k_atom0, false, true, true, one_pass_on(e));
-        level(o.fbond[l], e->EF, e->fbond.m, e->k_fbond0, true, false, true, one_pass_on(e));
-    }
-    level(o.frag, e->F, e->frag.m, 0, e->variant == 2, true, false);      // gat2_edge: the fragment graph has edge-embedding partials
-    o.total = b.used;
-    return o;
-}
-
-inline uint64_t blocks4(int64_t numel) { return (uint64_t)((numel + 3) / 4); }
-
-// Philox offsets consumed by the encoder, in order: input dropout of x_atoms, then per layer atoms, frags, bond, fbond
-struct RngPlan {
-    uint64_t in_atoms;
-    uint64_t y[FN_MAX_LAYERS][4];
-    uint64_t total;
-};
-RngPlan rng_plan(const fn_encoder* e) {
-    RngPlan r{};
-    uint64_t off = e->offset;
-    r.in_atoms = off;  off += blocks4(e->N * e->k_atom0);
-    for (int l = 0; l < e->n_layers; ++l) {
-        r.y[l][0] = off;  off += blocks4(e->N * FN_D);
-        r.y[l][1] = off;  off += blocks4(e->F * FN_D);
-        r.y[l][2] = off;  off += blocks4(e->E * FN_D);
-        r.y[l][3] = off;  off += blocks4(e->EF * FN_D);
-    }
-    r.total = off - e->offset;
-    return r;
-}
-
-// weight-gradient partials only (the reduction is deferred); *grid = partial rows written, *cls = kernel class
-int wgrad_partials(const float* dY, const float* X, int K, int64_t M, float* ws, hipStream_t st, int* grid, int* cls) {
-    const int rpb = wgrad_rows_per_block(M);
-    *grid = (int)((M + rpb - 1) / rpb);
-    if (K <= 16) { *cls = 0;  return launch_wgrad<1, 1>(dY, X, K, M, rpb, *grid, ws, nullptr, nullptr, st); }
-    if (K <= 32) { *cls = 1;  return launch_wgrad<1, 2>(dY, X, K, M, rpb, *grid, ws, nullptr, nullptr, st); }
-    if (K <= 128) { *cls = 2;  return launch_wgrad<4, 2>(dY, X, K, M, rpb, *grid, ws, nullptr, nullptr, st); }
-    if (K <= 192) { *cls = 3;  return launch_wgrad<6, 2>(dY, X, K, M, rpb, *grid, ws, nullptr, nullptr, st); }
-    return fail(FN_EUNSUPPORTED, "weight gradient: K > 192");
-}
-
-struct ReduceQueue {
-    ReduceTasks T{};
-    WgradTasks W{}, W0{};                   // W: the K = 128 products; W0: the others (layer 0), k_linear128_wgrad_mixed
-    int blocks = 0, wblocks = 0, w0blocks = 0;
-    bool defer_mixed = false;
-    int w_reduce[kMaxWgradTasks] = {};      // index in T of each grouped product's reduction
-    int w_fin[kMaxWgradTasks] = {};         // ... and of its level's RT_FINALIZE task when the product carries the deferred term (n_up is set at flush)
-    int last_index = -1;                    // index in T of the task pushed last
-    bool defer_wgrad = false;
-    hipStream_t st = nullptr;
-    // launches whatever the caller still holds back that the queued tasks read (the pipelined backward's pending source pass):
-    // a flush in the middle of a pass -- more than kMaxReduceTasks / kMaxWgradTasks queued, i.e. six or more layers -- would
-    // otherwise reduce partials and multiply rows that no kernel has written yet
-    std::function<int()> before_flush;
-    fn_adam_slice* rider = nullptr;         // fn_encoder.adam_rider: rides in the LAST deferred-reduction launch of the pass
-    int flush(bool last = false) {
-        if (before_flush) { if (int rc = before_flush()) return rc; }
-        if (int rc = flush_wgrad()) return rc;
-        const AdamRide R = make_adam_ride(last ? rider : nullptr, blocks, 1024, g_tune[FN_TUNE_RIDER_PIECES]);
-        if (T.n == 0 && R.nblk == 0) return 0;
-        hipLaunchKernelGGL(k_reduce_tasks, dim3(blocks + R.nblk), dim3(1024), 0, st, T, R);
-        T.n = 0;  blocks = 0;
-        const int rc = launch_status("deferred reductions");
-        if (rc == 0 && R.nblk > 0) rider->launched = 1;      // the caller's Adam launch may now skip the slice (fn_adam_slice.launched)
-        return rc;
-    }
-    int push(ReduceTask t, int nblk) {
-        if (T.n == kMaxReduceTasks) { if (int rc = flush()) return rc; }
-        t.first = blocks;  t.nblk = nblk;
-        T.first[T.n] = blocks;
-        last_index = T.n;
-        T.t[T.n++] = t;
-        blocks += nblk;
-        return 0;
-    }
-    // room for `tasks` more reductions and one more product in every group WITHOUT a flush in between: a deferred level's finalize
-    // task and its weight-gradient product must leave in the same pair of launches (the first reads what the second's partner wrote)
-    int reserve(int tasks) {
-        if (T.n + tasks > kMaxReduceTasks || W.n == kMaxWgradTasks || W0.n == kMaxWgradTasks) return flush();
-        return 0;
-    }
-    // up != null: the deferred form (ReduceTask::up); n_up is filled in when the level's weight-gradient product is queued (wgrad below)
-    int finalize(const float* part_a, int n_a, const float* part_e, int n_e, const fn_edge_term& et, const float* att, int att_w,
-                 int dst_off, int src_off, float* g_att, float* g_embW, float* g_embb, int H, const float* up = nullptr,
-                 const float* upW = nullptr, const float* upb = nullptr, int upK = 0) {
-        ReduceTask t{};
-        t.kind = RT_FINALIZE;  t.H = H;  t.p0 = part_a;  t.n0 = n_a;  t.p1 = part_e;  t.n1 = n_e;  t.et = et;
-        t.att = att;  t.att_w = att_w;  t.dst_off = dst_off;  t.src_off = src_off;  t.o0 = g_att;  t.o1 = g_embW;  t.o2 = g_embb;
-        t.up = up;  t.upW = upW;  t.upb = upb;  t.upK = upK;  t.n_up = 0;
-        return push(t, 2 * FN_D / 32 + (et.mode == 2 ? 1 : 0) + (up ? 4 : 0));
-    }
-    int colsum(const float* part, int n_rows, int cols, float* out, int ld, int off) {
-        ReduceTask t{};
-        t.kind = RT_COLSUM;  t.p0 = part;  t.n0 = n_rows;  t.o0 = out;  t.ld = ld;  t.off = off;
-        if (cols % 32) return fail(FN_EINVAL, "deferred column sum: column count must be a multiple of 32");
-        return push(t, cols / 32);
-    }
-    // dW [128,K], db [128] of a projection: partial kernel now (on `launch_on`), reduction with the rest
-    // gsd != null: the deferred term (WgradTask::gsd ..); fin: index in T of the level's RT_FINALIZE task (queued just before, reserve())
-    int wgrad(const float* dY, const float* X, int K, int64_t M, float* ws, float* dW, float* db, hipStream_t launch_on,
-              const int32_t* n_real = nullptr, const float* gsd = nullptr, const float* a_dst = nullptr, int att_w = 0, float* upart = nullptr,
-              int fin = -1) {
-        if (gsd && !(defer_wgrad && (K == FN_D ? g_tune[FN_TUNE_WGRAD_DIRECT] != 0 : (defer_mixed && K <= 192))))
-            return fail(FN_EUNSUPPORTED, "weight gradient: the deferred term needs the grouped direct kernels");
-        if (M == 0) {
-            hipLaunchKernelGGL(k_zero2_i32, dim3(flat_grid(128 * (K + 1), kGridCap)), dim3(kBlock), 0, launch_on,
-                               reinterpret_cast<int32_t*>(dW), (int64_t)128 * K, reinterpret_cast<int32_t*>(db), (int64_t)128);
-            return launch_status("weight gradient (empty)");
-        }
-        ReduceTask t{};
-        int grid = 0;
-        if (K == FN_D && defer_wgrad) {   // partial product joins the grouped launch in flush(); its block count is set there
-            if (W.n == kMaxWgradTasks || T.n == kMaxReduceTasks) { if (int rc = flush()) return rc; }
-            W.t[W.n] = WgradTask{dY, X, ws, M, 0, 0, 0, n_real, gsd, a_dst, att_w, upart};
-            w_fin[W.n] = gsd ? fin : -1;
-            w_reduce[W.n++] = T.n;
-            t.cls = g_tune[FN_TUNE_WGRAD_DIRECT] ? 4 : 2;
-        } else if (defer_wgrad && defer_mixed && K <= 192) {      // layer 0's products: one launch for them too (flush_wgrad)
-            if (W0.n == kMaxWgradTasks || T.n == kMaxReduceTasks) { if (int rc = flush()) return rc; }
-            // rows per block: a multiple of the per-product rule (FN_TUNE_WGRAD0_ROWS).  Fewer, longer blocks = fewer partial
-            // rows to write and to reduce: at 1 x layer 0's atom product alone wrote 217 partials of 98 KB (21 MB, more than the
-            // nine K = 128 products together).  2 x for it, 3 x for the narrow ones: -6 us per step; 3 x / 4 x for the wide one
-            // or 1 x for it lose (the long blocks become the launch's tail / the partial traffic is back)
-            const int tv = g_tune[FN_TUNE_WGRAD0_ROWS] > 0 ? g_tune[FN_TUNE_WGRAD0_ROWS] : 23;
-            const int mult = std::max(1, K > FN_D ? tv / 10 : tv % 10);          // tens: the wide product (atoms), units: the narrow ones
-            const int rpb = wgrad_rows_per_block(M) * mult;
-            grid = (int)((M + rpb - 1) / rpb);
-            W0.t[W0.n++] = WgradTask{dY, X, ws, M, rpb, w0blocks, K, n_real, gsd, a_dst, att_w, upart};
-            if (gsd && fin >= 0) T.t[fin].n_up = grid;
-            w0blocks += grid;
-            t.cls = K <= 32 ? 1 : K <= 128 ? 2 : 3;              // the instantiation k_linear128_wgrad_mixed runs for this K
-        } else if (int rc = wgrad_partials(dY, X, K, M, ws, launch_on, &grid, &t.cls)) return rc;
-        t.kind = RT_WGRAD;  t.p0 = ws;  t.n0 = grid;  t.K = K;  t.o0 = dW;  t.o1 = db;
-        // partial width of the instantiation that wrote them (the mixed launch runs K <= 16 in the K <= 32 class)
-        const int64_t pw = t.cls == 1 ? wgrad_part_width(32) : wgrad_part_width(K);
-        return push(t, (int)((pw + 1023) / 1024));
-    }
-    int flush_wgrad() {
-        size_t lds0 = 0;
-        if (W0.n) {
-            int kmax = 0;
-            for (int i = 0; i < W0.n; ++i) kmax = std::max(kmax, W0.t[i].K);
-            const int xw = kmax <= 32 ? 32 : kmax <= 128 ? 128 : 192;
-            lds0 = (size_t)2 * kWgChunk * (kBtLd + xw + 16) * sizeof(float);
-        }
-        if (W0.n && W.n && g_tune[FN_TUNE_WGRAD_DIRECT] == 1 && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0) {
-            // both groups in one launch (k_wgrad_all): block counts of the K = 128 group as below
-            int64_t total = 0;
-            for (int i = 0; i < W.n; ++i) total += W.t[i].M;
-            const int64_t target = g_tune[FN_TUNE_WGRAD_BLOCKS] > 0 ? g_tune[FN_TUNE_WGRAD_BLOCKS] : 256;
-            const int group_rpb = (int)(((total + target - 1) / target + kWgChunk - 1) / kWgChunk * kWgChunk);
-            wblocks = 0;
-            for (int i = 0; i < W.n; ++i) {
-                WgradTask& t = W.t[i];
-                t.rpb = std::max(group_rpb, wgrad_rows_per_block(t.M));
-                t.first = wblocks;
-                const int grid = (int)((t.M + t.rpb - 1) / t.rpb);
-                T.t[w_reduce[i]].n0 = grid;
-                if (w_fin[i] >= 0) T.t[w_fin[i]].n_up = grid;
-                wblocks += grid;
-            }
-            W.K = FN_D;
-            const size_t lds = std::max(lds0, (size_t)wd_lds_bytes<2>());
-            if (int rc = allow_lds(k_wgrad_all, lds)) return rc;
-            hipLaunchKernelGGL(k_wgrad_all, dim3(wblocks + w0blocks), dim3(512), lds, st, W, W0, wblocks);
-            W.n = 0;  wblocks = 0;  W0.n = 0;  w0blocks = 0;
-            return launch_status("weight-gradient partials (all products)");
-        }
-        if (W0.n) {
-            const size_t lds = lds0;
-            if (int rc = allow_lds(k_linear128_wgrad_mixed, lds)) return rc;
-            hipLaunchKernelGGL(k_linear128_wgrad_mixed, dim3(w0blocks), dim3(512), lds, st, W0);
-            W0.n = 0;  w0blocks = 0;
-            if (int rc = launch_status("weight-gradient partials (layer 0)")) return rc;
-        }
-        if (W.n == 0) return 0;
-        // rows per block from the WHOLE group: ~256 blocks (one per CU) instead of ~256 per product, which for the nine
-        // products of a backward pass was 1.6 k blocks writing 104 MB of 64-KB partials (now ~16 MB); never fewer rows
-        // than the per-product rule, so the partial workspace sized by fn_linear128_wgrad_ws still fits
-        int64_t total = 0;
-        for (int i = 0; i < W.n; ++i) total += W.t[i].M;
-        const int64_t target = g_tune[FN_TUNE_WGRAD_BLOCKS] > 0 ? g_tune[FN_TUNE_WGRAD_BLOCKS] : 256;
-        const int group_rpb = (int)(((total + target - 1) / target + kWgChunk - 1) / kWgChunk * kWgChunk);
-        wblocks = 0;
-        for (int i = 0; i < W.n; ++i) {
-            WgradTask& t = W.t[i];
-            t.rpb = std::max(group_rpb, wgrad_rows_per_block(t.M));
-            t.first = wblocks;
-            const int grid = (int)((t.M + t.rpb - 1) / t.rpb);
-            T.t[w_reduce[i]].n0 = grid;
-            if (w_fin[i] >= 0) T.t[w_fin[i]].n_up = grid;
-            wblocks += grid;
-        }
-        W.K = FN_D;
-        if (g_tune[FN_TUNE_WGRAD_DIRECT]) {
-            if (int rc = allow_lds(k_wgrad128_multi<2>, wd_lds_bytes<2>())) return rc;
-            hipLaunchKernelGGL(k_wgrad128_multi<2>, dim3(wblocks), dim3(wd_threads<2>()), wd_lds_bytes<2>(), st, W);
-        } else {
-            constexpr int XW = 16 * 4 * 2, XLD = XW + 16;
-            const size_t lds = (size_t)2 * kWgChunk * (kBtLd + XLD) * sizeof(float);
-            if (int rc = allow_lds(k_linear128_wgrad_multi<4, 2>, lds)) return rc;
-            hipLaunchKernelGGL((k_linear128_wgrad_multi<4, 2>), dim3(wblocks), dim3(512), lds, st, W);
-        }
-        W.n = 0;  wblocks = 0;
-        return launch_status("grouped weight-gradient partials");
-    }
-};
-
-// source pass of a level + backward of its edge term <feat[e], att[:, mid block]> as ONE launch (k_gat_bwd_src_rd); they
-// share nothing but their input dz.  *n_rd = blocks of the edge-term part (0: the level has no real edges).
-int bwd_src_and_edge_term(const float* g_out, const float* h, const float* pz_src, const float* g_s_dst, const float* att, int att_w,
-                          int dst_off, int src_off, const fn_gat_plan* plan, float* g_h, float* part_a, int* n_part_a,
-                          const float* dz_orig, const float* feat, int mid_off, float* g_feat, float* part_rd, bool accumulate,
-                          int* n_rd, int heads, hipStream_t st) {
-    GatBwdSrcArgs A;
-    if (int rc = prep_gat_bwd_src(g_out, h, pz_src, g_s_dst, att, att_w, dst_off, src_off, plan, g_h, part_a, n_part_a, heads, &A)) return rc;
-    *n_rd = plan->m_real > 0 ? row_grid(plan->m_real, g_tune[FN_TUNE_RD_BLOCKS] > 0 ? g_tune[FN_TUNE_RD_BLOCKS] : kRowDotsBwdBlocks) : 0;
-    if (*n_rd == 0) return launch_gat_bwd_src(A, heads, st);
-    const RowDotsBwdArgs T{dz_orig, feat, att, att_w, mid_off, heads, *plan, g_feat, part_rd, accumulate ? (const float*)g_feat : nullptr, 1, *n_rd};
-    if (A.nblk == 0) {
-        hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(T.nblk), dim3(kBlock), 0, st, T);
-        return launch_status("edge-term backward");
-    }
-    FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_src_rd<HH, kBwdRows>), dim3(A.nblk + T.nblk), dim3(kBlock), 0, st, A, T));
-    return launch_status("source pass + edge-term backward");
-}
-
-// GEMM tiles + edge-term blocks as one launch (k_lin_rd_cu: the dots ride in the products' epilogue; either part may be empty)
-static int launch_lin_rd(LinTasks& T, const RowDotsBwdArgs& R, hipStream_t st) {
-    int blocks = 0, live = 0;
-    bool aligned = true;
-    for (int i = 0; i < T.n; ++i) {
-        if (T.t[i].M <= 0) continue;
-        LinTask t = T.t[i];
-        if (((uintptr_t)t.X | (uintptr_t)t.Bt | (uintptr_t)t.Y | (uintptr_t)t.bias | (uintptr_t)t.mk.y) & 15) aligned = false;
-        t.first = blocks;
-        t.nblk = lin_blocks((t.M + kLinRows - 1) / kLinRows, 1);
-        blocks += t.nblk;
-        T.t[live++] = t;
-    }
-    T.n = live;  T.K = FN_D;  T.total = blocks;  T.base = 0;
-    if (!live) {
-        if (R.nblk) {
-            hipLaunchKernelGGL(k_row_dots_sorted_bwd, dim3(R.nblk), dim3(kBlock), 0, st, R);
-            return launch_status("edge-term backward");
-        }
-        return 0;
-    }
-    if (!aligned) return fail(FN_EINVAL, "input-gradient products: operands must be 16-byte aligned");
-    bool gs = false;
-    for (int i = 0; i < T.n; ++i) gs = gs || T.t[i].gs.dz != nullptr;
-    if (gs) hipLaunchKernelGGL(k_lin_rd_cu<true>, dim3(blocks + R.nblk), dim3(kBlock), kLinSideLdsGs, st, T, R);
-    else hipLaunchKernelGGL(k_lin_rd_cu<false>, dim3(blocks + R.nblk), dim3(kBlock), kLinSideLds, st, T, R);
-    return launch_status("input-gradient products (+ row dots) + edge-term backward");
-}
-
-int enc_check(const fn_encoder* e) {
-    if (!e) return fail(FN_EINVAL, "fn_encoder: null descriptor");
-    if (e->n_layers < 1 || e->n_layers > FN_MAX_LAYERS) return fail(FN_EINVAL, "fn_encoder: n_layers out of range");
-    if (e->heads != 1 && e->heads != 2 && e->heads != 4 && e->heads != 8) return fail(FN_EUNSUPPORTED, "fn_encoder: heads must be 1, 2, 4 or 8");
-    if (e->variant < 0 || e->variant > 2) return fail(FN_EUNSUPPORTED, "fn_encoder: variant must be 0 (gat2), 1 (gat2_lite) or 2 (gat2_edge)");
-    if (e->k_atom0 < 1 || e->k_atom0 > 168 || e->k_bond0 < 1 || e->k_bond0 > 168 || e->k_fbond0 < 1 || e->k_fbond0 > 168)
-        return fail(FN_EUNSUPPORTED, "fn_encoder: layer-0 feature widths must be in [1, 168]");
-    if (e->k_fattr < 1 || e->k_fattr > FN_MAX_EDGE_K) return fail(FN_EUNSUPPORTED, "fn_encoder: fragment-bond attribute width");
-    if (e->bond.n != e->E || e->atom.n != e->N || e->fbond.n != e->EF || e->frag.n != e->F || e->a2f.n_seg != e->F || e->a2f.n_items != e->N)
-        return fail(FN_EINVAL, "fn_encoder: plan sizes disagree with N/E/F/EF");
-    if (e->atom.m_real != e->E || e->frag.m_real != e->EF) return fail(FN_EINVAL, "fn_encoder: bond nodes must be the atom-graph edges");
-    if (!e->x_atoms || !e->bond_nodes || !e->fbond_nodes || !e->cos_sorted || !e->fattr_sorted || !e->ws)
-        return fail(FN_EINVAL, "fn_encoder: null input");
-    return 0;
-}
-
-int launch_tail_fwd(const fn_encoder* e, const EncLayout& lay, const LayerActs& a, const fn_layer_weights& w,
-                    const fn_act_epilogue& ep_frags, const float* y_atoms, hipStream_t st) {
-    const int H = e->heads, d = FN_D / H, wide = 2 * d + FN_D;
-    TailFwdArgs T{};
-    T.ext = reinterpret_cast<const MolExt*>(lay.mol_ext);  T.n_mols = (int)e->n_mols;  T.counts_dev = e->counts_dev;
-    T.atoms_new = lay.atoms_new;  T.a2f_rowptr = e->a2f.rowptr;  T.a2f_perm = e->a2f.perm;  T.a2f_base = e->a2f.pos_base;  T.a2f_items = (int)e->a2f.n_items;
-    T.frags = a.frags;  T.att = w.f;  T.att_w = wide;  T.dst_off = 0;  T.src_off = d + FN_D;  T.mid_off = d;
-    T.s_dst = lay.s_dst;  T.s_src = lay.s_src;  T.feat = a.new_fbond;  T.s_sorted = lay.s_sorted;
-    const fn_edge_term et_f{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
-    FN_TRY(prep_gat_fwd(a.frags, lay.s_dst, lay.s_src, w.f, wide, &et_f, &e->frag, 0.2f, nullptr, a.p_frag, nullptr, &ep_frags, H, &T.G));
-    T.y_atoms = y_atoms;  T.pooled = e->pooled;  T.force_global = g_tune[FN_TUNE_MOL_TAIL] == 2;
-    if (((uintptr_t)y_atoms | (uintptr_t)ep_frags.y | (uintptr_t)e->pooled) & 15) return fail(FN_EINVAL, "fragment tail: outputs must be 16-byte aligned");
-    const dim3 grid((unsigned)e->n_mols);
-    if (H == 2) hipLaunchKernelGGL((k_tail_fwd<2>), grid, dim3(kBlock), 0, st, T);
-    else if (H == 4) hipLaunchKernelGGL((k_tail_fwd<4>), grid, dim3(kBlock), 0, st, T);
-    else hipLaunchKernelGGL((k_tail_fwd<8>), grid, dim3(kBlock), 0, st, T);
-    return launch_status("fragment tail, molecule-resident (sums + fragment graph + readout)");
-}
-
-// partial rows written: one per molecule (*n_part), for rq.finalize (part_a) and rq.colsum (part_rd)
-int launch_tail_bwd(const fn_encoder* e, const LayerActs& a, const fn_layer_weights& w, const BwdLayout& bw, const float* y_atoms,
-                    const float* y_frags, const float* g_atoms, const float* g_frags, float gate_scale, bool accumulate_fbond,
-                    int* n_part, hipStream_t st, bool one_pass_dots = false, bool* rider_done = nullptr) {
-    const int H = e->heads, d = FN_D / H, wide = 2 * d + FN_D;
-    const LevelScratch& sf = bw.frag;
-    TailBwdArgs T{};
-    T.ext = reinterpret_cast<const MolExt*>(enc_layout(e, e->ws).mol_ext);  T.n_mols = (int)e->n_mols;  T.counts_dev = e->counts_dev;
-    T.g_atoms = g_atoms;  T.g_frags = g_frags;  T.g_pooled = e->g_pooled;  T.y_atoms = y_atoms;  T.y_frags = y_frags;  T.scale = gate_scale;
-    T.g_pre_atoms = bw.g_pre_atoms;  T.g_pre_frags = bw.g_pre_frags;  T.a2f_index = e->a2f.index;  T.n_atoms = e->N;  T.force_global = g_tune[FN_TUNE_MOL_TAIL] == 2;
-    const fn_edge_term et_f{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-    int n_e = 0, n_a = 0;
-    FN_TRY(prep_gat_bwd_dst(bw.g_pre_frags, a.frags, a.p_frag, &et_f, &e->frag, 0.2f, nullptr, sf.dz, sf.pz, sf.g_s_dst, nullptr, &n_e, H, &T.D));
-    FN_TRY(prep_gat_bwd_src(bw.g_pre_frags, a.frags, sf.pz, sf.g_s_dst, w.f, wide, 0, d + FN_D, &e->frag, bw.g_frags, sf.part_a, &n_a, H, &T.S));
-    T.R = RowDotsBwdArgs{sf.dz, a.new_fbond, w.f, wide, d, H, e->frag, bw.g_pre_fbond, sf.part_rd,
-                         accumulate_fbond ? (const float*)bw.g_pre_fbond : (const float*)nullptr, 1, 0};
-    if (one_pass_dots) {         // the last layer's atom and fragment-bond levels run the one-pass backward next: their rows' dots from here
-        const int l = e->n_layers - 1;
-        const EncLayout lay = enc_layout(e, e->ws);
-        T.cu_out = lay.atoms_new;  T.cu_out2 = a.o2_atom;  T.cu_sigma = a.sg_atom;  T.cu_c = bw.atom[l].cdot;  T.cu_u = bw.atom[l].g_s_dst;
-        if (H == 4) { T.R.cu_out2 = a.o2_fbond;  T.R.cu_sigma = a.sg_fbond;  T.R.cu_c = bw.fbond[l].cdot;  T.R.cu_u = bw.fbond[l].g_s_dst; }
-    }
-    if (((uintptr_t)y_atoms | (uintptr_t)y_frags | (uintptr_t)g_atoms | (uintptr_t)g_frags | (uintptr_t)e->g_pooled) & 15)
-        return fail(FN_EINVAL, "fragment tail backward: gradients must be 16-byte aligned");
-    // the first launch of the backward pass is latency-bound (one workgroup per molecule, 2 of 3 slots per CU taken): the head's Adam
-    // slice (fn_encoder.adam_rider) can stream beside it (FN_TUNE_RIDER_AT = 1; measured: this launch 18.5 -> 30.2 us, against
-    // 15.4 -> 22.5 us for the deferred-reduction launch, the default); *rider_done tells the caller
-    AdamRide R{};
-    if (rider_done) {
-        *rider_done = false;
-        if (g_tune[FN_TUNE_RIDER_AT] == 1 && e->adam_rider) {
-            R = make_adam_ride(e->adam_rider, (int)e->n_mols, kBlock, g_tune[FN_TUNE_RIDER_PIECES]);
-            *rider_done = R.nblk > 0;
-        }
-    }
-    const dim3 grid((unsigned)(e->n_mols + R.nblk));
-    if (H == 2) hipLaunchKernelGGL((k_tail_bwd<2>), grid, dim3(kBlock), 0, st, T, R);
-    else if (H == 4) hipLaunchKernelGGL((k_tail_bwd<4>), grid, dim3(kBlock), 0, st, T, R);
-    else hipLaunchKernelGGL((k_tail_bwd<8>), grid, dim3(kBlock), 0, st, T, R);
-    *n_part = (int)e->n_mols;
-    const int rc = launch_status("fragment tail backward, molecule-resident (gates + fragment graph + scatter to atoms)");
-    if (rc == 0 && R.nblk > 0) e->adam_rider->launched = 1;
-    return rc;
-}
-
-
-// ---- fn_encoder_backward with every attention level as ONE source-owner pass (csrc/gat_bwd_one.inc, FN_TUNE_BWD_ONE).
-// Gradient flows atom level -> bond levels only (through the edge term <new_bond[e], a[:, mid]>), so the atom level of layer l and
-// the bond / fragment-bond levels of layer l+1 are ready together: two launches per layer,
-//   L1  k_gat_bwd_one3 { bond level (l+1), atom level (l), fragment-bond level (l+1) }
-//   L2  k_lin_rd_cu    { dX of the atom projection (l) -> dL/d(atom rows of layer l-1); dX of the bond projection (l+1) + the atom
-//                        graph's edge-term gradient of layer l on the rows it writes (RowAdd) -> dL/d(bond rows of layer l); dX of
-//                        the fragment-bond projection (l+1) }  ||  the edge term's parameter partials,
-// and the products' epilogue (CuEpi) leaves the two node-local dots c = <g, out>, g_s_dst = <g, out2> - c sigma of every row it
-// finishes, which is all the next L1 needs besides the rows themselves.  Rows whose gradient is completed elsewhere (the last
-// layer's: by the fragment tail / the gates / the edge-term backward) get their dots from k_gat_cu.  Weight-gradient partial
-// products and parameter reductions are queued for the two launches at the very end, as in the two-pass path.
-int encoder_backward_one(const fn_encoder* e, const EncLayout& lay, const BwdLayout& bw, const RngPlan& rng, const float* out_atoms,
-                         const float* out_frags, const float* out_bond, const float* out_fbond, const float* g_atoms, const float* g_frags,
-                         const float* g_bond, const float* g_fbond, const fn_layer_weights* grads, hipStream_t hs) {
-    const int H = e->heads, d = FN_D / H, wide = 2 * d + FN_D, NL = e->n_layers;
-    const float p = e->training ? e->drop_p : 0.f;
-    const bool lite = e->variant == 1, edge = e->variant == 2, no_fb = lite || edge;
-    const float gate_scale = p > 0.f ? (p < 1.f ? 1.f / (1.f - p) : 0.f) : 1.f;
-    ReduceQueue rq;
-    rq.st = hs;
-    rq.defer_wgrad = true;
-    rq.defer_mixed = g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;
-    rq.rider = e->adam_rider;
-    const fn_edge_term et_a{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-    auto et_bond = [&](const fn_layer_weights& w) { return fn_edge_term{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b, lay.xs_bond}; };
-    auto et_fbond = [&](const fn_layer_weights& w) { return fn_edge_term{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b, lay.xs_fbond}; };
-    // a launch's resident workgroups are shared out among the levels it carries by their items (edges + rows: a bond row gathers
-    // twelve gradient rows where an atom row gathers four)
-    const int64_t one_total = g_tune[FN_TUNE_ONE_BLOCKS] > 0 ? g_tune[FN_TUNE_ONE_BLOCKS] : 768;
-    const int32_t* rr = pad_skip_on(e) ? reinterpret_cast<const int32_t*>(lay.real_rows) : nullptr;
-    const int32_t *nr_atoms = rr, *nr_bonds = rr ? rr + 1 : nullptr, *nr_conns = rr ? rr + 3 : nullptr;
-    const bool df = defer_on(e);
-    auto one_level = [&](const float* g_out, const float* h, const float* p_sorted, const fn_edge_term& et, const float* att, int att_w,
-                         int src_off, const fn_gat_plan& pl, const LevelScratch& sc, float* g_s_orig, int* n_a, int* n_e, GatBwdOneArgs* A,
-                         int64_t rows_in_launch) -> int {
-        // (sharing a fixed total out by items -- fewer, longer-lived workgroups -- measured 40-50 us against 33 for the launch of layer l)
-        const int64_t share = 0;  (void)rows_in_launch;  (void)one_total;
-        FN_TRY(prep_gat_bwd_one(g_out, h, p_sorted, sc.cdot, sc.g_s_dst, &et, att, att_w, 0, src_off, &pl, 0.2f, sc.g_h, nullptr, g_s_orig,
-                                sc.part_a, n_a, sc.part_e, n_e, H, A, share));
-        A->p_edge_major = 1;
-        A->n_real = &pl == &e->bond ? nr_bonds : (&pl == &e->atom ? nr_atoms : nr_conns);
-        if (df) A->dz_em = sc.dz_em;                        // the deferred form: dz at destination-order slots, no g_s_dst read
-        return 0;
-    };
-    // the deferred term of a level's g_h rows, for the product that reads them / the weight-gradient kernels (null: not deferred)
-    struct DeferTerm { const float* dz; const float* gsd_c; GsdEpi gs; const float* a_dst; int att_w; };
-    // z: the projection's slot in EncLayout::rmat (3 l + {0: bond, 1: atom, 2: fragment bond}; layer 0 has no product)
-    auto gs_of = [&](const fn_gat_plan& pl, const LevelScratch& sc, const float* att, int att_w, int z) {
-        if (!df || pl.m <= 0) return DeferTerm{nullptr, nullptr, GsdEpi{nullptr, nullptr, 0, nullptr, nullptr}, nullptr, 0};
-        return DeferTerm{sc.dz_em, sc.g_s_dst, GsdEpi{sc.dz_em, pl.rowptr_d, pl.pos_base_d, lay.rmat + (size_t)z * 512, sc.g_s_dst}, att, att_w};
-    };
-
-    bool have_atoms = false, have_bond = false, have_fbond = false;       // g_pre_* of the CURRENT layer complete, dots written
-    bool tail_dots_atoms = false, tail_dots_fbond = false;                // the fragment tail's launch wrote the last layer's dots
-    CuTasks cu_now{};         // rows of the current layer whose dots no product epilogue wrote
-    auto cu_add = [&](CuTasks& T, const float* g, const float* out, const float* out2, const float* sigma, const LevelScratch& sc, int64_t n) {
-        if (n > 0) T.t[T.n++] = CuTask{g, out, out2, sigma, 1.f, sc.cdot, sc.g_s_dst, n, 0, 0};
-    };
-
-    {   // ---- the last layer's output gradients: gates, the fragment levels, the scatter to the atoms
-        const int l = NL - 1;
-        const fn_layer_weights& w = e->w[l];
-        const fn_layer_weights& g = grads[l];
-        const LayerActs& a = lay.L[l];
-        const LevelScratch& sf = bw.frag;
-        const bool tail_mol = tail_mol_on(e) && (g_frags != nullptr || e->g_pooled != nullptr);
-        have_atoms = g_atoms != nullptr;  have_bond = g_bond != nullptr;  have_fbond = g_fbond != nullptr;
-        bool have_frags = g_frags != nullptr;
-        GateTasks G{};
-        auto add = [&](const float* gy, const float* y, float* o, int64_t numel) {
-            if (!gy) return;
-            GateTask& t = G.t[G.n++];
-            t.g = gy;  t.y = y;  t.o = o;  t.n4 = (numel + 3) / 4;  t.first = G.blocks;  t.nblk = flat_grid(t.n4, 512);
-            G.blocks += t.nblk;
-        };
-        if (!tail_mol) {
-            add(g_atoms, out_atoms, bw.g_pre_atoms, e->N * FN_D);
-            add(g_frags, out_frags, bw.g_pre_frags, e->F * FN_D);
-        }
-        add(g_bond, out_bond, bw.g_pre_bond, e->E * FN_D);
-        add(g_fbond, out_fbond, bw.g_pre_fbond, e->EF * FN_D);
-        if (G.blocks) {
-            G.scale = gate_scale;
-            hipLaunchKernelGGL(k_gate_many, dim3(G.blocks), dim3(kBlock), 0, hs, G);
-            FN_TRY(launch_status("fn_encoder_backward: activation backward"));
-        }
-        bool have_g_frags_h = false;
-        const float* g_frags_h = bw.g_frags;
-        int n_a = 0, n_e = 0;
-        if (tail_mol) {
-            int n_part = 0;
-            bool rode = false;
-            FN_TRY(launch_tail_bwd(e, a, w, bw, out_atoms, out_frags, g_atoms, g_frags, gate_scale, have_fbond, &n_part, hs, true, &rode));
-            if (rode) rq.rider = nullptr;          // the head's Adam slice went with this launch
-            const fn_edge_term et_f{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-            FN_TRY(rq.finalize(bw.frag.part_a, n_part, nullptr, 0, et_f, w.f, wide, 0, d + FN_D, g.f, nullptr, nullptr, H));
-            FN_TRY(rq.colsum(bw.frag.part_rd, n_part, H * FN_D, g.f, wide, d));
-            have_atoms = have_fbond = true;
-            tail_dots_atoms = true;  tail_dots_fbond = H == 4;
-        } else if (have_frags && lite) {
-            g_frags_h = bw.g_pre_frags;
-            have_g_frags_h = true;
-        } else if (have_frags && edge) {
-            fn_edge_term et_f{2, e->k_fattr, FN_D, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_frags, a.frags, a.p_frag, &et_f, &e->frag, 0.2f, nullptr, nullptr, sf.pz, sf.g_s_dst, sf.part_e, &n_e, H, hs));
-            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_frags, a.frags, sf.pz, sf.g_s_dst, w.f, wide, 0, d + FN_D, &e->frag, bw.g_frags, sf.part_a, &n_a, H, hs));
-            FN_TRY(rq.finalize(sf.part_a, n_a, sf.part_e, n_e, et_f, w.f, wide, 0, d + FN_D, g.f, g.emb_fb_w, g.emb_fb_b, H));
-            have_g_frags_h = true;
-        } else if (have_frags) {
-            fn_edge_term et_f{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_frags, a.frags, a.p_frag, &et_f, &e->frag, 0.2f, nullptr, sf.dz, sf.pz, sf.g_s_dst, nullptr, &n_e, H, hs));
-            int gr = 0;
-            FN_TRY(bwd_src_and_edge_term(bw.g_pre_frags, a.frags, sf.pz, sf.g_s_dst, w.f, wide, 0, d + FN_D, &e->frag, bw.g_frags, sf.part_a, &n_a,
-                                         sf.dz, a.new_fbond, d, bw.g_pre_fbond, sf.part_rd, have_fbond, &gr, H, hs));
-            if (gr) have_fbond = true;
-            FN_TRY(rq.finalize(sf.part_a, n_a, nullptr, 0, et_f, w.f, wide, 0, d + FN_D, g.f, nullptr, nullptr, H));
-            if (gr) FN_TRY(rq.colsum(sf.part_rd, gr, H * FN_D, g.f, wide, d));
-            have_g_frags_h = true;
-        }
-        if (have_g_frags_h) {
-            hipLaunchKernelGGL(k_gather_rows4, dim3(flat_grid(e->N * 32, kGridCap)), dim3(kBlock), 0, hs, g_frags_h, e->a2f.index,
-                               bw.g_pre_atoms, e->N, (int64_t)32, have_atoms ? (const float*)bw.g_pre_atoms : (const float*)nullptr);
-            FN_TRY(launch_status("fn_encoder_backward: gather(a2f)"));
-            have_atoms = true;
-        }
-        if (no_fb) have_fbond = false;
-        if (have_atoms && !tail_dots_atoms) cu_add(cu_now, bw.g_pre_atoms, lay.atoms_new, a.o2_atom, a.sg_atom, bw.atom[l], e->N);
-    }
-
-    GsdSegTasks seg0{};       // deferred form: layer 0's levels have no input-gradient product to form g_s_dst in: k_gsd_seg at the end
-    bool pend_b = false, pend_fb = false;        // bond / fragment-bond level of layer l+1: gradient rows and dots ready, pass not launched
-    for (int l = NL - 1; l >= 0; --l) {
-        const fn_layer_weights& w = e->w[l];
-        const fn_layer_weights& g = grads[l];
-        const LayerActs& a = lay.L[l];
-        const bool last = l + 1 == NL;
-        const float* in_atoms = l ? lay.L[l - 1].y_atoms : (lay.in_atoms0 ? lay.in_atoms0 : e->x_atoms);
-        const int ka = l ? FN_D : e->k_atom0;
-        const LevelScratch& sa = bw.atom[l];
-        if (cu_now.n) { FN_TRY(launch_gat_cu(cu_now, H, hs));  cu_now = CuTasks{}; }
-
-        // ---- L1: the atom level of this layer beside the bond / fragment-bond levels of layer l+1
-        GatBwdOneArgs oB{}, oA{}, oFB{};
-        int na_b = 0, ne_b = 0, na_a = 0, ne_a = 0, na_fb = 0, ne_fb = 0;
-        const int64_t rows_l1 = (pend_b ? e->bond.m + e->E : 0) + (have_atoms ? e->atom.m + e->N : 0) + (pend_fb ? e->fbond.m + e->EF : 0);
-        if (pend_b) {
-            const fn_layer_weights& wn = e->w[l + 1];
-            FN_TRY(one_level(bw.g_pre_bond, lay.L[l + 1].h_b, lay.L[l + 1].p_bond, et_bond(wn), wn.a_b, 3 * d, 2 * d, e->bond, bw.bond[l + 1], nullptr, &na_b, &ne_b, &oB, rows_l1));
-        }
-        if (have_atoms) FN_TRY(one_level(bw.g_pre_atoms, a.h_a, a.p_atom, et_a, w.a, wide, d + FN_D, e->atom, sa, sa.dz, &na_a, &ne_a, &oA, rows_l1));
-        if (pend_fb) {
-            const fn_layer_weights& wn = e->w[l + 1];
-            FN_TRY(one_level(bw.g_pre_fbond, lay.L[l + 1].h_fb, lay.L[l + 1].p_fbond, et_fbond(wn), wn.f_a_b, 3 * d, 2 * d, e->fbond, bw.fbond[l + 1], nullptr, &na_fb, &ne_fb, &oFB, rows_l1));
-        }
-        FN_TRY(launch_gat_bwd_one3(oB, oA, oFB, H, hs));
-
-        // ---- L2: input-gradient products of what L1 produced (+ the atom graph's edge term), and the deferred parameter work
-        LinTasks T{};
-        CuTasks cu_after{};       // rows finished in L2 whose dots the epilogue could not write
-        auto product = [&](const float* gh, const float* W, const float* Wt, float* gy, int64_t rows, const fn_act_epilogue& mk, const RowAdd* ra,
-                           const CuEpi& cu, const int32_t* n_real, const GsdEpi& gs) {
-            LinTask& t = T.t[T.n++];
-            t = LinTask{Wt, gh, W, nullptr, gy, rows, mk, NodeScalarEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0}, 0, 0};
-            if (ra) t.ra = *ra;
-            t.cu = cu;
-            t.gs = gs;
-            t.n_real = n_real;
-        };
-        bool nxt_bond = false, nxt_fbond = false, nxt_atoms = false;
-        const bool rd_rows_ride = have_atoms && pend_b && H == 4 && e->atom.m_real == e->E && e->E > 0;   // the bond product of layer l+1 carries the rows' term
-        const int gr = have_atoms && e->atom.m_real > 0 ? row_grid(e->atom.m_real, g_tune[FN_TUNE_RD_BLOCKS] > 0 ? g_tune[FN_TUNE_RD_BLOCKS] : kRowDotsBwdBlocks) : 0;
-        if (pend_b) {        // layer l+1's bond level: parameter work + dL/d(pre-activation bond output of layer l)
-            const fn_layer_weights& wn = e->w[l + 1];
-            const fn_layer_weights& gn = grads[l + 1];
-            const LevelScratch& sb = bw.bond[l + 1];
-            const DeferTerm gsb = gs_of(e->bond, sb, wn.a_b, 3 * d, 3 * (l + 1));
-            FN_TRY(rq.reserve(2));
-            FN_TRY(rq.finalize(sb.part_a, na_b, sb.part_e, ne_b, et_bond(wn), wn.a_b, 3 * d, 0, 2 * d, gn.a_b, gn.emb_b_w, gn.emb_b_b, H,
-                               gsb.dz ? sb.upart : nullptr, wn.proj_b_w, wn.proj_b_b, FN_D));
-            FN_TRY(rq.wgrad(sb.g_h, a.y_bond, FN_D, e->E, sb.wg_ws, gn.proj_b_w, gn.proj_b_b, hs, nr_bonds, gsb.gsd_c, gsb.a_dst, gsb.att_w, sb.upart, rq.last_index));
-            const fn_act_epilogue mk{const_cast<float*>(a.y_bond), p, 1, e->seed, rng.y[l][2], e->offset_dev};
-            const RowAdd ra{sa.dz, w.a + d, wide};
-            // the rows are complete in this epilogue unless the edge term's rows' part is added behind the product (no RowAdd carrier)
-            const bool complete = rd_rows_ride || gr == 0;
-            const CuEpi cu{a.new_bond, a.o2_bond, a.sg_bond, complete ? bw.bond[l].cdot : nullptr, bw.bond[l].g_s_dst, H};
-            product(sb.g_h, wn.proj_b_w, lay.bt + (size_t)(3 * (l + 1)) * 192 * FN_D, bw.g_pre_bond, e->E, mk, rd_rows_ride ? &ra : nullptr, cu, nr_bonds, gsb.gs);
-            if (!complete) cu_add(cu_after, bw.g_pre_bond, a.new_bond, a.o2_bond, a.sg_bond, bw.bond[l], e->E);
-            nxt_bond = true;
-        }
-        if (pend_fb) {
-            const fn_layer_weights& wn = e->w[l + 1];
-            const fn_layer_weights& gn = grads[l + 1];
-            const LevelScratch& sfb = bw.fbond[l + 1];
-            const DeferTerm gsf = gs_of(e->fbond, sfb, wn.f_a_b, 3 * d, 3 * (l + 1) + 2);
-            FN_TRY(rq.reserve(2));
-            FN_TRY(rq.finalize(sfb.part_a, na_fb, sfb.part_e, ne_fb, et_fbond(wn), wn.f_a_b, 3 * d, 0, 2 * d, gn.f_a_b, gn.emb_fb_w, gn.emb_fb_b, H,
-                               gsf.dz ? sfb.upart : nullptr, wn.proj_fb_w, wn.proj_fb_b, FN_D));
-            FN_TRY(rq.wgrad(sfb.g_h, a.y_fbond, FN_D, e->EF, sfb.wg_ws, gn.proj_fb_w, gn.proj_fb_b, hs, nr_conns, gsf.gsd_c, gsf.a_dst, gsf.att_w, sfb.upart, rq.last_index));
-            const fn_act_epilogue mk{const_cast<float*>(a.y_fbond), p, 1, e->seed, rng.y[l][3], e->offset_dev};
-            // this layer's fragment-bond rows get gradient through relu(dropout(.)) only (the fragment graph's edge term exists in the
-            // last layer alone): the gate's saved output stands in for the raw row
-            const CuEpi cu{nullptr, a.o2_fbond, a.sg_fbond, bw.fbond[l].cdot, bw.fbond[l].g_s_dst, H};
-            product(sfb.g_h, wn.proj_fb_w, lay.bt + (size_t)(3 * (l + 1) + 2) * 192 * FN_D, bw.g_pre_fbond, e->EF, mk, nullptr, cu, nr_conns, gsf.gs);
-            nxt_fbond = true;
-        }
-        RowDotsBwdArgs R{};
-        if (have_atoms) {
-            const DeferTerm gsa = gs_of(e->atom, sa, w.a, wide, 3 * l + 1);
-            // (layer 0 has no input-gradient product to form g_s_dst in: k_gsd_seg at the end of the pass, which also leaves dL/da_dst)
-            const bool seg_a = gsa.dz && l == 0 && na_a > 0;
-            if (seg_a) seg0.t[seg0.n++] = GsdSegTask{sa.dz_em, e->atom.rowptr_d, e->atom.pos_base_d, e->N, sa.g_s_dst, nr_atoms, a.h_a, sa.part_a, 0, na_a};
-            const bool up_a = gsa.dz && !seg_a;
-            FN_TRY(rq.reserve(2));
-            FN_TRY(rq.finalize(sa.part_a, na_a, nullptr, 0, et_a, w.a, wide, 0, d + FN_D, g.a, nullptr, nullptr, H,
-                               up_a ? sa.upart : nullptr, w.proj_a_w, w.proj_a_b, ka));
-            FN_TRY(rq.wgrad(sa.g_h, in_atoms, ka, e->N, sa.wg_ws, g.proj_a_w, g.proj_a_b, hs, nr_atoms, gsa.gsd_c, gsa.a_dst, gsa.att_w,
-                            up_a ? sa.upart : nullptr, rq.last_index));
-            if (l) {
-                const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_atoms), p, 1, e->seed, rng.y[l - 1][0], e->offset_dev};
-                const CuEpi cu{nullptr, lay.L[l - 1].o2_atom, lay.L[l - 1].sg_atom, bw.atom[l - 1].cdot, bw.atom[l - 1].g_s_dst, H};
-                product(sa.g_h, w.proj_a_w, lay.bt + (size_t)(3 * l + 1) * 192 * FN_D, bw.g_pre_atoms, e->N, mk, nullptr, cu, nr_atoms, gsa.gs);
-                nxt_atoms = true;
-            }
-            // the edge term <new_bond[e], a[:, d:d+128]> of the atom graph: parameter partials always; the rows' term (dL/dnew_bond)
-            // rides in the bond product above, or -- no product to ride in (top layer, H != 4) -- is written / accumulated here
-            if (gr) {
-                const bool have_b_now = pend_b || (last && have_bond);
-                R = RowDotsBwdArgs{sa.dz, a.new_bond, w.a, wide, d, H, e->atom, rd_rows_ride ? nullptr : bw.g_pre_bond, sa.part_rd,
-                                   (!rd_rows_ride && have_b_now) ? (const float*)bw.g_pre_bond : nullptr, 1, gr};
-                R.n_real = nr_bonds;
-                FN_TRY(rq.colsum(sa.part_rd, gr, H * FN_D, g.a, wide, d));
-                if (!pend_b) {
-                    // the bond rows of this layer are finished by the edge term's rows' part: with four heads it writes their dots too
-                    if (H == 4 && e->atom.m_real == e->E) { R.cu_out2 = a.o2_bond;  R.cu_sigma = a.sg_bond;  R.cu_c = bw.bond[l].cdot;  R.cu_u = bw.bond[l].g_s_dst; }
-                    else cu_add(cu_after, bw.g_pre_bond, a.new_bond, a.o2_bond, a.sg_bond, bw.bond[l], e->E);
-                }
-                nxt_bond = true;
-            }
-        }
-        if (R.nblk && !rd_rows_ride && pend_b) {
-            // (no RowAdd carrier: the product first, the rows' term accumulates behind it)
-            FN_TRY(launch_lin_rd(T, RowDotsBwdArgs{}, hs));
-            T = LinTasks{};
-        }
-        FN_TRY(launch_lin_rd(T, R, hs));
-
-        // ---- what the next iteration's L1 finds
-        if (last) {
-            if (have_bond && !nxt_bond) cu_add(cu_after, bw.g_pre_bond, a.new_bond, a.o2_bond, a.sg_bond, bw.bond[l], e->E);
-            if (have_fbond && !tail_dots_fbond) cu_add(cu_after, bw.g_pre_fbond, a.new_fbond, a.o2_fbond, a.sg_fbond, bw.fbond[l], e->EF);
-            nxt_bond = nxt_bond || have_bond;
-            nxt_fbond = nxt_fbond || have_fbond;
-        }
-        pend_b = nxt_bond;
-        pend_fb = nxt_fbond && !no_fb;
-        have_atoms = nxt_atoms;
-        have_bond = have_fbond = false;
-        cu_now = cu_after;
-    }
-    {   // the bond / fragment-bond levels of layer 0
-        if (cu_now.n) FN_TRY(launch_gat_cu(cu_now, H, hs));
-        const fn_layer_weights& w0 = e->w[0];
-        const fn_layer_weights& g0 = grads[0];
-        GatBwdOneArgs oB{}, oFB{};
-        int na_b = 0, ne_b = 0, na_fb = 0, ne_fb = 0;
-        const int64_t rows_l1 = (pend_b ? e->bond.m + e->E : 0) + (pend_fb ? e->fbond.m + e->EF : 0);
-        if (pend_b) FN_TRY(one_level(bw.g_pre_bond, lay.L[0].h_b, lay.L[0].p_bond, et_bond(w0), w0.a_b, 3 * d, 2 * d, e->bond, bw.bond[0], nullptr, &na_b, &ne_b, &oB, rows_l1));
-        if (pend_fb) FN_TRY(one_level(bw.g_pre_fbond, lay.L[0].h_fb, lay.L[0].p_fbond, et_fbond(w0), w0.f_a_b, 3 * d, 2 * d, e->fbond, bw.fbond[0], nullptr, &na_fb, &ne_fb, &oFB, rows_l1));
-        FN_TRY(prof_event(2, hs));
-        FN_TRY(launch_gat_bwd_one3(oB, GatBwdOneArgs{}, oFB, H, hs));
-        FN_TRY(prof_event(3, hs));
-        const DeferTerm gsb = gs_of(pend_b ? e->bond : fn_gat_plan{}, bw.bond[0], w0.a_b, 3 * d, 0);
-        const DeferTerm gsf = gs_of(pend_fb ? e->fbond : fn_gat_plan{}, bw.fbond[0], w0.f_a_b, 3 * d, 2);
-        if (gsb.dz && na_b > 0) seg0.t[seg0.n++] = GsdSegTask{gsb.dz, e->bond.rowptr_d, e->bond.pos_base_d, e->E, bw.bond[0].g_s_dst, nr_bonds, lay.L[0].h_b, bw.bond[0].part_a, 0, na_b};
-        if (gsf.dz && na_fb > 0) seg0.t[seg0.n++] = GsdSegTask{gsf.dz, e->fbond.rowptr_d, e->fbond.pos_base_d, e->EF, bw.fbond[0].g_s_dst, nr_conns, lay.L[0].h_fb, bw.fbond[0].part_a, 0, na_fb};
-        if (seg0.n) {         // g_s_dst and dL/da_dst of layer 0's levels (the inner layers' come out of their products' epilogues and the
-            int blocks = 0;   // weight-gradient kernels' side product): one small launch, a block per block of the level's pass
-            for (int i = 0; i < seg0.n; ++i) {
-                // (any block count up to the pass's own: the pass left zeros in the rows of part_a this launch does not overwrite.  Fewer,
-                // longer blocks: every block ends with 128 scattered 4-byte stores into the column-major partials)
-                seg0.t[i].nblk = std::min(seg0.t[i].nblk, std::max(1, g_tune[FN_TUNE_SRC_BLOCKS]));
-                seg0.t[i].first = blocks;
-                blocks += seg0.t[i].nblk;
-            }
-            FN_TRY(launch_gsd_seg(seg0, blocks, hs));
-            FN_TRY(launch_status("one-pass backward, deferred form: g_s_dst of layer 0"));
-        }
-        if (pend_b) {
-            FN_TRY(rq.reserve(2));
-            FN_TRY(rq.finalize(bw.bond[0].part_a, na_b, bw.bond[0].part_e, ne_b, et_bond(w0), w0.a_b, 3 * d, 0, 2 * d, g0.a_b, g0.emb_b_w, g0.emb_b_b, H));
-            FN_TRY(rq.wgrad(bw.bond[0].g_h, e->bond_nodes, e->k_bond0, e->E, bw.bond[0].wg_ws, g0.proj_b_w, g0.proj_b_b, hs, nr_bonds,
-                            gsb.gsd_c, gsb.a_dst, gsb.att_w, nullptr, -1));
-        }
-        if (pend_fb) {
-            FN_TRY(rq.reserve(2));
-            FN_TRY(rq.finalize(bw.fbond[0].part_a, na_fb, bw.fbond[0].part_e, ne_fb, et_fbond(w0), w0.f_a_b, 3 * d, 0, 2 * d, g0.f_a_b, g0.emb_fb_w, g0.emb_fb_b, H));
-            FN_TRY(rq.wgrad(bw.fbond[0].g_h, e->fbond_nodes, e->k_fbond0, e->EF, bw.fbond[0].wg_ws, g0.proj_fb_w, g0.proj_fb_b, hs, nr_conns,
-                            gsf.gsd_c, gsf.a_dst, gsf.att_w, nullptr, -1));
-        }
-    }
-    return rq.flush(true);
-}
-
-
-}  // namespace
-
-extern "C" {
-
-int fn_encoder_fused_tail(const fn_encoder* e) { return e && tail_mol_on(e) ? 1 : 0; }
-
-int64_t fn_encoder_ws_floats(const fn_encoder* e) { return e ? enc_layout(e, nullptr).total : 0; }
-int64_t fn_encoder_bwd_ws_floats(const fn_encoder* e) { return e ? bwd_layout(e, nullptr).total : 0; }
-uint64_t fn_encoder_rng_blocks(const fn_encoder* e) { return e ? rng_plan(e).total : 0; }
-
-int fn_encoder_forward(const fn_encoder* e, float* out_atoms, float* out_frags, float* out_bond, float* out_fbond,
-                       fn_stream_t st) {
-    FN_TRY(enc_check(e));
-    if (!out_atoms || !out_frags || !out_bond || !out_fbond) return fail(FN_EINVAL, "fn_encoder_forward: null output");
-    if (e->pooled && !tail_mol_on(e)) return fail(FN_EINVAL, "fn_encoder_forward: the readout is only produced by the fused fragment tail (fn_encoder_fused_tail)");
-    const EncLayout lay = enc_layout(e, e->ws);
-    if (lay.total > e->ws_floats) return fail(FN_EINVAL, "fn_encoder_forward: workspace too small");
-    latch_form(e);
-    const RngPlan rng = rng_plan(e);
-    const int H = e->heads, d = FN_D / H;
-    const float p = e->training ? e->drop_p : 0.f;
-    const int wide = 2 * d + FN_D;             // width of a / f
-    const bool lite = e->variant == 1, edge = e->variant == 2;      // gat2_lite / gat2_edge: neither has a fragment-bond graph
-    const bool no_fb = lite || edge;
-    // the atom graph's edge term <new_bond, a[:, d:d+128]> is produced by the bond-graph kernel's epilogue (one launch less per layer)
-    const bool fuse_rd = g_tune[FN_TUNE_FUSE_ROWDOTS] != 0 && e->atom.m > 0 && e->atom.m_real == e->E;
-    // projections ride along with the attention launches they do not depend on (k_gat_*_lin); needs the node scalars in the GEMM epilogue
-    const bool colaunch = H >= 2 && g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;
-    const fn_act_epilogue no_act_l{nullptr, 0.f, 0, 0, 0, nullptr};
-    // the backward will be one source-owner pass per level: the attention kernels also write out2 / sigma, probabilities edge-major
-    const bool one = one_pass_on(e);
-    // real rows per index space (device words written by the prologue below): the kernels skip the padding behind them
-    const int32_t* rr = pad_skip_on(e) ? reinterpret_cast<const int32_t*>(lay.real_rows) : nullptr;
-    const int32_t *nr_atoms = rr, *nr_bonds = rr ? rr + 1 : nullptr, *nr_conns = rr ? rr + 3 : nullptr;
-
-    const float* in_atoms = lay.in_atoms0 ? lay.in_atoms0 : e->x_atoms;
-    const float* in_bond = e->bond_nodes;
-    const float* in_fbond = e->fbond_nodes;
-    int ka = e->k_atom0, kb = e->k_bond0, kfb = e->k_fbond0;
-
-    {   // one launch: W^T of every projection, dropout(x_atoms), destination-order edge attributes
-        EncPrologue A{};
-        for (int l = 0; l < e->n_layers; ++l) {
-            A.tm.W[3 * l] = e->w[l].proj_b_w;       A.tm.K[3 * l] = l ? FN_D : e->k_bond0;
-            A.tm.W[3 * l + 1] = e->w[l].proj_a_w;   A.tm.K[3 * l + 1] = l ? FN_D : e->k_atom0;
-            A.tm.W[3 * l + 2] = e->w[l].proj_fb_w;  A.tm.K[3 * l + 2] = l ? FN_D : e->k_fbond0;
-            if (!A.tm.W[3 * l] || !A.tm.W[3 * l + 1] || !A.tm.W[3 * l + 2]) return fail(FN_EINVAL, "fn_encoder_forward: null projection weight");
-        }
-        A.bt_base = lay.bt;
-        A.n_t = 24 * 3 * e->n_layers;
-        if (lay.in_atoms0) {
-            A.dx = e->x_atoms;  A.dy = lay.in_atoms0;  A.dnumel = e->N * e->k_atom0;  A.p = p;  A.seed = e->seed;
-            A.offset = rng.in_atoms;  A.offset_dev = e->offset_dev;
-            A.n_d = flat_grid((A.dnumel + 3) / 4, 512);
-        }
-        if (e->cos_raw && e->bond.m > 0) {
-            A.sx[0] = e->cos_raw;  A.so[0] = const_cast<float*>(e->cos_sorted);  A.sK[0] = 1;  A.spl[0] = e->bond;
-            A.n_s[0] = flat_grid(e->bond.m, 512);
-        }
-        const fn_gat_plan& fattr_plan = edge ? e->frag : e->fbond;     // gat2_edge: cnx_attr rides on the fragment graph's edges
-        if (e->fattr_raw && fattr_plan.m > 0) {
-            A.sx[1] = e->fattr_raw;  A.so[1] = const_cast<float*>(e->fattr_sorted);  A.sK[1] = e->k_fattr;  A.spl[1] = fattr_plan;
-            A.n_s[1] = flat_grid(fattr_plan.m * e->k_fattr, 512);
-        }
-        if (one) {
-            if (e->bond.m > 0) {
-                A.ssr[0] = e->cos_raw;  A.sss[0] = e->cos_sorted;  A.sso[0] = lay.xs_bond;  A.sK[0] = 1;  A.spl[0] = e->bond;
-                A.n_ss[0] = flat_grid(e->bond.m, 512);
-            }
-            if (!no_fb && e->fbond.m > 0) {
-                A.ssr[1] = e->fattr_raw;  A.sss[1] = e->fattr_sorted;  A.sso[1] = lay.xs_fbond;  A.sK[1] = e->k_fattr;  A.spl[1] = e->fbond;
-                A.n_ss[1] = flat_grid(e->fbond.m * e->k_fattr, 512);
-            }
-        }
-        if (tail_mol_on(e) || pad_skip_on(e)) {
-            A.mx = MolExtArgs{e->mol_atoms.rowptr, e->mol_frags.rowptr, e->mol_atoms.pos_base, e->mol_frags.pos_base,
-                              e->bond, e->atom, no_fb ? fn_gat_plan{} : e->fbond, e->frag, (int)e->n_mols,
-                              reinterpret_cast<MolExt*>(lay.mol_ext), e->counts_dev, reinterpret_cast<int32_t*>(lay.real_rows)};
-            A.n_x = (int)((e->n_mols + 255) / 256);
-        }
-        if (fuse_rd) {
-            A.zp = lay.s_sorted;  A.zn = e->atom.m * H;  A.n_z = flat_grid(A.zn, 64);
-        }
-        if (defer_on(e)) {        // R of every K = 128 projection (layers >= 1): slot 3 l + {0: bond, 1: atom, 2: fragment bond}
-            for (int l = 1; l < e->n_layers; ++l) {
-                const fn_layer_weights& wl = e->w[l];
-                A.rW[3 * l] = wl.proj_b_w;       A.rA[3 * l] = wl.a_b;        A.rAw[3 * l] = 3 * d;
-                A.rW[3 * l + 1] = wl.proj_a_w;   A.rA[3 * l + 1] = wl.a;      A.rAw[3 * l + 1] = wide;
-                A.rW[3 * l + 2] = wl.proj_fb_w;  A.rA[3 * l + 2] = wl.f_a_b;  A.rAw[3 * l + 2] = 3 * d;
-            }
-            A.rOut = lay.rmat;
-            A.n_r = 2 * 3 * e->n_layers;
-        }
-        hipLaunchKernelGGL(k_enc_prologue, dim3(A.n_t + A.n_d + A.n_s[0] + A.n_s[1] + A.n_ss[0] + A.n_ss[1] + A.n_z + A.n_x + A.n_r), dim3(256), 0, S(st), A);
-        FN_TRY(launch_status("fn_encoder_forward: prologue"));
-    }
-
-    for (int l = 0; l < e->n_layers; ++l) {
-        const fn_layer_weights& w = e->w[l];
-        const LayerActs& a = lay.L[l];
-        const bool last = l + 1 == e->n_layers;
-        const float* bt_b = lay.bt + (size_t)(3 * l) * 192 * FN_D;
-        const float* bt_a = lay.bt + (size_t)(3 * l + 1) * 192 * FN_D;
-        const float* bt_fb = lay.bt + (size_t)(3 * l + 2) * 192 * FN_D;
-
-        float* y_atoms = last ? out_atoms : a.y_atoms;
-        float* y_frags = last ? out_frags : a.y_frags;
-        float* y_bond = last ? out_bond : a.y_bond;
-        float* y_fbond = last ? out_fbond : a.y_fbond;
-        // act(dropout(.)) of the four layer outputs rides in the producing kernels' epilogues
-        const fn_act_epilogue ep_atoms{y_atoms, p, 1, e->seed, rng.y[l][0], e->offset_dev}, ep_frags{y_frags, p, 1, e->seed, rng.y[l][1], e->offset_dev};
-        const fn_act_epilogue ep_bond{y_bond, p, 1, e->seed, rng.y[l][2], e->offset_dev}, ep_fbond{y_fbond, p, 1, e->seed, rng.y[l][3], e->offset_dev};
-        // L1 bond graph
-        const bool fuse_ns = H >= 2;         // a head's columns fit one wave's 64-column half for H >= 2
-        auto project = [&](const float* x, int k, const float* bt, const float* bias, float* hout, int64_t rows,
-                           const float* att, int att_w, int src_off, float* sdst, float* ssrc, fn_stream_t sq) -> int {
-            if (fuse_ns) return linear128_impl(x, k, bt, bias, hout, rows, nullptr, NodeScalarEpi{att, sdst, ssrc, att_w, 0, src_off, H}, sq);
-            FN_TRY(fn_linear128_f32(x, k, bt, bias, hout, rows, nullptr, sq));
-            return fn_node_scalars_f32(hout, att, att_w, 0, src_off, sdst, ssrc, rows, H, sq);
-        };
-        // layers >= 1: the three projections (K = 128) depend only on the previous layer.  With co-launching (FN_TUNE_GEMM_COLAUNCH)
-        // the bond / fragment-bond projections already ran beside the previous layer's atom level and the atom projection rides
-        // with this layer's bond levels below; otherwise one grouped launch for the three
-        const bool grouped = l > 0 && fuse_ns;
-        bool atoms_projected = false;
-        const fn_act_epilogue no_act{nullptr, 0.f, 0, 0, 0, nullptr};
-        LinTasks with_pair{};                      // rides with the bond + fragment-bond launch of this layer
-        if (grouped && colaunch) {
-            with_pair.n = 1;
-            with_pair.t[0] = LinTask{w.proj_a_w, in_atoms, bt_a, w.proj_a_b, a.h_a, e->N, no_act,
-                                     NodeScalarEpi{w.a, lay.s_dst_a, lay.s_src_a, wide, 0, d + FN_D, H}, 0, 0};
-            with_pair.t[0].n_real = nr_atoms;
-        } else if (grouped) {
-            LinTasks T{};
-            T.n = no_fb ? 2 : 3;
-            T.t[0] = LinTask{w.proj_b_w, in_bond, bt_b, w.proj_b_b, a.h_b, e->E, no_act,
-                             NodeScalarEpi{w.a_b, lay.s_dst, lay.s_src, 3 * d, 0, 2 * d, H}, 0, 0};
-            T.t[1] = LinTask{w.proj_a_w, in_atoms, bt_a, w.proj_a_b, a.h_a, e->N, no_act,
-                             NodeScalarEpi{w.a, lay.s_dst_a, lay.s_src_a, wide, 0, d + FN_D, H}, 0, 0};
-            T.t[2] = LinTask{w.proj_fb_w, in_fbond, bt_fb, w.proj_fb_b, a.h_fb, e->EF, no_act,
-                             NodeScalarEpi{w.f_a_b, lay.s_dst_fb, lay.s_src_fb, 3 * d, 0, 2 * d, H}, 0, 0};
-            T.t[0].n_real = nr_bonds;  T.t[1].n_real = nr_atoms;  T.t[2].n_real = nr_conns;
-            FN_TRY(launch_linear128_group(T, S(st)));
-        } else if (l == 0 && fuse_ns && !no_fb && kb <= 20 && kfb <= 20) {
-            LinTasks T{};                               // layer 0: both edge-feature projections have K <= 20 -> one launch
-            T.n = 2;
-            T.t[0] = LinTask{w.proj_b_w, in_bond, bt_b, w.proj_b_b, a.h_b, e->E, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
-                             NodeScalarEpi{w.a_b, lay.s_dst, lay.s_src, 3 * d, 0, 2 * d, H}, 0, 0, kb};
-            T.t[1] = LinTask{w.proj_fb_w, in_fbond, bt_fb, w.proj_fb_b, a.h_fb, e->EF, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
-                             NodeScalarEpi{w.f_a_b, lay.s_dst_fb, lay.s_src_fb, 3 * d, 0, 2 * d, H}, 0, 0, kfb};
-            if (colaunch && ka > 20 && ka <= 168) {     // the atom features' projection needs nothing of the bond levels either: same launch
-                T.t[2] = T.t[1];  T.t[1] = T.t[0];      // its (longer) workgroups first
-                T.t[0] = LinTask{w.proj_a_w, in_atoms, bt_a, w.proj_a_b, a.h_a, e->N, fn_act_epilogue{nullptr, 0.f, 0, 0, 0, nullptr},
-                                 NodeScalarEpi{w.a, lay.s_dst_a, lay.s_src_a, wide, 0, d + FN_D, H}, 0, 0, ka};
-                T.n = 3;
-                atoms_projected = true;
-            }
-            for (int q = 0; q < T.n; ++q) T.t[q].n_real = T.t[q].M == e->N && T.t[q].Y == a.h_a ? nr_atoms : (T.t[q].Y == a.h_b ? nr_bonds : nr_conns);
-            FN_TRY(launch_linear128_small_group(T, S(st)));
-        } else {
-            FN_TRY(project(in_bond, kb, bt_b, w.proj_b_b, a.h_b, e->E, w.a_b, 3 * d, 2 * d, lay.s_dst, lay.s_src, st));
-            if (!no_fb) FN_TRY(project(in_fbond, kfb, bt_fb, w.proj_fb_b, a.h_fb, e->EF, w.f_a_b, 3 * d, 2 * d, lay.s_dst_fb, lay.s_src_fb, st));
-        }
-        fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
-        fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
-        // L1 bond graph and L4a fragment-bond graph: neither reads the other's output -> one launch for both
-        GatFwdArgs gb, gfb{};
-        FN_TRY(prep_gat_fwd(a.h_b, lay.s_dst, lay.s_src, w.a_b, 3 * d, &et_b, &e->bond, 0.2f, a.new_bond, a.p_bond, nullptr, &ep_bond, H, &gb, a.o2_bond, a.sg_bond));
-        // (the raw fragment-bond rows are the fragment graph's edge attribute: read in the last layer only, like the raw atom rows below)
-        if (!no_fb) FN_TRY(prep_gat_fwd(a.h_fb, lay.s_dst_fb, lay.s_src_fb, w.f_a_b, 3 * d, &et_fb, &e->fbond, 0.2f, (last || !ep_fbond.y) ? a.new_fbond : nullptr,
-                                        a.p_fbond, nullptr, &ep_fbond, H, &gfb, a.o2_fbond, a.sg_fbond));
-        gb.p_edge_major = gfb.p_edge_major = one ? 1 : 0;
-        gb.n_real = nr_bonds;  gfb.n_real = nr_conns;
-        // (evaluation passes only, like FN_TUNE_FWD_BLOCKS_EVAL_LARGE: a training pass gets fewer, longer-lived half-waves from prep_gat_fwd
-        // on purpose, and the cap was only ever measured forward-only)
-        if (const int tail_rows = g_tune[FN_TUNE_FWD_TAIL_ROWS]; !(ep_fbond.y && ep_fbond.p > 0.f) && tail_rows > 0 && gfb.rows_per_hw > tail_rows) {
-            gfb.rows_per_hw = tail_rows;             // (the second level's workgroups start last: short ones)
-            gfb.nblk = (int)((e->fbond.n + (int64_t)kRows * tail_rows - 1) / ((int64_t)kRows * tail_rows));
-        }
-        if (fuse_rd) {
-            gb.rd_A = w.a + d;  gb.rd_lda = wide;  gb.rd_J = H;  gb.rd_out = lay.s_sorted;  gb.rd_pos = e->atom.inv_d;  gb.rd_m = e->atom.m;
-        }
-        if (l == 0) FN_TRY(prof_event(0, S(st)));
-        if (with_pair.n) {
-            FN_TRY(launch_gat_fwd_pair_lin(gb, gfb, with_pair, H, S(st)));
-        } else {
-            FN_TRY(launch_gat_fwd_pair(gb, gfb, H, S(st)));
-        }
-        if (l == 0) FN_TRY(prof_event(1, S(st)));
-
-        // L2 atom graph (+ self loops), edge term = <new_bond, a[:, d:d+128]>
-        if (!grouped && !atoms_projected) FN_TRY(project(in_atoms, ka, bt_a, w.proj_a_b, a.h_a, e->N, w.a, wide, d + FN_D, lay.s_dst_a, lay.s_src_a, st));
-        if (!fuse_rd) FN_TRY(fn_row_dots_sorted_f32(a.new_bond, w.a, wide, d, H, &e->atom, lay.s_sorted, st));
-        fn_edge_term et_a{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
-        if (colaunch && !last) {
-            // the next layer's bond / fragment-bond projections read this layer's bond-level outputs, not its atom level: same launch
-            const fn_layer_weights& wn = e->w[l + 1];
-            const LayerActs& an = lay.L[l + 1];
-            LinTasks T{};
-            T.n = no_fb ? 1 : 2;
-            T.t[0] = LinTask{wn.proj_b_w, y_bond, lay.bt + (size_t)(3 * (l + 1)) * 192 * FN_D, wn.proj_b_b, an.h_b, e->E, no_act_l,
-                             NodeScalarEpi{wn.a_b, lay.s_dst, lay.s_src, 3 * d, 0, 2 * d, H}, 0, 0};
-            T.t[1] = LinTask{wn.proj_fb_w, y_fbond, lay.bt + (size_t)(3 * (l + 1) + 2) * 192 * FN_D, wn.proj_fb_b, an.h_fb, e->EF, no_act_l,
-                             NodeScalarEpi{wn.f_a_b, lay.s_dst_fb, lay.s_src_fb, 3 * d, 0, 2 * d, H}, 0, 0};
-            T.t[0].n_real = nr_bonds;  T.t[1].n_real = nr_conns;
-            GatFwdArgs ga;
-            // (an inner layer's raw atom rows are read by nobody -- the fragment sums exist in the last layer only -- so only y is stored)
-            FN_TRY(prep_gat_fwd(a.h_a, lay.s_dst_a, lay.s_src_a, w.a, wide, &et_a, &e->atom, 0.2f, ep_atoms.y ? nullptr : lay.atoms_new, a.p_atom, nullptr, &ep_atoms, H, &ga,
-                                a.o2_atom, a.sg_atom));
-            ga.p_edge_major = one ? 1 : 0;
-            ga.n_real = nr_atoms;
-            FN_TRY(launch_gat_fwd_lin(ga, T, H, S(st)));
-        } else {
-            GatFwdArgs ga;
-            FN_TRY(prep_gat_fwd(a.h_a, lay.s_dst_a, lay.s_src_a, w.a, wide, &et_a, &e->atom, 0.2f, (last || !ep_atoms.y) ? lay.atoms_new : nullptr, a.p_atom, nullptr, &ep_atoms,
-                                H, &ga, a.o2_atom, a.sg_atom));
-            ga.p_edge_major = one ? 1 : 0;
-            ga.n_real = nr_atoms;
-            FN_TRY(launch_gat_fwd(ga, H, S(st)));
-        }
-
-        // L3 atom -> fragment sum.  Like L4b below it is only ever read in the last layer (the next layer recomputes its own
-        // sum from its own atoms before first use, gat2.py:234), so inner layers skip it too.
-        const bool tail_mol = last && tail_mol_on(e);      // sums + fragment graph + readout: one molecule-resident launch
-        const bool tail_fused = !tail_mol && last && !lite && !edge && H > 1 && e->F > 0 && e->N >= 4 * e->F && e->frag.m > 0 &&
-                                !(((uintptr_t)lay.atoms_new | (uintptr_t)a.frags) & 15);
-        if (last && !tail_fused && !tail_mol) FN_TRY(fn_segment_sum_f32(lay.atoms_new, FN_D, e->a2f.rowptr, e->a2f.perm, e->a2f.pos_base, a.frags, e->F, FN_D, e->N, st));
-
-        // L4b fragment graph on the raw fragment sums.  Only the last layer's result is ever read: the next layer
-        // overwrites x_frags with its own atom->fragment sum before first use (gat2.py:234), so inner
-        // layers skip this level entirely (the reference computes it and throws it away).
-        if (last && lite) {      // gat2_lite: the encoder's fragment output is act(dropout(.)) of the plain fragment sums
-            FN_TRY(fn_dropout_act_f32(a.frags, y_frags, e->F * FN_D, p, e->seed, rng.y[l][1], e->offset_dev, 1, st));
-        } else if (last && edge) {   // gat2_edge (gat2_edge.py:148-172): edge term = <Linear(8 -> 128)(cnx_attr), f[:, d:d+128]>, folded in-kernel
-            FN_TRY(fn_node_scalars_f32(a.frags, w.f, wide, 0, d + FN_D, lay.s_dst, lay.s_src, e->F, H, st));
-            fn_edge_term et_f{2, e->k_fattr, FN_D, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
-            FN_TRY(fn_gat_fwd_f32(a.frags, lay.s_dst, lay.s_src, w.f, wide, &et_f, &e->frag, 0.2f, nullptr, a.p_frag, nullptr, nullptr, nullptr, 0, &ep_frags, H, st));
-        } else if (last && tail_mol) {
-            FN_TRY(launch_tail_fwd(e, lay, a, w, ep_frags, y_atoms, S(st)));
-        } else if (last) {
-            if (tail_fused) {                                // atom -> fragment sum + node scalars + edge term: one launch
-                FragTailArgs T{};
-                T.src = lay.atoms_new;  T.rowptr = e->a2f.rowptr;  T.perm = e->a2f.perm;  T.pos_base = e->a2f.pos_base;  T.out = a.frags;
-                T.n_seg = e->F;  T.att = w.f;  T.att_w = wide;  T.dst_off = 0;  T.src_off = d + FN_D;  T.s_dst = lay.s_dst;  T.s_src = lay.s_src;
-                T.nblk_seg = (int)(e->F < 8 * kGridCap ? e->F : 8 * kGridCap);
-                T.feat = a.new_fbond;  T.A = w.f;  T.lda = wide;  T.off = d;  T.pl = e->frag;  T.s_sorted = lay.s_sorted;
-                T.nblk_rd = row_grid(e->frag.m, kGridCap);
-                const dim3 grid((unsigned)(T.nblk_seg + T.nblk_rd));
-                if (H == 2) hipLaunchKernelGGL((k_frag_tail<2>), grid, dim3(kBlock), 0, S(st), T);
-                else if (H == 4) hipLaunchKernelGGL((k_frag_tail<4>), grid, dim3(kBlock), 0, S(st), T);
-                else hipLaunchKernelGGL((k_frag_tail<8>), grid, dim3(kBlock), 0, S(st), T);
-                FN_TRY(launch_status("fragment tail (sum + node scalars + edge term)"));
-            } else {
-            FN_TRY(fn_row_dots_sorted_f32(a.new_fbond, w.f, wide, d, H, &e->frag, lay.s_sorted, st));
-            FN_TRY(fn_node_scalars_f32(a.frags, w.f, wide, 0, d + FN_D, lay.s_dst, lay.s_src, e->F, H, st));
-            }
-            fn_edge_term et_f{0, 0, 0, 0, lay.s_sorted, nullptr, nullptr, nullptr};
-            FN_TRY(fn_gat_fwd_f32(a.frags, lay.s_dst, lay.s_src, w.f, wide, &et_f, &e->frag, 0.2f, nullptr, a.p_frag, nullptr, nullptr, nullptr, 0, &ep_frags, H, st));
-        }
-        in_atoms = y_atoms;  in_bond = y_bond;  in_fbond = y_fbond;
-        ka = kb = kfb = FN_D;
-    }
-    return 0;
-}
-
-int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float* out_frags, const float* out_bond,
-                        const float* out_fbond, const float* g_atoms, const float* g_frags, const float* g_bond,
-                        const float* g_fbond, const fn_layer_weights* grads, float* scratch, int64_t scratch_floats,
-                        fn_stream_t st) {
-    FN_TRY(enc_check(e));
-    if (!grads || !scratch || !out_atoms || !out_frags || !out_bond || !out_fbond) return fail(FN_EINVAL, "fn_encoder_backward: null argument");
-    if (const fn_adam_slice* a = e->adam_rider) {
-        if (a->n < 0 || (a->n > 0 && (!a->p || !a->g || !a->m || !a->v || !a->lr_dev || !a->step_dev ||
-                                      (((uintptr_t)a->p | (uintptr_t)a->g | (uintptr_t)a->m | (uintptr_t)a->v) & 15))))
-            return fail(FN_EINVAL, "fn_encoder_backward: bad adam_rider (null or misaligned buffer, or no device step count / learning rate)");
-    }
-    if (!form_matches_forward(e))
-        return fail(FN_EINVAL, "fn_encoder_backward: FN_TUNE_BWD_ONE / FN_TUNE_DEFER_GSD changed since the forward pass that wrote this workspace");
-    const EncLayout lay = enc_layout(e, e->ws);
-    const BwdLayout bw = bwd_layout(e, scratch);
-    if (bw.total > scratch_floats) return fail(FN_EINVAL, "fn_encoder_backward: scratch too small");
-    const RngPlan rng = rng_plan(e);
-    if (e->g_pooled && !tail_mol_on(e)) return fail(FN_EINVAL, "fn_encoder_backward: dL/d(readout) is only taken by the fused fragment tail (fn_encoder_fused_tail)");
-    if (one_pass_on(e)) return encoder_backward_one(e, lay, bw, rng, out_atoms, out_frags, out_bond, out_fbond, g_atoms, g_frags, g_bond, g_fbond, grads, S(st));
-    const int H = e->heads, d = FN_D / H;
-    const float p = e->training ? e->drop_p : 0.f;
-    const int wide = 2 * d + FN_D;
-    hipStream_t hs = S(st);
-    const bool lite = e->variant == 1, edge = e->variant == 2;
-    ReduceQueue rq;
-    rq.st = hs;                      // all parameter-gradient reductions run as one launch at the very end
-    rq.defer_wgrad = true;           // ... and so do the K = 128 weight-gradient partial products
-    rq.defer_mixed = g_tune[FN_TUNE_GEMM_COLAUNCH] != 0;      // ... and layer 0's
-    rq.rider = e->adam_rider;
-
-    // (This is the general path: any head count, hand-built atom graphs, gat2_edge's fragment graph.  The configurations the one-pass
-    // backward covers never get here, so its launches run in plain dependency order: per layer the gates, the fragment levels (last
-    // layer), the atom level's two passes, the bond and fragment-bond levels' two passes each, and one grouped launch for the layer's
-    // input-gradient products.  The co-launched / pipelined forms of rounds 2-3 are retired: tools/probe/retired/.)
-    // gradients w.r.t. the current layer's post-activation outputs (null = zero)
-    bool pre_atoms = false, pre_bond = false, pre_fbond = false;   // g_pre_* already hold layer l's pre-activation grads
-    const float* gy_atoms = g_atoms;
-    const float* gy_frags = g_frags;
-    const float* gy_bond = g_bond;
-    const float* gy_fbond = g_fbond;
-
-    for (int l = e->n_layers - 1; l >= 0; --l) {
-        const fn_layer_weights& w = e->w[l];
-        const fn_layer_weights& g = grads[l];
-        const LayerActs& a = lay.L[l];
-        const bool last = l + 1 == e->n_layers;
-        const float* y_atoms = last ? out_atoms : a.y_atoms;
-        const float* y_frags = last ? out_frags : a.y_frags;
-        const float* y_bond = last ? out_bond : a.y_bond;
-        const float* y_fbond = last ? out_fbond : a.y_fbond;
-        const float* in_atoms = l ? lay.L[l - 1].y_atoms : (lay.in_atoms0 ? lay.in_atoms0 : e->x_atoms);
-        const float* in_bond = l ? lay.L[l - 1].y_bond : e->bond_nodes;
-        const float* in_fbond = l ? lay.L[l - 1].y_fbond : e->fbond_nodes;
-        const int ka = l ? FN_D : e->k_atom0, kb = l ? FN_D : e->k_bond0, kfb = l ? FN_D : e->k_fbond0;
-        const LevelScratch &sb = bw.bond[l], &sa = bw.atom[l], &sfb = bw.fbond[l], &sf = bw.frag;
-        int n_a = 0, n_e = 0;
-        // the three input-gradient products of a layer feed layer l-1 only: one grouped launch at the end of the layer
-        LinTasks dxT{};
-        // Wt: the transposed copy the forward prologue left in the workspace
-        auto input_grad = [&](const float* gh, const float* W, const float* Wt, float* gy, int64_t rows, const fn_act_epilogue& mk) -> int {
-            dxT.t[dxT.n++] = LinTask{Wt, gh, W, nullptr, gy, rows, mk, NodeScalarEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0}, 0, 0};
-            return 0;
-        };
-        const float* bt_b = lay.bt + (size_t)(3 * l) * 192 * FN_D;
-        const float* bt_a = lay.bt + (size_t)(3 * l + 1) * 192 * FN_D;
-        const float* bt_fb = lay.bt + (size_t)(3 * l + 2) * 192 * FN_D;
-
-        // ---- through act(dropout(.)): gradients of the pre-activation tensors.  For the last layer they come from
-        // the caller's output gradients; for inner layers the input-gradient GEMMs of layer l+1 already wrote them
-        // (mask and ReLU gate fused into their epilogue), flagged by pre_* below.
-        bool have_atoms = gy_atoms != nullptr || pre_atoms, have_frags = gy_frags != nullptr;
-        bool have_bond = gy_bond != nullptr || pre_bond, have_fbond = gy_fbond != nullptr || pre_fbond;
-        // last layer, molecule-resident tail (csrc/mol_tail.inc): the atoms' and fragments' gates, the fragment graph's two passes,
-        // its edge term's backward and the scatter to the atoms are ONE launch below; the readout's gradient enters there
-        const bool tail_mol = last && tail_mol_on(e) && (gy_frags != nullptr || e->g_pooled != nullptr);
-        const float gate_scale = p > 0.f ? (p < 1.f ? 1.f / (1.f - p) : 0.f) : 1.f;
-        {   // backward of relu(dropout(.)) of up to four layer outputs in one launch; y > 0 already encodes the mask
-            GateTasks G{};
-            auto add = [&](const float* g, const float* y, float* o, int64_t numel) {
-                if (!g) return;
-                GateTask& t = G.t[G.n++];
-                t.g = g;  t.y = y;  t.o = o;  t.n4 = (numel + 3) / 4;  t.first = G.blocks;  t.nblk = flat_grid(t.n4, 512);
-                G.blocks += t.nblk;
-            };
-            if (!tail_mol) {
-                add(gy_atoms, y_atoms, bw.g_pre_atoms, e->N * FN_D);
-                add(gy_frags, y_frags, bw.g_pre_frags, e->F * FN_D);
-            }
-            add(gy_bond, y_bond, bw.g_pre_bond, e->E * FN_D);
-            add(gy_fbond, y_fbond, bw.g_pre_fbond, e->EF * FN_D);
-            if (G.blocks) {
-                G.scale = gate_scale;
-                hipLaunchKernelGGL(k_gate_many, dim3(G.blocks), dim3(kBlock), 0, S(st), G);
-                FN_TRY(launch_status("fn_encoder_backward: activation backward"));
-            }
-        }
-        bool nxt_atoms = false, nxt_bond = false, nxt_fbond = false;     // what this layer hands to layer l-1
-
-        // ---- L4b fragment graph (only where its output is consumed: the last layer, reference fact SURVEY §0.8)
-        bool have_g_frags_h = false;
-        const float* g_frags_h = bw.g_frags;      // dL/d(fragment sums), scattered back to the atoms below
-        if (tail_mol) {
-            int n_part = 0;
-            FN_TRY(launch_tail_bwd(e, a, w, bw, y_atoms, y_frags, gy_atoms, gy_frags, gate_scale, have_fbond, &n_part, hs));
-            const fn_edge_term et_f{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-            FN_TRY(rq.finalize(bw.frag.part_a, n_part, nullptr, 0, et_f, w.f, wide, 0, d + FN_D, g.f, nullptr, nullptr, H));
-            FN_TRY(rq.colsum(bw.frag.part_rd, n_part, H * FN_D, g.f, wide, d));
-            have_atoms = have_fbond = true;        // g_pre_atoms and g_pre_fbond are complete (scatter to the atoms included)
-        } else if (have_frags && lite) {
-            g_frags_h = bw.g_pre_frags;            // no fragment graph in between
-            have_g_frags_h = true;
-        } else if (have_frags && edge) {   // gat2_edge: the edge term's parameters are the cnx_attr Linear (emb_fb_*) and f's middle block
-            fn_edge_term et_f{2, e->k_fattr, FN_D, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_frags, a.frags, a.p_frag, &et_f, &e->frag, 0.2f, nullptr, nullptr, sf.pz, sf.g_s_dst, sf.part_e, &n_e, H, st));
-            FN_TRY(fn_gat_bwd_src_f32(bw.g_pre_frags, a.frags, sf.pz, sf.g_s_dst, w.f, wide, 0, d + FN_D, &e->frag, bw.g_frags, sf.part_a, &n_a, H, st));
-            FN_TRY(rq.finalize(sf.part_a, n_a, sf.part_e, n_e, et_f, w.f, wide, 0, d + FN_D, g.f, g.emb_fb_w, g.emb_fb_b, H));
-            have_g_frags_h = true;
-        } else if (have_frags) {
-            fn_edge_term et_f{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_frags, a.frags, a.p_frag, &et_f, &e->frag, 0.2f, nullptr, sf.dz, sf.pz, sf.g_s_dst, nullptr, &n_e, H, st));
-            // source pass + edge term <new_fbond, f[:, d:d+128]> (dL/dnew_fbond accumulates into g_pre_fbond, dL/df mid block)
-            int gr = 0;
-            FN_TRY(bwd_src_and_edge_term(bw.g_pre_frags, a.frags, sf.pz, sf.g_s_dst, w.f, wide, 0, d + FN_D, &e->frag, bw.g_frags, sf.part_a, &n_a,
-                                         sf.dz, a.new_fbond, d, bw.g_pre_fbond, sf.part_rd, have_fbond, &gr, H, hs));
-            if (gr) have_fbond = true;
-            FN_TRY(rq.finalize(sf.part_a, n_a, nullptr, 0, et_f, w.f, wide, 0, d + FN_D, g.f, nullptr, nullptr, H));
-            if (gr) FN_TRY(rq.colsum(sf.part_rd, gr, H * FN_D, g.f, wide, d));
-            have_g_frags_h = true;
-        }
-
-        // ---- L3 atom -> fragment sum: dL/datoms_new += dL/dfrags[a2f]
-        if (have_g_frags_h) {
-            hipLaunchKernelGGL(k_gather_rows4, dim3(flat_grid(e->N * 32, kGridCap)), dim3(kBlock), 0, hs, g_frags_h, e->a2f.index,
-                               bw.g_pre_atoms, e->N, (int64_t)32, have_atoms ? (const float*)bw.g_pre_atoms : (const float*)nullptr);
-            FN_TRY(launch_status("fn_encoder_backward: gather(a2f)"));
-            have_atoms = true;
-        }
-
-        // ---- L2 atom graph
-        if (have_atoms) {
-            fn_edge_term et_a{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-            FN_TRY(fn_gat_bwd_dst_f32(bw.g_pre_atoms, a.h_a, a.p_atom, &et_a, &e->atom, 0.2f, nullptr, sa.dz, sa.pz, sa.g_s_dst, nullptr, &n_e, H, st));
-            // source pass + the edge term <new_bond, a[:, d:d+128]> (dL/dnew_bond accumulates into g_pre_bond, dL/da mid block)
-            int gr = 0;
-            FN_TRY(bwd_src_and_edge_term(bw.g_pre_atoms, a.h_a, sa.pz, sa.g_s_dst, w.a, wide, 0, d + FN_D, &e->atom, sa.g_h, sa.part_a, &n_a,
-                                         sa.dz, a.new_bond, d, bw.g_pre_bond, sa.part_rd, have_bond, &gr, H, hs));
-            if (gr) have_bond = true;
-            FN_TRY(rq.finalize(sa.part_a, n_a, nullptr, 0, et_a, w.a, wide, 0, d + FN_D, g.a, nullptr, nullptr, H));
-            if (gr) FN_TRY(rq.colsum(sa.part_rd, gr, H * FN_D, g.a, wide, d));
-            FN_TRY(rq.wgrad(sa.g_h, in_atoms, ka, e->N, sa.wg_ws, g.proj_a_w, g.proj_a_b, hs));
-            if (l) {
-                const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_atoms), p, 1, e->seed, rng.y[l - 1][0], e->offset_dev};
-                FN_TRY(input_grad(sa.g_h, w.proj_a_w, bt_a, bw.g_pre_atoms, e->N, mk));
-                nxt_atoms = true;
-            }
-        }
-
-        // ---- L1 bond graph and L4a fragment-bond graph
-        if (have_bond || have_fbond) {
-            fn_edge_term et_b{2, 1, d, d, nullptr, e->cos_sorted, w.emb_b_w, w.emb_b_b};
-            fn_edge_term et_fb{2, e->k_fattr, d, d, nullptr, e->fattr_sorted, w.emb_fb_w, w.emb_fb_b};
-            GatBwdDstArgs db{}, dfb{};
-            GatBwdSrcArgs sbA{}, sfbA{};
-            int n_a_b = 0, n_e_b = 0, n_a_fb = 0, n_e_fb = 0;
-            if (have_bond) {
-                FN_TRY(prep_gat_bwd_dst(bw.g_pre_bond, a.h_b, a.p_bond, &et_b, &e->bond, 0.2f, nullptr, nullptr, sb.pz, sb.g_s_dst, sb.part_e, &n_e_b, H, &db));
-                FN_TRY(prep_gat_bwd_src(bw.g_pre_bond, a.h_b, sb.pz, sb.g_s_dst, w.a_b, 3 * d, 0, 2 * d, &e->bond, sb.g_h, sb.part_a, &n_a_b, H, &sbA));
-            }
-            if (have_fbond) {
-                FN_TRY(prep_gat_bwd_dst(bw.g_pre_fbond, a.h_fb, a.p_fbond, &et_fb, &e->fbond, 0.2f, nullptr, nullptr, sfb.pz, sfb.g_s_dst, sfb.part_e, &n_e_fb, H, &dfb));
-                FN_TRY(prep_gat_bwd_src(bw.g_pre_fbond, a.h_fb, sfb.pz, sfb.g_s_dst, w.f_a_b, 3 * d, 0, 2 * d, &e->fbond, sfb.g_h, sfb.part_a, &n_a_fb, H, &sfbA));
-            }
-            FN_TRY(launch_gat_bwd_dst(db, H, hs));
-            FN_TRY(launch_gat_bwd_dst(dfb, H, hs));
-            FN_TRY(launch_gat_bwd_src(sbA, H, hs));
-            FN_TRY(launch_gat_bwd_src(sfbA, H, hs));
-            if (have_fbond) {
-                if (l) {     // dL/d(pre-activation fbond output of layer l-1), gated by that layer's dropout mask and ReLU
-                    const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_fbond), p, 1, e->seed, rng.y[l - 1][3], e->offset_dev};
-                    FN_TRY(input_grad(sfb.g_h, w.proj_fb_w, bt_fb, bw.g_pre_fbond, e->EF, mk));
-                    nxt_fbond = true;
-                }
-                FN_TRY(rq.finalize(sfb.part_a, n_a_fb, sfb.part_e, n_e_fb, et_fb, w.f_a_b, 3 * d, 0, 2 * d, g.f_a_b, g.emb_fb_w, g.emb_fb_b, H));
-                FN_TRY(rq.wgrad(sfb.g_h, in_fbond, kfb, e->EF, sfb.wg_ws, g.proj_fb_w, g.proj_fb_b, hs));
-            }
-            if (have_bond) {
-                FN_TRY(rq.finalize(sb.part_a, n_a_b, sb.part_e, n_e_b, et_b, w.a_b, 3 * d, 0, 2 * d, g.a_b, g.emb_b_w, g.emb_b_b, H));
-                    FN_TRY(rq.wgrad(sb.g_h, in_bond, kb, e->E, sb.wg_ws, g.proj_b_w, g.proj_b_b, hs));
-                if (l) {
-                    const fn_act_epilogue mk{const_cast<float*>(lay.L[l - 1].y_bond), p, 1, e->seed, rng.y[l - 1][2], e->offset_dev};
-                    FN_TRY(input_grad(sb.g_h, w.proj_b_w, bt_b, bw.g_pre_bond, e->E, mk));
-                    nxt_bond = true;
-                }
-            }
-        }
-        if (dxT.n) FN_TRY(launch_linear128_group(dxT, hs));
-        pre_atoms = nxt_atoms;  pre_bond = nxt_bond;  pre_fbond = nxt_fbond;
-        gy_atoms = gy_bond = gy_fbond = nullptr;
-        gy_frags = nullptr;        // a layer's x_frags input is dead in the reference (overwritten at gat2.py:234)
-    }
-    return rq.flush(true);
-}
-
-}  // extern "C"
+#include "encoder.inc"
