@@ -232,7 +232,9 @@ int fn_node_scalars_f32(const float* h /*[n,128]*/, const float* att, int att_w,
  * mode 0: s_sorted [H,m] given (fn_row_dots_sorted_f32; 0 at loop positions).
  * mode 2: s[pos,h] = <embW x_sorted[pos] + embb, att[h, mid_off:+d_e]> folded in-kernel (the reference's
  * edge_attr_bond_embed / edge_attr_fbond_embed Linear(K -> d_e), gat2.py:139,242); x_sorted is the raw
- * attribute permuted once per batch by fn_sort_edge_attr_f32 (it is the same in every layer). */
+ * attribute permuted once per batch by fn_sort_edge_attr_f32 (it is the same in every layer).  A loop item's raw attribute is
+ * zero (x_sorted is 0 at loop positions), so its term is <embb, att[h, mid_off:+d_e]> -- the reference adds self loops to the atom
+ * graph only, which is mode 0 (a zero row there: term 0). */
 typedef struct fn_edge_term {
     int32_t mode;
     int32_t K;                /* mode 2: raw attribute width (1 or 6) */
