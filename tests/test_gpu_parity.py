@@ -1,8 +1,9 @@
 """GPU parity: the HIP path (through the C-ABI) against the oracle and the golden vectors.
 
 Tolerance: the north star asks logits/loss within 1e-4 fp32 of the reference CPU path; integer index
-maps bit-exact.  Kernel-level comparisons use 2e-5 absolute on O(1) values (summation order differs
-from the reference's one-reduction ``torch.sum`` only in fp32 round-off).
+maps bit-exact.  GRADIENTS are held to the same budget since round 6: |got - ref| <= 1e-4 + 1e-4 |ref|
+(rounds 1-5 allowed 2e-3 relative; every case passes at 1e-4).  Kernel-level comparisons use 2e-5 absolute on
+O(1) values (summation order differs from the reference's one-reduction ``torch.sum`` only in fp32 round-off).
 """
 import numpy as np
 import pytest
@@ -332,7 +333,7 @@ def test_finetune_matches_reference_golden(case, use_engine):
     loss.backward()
     torch.cuda.synchronize()
     b["_fragnet_plan"].check()
-    check_grads(model, grads, atol=ATOL, rtol=2e-3)
+    check_grads(model, grads, atol=ATOL, rtol=1e-4)
 
 
 @pytest.mark.parametrize("case", ["ft_esol_b8", "ft_edge_b6"])
@@ -352,7 +353,7 @@ def test_deferred_backward_form_matches_reference_golden(case):
         loss.backward()
         torch.cuda.synchronize()
         b["_fragnet_plan"].check()
-        check_grads(model, grads, atol=ATOL, rtol=2e-3)
+        check_grads(model, grads, atol=ATOL, rtol=1e-4)
     finally:
         _lib.call("fn_set_tuning", 29, 0)
 
@@ -376,7 +377,7 @@ def test_gat2_lite_matches_reference_golden(use_engine):
     loss = torch.nn.functional.mse_loss(logits.view(-1), b["y"])
     assert abs(float(loss) - float(out["loss"])) < ATOL
     loss.backward()
-    check_grads(model, grads, atol=ATOL, rtol=2e-3)
+    check_grads(model, grads, atol=ATOL, rtol=1e-4)
 
 
 @pytest.mark.parametrize("use_engine", [True, False], ids=["engine", "per_level_ops"])
@@ -403,7 +404,7 @@ def test_gat2_edge_matches_reference_golden(use_engine):
     loss = torch.nn.functional.mse_loss(logits.view(-1), b["y"])
     assert abs(float(loss) - float(out["loss"])) < ATOL
     loss.backward()
-    check_grads(model, grads, atol=ATOL, rtol=2e-3)
+    check_grads(model, grads, atol=ATOL, rtol=1e-4)
 
 
 @pytest.mark.parametrize("use_engine", [True, False], ids=["engine", "per_level_ops"])
@@ -422,7 +423,7 @@ def test_pretrain_matches_reference_golden(use_engine):
     loss = ref.pretrain_loss(outs, b)
     assert abs(loss.item() - float(out["loss"])) < ATOL
     loss.backward()
-    check_grads(model, grads, atol=ATOL, rtol=2e-3)
+    check_grads(model, grads, atol=ATOL, rtol=1e-4)
     # bond-length head is differentiable too (the reference trainer just never uses it)
     model.zero_grad()
     outs = model(_to_dev(batch))
@@ -444,7 +445,7 @@ def test_bond_length_head_gradient_matches_oracle():
         if p1.grad is None:
             continue
         scale = max(1.0, float(p1.grad.abs().max()))
-        torch.testing.assert_close(p2.grad.cpu(), p1.grad, atol=ATOL * scale, rtol=2e-3, msg=lambda s: f"{n1}: {s}")
+        torch.testing.assert_close(p2.grad.cpu(), p1.grad, atol=ATOL * scale, rtol=1e-4, msg=lambda s: f"{n1}: {s}")
 
 
 def test_layer_attentions_and_masks_match_reference_golden():
@@ -552,7 +553,7 @@ def test_engine_matches_oracle_for_other_head_counts(heads):
         for (n, p), (_, q) in zip(model.named_parameters(), gold.named_parameters()):
             if q.grad is not None:
                 assert p.grad is not None, n
-                torch.testing.assert_close(p.grad.cpu(), q.grad, atol=ATOL, rtol=2e-3, msg=lambda m, n=n: f"{n}: {m}")
+                torch.testing.assert_close(p.grad.cpu(), q.grad, atol=ATOL, rtol=1e-4, msg=lambda m, n=n: f"{n}: {m}")
 
 
 def test_b512_training_step_is_bitwise_reproducible(esol512):
@@ -595,9 +596,9 @@ def test_b512_gradients_match_oracle_b64():
         # such a unit passes its gradient depends on the last bit of a 256-term fp32 sum, in the oracle as much as here, and a flip
         # moves that unit's row of dW by its (small) gradient times the inputs.  At most 8 elements per tensor may therefore sit
         # outside the tolerance, and none by more than 5 x.
-        over = (got - want).abs() > ATOL * scale + 2e-3 * want.abs()
-        assert int(over.sum()) <= 8, f"{n1}: {int(over.sum())} elements outside atol {ATOL * scale:g} / rtol 2e-3"
-        torch.testing.assert_close(got, want, atol=5 * ATOL * scale, rtol=2e-3, msg=lambda s: f"{n1}: {s}")
+        over = (got - want).abs() > ATOL * scale + 1e-4 * want.abs()
+        assert int(over.sum()) <= 8, f"{n1}: {int(over.sum())} elements outside atol {ATOL * scale:g} / rtol 1e-4"
+        torch.testing.assert_close(got, want, atol=5 * ATOL * scale, rtol=1e-4, msg=lambda s: f"{n1}: {s}")
 
 
 # ----------------------------------------------------------------- full size, the other BASELINE configs (3, 4, 5)
@@ -688,7 +689,7 @@ def test_fthead1_fthead2_match_reference_golden(case):
     assert abs(loss.item() - float(out["loss"])) < ATOL
     loss.backward()
     torch.cuda.synchronize()
-    check_grads(model, grads, atol=ATOL, rtol=2e-3)
+    check_grads(model, grads, atol=ATOL, rtol=1e-4)
 
 
 def test_fthead5_matches_reference_golden():
@@ -708,7 +709,7 @@ def test_fthead5_matches_reference_golden():
     (y * torch.arange(1, 16, dtype=torch.float32, device=DEV).view(5, 3)).sum().backward()
     torch.testing.assert_close(x.grad.cpu(), torch.from_numpy(z["gx"]), atol=ATOL, rtol=1e-4)
     for k, p in head.named_parameters():
-        torch.testing.assert_close(p.grad.cpu(), torch.from_numpy(z[f"g/{k}"]), atol=ATOL, rtol=2e-3)
+        torch.testing.assert_close(p.grad.cpu(), torch.from_numpy(z[f"g/{k}"]), atol=ATOL, rtol=1e-4)
 
 
 def test_gat2_edge_frag_self_loops_fail_like_the_reference():
@@ -797,7 +798,7 @@ def test_graph_step_loss_and_gradients_match_the_oracle_at_b512():
         flat, off = slot
         got = flat[off: off + p.numel()].view(p.shape).cpu()
         want = gold_params[name].grad
-        torch.testing.assert_close(got, want, atol=ATOL, rtol=2e-3, msg=lambda s: f"{name}: {s}")
+        torch.testing.assert_close(got, want, atol=ATOL, rtol=1e-4, msg=lambda s: f"{name}: {s}")
         checked += 1
     assert checked >= 60            # every live parameter of 4 layers + head
 
@@ -833,4 +834,4 @@ def test_engine_edge_shapes_match_the_oracle(n_layers, n_mols, p_cut):
     for (n, p), (_, q) in zip(model.named_parameters(), gold.named_parameters()):
         if q.grad is not None:
             assert p.grad is not None, n
-            torch.testing.assert_close(p.grad.cpu(), q.grad, atol=ATOL, rtol=2e-3, msg=lambda m, n=n: f"{n}: {m}")
+            torch.testing.assert_close(p.grad.cpu(), q.grad, atol=ATOL, rtol=1e-4, msg=lambda m, n=n: f"{n}: {m}")
