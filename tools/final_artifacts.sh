@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the per-round evidence set on a GPU box:  bash tools/final_artifacts.sh <tag>   (writes gpurun_out/<tag>/, copy into profiles/)
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -56,4 +56,6 @@ timeout 300 python3 $R/bench.py --no-cpu-baseline --no-roofline --epoch-batches 
 bash $R/tools/step_trace.sh $O/step_sequence_deferred_form.txt --steps 20 --warmup 5 --epoch-batches 0 --tune 29=1
 # the riders of round 4 off (last Linear / loss / its backward as three launches; one Adam launch over everything)
 (cd $R && FRAGNET_FUSED_HEAD_LOSS=0 FRAGNET_ADAM_RIDER=0 timeout 300 python3 bench.py --no-cpu-baseline --no-roofline --epoch-batches 0 2>/dev/null | tail -1) > $O/bench_no_riders.json
+# SQ / TA counters of every kernel of the replayed step (two more --pmc passes)
+(cd $R && bash tools/pmc_step_sq_ta.sh $TAG)
 ls -la $O
