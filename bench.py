@@ -229,7 +229,7 @@ def kernel_roofline(batch, model, iters=50, alternatives=False):
     """Dominant scatter kernels at the bond-graph level, timed back to back with HIP events on the launch stream: the pair the engine
     runs by default -- the training forward with its second output (`k_gat_fwd(+out2)`) and the one-pass backward (`k_gat_bwd_one`).
     ``alternatives`` (the dev loop, --kernels-only): also the plain forward, the dots kernel, the deferred form of the pass
-    (FN_TUNE_DEFER_GSD) and the general two-pass backward."""
+    (FN_TUNE_DEFER_GSD, HISTORY.md 4h) and the general two-pass backward."""
     import ctypes as C
     from fragnet_amd import _lib
     from fragnet_amd.plan import GraphPlan, _stream_ptr
@@ -270,7 +270,7 @@ def kernel_roofline(batch, model, iters=50, alternatives=False):
     # the engine's default backward: ONE source-owner pass (csrc/gat_bwd_one.inc).  It needs the forward's second output (out2, sigma:
     # `k_gat_fwd(+out2)` is that forward) and the two node-local dots c, g_s_dst, which inside the step ride in the epilogue of the
     # input-gradient GEMM that produces the gradient rows; `k_gat_cu` is the stand-alone kernel for them (last layer / operator path).
-    # The deferred form (dz_em) needs neither out2 nor g_s_dst: its consumers add the term
+    # The deferred form (dz_em) needs neither out2 nor g_s_dst: its consumers add the term (HISTORY.md 4h)
     out2, sigma, p_em = torch.empty(n, 128, **f32), torch.empty(n, H, **f32), torch.empty(m, H, **f32)
     cdot, g_s_dst1, g_h1 = torch.empty(n, H, **f32), torch.empty(n, H, **f32), torch.empty(n, 128, **f32)
     part_e1, part_a1 = torch.empty(4096, H * 2, **f32), torch.empty(4096, 256, **f32)

@@ -356,7 +356,7 @@ class GraphedTrainStep:
         start an asynchronous all-reduce of the head's gradients (83 % of the bytes for FTHead3) between them, so that it
         runs on RCCL's stream beside the encoder's backward pass; the encoder's own, small slice follows the second graph.
         Off by default: on this stack an async collective costs ~95 us of stream fork/join against ~20 us for a blocking
-        one (tools/allreduce_probe.py), which eats what the overlap hides at 8 MB of gradients."""
+        one (tools/allreduce_probe.py), which eats what the overlap hides at 8 MB of gradients (DESIGN.md section 7 and HISTORY.md section 7)."""
         self.model, self.opt, self.shapes, self.group = model, opt, shapes, group
         # force_distributed: run the N>1 step sequence (graph replay -> RCCL all-reduce -> Adam outside the graph, rank loss
         # weights through an all-reduce) even in a 1-rank process group, so that one GPU can test it

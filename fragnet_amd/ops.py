@@ -756,7 +756,7 @@ class _MLPHead(torch.autograd.Function):
                 gz = torch.cat([gz, gz.new_zeros((M - live, K))])
         grads[-2], grads[-1] = dW, db
         # (running the weight-gradient GEMMs on a side stream beside the gate -> input-gradient chain was measured: a
-        # two-branch hipGraph replays 9 % slower on ROCm 7.2 than the serial one)
+        # two-branch hipGraph replays 9 % slower on ROCm 7.2 than the serial one, HISTORY.md section 4)
         for i in range(n - 2, -1, -1):
             z, h_in, W = acts[i + 1], acts[i], Ws[i]
             dW, db = grad_buffer(P[2 * i], slots[2 * i]), grad_buffer(P[2 * i + 1], slots[2 * i + 1])

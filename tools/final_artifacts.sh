@@ -50,7 +50,7 @@ rm -rf /tmp/ph
 timeout 300 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/ph -o d -- python3 $R/tools/probe/hbm_cold_probe.py > /dev/null 2>&1
 python3 $R/tools/probe/hbm_cold_probe.py --summarise $(ls /tmp/ph/*/*.db /tmp/ph/*.db 2>/dev/null | head -1) > $O/hbm_cold_stream_table.md 2>&1
 # A/B in the same call: the general two-pass backward (22=0) and the deferred form of the one-pass backward (29=1: no second forward output;
-# the destination-side term is applied by the input-gradient GEMM and the weight gradient)
+# the destination-side term is applied by the input-gradient GEMM and the weight gradient, HISTORY.md section 4h)
 timeout 300 python3 $R/bench.py --no-cpu-baseline --no-roofline --epoch-batches 0 --tune 22=0 2>/dev/null | tail -1 > $O/bench_two_pass.json
 timeout 300 python3 $R/bench.py --no-cpu-baseline --no-roofline --epoch-batches 0 --tune 29=1 2>/dev/null | tail -1 > $O/bench_deferred_form.json
 bash $R/tools/step_trace.sh $O/step_sequence_deferred_form.txt --steps 20 --warmup 5 --epoch-batches 0 --tune 29=1

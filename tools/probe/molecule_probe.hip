@@ -1,4 +1,4 @@
-// Feasibility probe for the molecule-resident layer kernel: the bond-graph attention level of an
+// Feasibility probe for the molecule-resident layer kernel (HISTORY.md section 9.1): the bond-graph attention level of an
 // ESOL-shape batch with one workgroup per molecule and the molecule's node rows staged in LDS, against the per-level
 // kernel's 15.4 us for the same work.  Synthetic: 512 molecules x 55 directed bonds, 7 in-edges per bond from the same
 // molecule, H = 4 heads, D = 128.  Not part of the library.

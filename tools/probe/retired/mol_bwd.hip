@@ -1,7 +1,7 @@
 // Molecule-resident single-pass backward of an attention level (autograd of reference model/gat/gat2.py:146-169,
 // 196-224, 250-272, 286-316: scatter_softmax + weighted scatter_add of one level).
 // STATUS: parity-green, measured SLOWER than the two passes it was built to replace (39-42 us against 28 us, bond level at
-// ESOL batch 512) and therefore off by default (FN_TUNE_BWD_MOL); DESIGN.md section 4c and profiles/r03_molbwd_phases.md have the
+// ESOL batch 512) and therefore off by default (FN_TUNE_BWD_MOL); HISTORY.md section 4c and profiles/r03_molbwd_phases.md have the
 // phase timings and the reasons.
 //
 // The graphs of a collated batch are block-diagonal per molecule (dataset/data.py:877-948), so a workgroup that owns whole
