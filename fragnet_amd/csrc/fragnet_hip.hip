@@ -1069,12 +1069,13 @@ __global__ __launch_bounds__(kLinThreads) void k_linear128_layer0(LinTasks T) {
 // task carries one; the epilogue also writes the dot c = <g, out> of the rows it finishes, CuEpi)  ||  the parameter-gradient partials of
 // the atom graph's edge term
 // (GS: the deferred form -- every lane sums one dz segment into g_s_dst, one more MFMA step adds the rank-4 term, GsdEpi; c is the only dot left)
-template <bool GS = false>
+// (GO: the mixed form's boundary launches -- deferred rows in, rows of a layer with a second forward output out: both epilogues)
+template <bool GS = false, bool GO = false>
 __global__ __launch_bounds__(kBlock, 3) void k_lin_rd_cu(LinTasks T, RowDotsBwdArgs R) {
     extern __shared__ __attribute__((aligned(16))) float sBt[];
     __shared__ float sR[kRows][FN_D];
     const int b = (int)blockIdx.x;
-    if (b < T.total) { lin_side_block<true, GS>(sBt, T, b);  return; }
+    if (b < T.total) { lin_side_block<true, GS, GO>(sBt, T, b);  return; }
     row_dots_sorted_bwd_body(R, sR, b - T.total, R.nblk);
 }
 

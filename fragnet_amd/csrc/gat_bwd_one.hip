@@ -91,9 +91,14 @@ int launch_gat_bwd_one3(const GatBwdOneArgs& A, const GatBwdOneArgs& B, const Ga
     const int interleave = tune(FN_TUNE_ONE_INTERLEAVE) != 0 ? 1 : 0;
     const bool df = (A.nblk && A.dz_em) || (B.nblk && B.dz_em) || (C.nblk && C.dz_em);
     if (df) {
-        if (heads != 4 || (A.nblk && !A.dz_em) || (B.nblk && !B.dz_em) || (C.nblk && !C.dz_em))
-            return fail(FN_EUNSUPPORTED, "one-pass backward, deferred form: four heads, every level of the launch");
-        hipLaunchKernelGGL((k_gat_bwd_one3<4, kBwdRows, true>), dim3(A.nblk + B.nblk + C.nblk), dim3(kBwdRows * 32), 0, st, A, B, C, interleave);
+        // every level of the launch deferred, or -- the mixed form's boundary launch -- the bond / fragment-bond levels deferred and the
+        // atom level (the layer below's) not
+        const bool ac = !(A.nblk && !A.dz_em) && !(C.nblk && !C.dz_em);
+        if (heads != 4 || !ac) return fail(FN_EUNSUPPORTED, "one-pass backward, deferred form: four heads; the bond and fragment-bond levels of a launch share a form");
+        if (B.nblk && !B.dz_em)
+            hipLaunchKernelGGL((k_gat_bwd_one3<4, kBwdRows, true, false>), dim3(A.nblk + B.nblk + C.nblk), dim3(kBwdRows * 32), 0, st, A, B, C, interleave);
+        else
+            hipLaunchKernelGGL((k_gat_bwd_one3<4, kBwdRows, true>), dim3(A.nblk + B.nblk + C.nblk), dim3(kBwdRows * 32), 0, st, A, B, C, interleave);
         return launch_status("attention backward, one pass, deferred form (bond + atom + fragment-bond levels)");
     }
     FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_one3<HH, kBwdRows>), dim3(A.nblk + B.nblk + C.nblk), dim3(kBwdRows * 32), 0, st, A, B, C, interleave));

@@ -116,7 +116,9 @@ int fn_abi_version(void);
                                        * heads), the weight-gradient kernels (the block's partial; side product U = G^T X for dL/da_dst), one small
                                        * launch for layer 0.  0 (default): out2 / sigma in the forward, <g, out2> in the producers' epilogues.
                                        * Measured at ESOL batch 512 (round 5, same call): the forward launches 18 us shorter, the backward 32 us
-                                       * longer (weight-gradient launch + 21, layer 0's launch + 12): 0.797 against 0.783 ms per step */
+                                       * longer (weight-gradient launch + 21, layer 0's launch + 12): 0.797 against 0.783 ms per step.
+                                       * 2 (round 6): the MIXED form -- layers >= 1 deferred, layer 0 keeps out2 / sigma (no k_gsd_seg, layer 0's
+                                       * weight-gradient kernels plain); the two boundary launches carry both epilogues */
 #define FN_TUNE_FWD_BLOCKS_EVAL_LARGE 30 /* the plain forward (inference) of a level with more than 4 x FN_TUNE_FWD_BLOCKS_EVAL row groups (2048+ molecules
                                        * per batch) runs this many workgroups instead (default 6144): with the fixed count every half-wave walked 12-46
                                        * rows and the launch waited for its slowest workgroups.  0: one count for every size (rounds 1-4) */

@@ -336,15 +336,17 @@ def test_finetune_matches_reference_golden(case, use_engine):
     check_grads(model, grads, atol=ATOL, rtol=1e-4)
 
 
+@pytest.mark.parametrize("form", [1, 2], ids=["every_layer", "mixed_layer0_keeps_out2"])
 @pytest.mark.parametrize("case", ["ft_esol_b8", "ft_edge_b6"])
-def test_deferred_backward_form_matches_reference_golden(case):
+def test_deferred_backward_form_matches_reference_golden(case, form):
     """FN_TUNE_DEFER_GSD = 1 (include/fragnet_hip.h key 29): the engine's one-pass backward WITHOUT the forward's second output -- dz at
     destination-order slots, g_s_dst summed by the input-gradient product (one more MFMA step) / fn_gat_gsd's kernel for layer 0,
     dL/da_dst from the weight-gradient kernels' side product -- against the reference's golden logits, loss and gradients
-    (four heads; the edge-case molecules of ft_edge_b6 include one-fragment and fully cut molecules: edge-less levels)."""
+    (four heads; the edge-case molecules of ft_edge_b6 include one-fragment and fully cut molecules: edge-less levels).  Form 2 (round 6) is
+    the MIXED one: layers >= 1 deferred, layer 0 with out2 / sigma -- its two boundary launches carry both kinds of epilogue."""
     from fragnet_amd import _lib
     try:
-        _lib.call("fn_set_tuning", 29, 1)
+        _lib.call("fn_set_tuning", 29, form)
         cfg, b, out, grads, model, logits, _ = _run_ft(case, True)
         torch.testing.assert_close(logits.detach().cpu(), torch.from_numpy(out["logits"]), atol=ATOL, rtol=1e-4)
         from oracle import fragnet_ref as ref
