@@ -54,3 +54,34 @@ def test_committed_whole_step_table_is_consistent():
     assert d["kernels_per_step"] == len(d["sequence"])
     assert abs(sum(e["hbm_MB"] for e in d["sequence"]) / 1e3 - d["hbm_GB"]) < 2e-3
     assert abs(d["hbm_GB"] / d["step_algorithmic_GB"] - d["traffic_over_algorithmic"]) < 2e-3
+
+
+def test_isa_mix_classifies_instructions_and_finds_loops():
+    """tools/isa_mix.py: the class of an instruction (DPP forms by their operand modifiers, LDS broadcasts, Philox's integer
+    multiplies, scalar bookkeeping) and the loops of a kernel body (a backward branch to a label; a second back edge into the same
+    body is the same loop)."""
+    m = _load("tools/isa_mix.py", "isa_mix")
+    assert m.classify("global_load_dwordx4", False) == "vmem load"
+    assert m.classify("ds_bpermute_b32", False) == "lds / bpermute"
+    assert m.classify("v_add_f32_e32", True) == "dpp / lane"
+    assert m.classify("v_fmac_f32_e32", False) == "fp32 fma / mul / add"
+    assert m.classify("v_mul_hi_u32", False).startswith("int multiply")
+    assert m.classify("v_cndmask_b32_e32", False) == "fp32 max / min / cmp-select"
+    assert m.classify("s_and_saveexec_b64", False) == "scalar ALU"
+    assert m.classify("s_waitcnt", False) == "s_waitcnt"
+    body = ["k:", "\ts_mov_b32 s0, 0", ".LBB0_1:", "\tv_add_f32_e32 v0, v1, v2", ".LBB0_2:", "\tglobal_load_dword v3, v[4:5], off",
+            "\ts_cbranch_scc1 .LBB0_2", "\tv_exp_f32_e32 v0, v0", "\ts_cbranch_vccnz .LBB0_1", "\ts_endpgm"]
+    loops = m.loops(body)
+    assert loops[0] == (2, 8)                     # the outer loop first (largest body)
+    c, vb = m.mix(body, *loops[0])
+    assert c["vmem load"] == 1 and c["transcendental"] == 1 and c["fp32 fma / mul / add"] == 1 and vb["vmem load x4B"] == 1
+
+
+def test_committed_round6_tables_are_consistent():
+    """profiles/r06_pmc_step.json: per-kernel bytes add up to the totals, and the table is stamped with the source digest it was
+    collected under (bench.py drops it when that differs from the library's)."""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_step.json")))
+    assert d["kernels_per_step"] == len(d["sequence"]) == 35
+    assert abs(sum(e["hbm_MB"] for e in d["sequence"]) / 1e3 - d["hbm_GB"]) < 2e-3
+    assert len(d["source_digest"]) == 64
