@@ -56,6 +56,11 @@ timeout 300 python3 $R/bench.py --no-cpu-baseline --no-roofline --epoch-batches 
 bash $R/tools/step_trace.sh $O/step_sequence_deferred_form.txt --steps 20 --warmup 5 --epoch-batches 0 --tune 29=1
 # the riders of round 4 off (last Linear / loss / its backward as three launches; one Adam launch over everything)
 (cd $R && FRAGNET_FUSED_HEAD_LOSS=0 FRAGNET_ADAM_RIDER=0 timeout 300 python3 bench.py --no-cpu-baseline --no-roofline --epoch-batches 0 2>/dev/null | tail -1) > $O/bench_no_riders.json
+# the default bench line once more, now that every table it reads (in-graph trace, per-launch and whole-step PMC) was collected with THIS
+# library's sources (bench.py drops tables that carry another source digest): this is the line to commit as profiles/${TAG}_bench.json
+cp $O/pmc_per_launch.json $R/profiles/pmc_per_launch.json
+cp $O/pmc_step.json $R/profiles/${TAG}_pmc_step.json
+(cd $R && timeout 600 python3 bench.py > $O/bench.json 2> $O/bench.err); cut -c1-200 $O/bench.json
 # SQ / TA counters of every kernel of the replayed step (two more --pmc passes)
 (cd $R && bash tools/pmc_step_sq_ta.sh $TAG)
 ls -la $O
