@@ -1040,7 +1040,7 @@ def main():
                              "over_algorithmic": round(mb * 1e6 / base["bytes"], 2),
                              "source": "profiles/" + os.path.basename(ps) + " (FETCH_SIZE x 2 + WRITE_SIZE of k_gat_fwd_pair and layer 0's backward launch in "
                                        "one replayed step, another run; same kernel sources by digest where the table carries one) over the in-step durations above",
-                             "cold_stream_reference": "profiles/r05_hbm_cold_stream.md: a streaming kernel of 32-64 MB per direction moves 3.7-4.1 TB/s "
+                             "cold_stream_reference": "profiles/r06_hbm_cold_stream.md: a streaming kernel of 32-64 MB per direction moves 3.7-4.1 TB/s "
                                                       "when its operands are not cache-resident, 6.5-6.9 TB/s when they are"}
             # headline = what the step obeys: the bond-graph level's forward + backward bytes over its in-step durations -- measured in
             # this run when the event nodes gave usable times, else read from the committed trace when it describes this library, else the
