@@ -1710,7 +1710,7 @@ int prof_event(int i, hipStream_t st) {
     }
     return 0;
 }
-int g_tune[FN_TUNE_COUNT] = {1024, 0, 0, 192, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 512, 2, -1, 0, 1, 0, 0, 1, 23, 1, 768, 1, 0, 1, 1, 0, 0, 6144, 1};   // in the order of the FN_TUNE_* keys
+int g_tune[FN_TUNE_COUNT] = {1024, 0, 0, 192, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 512, 2, -1, 0, 1, 0, 0, 1, 23, 1, 768, 1, 0, 1, 1, 0, 0, 6144, 1, 1};   // in the order of the FN_TUNE_* keys
 }  // namespace
 namespace fni {      // hooks for the other translation units (fn_internal.h)
 int fail(int code, const char* what) { return ::fail(code, what); }
@@ -2264,6 +2264,13 @@ int fn_dense_fwd_f32(const float* X, const float* W, const float* bias, float* Y
     T.A = X;  T.Bsrc = W;  T.bias = bias;  T.OUT = Y;
     T.I = (int)M;  T.J = (int)N;  T.R = (int)K;  T.lda = (int)K;  T.ldb = (int)K;
     if (act) { T.act = *act;  T.act.y = Y; }
+    // tall inputs: workgroup-shared 64 x 128 operand tiles (dense_head.inc, k_dense_fwd_tiles).  32-bit element offsets as elsewhere
+    if (g_tune[FN_TUNE_DENSE_TILES] != 0 && K % kDtK == 0 && dense_tiles(M, kDtM) * dense_tiles(N, kDtN) >= kDtMinTiles) {
+        T.tiles_i = dense_tiles(M, kDtM);  T.tiles_j = dense_tiles(N, kDtN);
+        if (int rc = allow_lds(k_dense_fwd_tiles, kDtLdsBytes)) return rc;
+        hipLaunchKernelGGL(k_dense_fwd_tiles, dim3((unsigned)(8 * ((T.tiles_i * T.tiles_j + 7) / 8))), dim3(kDtThreads), kDtLdsBytes, S(stream), T);
+        return launch_status("fn_dense_fwd_f32 (workgroup-shared tiles)");
+    }
     T.tiles_i = dense_tiles(M, 32);  T.tiles_j = dense_tiles(N, kDnCols);
     const int narrow = T.tiles_i * T.tiles_j < 192;      // too few 32 x 64 tiles to occupy the chip: 32 x 32
     if (narrow) T.tiles_j = dense_tiles(N, 32);

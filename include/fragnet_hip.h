@@ -126,7 +126,10 @@ int fn_abi_version(void);
                                        * many rows: its workgroups are dispatched last, so long-lived ones are the launch's tail (only large batches
                                        * reach the cap: 2048 molecules per batch forward-only 1.13 -> 1.28 M molecules/s).  Evaluation passes only (no dropout
                                        * epilogue), as FN_TUNE_FWD_BLOCKS_EVAL_LARGE.  Default 1; 0: no cap */
-#define FN_TUNE_COUNT 32
+#define FN_TUNE_DENSE_TILES 32         /* 1 (default): fn_dense_fwd_f32 runs inputs of >= 192 tiles of 64 x 128 (1536+ rows at N = 1024) with K a multiple of 32 on
+                                       * workgroup-shared LDS macro-tiles (k_dense_fwd_tiles, round 6: 62 -> 43 us at M = 2048, K = N = 1024); 0: the per-wave
+                                       * operand kernel for every shape (A/B, and the parity test of the two against each other) */
+#define FN_TUNE_COUNT 33
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= 16 * 4 * workgroups 64-bit words) is set, every wave
  * of the one-pass attention backward (fn_gat_bwd_one_f32) writes s_memtime stamps of its phases into it (tools/probe/bwd_one_probe.py

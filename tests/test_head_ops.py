@@ -115,6 +115,43 @@ def test_dense_layer_kernels_match_torch(M, K, N):
 
 
 @gpu
+@pytest.mark.parametrize("M,K,N", [(2048, 1024, 1024), (2100, 128, 1024), (1600, 64, 1000), (4096, 32, 512), (1537, 96, 1024)])
+def test_dense_forward_on_workgroup_shared_tiles_matches_float64_and_the_per_wave_kernel(M, K, N):
+    """fn_dense_fwd_f32 on tall inputs (>= 192 tiles of 64 x 128, K a multiple of 32: k_dense_fwd_tiles, FN_TUNE_DENSE_TILES): ragged row
+    and column edges, reductions shorter than the ring (K = 32, 64), against float64 products, against the standalone Philox stream
+    (bias + dropout + ReLU epilogue) and against the per-wave-operand kernel the same call runs with the key off."""
+    import ctypes as C
+    from fragnet_amd import _lib
+    from fragnet_amd.plan import _stream_ptr
+    dev = _dev()
+    st = _stream_ptr(dev)
+    assert -(-M // 64) * -(-N // 128) >= 192 and K % 32 == 0
+    torch.manual_seed(M + K + N)
+    x, w, b = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) / K ** 0.5, torch.randn(N, device=dev)
+    lin = (x.double() @ w.double().t() + b.double()).float()
+    y = torch.full((M + 3, N), 7.0, device=dev)                      # three guard rows behind the output
+    _lib.call("fn_dense_fwd_f32", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, K, N, None, st)
+    torch.testing.assert_close(y[:M], lin, atol=2e-5, rtol=1e-5)
+    assert bool((y[M:] == 7.0).all())
+    off_dev = torch.tensor([40], dtype=torch.int64, device=dev)
+    act = _lib.ActEpilogue(None, 0.25, 1, 99, 1000, off_dev.data_ptr())
+    z = torch.full((M, N), 7.0, device=dev)
+    _lib.call("fn_dense_fwd_f32", x.data_ptr(), w.data_ptr(), b.data_ptr(), z.data_ptr(), M, K, N, C.byref(act), st)
+    want = torch.empty((M, N), device=dev)
+    plain = y[:M].contiguous()
+    _lib.call("fn_dropout_act_f32", plain.data_ptr(), want.data_ptr(), plain.numel(), 0.25, 99, 1040, None, 1, st)
+    torch.testing.assert_close(z, want, atol=3e-5, rtol=1e-5)
+    try:
+        _lib.call("fn_set_tuning", 32, 0)
+        z0 = torch.full((M, N), 7.0, device=dev)
+        _lib.call("fn_dense_fwd_f32", x.data_ptr(), w.data_ptr(), b.data_ptr(), z0.data_ptr(), M, K, N, C.byref(act), st)
+    finally:
+        _lib.call("fn_set_tuning", 32, 1)
+    assert ((z > 0) != (z0 > 0)).sum() <= 2                          # the same masks; pre-activations within rounding of 0 may flip
+    torch.testing.assert_close(z, z0, atol=3e-5, rtol=1e-5)
+
+
+@gpu
 def test_dense_layer_kernels_reject_bad_shapes():
     from fragnet_amd import _lib
     from fragnet_amd.plan import _stream_ptr

@@ -44,10 +44,18 @@ __global__ __launch_bounds__(kThreads) void k_tile_fwd(const float* __restrict__
     // XCD-aware mapping: blocks b, b + 8 share an XCD (round-robin dealing).  XCD x owns the reduction slice x % S and a contiguous
     // share of the column tiles for all row tiles: its L2 holds one k-slice of X and of its W rows, nothing twice.
     const int b = (int)blockIdx.x, x = b & 7, i = b >> 3;
-    const int per_x = tiles_m * tiles_n * S / 8;           // host guarantees divisibility
-    const int cgroups = 8 / S, tn_per = tiles_n / cgroups;
-    const int ks = x % S, tn = (x / S) * tn_per + i / tiles_m, tm = i % tiles_m;
-    (void)per_x;
+    int ks, tn, tm;
+    if (S > 0) {
+        const int cgroups = 8 / S, tn_per = tiles_n / cgroups;       // host guarantees divisibility
+        ks = x % S;  tn = (x / S) * tn_per + i / tiles_m;  tm = i % tiles_m;
+    } else {
+        // S = 0: no split, any tile count -- XCD x takes the x-th contiguous eighth of the tiles (column tile major: the workgroups of an
+        // XCD share their W rows in its L2); the grid is 8 x ceil(tiles / 8), surplus workgroups leave
+        const int total = tiles_m * tiles_n, per_x = (total + 7) / 8, t = x * per_x + i;
+        if (i >= per_x || t >= total) return;
+        ks = 0;  tn = t / tiles_m;  tm = t % tiles_m;
+    }
+    if (S == 0) S = 1;
     const int i0 = tm * TM, j0 = tn * TN;
     const int kbeg = ks * (K / S), nk = (K / S) / KC;
     const int tr = wv & 1, tc = wv >> 1;                   // this wave's 32 x 64 sub-tile
@@ -187,14 +195,18 @@ int main(int argc, char** argv) {
 }
 template <int NSLOT> void run(bool cold) {
     struct Shape { int M, K, N, S; };
-    const Shape shapes[] = {{512, 1024, 1024, 4}, {512, 1024, 1024, 2}, {512, 1024, 1024, 8}, {512, 1024, 512, 8}, {512, 128, 1024, 4}, {2048, 1024, 1024, 1}};
+    // S = 0: no split and the general tile mapping (what a production kernel for tall inputs would run)
+    const Shape shapes[] = {{512, 1024, 1024, 4}, {512, 1024, 1024, 2}, {512, 1024, 1024, 8}, {512, 1024, 512, 8}, {512, 128, 1024, 4}, {2048, 1024, 1024, 1},
+                            {2048, 1024, 1024, 0}, {2048, 1024, 512, 0}, {2048, 128, 1024, 0}, {1024, 1024, 1024, 0}, {1100, 1024, 1024, 0},
+                            {8192, 1024, 1024, 0}, {8192, 1024, 512, 0}, {8192, 128, 1024, 0}, {8192, 256, 128, 0}};
     float4* junk = nullptr;
     const size_t junk_n4 = (512u << 20) / 16;
     if (cold) CK(hipMalloc(&junk, junk_n4 * 16));
     for (const Shape& sh : shapes) {
         const int M = sh.M, K = sh.K, N = sh.N, S = sh.S;
         const int tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
-        if ((K / S) % KC || 8 % S || tiles_n % (8 / S) || (tiles_m * tiles_n * S) % 8) { printf("shape %d %d %d S=%d: skipped (mapping)\n", M, K, N, S); continue; }
+        if (S > 0 && ((K / S) % KC || 8 % S || tiles_n % (8 / S) || (tiles_m * tiles_n * S) % 8)) { printf("shape %d %d %d S=%d: skipped (mapping)\n", M, K, N, S); continue; }
+        if (S == 0 && K % KC) { printf("shape %d %d %d: skipped (K %% 32)\n", M, K, N); continue; }
         std::vector<float> hX((size_t)M * K), hW((size_t)N * K), hb(N);
         uint32_t st = 12345u;
         auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.f - 0.5f; };
@@ -203,11 +215,11 @@ template <int NSLOT> void run(bool cold) {
         for (auto& v : hb) v = rnd();
         float *X, *W, *bias, *P, *Y, *Yl;
         CK(hipMalloc(&X, hX.size() * 4));  CK(hipMalloc(&W, hW.size() * 4));  CK(hipMalloc(&bias, N * 4));
-        CK(hipMalloc(&P, (size_t)S * M * N * 4));  CK(hipMalloc(&Y, (size_t)M * N * 4));  CK(hipMalloc(&Yl, (size_t)M * N * 4));
+        CK(hipMalloc(&P, (size_t)(S ? S : 1) * M * N * 4));  CK(hipMalloc(&Y, (size_t)M * N * 4));  CK(hipMalloc(&Yl, (size_t)M * N * 4));
         CK(hipMemcpy(X, hX.data(), hX.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(bias, hb.data(), N * 4, hipMemcpyHostToDevice));
-        const int grid = tiles_m * tiles_n * S, MN4 = M * N / 4;
+        const int grid = S ? tiles_m * tiles_n * S : 8 * ((tiles_m * tiles_n + 7) / 8), MN4 = M * N / 4;
         const size_t lds = (size_t)NSLOT * kSlotFloats * 4;
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_fwd<NSLOT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_fwd<NSLOT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -217,7 +229,7 @@ template <int NSLOT> void run(bool cold) {
         auto lib = [&]() { flush();  if (fn_dense_fwd_f32(X, W, bias, Yl, M, K, N, &act, nullptr)) { printf("lib: %s\n", fn_last_error()); exit(1); } };
         auto mainf = [&]() { flush();  hipLaunchKernelGGL((k_tile_fwd<NSLOT, false>), dim3(grid), dim3(kThreads), lds, 0, X, W, P, M, N, K, S, tiles_m, tiles_n); };
         auto main6 = [&]() { flush();  hipLaunchKernelGGL((k_tile_fwd<NSLOT, true>), dim3(grid), dim3(kThreads), lds, 0, X, W, P, M, N, K, S, tiles_m, tiles_n); };
-        auto comb = [&]() { hipLaunchKernelGGL(k_combine, dim3((MN4 + 255) / 256), dim3(256), 0, 0, P, bias, Y, MN4, N, S); };
+        auto comb = [&]() { hipLaunchKernelGGL(k_combine, dim3((MN4 + 255) / 256), dim3(256), 0, 0, P, bias, Y, MN4, N, S ? S : 1); };
         // ---- errors against fp64 on a sample of entries
         auto check = [&](const char* what, const float* dev) {
             std::vector<float> h((size_t)M * N);
