@@ -164,6 +164,11 @@ FNI_HIDDEN bool bad_edge_term(const fn_edge_term* et, int64_t m);
 namespace {
 inline hipStream_t S(fn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 #define FN_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+// forward kind 2 (gat_fwd.inc): this level's run-time flags are the engine's training constants
+inline bool fwd_kind_tr(const fni::GatFwdArgs& A, int heads) {
+    return fni::tune(FN_TUNE_ENGINE_CONST) != 0 && A.out2 != nullptr && A.p_edge_major != 0 && A.probs_orig == nullptr && A.pl.m >= 2 &&
+           (A.ep.y == nullptr || (A.ep.relu != 0 && A.ep.p > 0.f)) && (A.rd_out == nullptr || A.rd_J == heads);
+}
 #define FN_DISPATCH_H(heads, CALL)                         \
     switch (heads) {                                       \
         case 1: { constexpr int HH = 1; CALL; } break;     \

@@ -1710,7 +1710,7 @@ int prof_event(int i, hipStream_t st) {
     }
     return 0;
 }
-int g_tune[FN_TUNE_COUNT] = {1024, 0, 0, 192, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 512, 2, -1, 0, 1, 0, 0, 1, 23, 1, 768, 1, 0, 1, 1, 0, 0, 6144, 1, 1};   // in the order of the FN_TUNE_* keys
+int g_tune[FN_TUNE_COUNT] = {1024, 0, 0, 192, 0, 0, 0, 1, 1, 0, 1792, 1536, 512, 512, 2, -1, 0, 1, 0, 0, 1, 23, 1, 768, 1, 0, 1, 1, 0, 0, 6144, 1, 1, 1};   // in the order of the FN_TUNE_* keys
 }  // namespace
 namespace fni {      // hooks for the other translation units (fn_internal.h)
 int fail(int code, const char* what) { return ::fail(code, what); }

@@ -60,9 +60,23 @@ int prep_gat_bwd_one(const float* g_out, const float* h, const float* p_sorted, 
     }     // dev aid, see GatBwdOneArgs
     return 0;
 }
+// the engine's configuration of a level (gat_bwd_one.inc, EN): its uniform flags become compile-time constants.  An absent level
+// (nblk == 0) of a multi-level launch does not matter
+static bool one_kind_en(const GatBwdOneArgs& A) {
+    if (A.nblk == 0) return true;
+    const int kl = edge_class(&A.et);
+    return tune(FN_TUNE_ENGINE_CONST) != 0 && A.p_edge_major != 0 && A.stamps == nullptr && A.pl.m >= 2 && A.dz_em == nullptr && A.dz_sorted == nullptr &&
+           (kl != 1 || A.x_src != nullptr) && (kl != 0 || A.g_s_orig != nullptr);
+}
 int launch_gat_bwd_one(const GatBwdOneArgs& A, int heads, hipStream_t st) {
     if (A.nblk == 0) return 0;
     const int kl = edge_class(&A.et);
+    if (heads == 4 && !A.dz_em && one_kind_en(A)) {      // the engine's launches (four heads)
+        if (kl == 0) hipLaunchKernelGGL((k_gat_bwd_one<4, 0, kBwdRows, false, true>), dim3(A.nblk), dim3(kBwdRows * 32), 0, st, A);
+        else if (kl == 1) hipLaunchKernelGGL((k_gat_bwd_one<4, 1, kBwdRows, false, true>), dim3(A.nblk), dim3(kBwdRows * 32), 0, st, A);
+        else hipLaunchKernelGGL((k_gat_bwd_one<4, FN_MAX_EDGE_K, kBwdRows, false, true>), dim3(A.nblk), dim3(kBwdRows * 32), 0, st, A);
+        return launch_status("fn_gat_bwd_one_f32");
+    }
     if (A.dz_em) {            // the deferred form (DF): four heads
         if (heads != 4) return fail(FN_EUNSUPPORTED, "one-pass backward, deferred form: four heads");
         if (kl == 0) hipLaunchKernelGGL((k_gat_bwd_one<4, 0, kBwdRows, true>), dim3(A.nblk), dim3(kBwdRows * 32), 0, st, A);
@@ -100,6 +114,10 @@ int launch_gat_bwd_one3(const GatBwdOneArgs& A, const GatBwdOneArgs& B, const Ga
         else
             hipLaunchKernelGGL((k_gat_bwd_one3<4, kBwdRows, true>), dim3(A.nblk + B.nblk + C.nblk), dim3(kBwdRows * 32), 0, st, A, B, C, interleave);
         return launch_status("attention backward, one pass, deferred form (bond + atom + fragment-bond levels)");
+    }
+    if (heads == 4 && one_kind_en(A) && one_kind_en(B) && one_kind_en(C)) {      // the engine's launches (four heads)
+        hipLaunchKernelGGL((k_gat_bwd_one3<4, kBwdRows, false, false, true>), dim3(A.nblk + B.nblk + C.nblk), dim3(kBwdRows * 32), 0, st, A, B, C, interleave);
+        return launch_status("attention backward, one pass (bond + atom + fragment-bond levels)");
     }
     FN_DISPATCH_H(heads, hipLaunchKernelGGL((k_gat_bwd_one3<HH, kBwdRows>), dim3(A.nblk + B.nblk + C.nblk), dim3(kBwdRows * 32), 0, st, A, B, C, interleave));
     return launch_status("attention backward, one pass (bond + atom + fragment-bond levels)");

@@ -12,19 +12,19 @@ using fni::bad_edge_term;
 
 // (O2 instances -- the training forward of the one-pass backward, gat_bwd_one.inc -- ask for four waves per SIMD explicitly: their
 // second accumulator would otherwise tip the allocation over 128 registers)
-template <int H, int KL, bool O2 = false>
+template <int H, int KL, int O2 = 0>
 __global__ __launch_bounds__(kBlock, 4) void k_gat_fwd(GatFwdArgs A) {
     __shared__ float sWf[8][kWfLd];
     gat_fwd_body<H, KL, false, O2>(A, sWf, (int)blockIdx.x, (int)gridDim.x);
 }
 // two independent levels in one launch (bond graph + fragment-bond graph: neither reads the other's output)
-template <int H, int KLA, int KLB, bool RDA = false, bool O2 = false>
+template <int H, int KLA, int KLB, bool RDA = false, int O2 = 0>
 __global__ __launch_bounds__(kBlock, 4) void k_gat_fwd_pair(GatFwdArgs A, GatFwdArgs B) {
     __shared__ float sWf[8][kWfLd];
     if ((int)blockIdx.x < A.nblk) gat_fwd_body<H, KLA, RDA, O2>(A, sWf, (int)blockIdx.x, A.nblk);
     else gat_fwd_body<H, KLB, false, O2>(B, sWf, (int)blockIdx.x - A.nblk, B.nblk);
 }
-template <int H, bool O2 = false>
+template <int H, int O2 = 0>
 __global__ __launch_bounds__(kBlock, 4) void k_gat_fwd_rd(GatFwdArgs A) {          // single bond-graph level with the row-dots epilogue
     __shared__ float sWf[8][kWfLd];
     gat_fwd_body<H, 1, true, O2>(A, sWf, (int)blockIdx.x, (int)gridDim.x);
@@ -73,16 +73,18 @@ int launch_gat_fwd(const GatFwdArgs& A, int heads, hipStream_t st) {
     if (A.rd_out) {
         if (kl != 1) return fail(FN_EUNSUPPORTED, "attention forward: the row-dots epilogue exists for the single-attribute (bond graph) level");
         FN_DISPATCH_H(heads, {
-            if (o2) hipLaunchKernelGGL((k_gat_fwd_rd<HH, true>), dim3(A.nblk), dim3(kBlock), 0, st, A);
+            if (o2) hipLaunchKernelGGL((k_gat_fwd_rd<HH, 1>), dim3(A.nblk), dim3(kBlock), 0, st, A);
             else hipLaunchKernelGGL((k_gat_fwd_rd<HH>), dim3(A.nblk), dim3(kBlock), 0, st, A);
         });
         return launch_status("fn_gat_fwd_f32 (+ row dots)");
     }
 #define FN_FWD1(KLV)                                                                                          \
     do {                                                                                                      \
-        if (o2) hipLaunchKernelGGL((k_gat_fwd<HH, KLV, true>), dim3(A.nblk), dim3(kBlock), 0, st, A);         \
+        if constexpr (HH == 4) { if (o2 && tr) { hipLaunchKernelGGL((k_gat_fwd<HH, KLV, 2>), dim3(A.nblk), dim3(kBlock), 0, st, A);  break; } } \
+        if (o2) hipLaunchKernelGGL((k_gat_fwd<HH, KLV, 1>), dim3(A.nblk), dim3(kBlock), 0, st, A);            \
         else hipLaunchKernelGGL((k_gat_fwd<HH, KLV>), dim3(A.nblk), dim3(kBlock), 0, st, A);                  \
     } while (0)
+    const bool tr = fwd_kind_tr(A, heads);        // (four heads: the engine's training launches take the kind whose uniform flags are compile-time)
     FN_DISPATCH_H(heads, {
         if (kl == 0) FN_FWD1(0);
         else if (kl == 1) FN_FWD1(1);
@@ -105,9 +107,11 @@ int launch_gat_fwd_pair(const GatFwdArgs& A, const GatFwdArgs& B, int heads, hip
     }
 #define FN_FWD2(KB, RD)                                                                                                            \
     do {                                                                                                                           \
-        if (o2) hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, KB, RD, true>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);       \
+        if constexpr (HH == 4) { if (o2 && tr) { hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, KB, RD, 2>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);  break; } } \
+        if (o2) hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, KB, RD, 1>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);          \
         else hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, KB, RD>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);                \
     } while (0)
+    const bool tr = fwd_kind_tr(A, heads) && fwd_kind_tr(B, heads);
     FN_DISPATCH_H(heads, {
         if (A.rd_out) { if (kb == 1) FN_FWD2(1, true); else FN_FWD2(FN_MAX_EDGE_K, true); }
         else { if (kb == 1) FN_FWD2(1, false); else FN_FWD2(FN_MAX_EDGE_K, false); }

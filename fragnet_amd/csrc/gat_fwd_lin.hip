@@ -14,7 +14,7 @@ using fni::tune;
 // __launch_bounds__(.., 4): four waves per SIMD as for the plain attention kernels -- without it the accumulators of the GEMM
 // branch go to AGPRs ON TOP of the attention branch's VGPRs and the launch drops to three (the two-level destination pass
 // with the 8-attribute edge class is at three either way and would spill, so it keeps the default).
-template <int H, int KL, bool O2 = false>
+template <int H, int KL, int O2 = 0>
 __global__ __launch_bounds__(kBlock, 4) void k_gat_fwd_lin(GatFwdArgs A, LinTasks T, int gat_base) {
     extern __shared__ __attribute__((aligned(16))) float sBt[];
     __shared__ float sWf[8][kWfLd];
@@ -22,7 +22,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_gat_fwd_lin(GatFwdArgs A, LinTask
     if (lin_side_role(T, gat_base, &g)) { if (g < T.total) lin_side_block(sBt, T, g);  return; }
     if (g < A.nblk) gat_fwd_body<H, KL, false, O2>(A, sWf, g, A.nblk);
 }
-template <int H, int KLA, int KLB, bool RDA, bool O2 = false>
+template <int H, int KLA, int KLB, bool RDA, int O2 = 0>
 __global__ __launch_bounds__(kBlock, 4) void k_gat_fwd_pair_lin(GatFwdArgs A, GatFwdArgs B, LinTasks T, int gat_base) {
     extern __shared__ __attribute__((aligned(16))) float sBt[];
     __shared__ float sWf[8][kWfLd];
@@ -76,8 +76,10 @@ int launch_gat_fwd_lin(const GatFwdArgs& A, LinTasks& T, int heads, hipStream_t 
         if (int rc = launch_gat_fwd(A, heads, st)) return rc;
         return T.n ? launch_linear128_group(T, st) : 0;
     }
+    const bool tr = fwd_kind_tr(A, heads);
     FN_DISPATCH_H(heads, {
-        if (A.out2) hipLaunchKernelGGL((k_gat_fwd_lin<HH, 0, true>), dim3(grid), dim3(kBlock), kLinSideLds, st, A, T, gb);
+        if constexpr (HH == 4) { if (A.out2 && tr) { hipLaunchKernelGGL((k_gat_fwd_lin<HH, 0, 2>), dim3(grid), dim3(kBlock), kLinSideLds, st, A, T, gb);  break; } }
+        if (A.out2) hipLaunchKernelGGL((k_gat_fwd_lin<HH, 0, 1>), dim3(grid), dim3(kBlock), kLinSideLds, st, A, T, gb);
         else hipLaunchKernelGGL((k_gat_fwd_lin<HH, 0>), dim3(grid), dim3(kBlock), kLinSideLds, st, A, T, gb);
     });
     return launch_status("attention forward + projections of the next level");
@@ -94,9 +96,11 @@ int launch_gat_fwd_pair_lin(const GatFwdArgs& A, const GatFwdArgs& B, LinTasks& 
     const dim3 grid(nwg);
 #define FN_PAIR_LIN(KB, RD)                                                                                                  \
     do {                                                                                                                     \
-        if (o2) hipLaunchKernelGGL((k_gat_fwd_pair_lin<HH, 1, KB, RD, true>), grid, dim3(kBlock), kLinSideLds, st, A, B, T, gb); \
+        if constexpr (HH == 4) { if (o2 && tr) { hipLaunchKernelGGL((k_gat_fwd_pair_lin<HH, 1, KB, RD, 2>), grid, dim3(kBlock), kLinSideLds, st, A, B, T, gb);  break; } } \
+        if (o2) hipLaunchKernelGGL((k_gat_fwd_pair_lin<HH, 1, KB, RD, 1>), grid, dim3(kBlock), kLinSideLds, st, A, B, T, gb);   \
         else hipLaunchKernelGGL((k_gat_fwd_pair_lin<HH, 1, KB, RD>), grid, dim3(kBlock), kLinSideLds, st, A, B, T, gb);      \
     } while (0)
+    const bool tr = fwd_kind_tr(A, heads) && fwd_kind_tr(B, heads);
     FN_DISPATCH_H(heads, {
         if (A.rd_out) { if (kb == 1) FN_PAIR_LIN(1, true); else FN_PAIR_LIN(FN_MAX_EDGE_K, true); }
         else { if (kb == 1) FN_PAIR_LIN(1, false); else FN_PAIR_LIN(FN_MAX_EDGE_K, false); }

@@ -24,20 +24,20 @@ def _encoder_run(model, batch, offset):
     return [t.detach().clone() for t in outs if t is not None], {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
 
 
-@pytest.mark.parametrize("key,value", [(8, 0), (7, 0), (14, 0), (20, 0), (29, 1), (29, 2), (22, 0)])
+@pytest.mark.parametrize("key,value", [(8, 0), (7, 0), (14, 0), (20, 0), (29, 1), (29, 2), (22, 0), (33, 0)])
 def test_alternative_kernels_behind_tuning_keys_stay_parity_green(key, value):
     """The alternative paths that stay selectable (include/fragnet_hip.h FN_TUNE_*): 8 = 0 the LDS-staged grouped weight-gradient
     kernel, 7 = 0 the separate row-dots launch, 14 = 0 the projection GEMMs as launches of their own instead of riding with the
     attention launches, 20 = 0 the last layer's fragment tail as separate launches instead of the
     molecule-resident pair, 29 = 1 the one-pass backward in its deferred form (no second forward output: the g_s_dst term is added by the
-    consumers of g_h; 29 = 2 its mixed form: layer 0 keeps the second output), 22 = 0 the destination + source passes.  Each must reproduce the default path's outputs and gradients (same Philox
+    consumers of g_h; 29 = 2 its mixed form: layer 0 keeps the second output), 22 = 0 the destination + source passes, 33 = 0 the general kernel instances instead of the engine-constant ones (round 6).  Each must reproduce the default path's outputs and gradients (same Philox
     stream) on a training step with dropout."""
     from fragnet_amd import _lib, data, model as M, synth
     torch.manual_seed(0)
     net = M.FragNetFineTune(n_classes=1, num_layer=3, drop_ratio=0.1, h1=32, h2=32, h3=32, h4=32, act="relu", fthead="FTHead3").to(DEV)
     net.train()
     batch = data.batch_to(data.collate_fn(synth.synth_molecules(96, seed=17, profile="esol")), DEV)
-    default = {7: 1, 8: 1, 14: 2, 20: 1, 29: 0, 22: 1}[key]
+    default = {7: 1, 8: 1, 14: 2, 20: 1, 29: 0, 22: 1, 33: 1}[key]
     try:
         o0, g0 = _encoder_run(net, batch, 999)
         _lib.call("fn_set_tuning", key, value)
