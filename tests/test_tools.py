@@ -23,6 +23,14 @@ def test_pmc_summary_tells_the_two_forward_variants_apart():
     assert not t._match("void (anonymous namespace)::k_gat_fwd_pair<4, 1, 8, true, true>(...)", "k_gat_fwd", True)
     assert t._match("void (anonymous namespace)::k_gat_bwd_one<4, 1, 8>(...)", "k_gat_bwd_one", None)
     assert not t._match("void (anonymous namespace)::k_gat_bwd_one3<4, 8>(...)", "k_gat_bwd_one", None)
+    # round 6: the forward's third argument is a KIND (0 plain, 1 / 2 with the second output), the backward's fifth an engine-constant flag
+    assert t._match("void (anonymous namespace)::k_gat_fwd<4, 1, 2>(fni::GatFwdArgs)", "k_gat_fwd", True)
+    assert t._match("void (anonymous namespace)::k_gat_fwd<4, 1, 0>(fni::GatFwdArgs)", "k_gat_fwd", False)
+    assert t._match("_ZN12_GLOBAL__N_19k_gat_fwdILi4ELi1ELi2EEEvN3fni10GatFwdArgsE", "k_gat_fwd", True)
+    assert t._match("void (anonymous namespace)::k_gat_bwd_one<4, 1, 8, false, true>(...)", "k_gat_bwd_one", False)      # engine-constant, not deferred
+    assert t._match("void (anonymous namespace)::k_gat_bwd_one<4, 1, 8, true>(...)", "k_gat_bwd_one", True)
+    assert t._match("void (anonymous namespace)::k_gat_bwd_one<4, 1, 8>(...)", "k_gat_bwd_one", False)
+    assert t._match("_ZN12_GLOBAL__N_113k_gat_bwd_oneILi4ELi1ELi8ELb0ELb1EEEvN3fni13GatBwdOneArgsE", "k_gat_bwd_one", False)
 
 
 def test_physical_core_count_is_a_positive_integer_not_above_the_logical_count():

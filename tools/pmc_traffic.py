@@ -22,19 +22,33 @@ KERNELS = {"k_gat_fwd": ("k_gat_fwd", False), "k_gat_fwd(+out2)": ("k_gat_fwd", 
            "k_gat_cu": ("k_gat_cu", None), "k_gat_bwd_dst": ("k_gat_bwd_dst", None), "k_gat_bwd_src": ("k_gat_bwd_src", None)}
 
 
-def _match(name, base, o2):
+# which template argument carries the variant, and which of its spellings mean "on":
+#   k_gat_fwd<H, KL, KIND>           KIND 0 plain | 1 second output | 2 second output, engine-constant instance (round 6; bool until then)
+#   k_gat_bwd_one<H, KL, RB, DF, EN> DF = the deferred form (EN: engine-constant instance of the same pass, round 6)
+_VARIANT_ARG = {"k_gat_fwd": 2, "k_gat_bwd_one": 3}
+_ON = ("true", "1", "2")
+
+
+def _template_args(name, base):
+    """The kernel's template arguments as strings ('4', '1', 'true', ...), from a demangled or an Itanium-mangled name; None: another kernel."""
     import re
     if base + "<" in name:                          # demangled
-        if o2 is None:
-            return True
-        args = name.split(base + "<", 1)[1].split(">", 1)[0]
-        return args.strip().endswith("true") == o2
+        return [a.strip() for a in name.split(base + "<", 1)[1].split(">", 1)[0].split(",")]
     m = re.search(base + r"I((?:L[ib]\d+E)+)E", name)       # mangled: template arguments as Li4ELi1ELb1E
     if not m:
+        return None
+    return [("true" if v != "0" else "false") if t == "b" else v for t, v in re.findall(r"L([ib])(\d+)E", m.group(1))]
+
+
+def _match(name, base, o2):
+    args = _template_args(name, base)
+    if args is None:
         return False
     if o2 is None:
         return True
-    return m.group(1).endswith("Lb1E") == o2
+    i = _VARIANT_ARG.get(base, len(args) - 1)
+    on = i < len(args) and args[i] in _ON
+    return on == o2
 
 
 def per_kernel(path, counter):
