@@ -169,6 +169,11 @@ inline bool fwd_kind_tr(const fni::GatFwdArgs& A, int heads) {
     return fni::tune(FN_TUNE_ENGINE_CONST) != 0 && A.out2 != nullptr && A.p_edge_major != 0 && A.probs_orig == nullptr && A.pl.m >= 2 &&
            (A.ep.y == nullptr || (A.ep.relu != 0 && A.ep.p > 0.f)) && (A.rd_out == nullptr || A.rd_J == heads);
 }
+// forward kind 3: the engine's evaluation launches (no second output, head-major probabilities, ReLU epilogue without dropout)
+inline bool fwd_kind_ev(const fni::GatFwdArgs& A, int heads) {
+    return fni::tune(FN_TUNE_ENGINE_CONST) != 0 && A.out2 == nullptr && A.p_edge_major == 0 && A.probs_orig == nullptr && A.pl.m >= 2 &&
+           (A.ep.y == nullptr || (A.ep.relu != 0 && !(A.ep.p > 0.f))) && (A.rd_out == nullptr || A.rd_J == heads);
+}
 #define FN_DISPATCH_H(heads, CALL)                         \
     switch (heads) {                                       \
         case 1: { constexpr int HH = 1; CALL; } break;     \

@@ -81,10 +81,11 @@ int launch_gat_fwd(const GatFwdArgs& A, int heads, hipStream_t st) {
 #define FN_FWD1(KLV)                                                                                          \
     do {                                                                                                      \
         if constexpr (HH == 4) { if (o2 && tr) { hipLaunchKernelGGL((k_gat_fwd<HH, KLV, 2>), dim3(A.nblk), dim3(kBlock), 0, st, A);  break; } } \
+        if constexpr (HH == 4) { if (!o2 && ev) { hipLaunchKernelGGL((k_gat_fwd<HH, KLV, 3>), dim3(A.nblk), dim3(kBlock), 0, st, A);  break; } } \
         if (o2) hipLaunchKernelGGL((k_gat_fwd<HH, KLV, 1>), dim3(A.nblk), dim3(kBlock), 0, st, A);            \
         else hipLaunchKernelGGL((k_gat_fwd<HH, KLV>), dim3(A.nblk), dim3(kBlock), 0, st, A);                  \
     } while (0)
-    const bool tr = fwd_kind_tr(A, heads);        // (four heads: the engine's training launches take the kind whose uniform flags are compile-time)
+    const bool tr = fwd_kind_tr(A, heads), ev = fwd_kind_ev(A, heads);      // (four heads: the engine's launches take the kinds whose uniform flags are compile-time)
     FN_DISPATCH_H(heads, {
         if (kl == 0) FN_FWD1(0);
         else if (kl == 1) FN_FWD1(1);
@@ -108,10 +109,11 @@ int launch_gat_fwd_pair(const GatFwdArgs& A, const GatFwdArgs& B, int heads, hip
 #define FN_FWD2(KB, RD)                                                                                                            \
     do {                                                                                                                           \
         if constexpr (HH == 4) { if (o2 && tr) { hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, KB, RD, 2>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);  break; } } \
+        if constexpr (HH == 4) { if (!o2 && ev) { hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, KB, RD, 3>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);  break; } } \
         if (o2) hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, KB, RD, 1>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);          \
         else hipLaunchKernelGGL((k_gat_fwd_pair<HH, 1, KB, RD>), dim3(A.nblk + B.nblk), dim3(kBlock), 0, st, A, B);                \
     } while (0)
-    const bool tr = fwd_kind_tr(A, heads) && fwd_kind_tr(B, heads);
+    const bool tr = fwd_kind_tr(A, heads) && fwd_kind_tr(B, heads), ev = fwd_kind_ev(A, heads) && fwd_kind_ev(B, heads);
     FN_DISPATCH_H(heads, {
         if (A.rd_out) { if (kb == 1) FN_FWD2(1, true); else FN_FWD2(FN_MAX_EDGE_K, true); }
         else { if (kb == 1) FN_FWD2(1, false); else FN_FWD2(FN_MAX_EDGE_K, false); }

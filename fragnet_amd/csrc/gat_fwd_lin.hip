@@ -76,9 +76,10 @@ int launch_gat_fwd_lin(const GatFwdArgs& A, LinTasks& T, int heads, hipStream_t 
         if (int rc = launch_gat_fwd(A, heads, st)) return rc;
         return T.n ? launch_linear128_group(T, st) : 0;
     }
-    const bool tr = fwd_kind_tr(A, heads);
+    const bool tr = fwd_kind_tr(A, heads), ev = fwd_kind_ev(A, heads);
     FN_DISPATCH_H(heads, {
         if constexpr (HH == 4) { if (A.out2 && tr) { hipLaunchKernelGGL((k_gat_fwd_lin<HH, 0, 2>), dim3(grid), dim3(kBlock), kLinSideLds, st, A, T, gb);  break; } }
+        if constexpr (HH == 4) { if (!A.out2 && ev) { hipLaunchKernelGGL((k_gat_fwd_lin<HH, 0, 3>), dim3(grid), dim3(kBlock), kLinSideLds, st, A, T, gb);  break; } }
         if (A.out2) hipLaunchKernelGGL((k_gat_fwd_lin<HH, 0, 1>), dim3(grid), dim3(kBlock), kLinSideLds, st, A, T, gb);
         else hipLaunchKernelGGL((k_gat_fwd_lin<HH, 0>), dim3(grid), dim3(kBlock), kLinSideLds, st, A, T, gb);
     });
@@ -97,10 +98,11 @@ int launch_gat_fwd_pair_lin(const GatFwdArgs& A, const GatFwdArgs& B, LinTasks& 
 #define FN_PAIR_LIN(KB, RD)                                                                                                  \
     do {                                                                                                                     \
         if constexpr (HH == 4) { if (o2 && tr) { hipLaunchKernelGGL((k_gat_fwd_pair_lin<HH, 1, KB, RD, 2>), grid, dim3(kBlock), kLinSideLds, st, A, B, T, gb);  break; } } \
+        if constexpr (HH == 4) { if (!o2 && ev) { hipLaunchKernelGGL((k_gat_fwd_pair_lin<HH, 1, KB, RD, 3>), grid, dim3(kBlock), kLinSideLds, st, A, B, T, gb);  break; } } \
         if (o2) hipLaunchKernelGGL((k_gat_fwd_pair_lin<HH, 1, KB, RD, 1>), grid, dim3(kBlock), kLinSideLds, st, A, B, T, gb);   \
         else hipLaunchKernelGGL((k_gat_fwd_pair_lin<HH, 1, KB, RD>), grid, dim3(kBlock), kLinSideLds, st, A, B, T, gb);      \
     } while (0)
-    const bool tr = fwd_kind_tr(A, heads) && fwd_kind_tr(B, heads);
+    const bool tr = fwd_kind_tr(A, heads) && fwd_kind_tr(B, heads), ev = fwd_kind_ev(A, heads) && fwd_kind_ev(B, heads);
     FN_DISPATCH_H(heads, {
         if (A.rd_out) { if (kb == 1) FN_PAIR_LIN(1, true); else FN_PAIR_LIN(FN_MAX_EDGE_K, true); }
         else { if (kb == 1) FN_PAIR_LIN(1, false); else FN_PAIR_LIN(FN_MAX_EDGE_K, false); }

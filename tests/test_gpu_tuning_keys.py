@@ -77,3 +77,39 @@ def test_launch_geometry_keys_of_the_plain_forward_do_not_change_a_bit():
     finally:
         for k, v in {10: 1792, 30: 6144, 31: 1}.items():
             _lib.call("fn_set_tuning", k, v)
+
+
+def test_engine_constant_instances_do_not_change_a_bit():
+    """FN_TUNE_ENGINE_CONST (33): the attention launches of the engine run kernel instances whose uniform run-time flags are
+    compile-time constants (forward kinds 2 / 3, the one-pass backward's EN instances).  Same arithmetic: an inference pass and a
+    training step with dropout (outputs and every gradient) are BIT-identical with the key off."""
+    from fragnet_amd import _lib, data, model as M, synth
+    torch.manual_seed(2)
+    net = M.FragNetFineTune(n_classes=1, num_layer=3, drop_ratio=0.1, h1=32, h2=32, h3=32, h4=32, act="relu", fthead="FTHead3").to(DEV)
+    batch = data.batch_to(data.collate_fn(synth.synth_molecules(96, seed=29, profile="esol")), DEV)
+
+    def infer():
+        net.eval()
+        batch.pop("_fragnet_plan", None)
+        with torch.no_grad():
+            out = net(batch)
+        torch.cuda.synchronize()
+        return out.detach().clone()
+
+    def train():
+        net.train()
+        return _encoder_run(net, batch, 777)
+
+    try:
+        _lib.call("fn_set_tuning", 33, 0)
+        e0, (o0, g0) = infer(), train()
+        _lib.call("fn_set_tuning", 33, 1)
+        e1, (o1, g1) = infer(), train()
+    finally:
+        _lib.call("fn_set_tuning", 33, 1)
+    assert torch.equal(e0, e1)
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    assert set(g0) == set(g1)
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
