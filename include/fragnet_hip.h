@@ -129,11 +129,13 @@ int fn_abi_version(void);
 #define FN_TUNE_DENSE_TILES 32         /* 1 (default): fn_dense_fwd_f32 runs inputs of >= 192 tiles of 64 x 128 (1536+ rows at N = 1024) with K a multiple of 32 on
                                        * workgroup-shared LDS macro-tiles (k_dense_fwd_tiles, round 6: 62 -> 43 us at M = 2048, K = N = 1024); 0: the per-wave
                                        * operand kernel for every shape (A/B, and the parity test of the two against each other) */
-#define FN_TUNE_ENGINE_CONST 33        /* 1 (default): the attention launches of the engine's training pass (four heads: edge-major probabilities, no
-                                       * probs_orig / stamp buffer, relu(dropout(.)) epilogues with p > 0, levels of >= 2 edges) run kernel instances in
-                                       * which those uniform run-time flags are compile-time constants -- same arithmetic, bit-identical results, fewer
-                                       * scalar tests and branches in the issue-bound row loops (round 6: 0.761 -> 0.75 ms per step); 0: the general
-                                       * instances for every launch (A/B, and the parity test of the two against each other) */
+#define FN_TUNE_ENGINE_CONST 33        /* 1 (default): the attention launches of the engine (four heads, levels of >= 2 edges, no probs_orig / stamp buffer)
+                                       * run kernel instances in which their uniform run-time flags are compile-time constants -- a training pass:
+                                       * edge-major probabilities, relu(dropout(.)) epilogues with p > 0 (forward kind 2, the one-pass backward's EN
+                                       * instances); an evaluation pass: head-major probabilities, ReLU epilogues without dropout (forward kind 3).  Same
+                                       * arithmetic, bit-identical results, fewer scalar tests and branches in the issue-bound row loops (round 6: 0.769 ->
+                                       * 0.755 ms per training step, the forward-only sweep - 4 ... - 7 %); 0: the general instances for every launch (A/B,
+                                       * and the parity test of the two against each other) */
 #define FN_TUNE_COUNT 34
 int fn_set_tuning(int key, int value);
 /* Profiling aid (process-wide, like the tuning knobs): while `buf` (device, n_u64 >= 16 * 4 * workgroups 64-bit words) is set, every wave
