@@ -1017,8 +1017,8 @@ def main():
                 live["k_gat_bwd_one3 (layer 0: bond + fragment-bond levels)"] = {"us": t_b, "bytes": b1 + b2, "frac": round((b1 + b2) / t_b / 1e3 / HBM_PEAK_GBPS, 4)}
                 live["fwd+bwd"] = {"us": round(t_f + t_b, 2), "bytes": f1 + f2 + b1 + b2, "GBps": round((f1 + f2 + b1 + b2) / (t_f + t_b) / 1e3, 1),
                                    "frac": round((f1 + f2 + b1 + b2) / (t_f + t_b) / 1e3 / HBM_PEAK_GBPS, 4)}
-            # what the headline launches MOVE inside the step (whole-step PMC table, profiles/r04_pmc_step.json) next to what a streaming
-            # kernel of that size gets with cold caches on this part (profiles/r04_hbm_cold_stream.md): context for `frac`, not a metric
+            # what the headline launches MOVE inside the step (whole-step PMC table, profiles/rNN_pmc_step.json) next to what a plain copy
+            # of that size gets on this part (profiles/r06_cold_stream_probe.txt): context for `frac`, not a metric
             moved = None
             # (the newest committed table; dropped -- like the trace's durations -- when it was collected with other kernel sources)
             import glob
@@ -1040,8 +1040,9 @@ def main():
                              "over_algorithmic": round(mb * 1e6 / base["bytes"], 2),
                              "source": "profiles/" + os.path.basename(ps) + " (FETCH_SIZE x 2 + WRITE_SIZE of k_gat_fwd_pair and layer 0's backward launch in "
                                        "one replayed step, another run; same kernel sources by digest where the table carries one) over the in-step durations above",
-                             "cold_stream_reference": "profiles/r06_hbm_cold_stream.md: a streaming kernel of 32-64 MB per direction moves 3.7-4.1 TB/s "
-                                                      "when its operands are not cache-resident, 6.5-6.9 TB/s when they are"}
+                             "copy_reference": "profiles/r06_cold_stream_probe.txt (device timestamps): a plain copy of 32-64 MB per direction moves 7.0-7.5 TB/s "
+                                               "hot AND cold behind a read-only evicting pass; 3.3-3.7 TB/s only behind a FILL that left the memory-side "
+                                               "cache dirty (the 3.7-4.1 TB/s 'cold' figure of r04-r06_hbm_cold_stream.md is that case)"}
             # headline = what the step obeys: the bond-graph level's forward + backward bytes over its in-step durations -- measured in
             # this run when the event nodes gave usable times, else read from the committed trace when it describes this library, else the
             # stand-alone launches (and the line says which)

@@ -10,7 +10,8 @@ the default bench command, held against the step's algorithmic bytes.
 
 With the step sequence of a kernel trace of the same command (tools/rocpd_sequence.py) every kernel also gets its duration there and
 the bandwidth it MOVED (hbm_MB / us): what the launch actually pulled through the fabric, to be held against what a streaming kernel
-of that size gets with cold caches (profiles/r04_hbm_cold_stream.md), not against the 8 TB/s of the roofline.
+of that size gets (profiles/r06_cold_stream_probe.txt: 7+ TB/s hot or clean-cold, 3.3-3.7 behind a pass that left the memory-side
+cache dirty -- the case profiles/r04_hbm_cold_stream.md measured), not against the 8 TB/s of the roofline.
 `--join <existing.json> <step_sequence.txt>` adds those two columns to a table collected earlier.
 
 One step = the dispatches between the last two k_stage_padded launches of the run (dispatch-id order).  Units and the gfx950
