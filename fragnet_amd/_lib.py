@@ -118,7 +118,7 @@ class Encoder(C.Structure):
                 ("cos_raw", vp), ("fattr_raw", vp),
                 ("w", LayerWeights * FN_MAX_LAYERS), ("ws", vp), ("ws_floats", i64),
                 ("mol_atoms", SegPlan), ("mol_frags", SegPlan), ("n_mols", i64), ("counts_dev", vp), ("status", vp),
-                ("mol_contiguous", i32), ("pad3_", i32), ("pooled", vp), ("g_pooled", vp), ("adam_rider", vp)]
+                ("mol_contiguous", i32), ("no_backward", i32), ("pooled", vp), ("g_pooled", vp), ("adam_rider", vp)]
 
 
 # name -> argtypes; every function returns int (0 ok / <0 argument error / >0 hipError_t) unless noted.

@@ -7,6 +7,7 @@ instead of ~250 autograd nodes.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Sequence
 
 import torch
@@ -14,6 +15,9 @@ import torch
 from . import _lib, ops
 from ._lib import Encoder, FN_D, LAYER_FIELDS, LayerWeights, SegPlan
 from .plan import GraphPlan, _stream_ptr
+
+# dev switch for A/B measurements: evaluation passes save everything a backward pass would read even when none can follow
+_EVAL_SAVES = os.environ.get("FRAGNET_EVAL_SAVES", "0") == "1"
 
 
 def layer_param_list(layer) -> List[torch.nn.Parameter]:
@@ -46,12 +50,13 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
 
 def _describe(plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, params: Sequence[torch.Tensor],
               n_layers: int, heads: int, drop_p: float, training: bool, seed: int, offset: int, offset_dev=None,
-              variant: int = 0) -> Encoder:
+              variant: int = 0, no_backward: bool = False) -> Encoder:
     e = Encoder()
     e.n_layers, e.heads = n_layers, heads
     e.k_atom0, e.k_bond0, e.k_fbond0 = x_atoms.shape[1], bond_nodes.shape[1], fbond_nodes.shape[1]
     e.k_fattr = fattr_sorted.shape[0]
     e.training, e.drop_p = int(training), float(drop_p)
+    e.no_backward = int(bool(no_backward) and not training)       # an evaluation pass nobody differentiates saves nothing for a backward pass
     e.variant = int(variant)
     e.seed, e.offset = seed, offset
     e.offset_dev = None if offset_dev is None else offset_dev.data_ptr()
@@ -84,14 +89,14 @@ def _describe(plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fat
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, plan, n_layers, heads, drop_p, training,
-                seed, offset, offset_dev, variant, *params):
+                seed, offset, offset_dev, variant, no_backward, *params):
         x_atoms, bond_nodes, fbond_nodes = _f32(x_atoms, "x_atoms"), _f32(bond_nodes, "node_features_bonds"), _f32(fbond_nodes, "node_features_fbonds")
         ctx.param_objs, ctx.slots = params, [ops.grad_slot(p) for p in params]
         params = tuple(_f32(p, "parameter") for p in params)
         dev = x_atoms.device
         lib = _lib.load()
         e = _describe(plan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, params, n_layers, heads, drop_p,
-                      training, seed, offset, offset_dev, variant)
+                      training, seed, offset, offset_dev, variant, no_backward)
         ws = torch.empty(lib.fn_encoder_ws_floats(C.byref(e)), dtype=torch.float32, device=dev)
         e.ws, e.ws_floats = ws.data_ptr(), ws.numel()
         outs = [torch.empty((n, FN_D), dtype=torch.float32, device=dev) for n in (e.N, e.F, e.E, e.EF)]
@@ -158,7 +163,7 @@ class _EncoderFn(torch.autograd.Function):
                 if ctx.variant == 2 and (k in EDGE_DEAD or (k in EDGE_LAST_ONLY and not (l == n_layers - 1 and have_frags))):
                     live = False
                 out.append(grads[l * NP + k] if live else None)
-        return (None,) * 14 + tuple(out)
+        return (None,) * 15 + tuple(out)
 
 
 _ADAM_RIDER = [None, False]       # [armed fn_adam_slice, was it handed to a backward pass]
@@ -209,5 +214,8 @@ def encoder_forward(layers, plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, c
         seed, offset = rng.take(4 * blocks)
     else:
         seed, offset = 0, 0
+    # under torch.no_grad(), or when nothing it reads requires a gradient, no backward pass can follow: an evaluation pass then
+    # stores nothing for one (fn_encoder.no_backward).  (Inside Function.forward grad mode is always off: it is read here.)
+    no_backward = not _EVAL_SAVES and not (torch.is_grad_enabled() and any(t.requires_grad for t in (x_atoms, bond_nodes, fbond_nodes, *params)))
     return _EncoderFn.apply(x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, plan, n_layers, heads, p_eff,
-                            bool(training), seed, offset, rng.dev if p_eff > 0.0 else None, int(variant), *params)
+                            bool(training), seed, offset, rng.dev if p_eff > 0.0 else None, int(variant), no_backward, *params)

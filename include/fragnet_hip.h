@@ -719,7 +719,13 @@ typedef struct fn_encoder {
      * cat(scatter_add(out_atoms, batch), scatter_add(out_frags, frag_batch)) [n_mols, 256] (gat2.py:820-823) run as ONE
      * molecule-resident launch, and their backward (with dL/d(pooled) in `g_pooled`, nullable, added to g_atoms / g_frags) as
      * one more.  fn_encoder_fused_tail() says whether a descriptor takes that path; `pooled` / `g_pooled` must be NULL if not. */
-    int32_t mol_contiguous, pad3_;
+    int32_t mol_contiguous;
+    /* no_backward (was padding: 0 keeps the old behaviour): the caller's word that no fn_encoder_backward will follow this
+     * fn_encoder_forward (torch.no_grad() / nothing requires a gradient).  An EVALUATION pass (training == 0) then saves nothing
+     * for one: the attention probabilities of its levels are not stored, nor the raw bond rows once their only forward reader --
+     * the atom graph's edge term -- was folded into the bond level's launch (FN_TUNE_FUSE_ROWDOTS).  Outputs are bit-identical;
+     * fn_encoder_backward on such a descriptor returns FN_EINVAL.  Ignored by training passes. */
+    int32_t no_backward;
     float* pooled;
     const float* g_pooled;
     /* fn_encoder_backward only, nullable: an Adam update (fn_adam_dev_f32's arithmetic) of a slice of the flat parameter buffer whose
