@@ -89,7 +89,7 @@ def _describe(plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fat
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, plan, n_layers, heads, drop_p, training,
-                seed, offset, offset_dev, variant, no_backward, *params):
+                seed, offset, offset_dev, variant, no_backward, edge_outputs, *params):
         x_atoms, bond_nodes, fbond_nodes = _f32(x_atoms, "x_atoms"), _f32(bond_nodes, "node_features_bonds"), _f32(fbond_nodes, "node_features_fbonds")
         ctx.param_objs, ctx.slots = params, [ops.grad_slot(p) for p in params]
         params = tuple(_f32(p, "parameter") for p in params)
@@ -99,14 +99,17 @@ class _EncoderFn(torch.autograd.Function):
                       training, seed, offset, offset_dev, variant, no_backward)
         ws = torch.empty(lib.fn_encoder_ws_floats(C.byref(e)), dtype=torch.float32, device=dev)
         e.ws, e.ws_floats = ws.data_ptr(), ws.numel()
-        outs = [torch.empty((n, FN_D), dtype=torch.float32, device=dev) for n in (e.N, e.F, e.E, e.EF)]
+        # edge_outputs = False: the caller reads neither the bond nor the fragment-bond output (a finetune head): the library gets NULL for
+        # them and does not store the last layer's activated rows; two empty, non-differentiable tensors stand in
+        outs = [torch.empty((n if (edge_outputs or k < 2) else 0, FN_D), dtype=torch.float32, device=dev) for k, n in enumerate((e.N, e.F, e.E, e.EF))]
         # molecule-contiguous batches: the last layer's fragment tail is one molecule-resident launch that also writes the
         # readout cat(scatter_add(x_atoms, batch), scatter_add(x_frags, frag_batch)) (gat2.py:820-823) -- a fifth output
         pooled = None
         if lib.fn_encoder_fused_tail(C.byref(e)):
             pooled = torch.empty((e.n_mols, 2 * FN_D), dtype=torch.float32, device=dev)
             e.pooled = pooled.data_ptr()
-        _lib.check(lib.fn_encoder_forward(C.byref(e), *(o.data_ptr() for o in outs), _stream_ptr(dev)), "fn_encoder_forward")
+        _lib.check(lib.fn_encoder_forward(C.byref(e), *((o.data_ptr() if (edge_outputs or k < 2) else None) for k, o in enumerate(outs)),
+                                          _stream_ptr(dev)), "fn_encoder_forward")
         e.pooled = None
         plan.pending.pop("bond", None)
         plan.pending.pop("frag" if variant == 2 else "fbond", None)
@@ -115,11 +118,15 @@ class _EncoderFn(torch.autograd.Function):
         ctx.keep = (plan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, ws, offset_dev)
         ctx.n_layers = n_layers
         ctx.variant = int(variant)
+        ctx.edge_outputs = bool(edge_outputs)
         ctx.save_for_backward(*params, *outs)
         ctx.set_materialize_grads(False)
+        dead = [] if edge_outputs else [outs[2], outs[3]]
         if pooled is None:                   # placeholder: the caller pools with ops.pool_cat
             pooled = torch.empty(0, dtype=torch.float32, device=dev)
-            ctx.mark_non_differentiable(pooled)
+            dead.append(pooled)
+        if dead:
+            ctx.mark_non_differentiable(*dead)           # (at most one call per forward)
         return tuple(outs) + (pooled,)
 
     @staticmethod
@@ -144,7 +151,7 @@ class _EncoderFn(torch.autograd.Function):
         if rider is not None:
             rider.launched = 0
         try:
-            _lib.check(lib.fn_encoder_backward(C.byref(e), *(o.data_ptr() for o in outs),
+            _lib.check(lib.fn_encoder_backward(C.byref(e), *((o.data_ptr() if (ctx.edge_outputs or k < 2) else None) for k, o in enumerate(outs)),
                                                *(None if g is None else g.data_ptr() for g in gs), gw, scratch.data_ptr(),
                                                scratch.numel(), _stream_ptr(dev)), "fn_encoder_backward")
         finally:
@@ -163,7 +170,7 @@ class _EncoderFn(torch.autograd.Function):
                 if ctx.variant == 2 and (k in EDGE_DEAD or (k in EDGE_LAST_ONLY and not (l == n_layers - 1 and have_frags))):
                     live = False
                 out.append(grads[l * NP + k] if live else None)
-        return (None,) * 15 + tuple(out)
+        return (None,) * 16 + tuple(out)
 
 
 _ADAM_RIDER = [None, False]       # [armed fn_adam_slice, was it handed to a backward pass]
@@ -192,7 +199,7 @@ def adam_rider_taken() -> bool:
 
 
 def encoder_forward(layers, plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, heads: int,
-                    drop_p: float, training: bool, rng, variant: int = 0) -> tuple:
+                    drop_p: float, training: bool, rng, variant: int = 0, edge_outputs: bool = True) -> tuple:
     """Runs all ``layers`` (FragNetLayerA modules) + the inter-layer act(dropout(.)); returns the four outputs and, fifth,
     the readout [n_mols, 256] when the fused fragment tail produced it (an empty tensor otherwise)."""
     params = [p for layer in layers for p in layer_param_list(layer)]
@@ -218,4 +225,4 @@ def encoder_forward(layers, plan: GraphPlan, x_atoms, bond_nodes, fbond_nodes, c
     # stores nothing for one (fn_encoder.no_backward).  (Inside Function.forward grad mode is always off: it is read here.)
     no_backward = not _EVAL_SAVES and not (torch.is_grad_enabled() and any(t.requires_grad for t in (x_atoms, bond_nodes, fbond_nodes, *params)))
     return _EncoderFn.apply(x_atoms, bond_nodes, fbond_nodes, cos_sorted, fattr_sorted, plan, n_layers, heads, p_eff,
-                            bool(training), seed, offset, rng.dev if p_eff > 0.0 else None, int(variant), no_backward, *params)
+                            bool(training), seed, offset, rng.dev if p_eff > 0.0 else None, int(variant), no_backward, bool(edge_outputs), *params)

@@ -426,10 +426,10 @@ class GraphedTrainStep:
 
     def _part_a(self):
         """forward, loss, and the backward pass of loss + head; leaves d loss / d pooled in ``leaf.grad``."""
-        from .model import pooled
+        from .model import _KEEP_EDGE_OUTPUTS, pooled
         sb = self.static.t
         sb.pop(PLAN_KEY, None)
-        x_atoms, x_frags, _, _ = self.model.pretrain(sb)
+        x_atoms, x_frags, _, _ = self.model.pretrain(sb, edge_outputs=_KEEP_EDGE_OUTPUTS)
         pooled_t = pooled(x_atoms, x_frags, sb)
         leaf = pooled_t.detach().requires_grad_(True)
         self.model.fthead.live_rows = sb.get(LIVE_MOLS_KEY)

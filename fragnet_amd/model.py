@@ -19,6 +19,8 @@ without gradient, exactly as there.  GPU tensors only: there is no CPU fallback.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -26,6 +28,9 @@ import torch.nn.functional as F
 from . import engine, ops
 from ._lib import FN_D
 from .plan import LIVE_MOLS_KEY, plan_for
+
+# dev switch for A/B measurements: the finetune models ask the encoder for its bond / fragment-bond outputs although they read neither
+_KEEP_EDGE_OUTPUTS = os.environ.get("FRAGNET_KEEP_EDGE_OUTPUTS", "0") == "1"
 
 _ACTS = {
     "relu": nn.ReLU, "silu": nn.SiLU, "gelu": nn.GELU, "celu": nn.CELU, "selu": nn.SELU,
@@ -282,7 +287,9 @@ class FragNet(nn.Module):
                                              edge_in=emb_dim, edge_out=emb_dim, fedge_in=emb_dim,
                                              fbond_edge_in=fbond_edge_in, num_heads=num_heads))
 
-    def forward(self, batch):
+    def forward(self, batch, edge_outputs: bool = True):
+        """``edge_outputs=False`` (what the finetune models pass: their heads pool atoms and fragments only, gat2.py:816-826): the engine does
+        not store the last layer's activated bond / fragment-bond rows; the third and fourth result are then empty tensors."""
         plan = plan_for(batch)
         p, train = self.dropout.p, self.training
         if self.variant == "gat2_edge" and self.use_engine and not any(l.return_attentions for l in self.layers):
@@ -290,7 +297,7 @@ class FragNet(nn.Module):
             outs = engine.encoder_forward(self.layers, plan, batch["x_atoms"], batch["node_features_bonds"],
                                           batch["node_features_fbonds"], plan.sorted_attr("bond", batch["edge_attr_bonds"], defer=True),
                                           plan.sorted_attr("frag", batch["cnx_attr"], defer=True), self.layers[0].num_heads,
-                                          p, train, self.rng, variant=2)
+                                          p, train, self.rng, variant=2, edge_outputs=edge_outputs)
             return outs[0], outs[1], outs[2], None
         if self.variant == "gat2_edge":                      # gat2_edge.py:198-236: three tensors travel between layers
             x_atoms = ops.dropout_act(batch["x_atoms"], p, train, False, self.rng)
@@ -310,7 +317,7 @@ class FragNet(nn.Module):
             outs = engine.encoder_forward(self.layers, plan, batch["x_atoms"], batch["node_features_bonds"],
                                           batch["node_features_fbonds"], plan.sorted_attr("bond", batch["edge_attr_bonds"], defer=True),
                                           plan.sorted_attr("fbond", batch["edge_attr_fbonds"], defer=True), self.layers[0].num_heads,
-                                          p, train, self.rng, variant=1 if lite else 0)
+                                          p, train, self.rng, variant=1 if lite else 0, edge_outputs=edge_outputs)
             if outs[4].numel():      # the fused fragment tail also produced the readout: pooled() below hands it out
                 # (with the versions of both tensors at this point: an in-place edit of either -- a mask, an attribution hook --
                 # between the encoder and pooled() must not be answered with the readout of the unedited rows)
@@ -456,7 +463,7 @@ class FragNetFineTune(nn.Module):
             self.fthead.rng = self.pretrain.rng
 
     def forward(self, batch):
-        x_atoms, x_frags, _, _ = self.pretrain(batch)
+        x_atoms, x_frags, _, _ = self.pretrain(batch, edge_outputs=_KEEP_EDGE_OUTPUTS)
         self.fthead.live_rows = batch.get(LIVE_MOLS_KEY)     # static-shape batches: the rows behind it are padding molecules
         return self.fthead(pooled(x_atoms, x_frags, batch))
 

@@ -740,9 +740,13 @@ int fn_encoder_fused_tail(const fn_encoder* e);      /* 1: fn_encoder_forward / 
 int64_t fn_encoder_ws_floats(const fn_encoder* e);
 int64_t fn_encoder_bwd_ws_floats(const fn_encoder* e);
 uint64_t fn_encoder_rng_blocks(const fn_encoder* e);
+/* out_bond and out_fbond may both be NULL: the caller reads neither (a finetune head pools atoms and fragments only, gat2.py:816-826)
+ * and the last layer's activated bond / fragment-bond rows are not stored (the levels themselves still run: the atom and fragment
+ * graphs read their raw rows).  The other outputs do not change a bit. */
 int fn_encoder_forward(const fn_encoder* e, float* out_atoms /*[N,128]*/, float* out_frags /*[F,128]*/,
-                       float* out_bond /*[E,128]*/, float* out_fbond /*[EF,128]*/, fn_stream_t stream);
-/* g_* are dL/d(out_*) (nullable = zero); out_* are the forward outputs (needed for the ReLU mask). */
+                       float* out_bond /*[E,128], nullable*/, float* out_fbond /*[EF,128], nullable*/, fn_stream_t stream);
+/* g_* are dL/d(out_*) (nullable = zero); out_* are the forward outputs (needed for the ReLU mask; out_bond / out_fbond may be
+ * NULL where the forward pass was given NULL -- their gradients must then be NULL too). */
 int fn_encoder_backward(const fn_encoder* e, const float* out_atoms, const float* out_frags, const float* out_bond,
                         const float* out_fbond, const float* g_atoms, const float* g_frags, const float* g_bond,
                         const float* g_fbond, const fn_layer_weights* grads /*[n_layers]*/, float* scratch,

@@ -94,3 +94,38 @@ def test_the_library_refuses_a_backward_pass_after_a_forward_that_saved_nothing(
     with pytest.raises(_lib.FragnetHipError, match="no_backward"):
         sum(t.square().mean() for t in outs).backward()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("variant", ["gat2", "gat2_lite", "gat2_edge"])
+def test_a_finetune_model_without_the_edge_outputs_it_never_reads_is_the_same_model(variant):
+    """FragNetFineTune pools atoms and fragments only (gat2.py:816-826): its encoder call passes edge_outputs=False and the library does not
+    store the last layer's activated bond / fragment-bond rows (out_bond = out_fbond = NULL).  Logits and every gradient of a training
+    step with dropout are BIT-identical to the head applied to the encoder's full result; the two unwanted outputs come back empty."""
+    from fragnet_amd import model as M
+    net, batch = _net_and_batch(drop=0.1, variant=variant)
+    net.train()
+
+    def step(full):
+        net.zero_grad(set_to_none=True)
+        net.pretrain.rng.offset = 4242
+        batch.pop("_fragnet_plan", None)
+        if full:
+            outs = net.pretrain(batch)                         # all outputs stored
+            assert outs[2].shape[0] > 0
+            net.fthead.live_rows = None
+            logit = net.fthead(M.pooled(outs[0], outs[1], batch))
+        else:
+            logit = net(batch)
+        logit.square().mean().backward()
+        torch.cuda.synchronize()
+        return logit.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    l_full, g_full = step(True)
+    l_lean, g_lean = step(False)
+    assert torch.equal(l_full, l_lean)
+    assert set(g_full) == set(g_lean) and len(g_lean) > 20
+    for n in g_full:
+        assert torch.equal(g_full[n], g_lean[n]), n
+    batch.pop("_fragnet_plan", None)
+    lean = net.pretrain(batch, edge_outputs=False)
+    assert lean[2].numel() == 0 and (lean[3] is None or lean[3].numel() == 0) and not lean[2].requires_grad
